@@ -1,0 +1,305 @@
+"""cudagaussianrenderer_amd -- Python host over libgsplat_hip.so (MI355X / gfx950).
+
+Mirrors the reference's host interface for the per-frame path (src/GaussianRender.cuh:118-143,
+src/Demo.cpp:394-479, src/PlyParser.h:13-21): the eight staged calls, `DeviceBuffer`, `DoubleBuffer`,
+`parse_ply`, and a `Renderer` that is the frame-loop body as `render(scene, camera)`.
+All arithmetic happens in the HIP library; this module only moves pointers and numpy arrays.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import CameraData, FrameStats, GlobalArgs, GsplatLibraryMissing, TileListArgs  # noqa: F401
+
+TILE_SIZE = 16
+SH_GROUP_SIZE = 256
+
+
+def lib():
+    return _capi.load()
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ---- DeviceBuffer<T> (src/DeviceBuffer.cu:8-127) ---------------------------------------------------
+class DeviceBuffer:
+    """RAII device allocation with upload/download, grow-only resize and byte memset."""
+
+    def __init__(self, data=None, nbytes=None, dtype=None):
+        self.ptr = None
+        self.nbytes = 0
+        self.allocated = 0
+        self.dtype = np.dtype(dtype) if dtype is not None else None
+        if data is not None:
+            self.copy_from(data)
+        elif nbytes is not None:
+            self.resize_if_needed(nbytes)
+
+    def resize_if_needed(self, nbytes):
+        """DeviceBuffer.cu:47-64. Returns True when a new allocation was made."""
+        if nbytes > self.allocated:
+            self.release()
+            self.ptr = lib().gs_device_alloc(nbytes)
+            self.allocated = nbytes
+            self.nbytes = nbytes
+            return True
+        self.nbytes = nbytes
+        return False
+
+    def copy_from(self, array):
+        a = np.ascontiguousarray(array)
+        self.dtype = a.dtype
+        self.resize_if_needed(a.nbytes)
+        if a.nbytes:
+            lib().gs_device_upload(self.ptr, a.ctypes.data_as(C.c_void_p), a.nbytes)
+
+    def copy_to(self, count=None, dtype=None, shape=None):
+        dt = np.dtype(dtype) if dtype is not None else self.dtype
+        n = (self.nbytes // dt.itemsize) if count is None else count
+        out = np.empty(n, dt)
+        if n:
+            lib().gs_device_download(out.ctypes.data_as(C.c_void_p), self.ptr, out.nbytes)
+        return out.reshape(shape) if shape is not None else out
+
+    def clear_memory(self, value):
+        """DeviceBuffer.cu:40-44: byte-wise memset (value 255 -> int32 -1)."""
+        if self.nbytes:
+            lib().gs_device_memset(self.ptr, value, self.nbytes)
+
+    def release(self):
+        if self.ptr:
+            lib().gs_device_free(self.ptr)
+        self.ptr = None
+        self.nbytes = 0
+        self.allocated = 0
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class DoubleBuffer:
+    """GaussianRender.cuh:87-116."""
+
+    def __init__(self, current, alternate):
+        self.buffers = [current, alternate]
+        self.selector = 0
+
+    def current(self):
+        return self.buffers[self.selector]
+
+    def alternate(self):
+        return self.buffers[self.selector ^ 1]
+
+
+class GpuTimer:
+    """Utilities.h:155-187 CudaTimer."""
+
+    def __init__(self):
+        self.handle = lib().gs_timer_create()
+
+    def elapsed_ms(self):
+        return float(lib().gs_timer_elapsed_ms(self.handle))
+
+    def __del__(self):
+        try:
+            lib().gs_timer_destroy(self.handle)
+        except Exception:
+            pass
+
+
+# ---- the eight staged functions, reference names ---------------------------------------------------
+def set_global_args(args):
+    lib().gs_set_global_args(C.byref(args))
+
+
+def set_tile_list_args(args):
+    lib().gs_set_tile_list_args(C.byref(args))
+
+
+def _t(timer):
+    return timer.handle if timer is not None else None
+
+
+def evaluate_spherical_harmonics(timer, count):
+    lib().gs_evaluate_spherical_harmonics(_t(timer), count)
+
+
+def evaluate_splat_clip_data(timer, count):
+    lib().gs_evaluate_splat_clip_data(_t(timer), count)
+
+
+def build_tile_list(timer, num_blocks, capacity):
+    return int(lib().gs_build_tile_list(_t(timer), num_blocks, capacity))
+
+
+def sort_tile_list(timer, size, temp, keys, values):
+    """`temp` is a two-element list [ptr, nbytes] owned by the caller, updated in place (void*&, size_t&)."""
+    k = _capi.DoubleBufferU64((C.c_void_p * 2)(keys.buffers[0].ptr, keys.buffers[1].ptr), keys.selector)
+    v = _capi.DoubleBufferI32((C.c_void_p * 2)(values.buffers[0].ptr, values.buffers[1].ptr), values.selector)
+    tp = C.c_void_p(temp[0])
+    tb = C.c_size_t(temp[1])
+    lib().gs_sort_tile_list(_t(timer), size, C.byref(tp), C.byref(tb), C.byref(k), C.byref(v))
+    temp[0], temp[1] = tp.value, tb.value
+    keys.selector = k.selector
+    values.selector = v.selector
+
+
+def evaluate_tile_range(timer, size):
+    lib().gs_evaluate_tile_range(_t(timer), size)
+
+
+def rasterize_tile(timer):
+    lib().gs_rasterize_tile(_t(timer))
+
+
+def synchronize():
+    lib().gs_synchronize()
+
+
+# ---- host helpers -----------------------------------------------------------------------------------
+def encode_vec4(v):
+    return int(lib().gs_encode_vec4(_fp(_f32(v))))
+
+
+def sort_end_bit(width, height):
+    return int(lib().gs_sort_end_bit(width, height))
+
+
+def tile_counts(width, height):
+    tx, ty = C.c_int(), C.c_int()
+    lib().gs_tile_counts(width, height, C.byref(tx), C.byref(ty))
+    return tx.value, ty.value
+
+
+def realign_spherical_harmonics(sh, sh_count, splat_count, group_size=SH_GROUP_SIZE):
+    src = _f32(sh).reshape(-1)
+    n = lib().gs_realigned_sh_size(group_size, sh_count, splat_count)
+    dst = np.zeros(n, np.float32)
+    lib().gs_realign_spherical_harmonics(_fp(src), _fp(dst), group_size, sh_count, splat_count)
+    return dst
+
+
+def camera_from_bounds(bounds_min, bounds_max, width, height):
+    cam = CameraData()
+    lib().gs_camera_from_bounds(_fp(_f32(bounds_min)), _fp(_f32(bounds_max)), width, height, C.byref(cam))
+    return cam
+
+
+def camera_from_pose(position, rotation_xyzw, width, height):
+    cam = CameraData()
+    lib().gs_camera_from_pose(_fp(_f32(position)), _fp(_f32(rotation_xyzw)), width, height, C.byref(cam))
+    return cam
+
+
+def generate_random_gaussians(count, seed=1234, min_scale=0.01, max_scale=0.5, extent=4.0):
+    """Demo.cpp:119-143,258-269 with a seeded PRNG. Returns position, scaleAndRotation, color (N,4) float32."""
+    pos = np.zeros((count, 4), np.float32)
+    sr = np.zeros((count, 4), np.float32)
+    col = np.zeros((count, 4), np.float32)
+    lo = _f32([-extent] * 3)
+    hi = _f32([extent] * 3)
+    lib().gs_generate_random_gaussians(count, seed, min_scale, max_scale, _fp(lo), _fp(hi), _fp(pos), _fp(sr), _fp(col))
+    return pos, sr, col
+
+
+class PlyError(ValueError):
+    """The reference throws std::invalid_argument (PlyParser.cpp:39-237); same message text."""
+
+
+def parse_ply(path):
+    """parsePly (PlyParser.h:13-21). Returns a dict of numpy arrays."""
+    import os
+
+    ply = _capi.Ply()
+    err = C.create_string_buffer(512)
+    n = lib().gs_parse_ply(os.fsencode(path), C.byref(ply), err, 512)
+    if n < 0:
+        raise PlyError(err.value.decode())
+    try:
+        def arr(ptr, count):
+            return np.ctypeslib.as_array(ptr, shape=(count,)).copy() if count else np.zeros(0, np.float32)
+        deg, cnt = ply.sphericalHarmonicsDegree, ply.sphericalHarmonicsCount
+        return {
+            "vertexCount": n,
+            "shDegree": deg,
+            "shCount": cnt,
+            "boundsMin": np.array(ply.boundsMin[:], np.float32),
+            "boundsMax": np.array(ply.boundsMax[:], np.float32),
+            "position": arr(ply.position, 4 * n).reshape(n, 4),
+            "scaleAndRotation": arr(ply.scaleAndRotation, 4 * n).reshape(n, 4),
+            "color": arr(ply.color, 4 * n).reshape(n, 4),
+            "sh": arr(ply.sphericalHarmonics, cnt * n).reshape(n, cnt) if deg else np.zeros((n, 0), np.float32),
+        }
+    finally:
+        lib().gs_free_ply(C.byref(ply))
+
+
+# ---- render(scene, camera) ----------------------------------------------------------------------------
+class Renderer:
+    """The frame loop body of src/Demo.cpp:352-479 behind one call."""
+
+    def __init__(self, width, height, tile_rows=None):
+        self.width, self.height = width, height
+        self.handle = lib().gs_renderer_create(width, height)
+        if tile_rows is not None:
+            lib().gs_renderer_set_tile_rows(self.handle, tile_rows[0], tile_rows[1])
+        self.splat_count = 0
+
+    def set_scene(self, position, scale_and_rotation, color, sh=None, sh_degree=0, sh_count=0):
+        pos, sr, col = _f32(position), _f32(scale_and_rotation), _f32(color)
+        n = pos.shape[0]
+        shp = _fp(_f32(sh).reshape(-1)) if sh_degree else None
+        rc = lib().gs_renderer_set_scene(self.handle, n, _fp(pos), _fp(sr), _fp(col), shp, sh_degree, sh_count)
+        if rc != 0:
+            raise ValueError("gs_renderer_set_scene failed")
+        self.splat_count = n
+
+    def set_back_buffer(self, device_ptr):
+        lib().gs_renderer_set_back_buffer(self.handle, device_ptr)
+
+    def render(self, camera, timed=False, stats=False):
+        st = FrameStats() if (stats or timed) else None
+        rc = lib().gs_renderer_render(self.handle, C.byref(camera), 1 if timed else 0, C.byref(st) if st is not None else None)
+        if rc != 0:
+            raise RuntimeError(f"gs_renderer_render failed ({rc})")
+        return st
+
+    def read_image(self):
+        img = np.empty((self.height, self.width, 4), np.uint8)
+        lib().gs_renderer_read_back_buffer(self.handle, img.ctypes.data_as(C.c_void_p))
+        return img
+
+    def back_buffer_ptr(self):
+        return lib().gs_renderer_back_buffer(self.handle)
+
+    def buffers(self):
+        b = _capi.RendererBuffers()
+        lib().gs_renderer_buffers(self.handle, C.byref(b))
+        return b
+
+    def download(self, ptr, count, dtype):
+        out = np.empty(count, dtype)
+        if count:
+            lib().gs_device_download(out.ctypes.data_as(C.c_void_p), ptr, out.nbytes)
+        return out
+
+    def close(self):
+        if self.handle:
+            lib().gs_renderer_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

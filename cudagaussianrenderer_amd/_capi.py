@@ -1,0 +1,191 @@
+"""ctypes declarations for libgsplat_hip.so (include/gsplat_hip.h).
+
+The library is the product: there is no fallback.  If it is missing, loading fails loudly
+(`GsplatLibraryMissing`) instead of silently computing something else.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsplat_hip.so")
+
+
+class GsplatLibraryMissing(RuntimeError):
+    pass
+
+
+class CameraData(C.Structure):
+    """GsCameraData == the reference's CameraData (GaussianRender.cuh:17-26)."""
+
+    _fields_ = [
+        ("viewProjection", C.c_float * 16),
+        ("projection", C.c_float * 16),
+        ("view", C.c_float * 16),
+        ("fovCotangent", C.c_float * 2),
+        ("depthScaleBias", C.c_float * 2),
+        ("position", C.c_float * 3),
+        ("aspect", C.c_float),
+    ]
+
+
+class GlobalArgs(C.Structure):
+    """GsGlobalArgs == the reference's GlobalArgs (GaussianRender.cuh:56-74) + width/height/band."""
+
+    _fields_ = [
+        ("cameraData", CameraData),
+        ("position", C.c_void_p),
+        ("scaleAndRotation", C.c_void_p),
+        ("color", C.c_void_p),
+        ("sphericalHarmonicsDegree", C.c_int32),
+        ("sphericalHarmonicsCount", C.c_int32),
+        ("sphericalHarmonics", C.c_void_p),
+        ("positionClipSpaceXY", C.c_void_p),
+        ("positionClipSpaceZ", C.c_void_p),
+        ("conic", C.c_void_p),
+        ("screenEllipse", C.c_void_p),
+        ("splatCount", C.c_int32),
+        ("backBuffer", C.c_void_p),
+        ("tileRange", C.c_void_p),
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("tileRowBegin", C.c_int32),
+        ("tileRowEnd", C.c_int32),
+    ]
+
+
+class TileListArgs(C.Structure):
+    _fields_ = [("keys", C.c_void_p), ("values", C.c_void_p), ("size", C.c_int32), ("capacity", C.c_int32)]
+
+
+class DoubleBufferU64(C.Structure):
+    _fields_ = [("buffers", C.c_void_p * 2), ("selector", C.c_int32)]
+
+
+class DoubleBufferI32(C.Structure):
+    _fields_ = [("buffers", C.c_void_p * 2), ("selector", C.c_int32)]
+
+
+class Ply(C.Structure):
+    _fields_ = [
+        ("vertexCount", C.c_int32),
+        ("sphericalHarmonicsDegree", C.c_int32),
+        ("sphericalHarmonicsCount", C.c_int32),
+        ("boundsMin", C.c_float * 3),
+        ("boundsMax", C.c_float * 3),
+        ("position", C.POINTER(C.c_float)),
+        ("scaleAndRotation", C.POINTER(C.c_float)),
+        ("color", C.POINTER(C.c_float)),
+        ("sphericalHarmonics", C.POINTER(C.c_float)),
+    ]
+
+
+class FrameStats(C.Structure):
+    _fields_ = [
+        ("msSphericalHarmonics", C.c_float),
+        ("msClipData", C.c_float),
+        ("msBuildTileList", C.c_float),
+        ("msSortTileList", C.c_float),
+        ("msTileRanges", C.c_float),
+        ("msRasterize", C.c_float),
+        ("msFrame", C.c_float),
+        ("tileListSize", C.c_int64),
+        ("consumedPairs", C.c_int64),
+        ("tileListCapacity", C.c_int32),
+        ("grewTileList", C.c_int32),
+    ]
+
+
+class RendererBuffers(C.Structure):
+    _fields_ = [
+        ("position", C.c_void_p),
+        ("scaleAndRotation", C.c_void_p),
+        ("color", C.c_void_p),
+        ("sphericalHarmonics", C.c_void_p),
+        ("positionClipSpaceXY", C.c_void_p),
+        ("positionClipSpaceZ", C.c_void_p),
+        ("conic", C.c_void_p),
+        ("screenEllipse", C.c_void_p),
+        ("tileRange", C.c_void_p),
+        ("keys", C.c_void_p),
+        ("values", C.c_void_p),
+        ("splatCount", C.c_int32),
+        ("tileListSize", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); exactly the symbols include/gsplat_hip.h declares.
+SIGNATURES = {
+    "gs_timer_create": (C.c_void_p, []),
+    "gs_timer_destroy": (None, [C.c_void_p]),
+    "gs_timer_start": (None, [C.c_void_p]),
+    "gs_timer_stop": (None, [C.c_void_p]),
+    "gs_timer_elapsed_ms": (C.c_float, [C.c_void_p]),
+    "gs_timer_set_blocking": (None, [C.c_void_p, C.c_int]),
+    "gs_set_global_args": (None, [C.POINTER(GlobalArgs)]),
+    "gs_set_tile_list_args": (None, [C.POINTER(TileListArgs)]),
+    "gs_evaluate_spherical_harmonics": (None, [C.c_void_p, C.c_int32]),
+    "gs_evaluate_splat_clip_data": (None, [C.c_void_p, C.c_int32]),
+    "gs_build_tile_list": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32]),
+    "gs_last_tile_list_demand": (C.c_int64, []),
+    "gs_sort_tile_list": (None, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t),
+                                 C.POINTER(DoubleBufferU64), C.POINTER(DoubleBufferI32)]),
+    "gs_evaluate_tile_range": (None, [C.c_void_p, C.c_int32]),
+    "gs_rasterize_tile": (None, [C.c_void_p]),
+    "gs_set_collect_raster_stats": (None, [C.c_int]),
+    "gs_last_raster_consumed_pairs": (C.c_int64, []),
+    "gs_set_raster_pixels_per_lane": (None, [C.c_int]),
+    "gs_get_raster_pixels_per_lane": (C.c_int, []),
+    "gs_set_device": (None, [C.c_int]),
+    "gs_set_stream": (None, [C.c_void_p]),
+    "gs_get_stream": (C.c_void_p, []),
+    "gs_synchronize": (None, []),
+    "gs_device_info": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    "gs_device_alloc": (C.c_void_p, [C.c_size_t]),
+    "gs_device_free": (None, [C.c_void_p]),
+    "gs_device_upload": (None, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "gs_device_download": (None, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "gs_device_memset": (None, [C.c_void_p, C.c_int, C.c_size_t]),
+    "gs_encode_vec4": (C.c_uint32, [C.POINTER(C.c_float)]),
+    "gs_sort_end_bit": (C.c_int, [C.c_int, C.c_int]),
+    "gs_tile_counts": (None, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gs_realigned_sh_size": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "gs_realign_spherical_harmonics": (None, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int]),
+    "gs_camera_from_bounds": (None, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(CameraData)]),
+    "gs_camera_from_pose": (None, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(CameraData)]),
+    "gs_generate_random_gaussians": (None, [C.c_int32, C.c_uint64, C.c_float, C.c_float, C.POINTER(C.c_float),
+                                            C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                            C.POINTER(C.c_float)]),
+    "gs_parse_ply": (C.c_int, [C.c_char_p, C.POINTER(Ply), C.c_char_p, C.c_size_t]),
+    "gs_free_ply": (None, [C.POINTER(Ply)]),
+    "gs_renderer_create": (C.c_void_p, [C.c_int, C.c_int]),
+    "gs_renderer_destroy": (None, [C.c_void_p]),
+    "gs_renderer_set_tile_rows": (None, [C.c_void_p, C.c_int, C.c_int]),
+    "gs_renderer_set_scene": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                        C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int]),
+    "gs_renderer_render": (C.c_int, [C.c_void_p, C.POINTER(CameraData), C.c_int, C.POINTER(FrameStats)]),
+    "gs_renderer_back_buffer": (C.c_void_p, [C.c_void_p]),
+    "gs_renderer_set_back_buffer": (None, [C.c_void_p, C.c_void_p]),
+    "gs_renderer_read_back_buffer": (None, [C.c_void_p, C.c_void_p]),
+    "gs_renderer_buffers": (None, [C.c_void_p, C.POINTER(RendererBuffers)]),
+    "gs_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load libgsplat_hip.so and bind every declared symbol. Raises if the extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GsplatLibraryMissing(
+            f"{LIB_PATH} not found: build it with `make -C cudagaussianrenderer_amd/csrc` "
+            "(or __graft_entry__.build()). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library disagree
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib

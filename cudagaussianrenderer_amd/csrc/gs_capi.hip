@@ -1,0 +1,542 @@
+// gs_capi.hip -- the C ABI of include/gsplat_hip.h: library state, timers, device buffers, the eight
+// staged host functions (GaussianRender.cuh:118-143) and the one-call renderer (Demo.cpp:352-479).
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "gs_internal.h"
+
+namespace gs
+{
+
+void setRasterPixelsPerLane(int ppl);
+int rasterPixelsPerLane();
+
+Screen makeScreen(int width, int height, int rowBegin, int rowEnd)
+{
+    if (width <= 0) width = GS_DEFAULT_SCREEN_SIZE;
+    if (height <= 0) height = GS_DEFAULT_SCREEN_SIZE;
+    Screen s;
+    s.width = width;
+    s.height = height;
+    s.tilesX = (width + kTileSize - 1) / kTileSize;
+    s.tilesY = (height + kTileSize - 1) / kTileSize;
+    s.totalTiles = s.tilesX * s.tilesY;
+    if (rowBegin == 0 && rowEnd == 0) rowEnd = s.tilesY;
+    s.rowBegin = std::min(std::max(rowBegin, 0), s.tilesY);
+    s.rowEnd = std::min(std::max(rowEnd, s.rowBegin), s.tilesY);
+    s.tilesPerScreenX = (float) width / (float) kTileSize;
+    s.tilesPerScreenY = (float) height / (float) kTileSize;
+    s.tileClipSizeX = ((float) kTileSize / (float) width) * 2.0f;
+    s.tileClipSizeY = ((float) kTileSize / (float) height) * 2.0f;
+    s.pixelClipSizeX = 2.0f / (float) width;
+    s.pixelClipSizeY = 2.0f / (float) height;
+    const float pi = 3.14159265359f;
+    s.traceBump = (1.0f / pi) * s.pixelClipSizeX * s.pixelClipSizeY;
+    return s;
+}
+
+namespace
+{
+
+// The reference keeps these in __constant__ symbols (GaussianRender.cu:42-43); here they are a host
+// copy and every launch passes what its kernel needs by value.
+struct State
+{
+    GsGlobalArgs global{};
+    GsTileListArgs tileList{};
+    hipStream_t stream = nullptr;
+    TileListScratch scratch;
+    int64_t lastDemand = 0;
+    bool collectRasterStats = false;
+    unsigned long long* consumedDevice = nullptr;
+    int64_t lastConsumed = 0;
+};
+State g;
+
+Screen currentScreen() { return makeScreen(g.global.width, g.global.height, g.global.tileRowBegin, g.global.tileRowEnd); }
+
+ClipCamera currentCamera()
+{
+    ClipCamera c;
+    std::memcpy(c.view, g.global.cameraData.view, sizeof(c.view));
+    c.fovCotX = g.global.cameraData.fovCotangent[0];
+    c.fovCotY = g.global.cameraData.fovCotangent[1];
+    c.depthScale = g.global.cameraData.depthScaleBias[0];
+    c.depthBias = g.global.cameraData.depthScaleBias[1];
+    return c;
+}
+
+void reportLaunch(const char* stage)
+{
+    if (hipGetLastError() != hipSuccess) printf("kernel error %s\n", stage);
+}
+
+} // namespace
+} // namespace gs
+
+using namespace gs;
+
+// ---- timer (Utilities.h:155-187) ------------------------------------------------------------------
+struct GsTimer
+{
+    hipEvent_t start, stop;
+    float elapsedMs;
+    int blocking;
+};
+
+extern "C" GsTimer* gs_timer_create(void)
+{
+    GsTimer* t = new GsTimer{};
+    GS_CHECK(hipEventCreate(&t->start));
+    GS_CHECK(hipEventCreate(&t->stop));
+    t->blocking = 1;
+    return t;
+}
+extern "C" void gs_timer_destroy(GsTimer* t)
+{
+    if (!t) return;
+    (void) hipEventDestroy(t->start);
+    (void) hipEventDestroy(t->stop);
+    delete t;
+}
+extern "C" void gs_timer_set_blocking(GsTimer* t, int blocking) { t->blocking = blocking; }
+extern "C" void gs_timer_start(GsTimer* t)
+{
+    if (t) GS_CHECK(hipEventRecord(t->start, g.stream));
+}
+extern "C" void gs_timer_stop(GsTimer* t)
+{
+    if (!t) return;
+    GS_CHECK(hipEventRecord(t->stop, g.stream));
+    if (t->blocking)
+    {
+        GS_CHECK(hipEventSynchronize(t->stop));
+        GS_CHECK(hipEventElapsedTime(&t->elapsedMs, t->start, t->stop));
+    }
+}
+extern "C" float gs_timer_elapsed_ms(const GsTimer* t)
+{
+    if (!t->blocking)
+    {
+        float ms = 0.0f;
+        GS_CHECK(hipEventSynchronize(t->stop));
+        GS_CHECK(hipEventElapsedTime(&ms, t->start, t->stop));
+        return ms;
+    }
+    return t->elapsedMs;
+}
+
+// ---- device / stream ------------------------------------------------------------------------------
+extern "C" void gs_set_device(int device) { GS_CHECK(hipSetDevice(device)); }
+extern "C" void gs_set_stream(void* s) { g.stream = (hipStream_t) s; }
+extern "C" void* gs_get_stream(void) { return (void*) g.stream; }
+extern "C" void gs_synchronize(void) { GS_CHECK(hipStreamSynchronize(g.stream)); }
+extern "C" int gs_device_info(char* name, size_t nameLen, int* computeUnits, size_t* totalMemBytes)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    if (name && nameLen) snprintf(name, nameLen, "%s (%s)", prop.name, prop.gcnArchName);
+    if (computeUnits) *computeUnits = prop.multiProcessorCount;
+    if (totalMemBytes) *totalMemBytes = prop.totalGlobalMem;
+    return 0;
+}
+
+// ---- DeviceBuffer (DeviceBuffer.cu) -----------------------------------------------------------------
+extern "C" void* gs_device_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    GS_CHECK(hipMalloc(&p, bytes ? bytes : 1));
+    return p;
+}
+extern "C" void gs_device_free(void* p)
+{
+    if (p) GS_CHECK(hipFree(p));
+}
+extern "C" void gs_device_upload(void* dst, const void* src, size_t bytes)
+{
+    if (bytes) GS_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+}
+extern "C" void gs_device_download(void* dst, const void* src, size_t bytes)
+{
+    if (bytes)
+    {
+        GS_CHECK(hipStreamSynchronize(g.stream));
+        GS_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    }
+}
+extern "C" void gs_device_memset(void* p, int value, size_t bytes)
+{
+    if (bytes) GS_CHECK(hipMemsetAsync(p, value, bytes, g.stream));
+}
+
+// ---- staged API -----------------------------------------------------------------------------------
+extern "C" void gs_set_global_args(const GsGlobalArgs* a) { g.global = *a; }
+extern "C" void gs_set_tile_list_args(const GsTileListArgs* a) { g.tileList = *a; }
+
+extern "C" int gs_sort_end_bit(int width, int height) { return sortEndBit(makeScreen(width, height, 0, 0).totalTiles); }
+extern "C" void gs_tile_counts(int width, int height, int* tilesX, int* tilesY)
+{
+    const Screen s = makeScreen(width, height, 0, 0);
+    if (tilesX) *tilesX = s.tilesX;
+    if (tilesY) *tilesY = s.tilesY;
+}
+
+extern "C" void gs_evaluate_spherical_harmonics(GsTimer* timer, int32_t count)
+{
+    gs_timer_start(timer);
+    const float* cp = g.global.cameraData.position;
+    launchSphericalHarmonics(g.stream, count, g.global.sphericalHarmonicsDegree, g.global.sphericalHarmonicsCount,
+                             (const float4*) g.global.position, g.global.sphericalHarmonics, make_float3(cp[0], cp[1], cp[2]),
+                             (float4*) g.global.color);
+    gs_timer_stop(timer);
+    reportLaunch("evaluateSphericalHarmonics");
+}
+
+extern "C" void gs_evaluate_splat_clip_data(GsTimer* timer, int32_t count)
+{
+    gs_timer_start(timer);
+    launchSplatClipData(g.stream, count, currentScreen(), currentCamera(), (const float4*) g.global.position,
+                        (const float4*) g.global.scaleAndRotation, (float2*) g.global.positionClipSpaceXY,
+                        g.global.positionClipSpaceZ, (float4*) g.global.screenEllipse, (float4*) g.global.conic);
+    gs_timer_stop(timer);
+    reportLaunch("evaluateSplatsClipData");
+}
+
+extern "C" int32_t gs_build_tile_list(GsTimer* timer, int32_t /*numBlocks*/, int32_t tileListCapacity)
+{
+    const Screen scr = currentScreen();
+    const int count = g.global.splatCount;
+    gs_timer_start(timer);
+    launchTileListCount(g.stream, count, scr, (const float2*) g.global.positionClipSpaceXY, (const float4*) g.global.screenEllipse,
+                        g.scratch);
+    launchTileListEmit(g.stream, count, scr, (const float2*) g.global.positionClipSpaceXY, g.global.positionClipSpaceZ,
+                       (const float4*) g.global.screenEllipse, g.scratch, g.tileList.keys, g.tileList.values, tileListCapacity);
+    gs_timer_stop(timer);
+    // The reference reads the pair counter back here too (GaussianRender.cu:793), a host sync point.
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    reportLaunch("buildTileList");
+    g.lastDemand = *g.scratch.totalHost;
+    return (int32_t) std::min<int64_t>(g.lastDemand, (int64_t) tileListCapacity); // GaussianRender.cu:800-801
+}
+
+extern "C" int64_t gs_last_tile_list_demand(void) { return g.lastDemand; }
+
+extern "C" void gs_sort_tile_list(GsTimer* timer, int32_t size, void** deviceTempStorage, size_t* tempStorageSizeInBytes,
+                                  GsDoubleBufferU64* keys, GsDoubleBufferI32* values)
+{
+    gs_timer_start(timer);
+    if (size > 0)
+    {
+        const int endBit = sortEndBit(currentScreen().totalTiles);
+        const size_t required = sortTempBytes(size, endBit);
+        if (required > *tempStorageSizeInBytes) // GaussianRender.cu:831-839
+        {
+            if (*deviceTempStorage != nullptr) GS_CHECK(hipFree(*deviceTempStorage));
+            GS_CHECK(hipMalloc(deviceTempStorage, required));
+            *tempStorageSizeInBytes = required;
+        }
+        // Keys and values may start on different selectors only if the caller mixed them up; follow keys.
+        const int sel = launchSortPairs(g.stream, *deviceTempStorage, *tempStorageSizeInBytes, keys->buffers[0], keys->buffers[1],
+                                        values->buffers[0], values->buffers[1], keys->selector, size, endBit);
+        keys->selector = sel;
+        values->selector = sel;
+    }
+    gs_timer_stop(timer);
+    if (hipGetLastError() != hipSuccess) printf("error sortTileList\n");
+}
+
+extern "C" void gs_evaluate_tile_range(GsTimer* timer, int32_t size)
+{
+    gs_timer_start(timer);
+    launchTileRanges(g.stream, size, g.tileList.keys, g.global.tileRange);
+    gs_timer_stop(timer);
+    reportLaunch("evaluateTileRanges");
+}
+
+extern "C" void gs_set_collect_raster_stats(int enabled)
+{
+    g.collectRasterStats = enabled != 0;
+    if (enabled && g.consumedDevice == nullptr) GS_CHECK(hipMalloc((void**) &g.consumedDevice, sizeof(unsigned long long)));
+}
+
+extern "C" int64_t gs_last_raster_consumed_pairs(void)
+{
+    if (g.consumedDevice == nullptr) return 0;
+    unsigned long long v = 0;
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    GS_CHECK(hipMemcpy(&v, g.consumedDevice, sizeof(v), hipMemcpyDeviceToHost));
+    return (int64_t) v;
+}
+
+extern "C" void gs_set_raster_pixels_per_lane(int ppl) { setRasterPixelsPerLane(ppl); }
+extern "C" int gs_get_raster_pixels_per_lane(void) { return rasterPixelsPerLane(); }
+
+extern "C" void gs_rasterize_tile(GsTimer* timer)
+{
+    unsigned long long* consumed = g.collectRasterStats ? g.consumedDevice : nullptr;
+    if (consumed) GS_CHECK(hipMemsetAsync(consumed, 0, sizeof(unsigned long long), g.stream));
+    gs_timer_start(timer);
+    launchRasterize(g.stream, currentScreen(), g.global.tileRange, g.tileList.values, (const float2*) g.global.positionClipSpaceXY,
+                    (const float4*) g.global.conic, (const float4*) g.global.color, (uchar4*) g.global.backBuffer, consumed);
+    gs_timer_stop(timer);
+    reportLaunch("renderDepthBuffer");
+}
+
+// ---- one-call renderer (Demo.cpp:314-331 buffers, :352-479 frame) ---------------------------------
+struct GsRenderer
+{
+    int width = 0, height = 0, rowBegin = 0, rowEnd = 0;
+    int32_t splatCount = 0, shDegree = 0, shCount = 0;
+    float *position = nullptr, *scaleAndRotation = nullptr, *color = nullptr, *sh = nullptr;
+    float *clipXY = nullptr, *clipZ = nullptr, *conic = nullptr, *ellipse = nullptr;
+    int32_t* tileRange = nullptr;
+    uint8_t* backBufferOwned = nullptr;
+    uint8_t* backBuffer = nullptr;
+    int32_t tileListCapacity = 0;
+    uint64_t* keys[2] = {nullptr, nullptr};
+    int32_t* values[2] = {nullptr, nullptr};
+    int selector = 0;
+    int32_t tileListSize = 0;
+    void* sortTemp = nullptr;
+    size_t sortTempBytes = 0;
+    GsTimer* timer = nullptr;
+    hipEvent_t frameStart = nullptr, frameStop = nullptr;
+};
+
+namespace
+{
+void freeTileList(GsRenderer* r)
+{
+    for (int i = 0; i != 2; ++i)
+    {
+        gs_device_free(r->keys[i]);
+        gs_device_free(r->values[i]);
+        r->keys[i] = nullptr;
+        r->values[i] = nullptr;
+    }
+}
+void allocTileList(GsRenderer* r, int32_t capacity)
+{
+    freeTileList(r);
+    for (int i = 0; i != 2; ++i)
+    {
+        r->keys[i] = (uint64_t*) gs_device_alloc(sizeof(uint64_t) * (size_t) capacity);
+        r->values[i] = (int32_t*) gs_device_alloc(sizeof(int32_t) * (size_t) capacity);
+    }
+    r->tileListCapacity = capacity;
+}
+void freeScene(GsRenderer* r)
+{
+    float** bufs[] = {&r->position, &r->scaleAndRotation, &r->color, &r->sh, &r->clipXY, &r->clipZ, &r->conic, &r->ellipse};
+    for (float** b : bufs)
+    {
+        gs_device_free(*b);
+        *b = nullptr;
+    }
+}
+} // namespace
+
+extern "C" GsRenderer* gs_renderer_create(int width, int height)
+{
+    GsRenderer* r = new GsRenderer{};
+    const Screen scr = makeScreen(width, height, 0, 0);
+    r->width = scr.width;
+    r->height = scr.height;
+    r->tileRange = (int32_t*) gs_device_alloc(sizeof(int32_t) * 2 * (size_t) scr.totalTiles);
+    r->backBufferOwned = (uint8_t*) gs_device_alloc((size_t) scr.width * scr.height * 4);
+    r->backBuffer = r->backBufferOwned;
+    r->timer = gs_timer_create();
+    GS_CHECK(hipEventCreate(&r->frameStart));
+    GS_CHECK(hipEventCreate(&r->frameStop));
+    return r;
+}
+
+extern "C" void gs_renderer_destroy(GsRenderer* r)
+{
+    if (!r) return;
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    freeScene(r);
+    freeTileList(r);
+    gs_device_free(r->tileRange);
+    gs_device_free(r->backBufferOwned);
+    gs_device_free(r->sortTemp);
+    gs_timer_destroy(r->timer);
+    (void) hipEventDestroy(r->frameStart);
+    (void) hipEventDestroy(r->frameStop);
+    delete r;
+}
+
+extern "C" void gs_renderer_set_tile_rows(GsRenderer* r, int begin, int end)
+{
+    r->rowBegin = begin;
+    r->rowEnd = end;
+}
+
+extern "C" int gs_renderer_set_scene(GsRenderer* r, int32_t n, const float* position4, const float* scaleAndRotation4,
+                                     const float* color4, const float* sh, int shDegree, int shCount)
+{
+    if (n < 0 || (shDegree != 0 && sh == nullptr)) return -1;
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    freeScene(r);
+    r->splatCount = n;
+    r->shDegree = shDegree;
+    r->shCount = shCount;
+    const size_t f4 = sizeof(float) * 4 * (size_t) n;
+    r->position = (float*) gs_device_alloc(f4);
+    r->scaleAndRotation = (float*) gs_device_alloc(f4);
+    r->color = (float*) gs_device_alloc(f4);
+    r->conic = (float*) gs_device_alloc(f4);
+    r->ellipse = (float*) gs_device_alloc(f4);
+    r->clipXY = (float*) gs_device_alloc(sizeof(float) * 2 * (size_t) n);
+    r->clipZ = (float*) gs_device_alloc(sizeof(float) * (size_t) n);
+    gs_device_upload(r->position, position4, f4);
+    gs_device_upload(r->scaleAndRotation, scaleAndRotation4, f4);
+    gs_device_upload(r->color, color4, f4);
+    if (shDegree != 0)
+    {
+        // Demo.cpp:291-296
+        const size_t total = gs_realigned_sh_size(GS_SH_GROUP_SIZE, shCount, n);
+        std::vector<float> aligned(total);
+        gs_realign_spherical_harmonics(sh, aligned.data(), GS_SH_GROUP_SIZE, shCount, n);
+        r->sh = (float*) gs_device_alloc(total * sizeof(float));
+        gs_device_upload(r->sh, aligned.data(), total * sizeof(float));
+    }
+    // Demo.cpp:325: 8 pairs per splat to start with; grown on demand.
+    if (r->tileListCapacity < std::max(n, 1) * 8) allocTileList(r, std::max(n, 1) * 8);
+    return 0;
+}
+
+extern "C" uint8_t* gs_renderer_back_buffer(GsRenderer* r) { return r->backBuffer; }
+extern "C" void gs_renderer_set_back_buffer(GsRenderer* r, uint8_t* p) { r->backBuffer = p ? p : r->backBufferOwned; }
+
+extern "C" void gs_renderer_read_back_buffer(GsRenderer* r, uint8_t* hostRgba)
+{
+    gs_device_download(hostRgba, r->backBuffer, (size_t) r->width * r->height * 4);
+}
+
+extern "C" void gs_renderer_buffers(GsRenderer* r, GsRendererBuffers* out)
+{
+    out->position = r->position;
+    out->scaleAndRotation = r->scaleAndRotation;
+    out->color = r->color;
+    out->sphericalHarmonics = r->sh;
+    out->positionClipSpaceXY = r->clipXY;
+    out->positionClipSpaceZ = r->clipZ;
+    out->conic = r->conic;
+    out->screenEllipse = r->ellipse;
+    out->tileRange = r->tileRange;
+    out->keys = r->keys[r->selector];
+    out->values = r->values[r->selector];
+    out->splatCount = r->splatCount;
+    out->tileListSize = r->tileListSize;
+}
+
+extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsFrameStats* stats)
+{
+    const Screen scr = makeScreen(r->width, r->height, r->rowBegin, r->rowEnd);
+    GsTimer* timer = timed ? r->timer : nullptr;
+    GsFrameStats st{};
+    const int n = r->splatCount;
+
+    GS_CHECK(hipEventRecord(r->frameStart, g.stream));
+
+    // Clears (Demo.cpp:399,403). Only this GPU's band of the back buffer and of the range table.
+    const size_t rowBytes = (size_t) r->width * 4;
+    const int pixelRowBegin = scr.rowBegin * kTileSize;
+    const int pixelRowEnd = std::min(scr.rowEnd * kTileSize, r->height);
+    if (pixelRowEnd > pixelRowBegin)
+        gs_device_memset(r->backBuffer + rowBytes * pixelRowBegin, 0, rowBytes * (size_t) (pixelRowEnd - pixelRowBegin));
+    gs_device_memset(r->tileRange, 0xFF, sizeof(int32_t) * 2 * (size_t) scr.totalTiles);
+
+    // Demo.cpp:406-430
+    GsGlobalArgs args{};
+    args.cameraData = *camera;
+    args.position = r->position;
+    args.scaleAndRotation = r->scaleAndRotation;
+    args.color = r->color;
+    args.sphericalHarmonicsDegree = r->shDegree;
+    args.sphericalHarmonicsCount = r->shCount;
+    args.sphericalHarmonics = r->sh;
+    args.positionClipSpaceXY = r->clipXY;
+    args.positionClipSpaceZ = r->clipZ;
+    args.conic = r->conic;
+    args.screenEllipse = r->ellipse;
+    args.splatCount = n;
+    args.backBuffer = r->backBuffer;
+    args.tileRange = r->tileRange;
+    args.width = r->width;
+    args.height = r->height;
+    args.tileRowBegin = scr.rowBegin;
+    args.tileRowEnd = scr.rowEnd;
+    gs_set_global_args(&args);
+
+    if (r->shDegree != 0) // Demo.cpp:432
+    {
+        gs_evaluate_spherical_harmonics(timer, n);
+        if (timed) st.msSphericalHarmonics = gs_timer_elapsed_ms(timer);
+    }
+    gs_evaluate_splat_clip_data(timer, n);
+    if (timed) st.msClipData = gs_timer_elapsed_ms(timer);
+
+    // Tile list: count first, grow if the demand exceeds the capacity (instead of rendering a truncated
+    // frame and doubling for the next one, Demo.cpp:357-366,447), then emit.
+    gs_timer_start(timer);
+    launchTileListCount(g.stream, n, scr, (const float2*) r->clipXY, (const float4*) r->ellipse, g.scratch);
+    GS_CHECK(hipStreamSynchronize(g.stream)); // pair count readback, as GaussianRender.cu:793
+    const int64_t demand = *g.scratch.totalHost;
+    g.lastDemand = demand;
+    if (demand > 0x7FFFFFFF)
+    {
+        printf("tile list demand %lld exceeds the int32 list size of the interface\n", (long long) demand);
+        return -2;
+    }
+    if (demand > r->tileListCapacity)
+    {
+        int64_t cap = r->tileListCapacity > 0 ? r->tileListCapacity : 1;
+        while (cap < demand) cap <<= 1; // Demo.cpp:360
+        cap = std::min<int64_t>(cap, 0x7FFFFFFF);
+        allocTileList(r, (int32_t) cap);
+        st.grewTileList = 1;
+    }
+    r->selector = 0;
+    const int32_t size = (int32_t) demand;
+    launchTileListEmit(g.stream, n, scr, (const float2*) r->clipXY, r->clipZ, (const float4*) r->ellipse, g.scratch, r->keys[0],
+                       r->values[0], r->tileListCapacity);
+    gs_timer_stop(timer);
+    if (timed) st.msBuildTileList = gs_timer_elapsed_ms(timer);
+    r->tileListSize = size;
+    st.tileListSize = size;
+    st.tileListCapacity = r->tileListCapacity;
+
+    GsDoubleBufferU64 keys{{r->keys[0], r->keys[1]}, 0};
+    GsDoubleBufferI32 values{{r->values[0], r->values[1]}, 0};
+    gs_sort_tile_list(timer, size, &r->sortTemp, &r->sortTempBytes, &keys, &values); // Demo.cpp:458
+    if (timed) st.msSortTileList = gs_timer_elapsed_ms(timer);
+    r->selector = keys.selector;
+
+    GsTileListArgs tl{keys.buffers[keys.selector], values.buffers[values.selector], size, r->tileListCapacity};
+    gs_set_tile_list_args(&tl); // Demo.cpp:463-466
+
+    if (size != 0) // Demo.cpp:469
+    {
+        gs_evaluate_tile_range(timer, size);
+        if (timed) st.msTileRanges = gs_timer_elapsed_ms(timer);
+    }
+    gs_rasterize_tile(timer);
+    if (timed) st.msRasterize = gs_timer_elapsed_ms(timer);
+
+    GS_CHECK(hipEventRecord(r->frameStop, g.stream));
+    if (stats)
+    {
+        GS_CHECK(hipEventSynchronize(r->frameStop));
+        GS_CHECK(hipEventElapsedTime(&st.msFrame, r->frameStart, r->frameStop));
+        if (g.collectRasterStats) st.consumedPairs = gs_last_raster_consumed_pairs();
+        *stats = st;
+    }
+    return 0;
+}
+
+extern "C" const char* gs_version(void) { return "gsplat_hip 0.1 (gfx950)"; }

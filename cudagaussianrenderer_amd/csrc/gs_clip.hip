@@ -1,0 +1,148 @@
+// gs_clip.hip -- per-splat world -> clip data: centre, depth, 3-sigma screen ellipse, conic.
+//
+// Replaces evaluateSplatClipDataKernel (GaussianRender.cu:204-329).  Pure streaming kernel:
+// 32 B read + 44 B written per splat, one splat per lane with 16-byte coalesced loads/stores.
+// The arithmetic follows the reference's order (covariance = (R S)(R S)^T, para-perspective
+// Jacobian, J W Sigma^T (J W)^T, trace bump, eigen decomposition, conic = Sigma^-1) on plain floats;
+// glm's 3x3 products are written out so the symmetric halves are not recomputed.
+//
+// One deliberate simplification: the reference stores (cos(atan2(e.y,e.x)), sin(atan2(e.y,e.x)))
+// of the NORMALISED principal eigenvector e; that is e itself, which is what is stored here.
+#include "gs_internal.h"
+
+namespace gs
+{
+namespace
+{
+
+struct Sym3
+{
+    float xx, xy, xz, yy, yz, zz;
+};
+
+__global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr, ClipCamera cam, const float4* __restrict__ position,
+                                                            const float4* __restrict__ scaleAndRotation,
+                                                            float2* __restrict__ clipXY, float* __restrict__ clipZ,
+                                                            float4* __restrict__ screenEllipse, float4* __restrict__ conicOut)
+{
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= count) return;
+
+    const float4 pd = position[index];
+    const float4 sr = scaleAndRotation[index];
+
+    // decodeVec4 (GaussianRender.cu:55-58,220-221): four truncated bytes -> [-1,1], x in the top byte;
+    // the quaternion is NOT renormalised.
+    const uint32_t bits = __float_as_uint(sr.w);
+    const float qx = (float) ((bits >> 24) & 0xFFu) / 255.0f * 2.0f - 1.0f;
+    const float qy = (float) ((bits >> 16) & 0xFFu) / 255.0f * 2.0f - 1.0f;
+    const float qz = (float) ((bits >> 8) & 0xFFu) / 255.0f * 2.0f - 1.0f;
+    const float qw = (float) (bits & 0xFFu) / 255.0f * 2.0f - 1.0f;
+
+    // R = mat3_cast(q) (glm/gtc/quaternion.inl:47-72); r{col}{row}
+    const float qxx = qx * qx, qyy = qy * qy, qzz = qz * qz;
+    const float qxz = qx * qz, qxy = qx * qy, qyz = qy * qz;
+    const float qwx = qw * qx, qwy = qw * qy, qwz = qw * qz;
+    const float r00 = 1.0f - 2.0f * (qyy + qzz), r01 = 2.0f * (qxy + qwz), r02 = 2.0f * (qxz - qwy);
+    const float r10 = 2.0f * (qxy - qwz), r11 = 1.0f - 2.0f * (qxx + qzz), r12 = 2.0f * (qyz + qwx);
+    const float r20 = 2.0f * (qxz + qwy), r21 = 2.0f * (qyz - qwx), r22 = 1.0f - 2.0f * (qxx + qyy);
+
+    // RS = R * diag(s): column c scaled by s_c.  Sigma = RS * RS^T (GaussianRender.cu:223-224), symmetric.
+    const float m00 = r00 * sr.x, m01 = r01 * sr.x, m02 = r02 * sr.x;
+    const float m10 = r10 * sr.y, m11 = r11 * sr.y, m12 = r12 * sr.y;
+    const float m20 = r20 * sr.z, m21 = r21 * sr.z, m22 = r22 * sr.z;
+    Sym3 S;
+    S.xx = m00 * m00 + m10 * m10 + m20 * m20;
+    S.xy = m00 * m01 + m10 * m11 + m20 * m21;
+    S.xz = m00 * m02 + m10 * m12 + m20 * m22;
+    S.yy = m01 * m01 + m11 * m11 + m21 * m21;
+    S.yz = m01 * m02 + m11 * m12 + m21 * m22;
+    S.zz = m02 * m02 + m12 * m12 + m22 * m22;
+
+    // View-space centre (GaussianRender.cu:227); v[col*4+row].
+    const float* v = cam.view;
+    const float vx = (v[0] * pd.x + v[4] * pd.y) + (v[8] * pd.z + v[12]);
+    const float vy = (v[1] * pd.x + v[5] * pd.y) + (v[9] * pd.z + v[13]);
+    const float vz = (v[2] * pd.x + v[6] * pd.y) + (v[10] * pd.z + v[14]);
+
+    // Para-perspective Jacobian (GaussianRender.cu:236-259).
+    const float zRcp = 1.0f / vz;
+    const float zRcpSqr = zRcp * zRcp;
+    const float scaleX = -cam.fovCotX * zRcp;
+    const float scaleY = -cam.fovCotY * zRcp;
+    const float cotTrsX = cam.fovCotX * vx;
+    const float cotTrsY = cam.fovCotY * vy;
+    const float shearX = cotTrsX * zRcpSqr;
+    const float shearY = cotTrsY * zRcpSqr;
+
+    // Rows 0 and 1 of VP = mat3(J) * mat3(view) (GaussianRender.cu:262); row 2 never reaches the 2x2 block we need.
+    //   J row0 = (scaleX, 0, shearX), row1 = (0, scaleY, shearY)
+    const float a0 = scaleX * v[0] + shearX * v[2], a1 = scaleX * v[4] + shearX * v[6], a2 = scaleX * v[8] + shearX * v[10];
+    const float b0 = scaleY * v[1] + shearY * v[2], b1 = scaleY * v[5] + shearY * v[6], b2 = scaleY * v[9] + shearY * v[10];
+
+    // Clip covariance 2x2 block = rows(a,b) * Sigma * rows(a,b)^T (GaussianRender.cu:264).
+    const float sa0 = S.xx * a0 + S.xy * a1 + S.xz * a2;
+    const float sa1 = S.xy * a0 + S.yy * a1 + S.yz * a2;
+    const float sa2 = S.xz * a0 + S.yz * a1 + S.zz * a2;
+    const float sb0 = S.xx * b0 + S.xy * b1 + S.xz * b2;
+    const float sb1 = S.xy * b0 + S.yy * b1 + S.yz * b2;
+    const float sb2 = S.xz * b0 + S.yz * b1 + S.zz * b2;
+    float covA = a0 * sa0 + a1 * sa1 + a2 * sa2; // [0][0]
+    const float covB = b0 * sa0 + b1 * sa1 + b2 * sa2; // [1][0]
+    float covC = b0 * sb0 + b1 * sb1 + b2 * sb2; // [1][1]
+
+    // Clip position = J * (view pos, 1) (GaussianRender.cu:265): x = scaleX*vx + shearX*vz + translationX.
+    float clipX = (scaleX * vx + 0.0f * vy) + (shearX * vz + (-cotTrsX * zRcp));
+    float clipY = (0.0f * vx + scaleY * vy) + (shearY * vz + (-cotTrsY * zRcp));
+    float clipDepth = (0.0f * vx + 0.0f * vy) + (cam.depthScale * vz + cam.depthBias);
+
+    // Trace bump (GaussianRender.cu:271-276).
+    covA += scr.traceBump;
+    covC += scr.traceBump;
+
+    // Eigen decomposition (GaussianRender.cu:279-302).
+    const float det = covA * covC - covB * covB;
+    const float mid = 0.5f * (covA + covC);
+    constexpr float epsilon = 1e-12f;
+    const float radius = sqrtf(fmaxf(epsilon, mid * mid - det));
+    const float lambda0 = mid + radius;
+    const float l1 = mid - radius;
+    const float lambda1 = (0.0f < l1) ? l1 : 0.0f; // glm::max(0, x): NaN -> 0
+    const float ex = covB, ey = lambda0 - covA;
+    const float invLen = 1.0f / sqrtf(ex * ex + ey * ey);
+    const float cosA = ex * invLen, sinA = ey * invLen;
+    float extentX = sqrtf(lambda0) * 3.0f;
+    float extentY = sqrtf(lambda1) * 3.0f;
+
+    // Conic (GaussianRender.cu:305-307).
+    const float invDet = 1.0f / fmaxf(epsilon, det);
+
+    // Centre-in-frustum cull (GaussianRender.cu:316-321). step(edge,x) = x < edge ? 0 : 1, so NaN passes, as in glm.
+    const bool inside = !(clipX < -1.0f) && !(1.0f < clipX) && !(clipY < -1.0f) && !(1.0f < clipY) && !(clipDepth < -1.0f) &&
+                        !(1.0f < clipDepth) && !(lambda1 < 0.0f);
+    const float isVisible = inside ? 1.0f : 0.0f;
+    // mix(-128, clip, v) = -128*(1-v) + clip*v ; extent *= v  (kept as arithmetic so inf/NaN propagate as in the reference)
+    clipX = -128.0f * (1.0f - isVisible) + clipX * isVisible;
+    clipY = -128.0f * (1.0f - isVisible) + clipY * isVisible;
+    clipDepth = -128.0f * (1.0f - isVisible) + clipDepth * isVisible;
+    extentX *= isVisible;
+    extentY *= isVisible;
+
+    clipXY[index] = make_float2(clipX, clipY);
+    clipZ[index] = clipDepth;
+    screenEllipse[index] = make_float4(cosA, sinA, extentX, extentY);
+    conicOut[index] = make_float4(covC * invDet, -covB * invDet, covA * invDet, 0.0f);
+}
+
+} // namespace
+
+void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const ClipCamera& cam, const float4* position,
+                         const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic)
+{
+    if (count <= 0) return;
+    const dim3 grid((count + 255) / 256), block(256);
+    hipLaunchKernelGGL(splatClipDataKernel, grid, block, 0, stream, count, scr, cam, position, scaleAndRotation, clipXY, clipZ,
+                       screenEllipse, conic);
+}
+
+} // namespace gs

@@ -1,0 +1,409 @@
+// gs_host.cpp -- host-side parts of the path: PLY ingest, quaternion packing, SH re-layout,
+// default camera, procedural scene.  No GPU code; plain C++17.
+//
+//   gs_parse_ply                    <- parsePly            src/PlyParser.cpp:15-339
+//   gs_encode_vec4                  <- encodeVec4          src/PlyParser.cpp:155-165
+//   gs_realign_spherical_harmonics  <- realignSphericalHarmonics  src/Demo.cpp:160-194
+//   gs_camera_from_bounds           <- CameraControls::setBounds/getView/getProjection
+//                                      src/CameraControls.cpp:79-96,132-146 + CameraData fill src/Demo.cpp:377-392
+//   gs_generate_random_gaussians    <- generateRandomGaussians   src/Demo.cpp:119-143
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "gsplat_hip.h"
+
+namespace
+{
+
+inline float clamp01(float x) { return std::min(std::max(x, 0.0f), 1.0f); }
+
+// ---------------------------------------------------------------------------------------------
+// PLY: the reference reads the body with one 4-byte ifstream::read per value (62 M reads for a 1 M
+// splat file); here the body is read in one block and transposed, with identical results.
+// ---------------------------------------------------------------------------------------------
+struct Header
+{
+    std::vector<std::string> properties;
+    int vertexCount = -1;
+    std::streampos bodyOffset = 0;
+};
+
+Header parseHeader(std::ifstream& in)
+{
+    Header h;
+    std::string line;
+    bool littleEndian = false;
+    int iteration = 0;
+    while (std::getline(in, line))
+    {
+        std::stringstream ss(line);
+        std::string word;
+        if (!(ss >> word)) throw std::invalid_argument("Unexpected empty line.");
+        if (word == "ply") continue; // not counted against the header-length limit, as in the reference
+        if (word == "format")
+        {
+            std::string fmt;
+            littleEndian = static_cast<bool>(ss >> fmt) && fmt == "binary_little_endian";
+        }
+        else if (word == "element")
+        {
+            std::string kind, n;
+            if (!(ss >> kind) || kind != "vertex") throw std::invalid_argument("Unexpected element type.");
+            if (!(ss >> n)) throw std::invalid_argument("Unexpected element count.");
+            h.vertexCount = std::stoi(n);
+        }
+        else if (word == "property")
+        {
+            std::string type, name;
+            if (!(ss >> type) || type != "float") throw std::invalid_argument("Unexpected property format, expected float.");
+            if (!(ss >> name)) throw std::invalid_argument("Unexpected property, missing name.");
+            if (std::find(h.properties.begin(), h.properties.end(), name) != h.properties.end())
+                throw std::invalid_argument("Duplicated property \"" + name + "\".");
+            h.properties.push_back(name);
+        }
+        else if (word == "end_header")
+        {
+            if (!littleEndian || h.vertexCount == -1) throw std::invalid_argument("Invalid header. Format or vertex count not found.");
+            break;
+        }
+        if (++iteration > 256) throw std::invalid_argument("Invalid header. End not found.");
+    }
+    h.bodyOffset = in.tellg();
+    return h;
+}
+
+int findProperty(const std::vector<std::string>& props, const std::string& name)
+{
+    auto it = std::find(props.begin(), props.end(), name);
+    if (it == props.end()) throw std::invalid_argument("Missing property \"" + name + "\".");
+    return (int) (it - props.begin());
+}
+
+float* allocFloats(size_t n) { return static_cast<float*>(std::malloc(std::max<size_t>(n, 1) * sizeof(float))); }
+
+// splitmix64: small, seedable, identical everywhere (the reference uses std::rand through glm).
+struct SplitMix64
+{
+    uint64_t state;
+    uint64_t next()
+    {
+        uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    float uniform() { return (float) (next() >> 40) * (1.0f / 16777216.0f); } // [0,1), 24 bits
+    float uniform(float lo, float hi) { return lo + (hi - lo) * uniform(); }
+};
+
+void fillCamera(const float position[3], const float q[4], int width, int height, GsCameraData* out)
+{
+    // CameraControls.h:35-37
+    const float nearZ = 0.1f, farZ = 100.0f, fov = 60.0f * 0.01745329251994329576923690768489f;
+    const float aspect = (float) width / (float) height;
+    std::memset(out, 0, sizeof(*out));
+
+    // Rotation matrix of the unit quaternion (x,y,z,w), columns c0..c2.
+    const float x = q[0], y = q[1], z = q[2], w = q[3];
+    const float R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y)},
+                           {2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x)},
+                           {2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)}}; // R[col][row]
+    // view = inverse(T * R) = [R^T | -R^T p]  (CameraControls.cpp:79-86)
+    float view[4][4] = {};
+    for (int c = 0; c != 3; ++c)
+        for (int r = 0; r != 3; ++r) view[c][r] = R[r][c];
+    for (int r = 0; r != 3; ++r) view[3][r] = -(R[r][0] * position[0] + R[r][1] * position[1] + R[r][2] * position[2]);
+    view[3][3] = 1.0f;
+
+    // glm::perspective (RH, depth -1..1)
+    const float tanHalf = std::tan(fov / 2.0f);
+    float proj[4][4] = {};
+    proj[0][0] = 1.0f / (aspect * tanHalf);
+    proj[1][1] = 1.0f / tanHalf;
+    proj[2][2] = -(farZ + nearZ) / (farZ - nearZ);
+    proj[2][3] = -1.0f;
+    proj[3][2] = -(2.0f * farZ * nearZ) / (farZ - nearZ);
+
+    for (int c = 0; c != 4; ++c)
+        for (int r = 0; r != 4; ++r)
+        {
+            out->view[c * 4 + r] = view[c][r];
+            out->projection[c * 4 + r] = proj[c][r];
+            float s = 0.0f;
+            for (int k = 0; k != 4; ++k) s += proj[k][r] * view[c][k];
+            out->viewProjection[c * 4 + r] = s;
+        }
+    // Demo.cpp:383-392
+    const float cotY = 1.0f / std::tan(fov * 0.5f);
+    out->fovCotangent[0] = cotY / aspect;
+    out->fovCotangent[1] = cotY;
+    out->depthScaleBias[0] = -2.0f / (farZ - nearZ);
+    out->depthScaleBias[1] = -(farZ + nearZ) / (farZ - nearZ);
+    for (int k = 0; k != 3; ++k) out->position[k] = position[k];
+    out->aspect = aspect;
+}
+
+} // namespace
+
+extern "C" uint32_t gs_encode_vec4(const float v[4])
+{
+    // Truncating (not rounding) 8-bit pack, x in the top byte.
+    uint32_t out = 0;
+    for (int i = 0; i != 4; ++i) out = (out << 8) | (uint32_t) (clamp01(v[i]) * 255.0f);
+    return out;
+}
+
+extern "C" size_t gs_realigned_sh_size(int groupSize, int shCount, int splatCount)
+{
+    const int groups = (splatCount + groupSize - 1) / groupSize;
+    return (size_t) groups * groupSize * shCount;
+}
+
+extern "C" void gs_realign_spherical_harmonics(const float* src, float* dst, int groupSize, int shCount, int splatCount)
+{
+    // [splat][coef] -> [group][coef][lane]; the unused tail of the last group is zero-filled.
+    const size_t total = gs_realigned_sh_size(groupSize, shCount, splatCount);
+    std::fill(dst, dst + total, 0.0f);
+    for (int splat = 0; splat != splatCount; ++splat)
+    {
+        const int group = splat / groupSize, lane = splat % groupSize;
+        const float* s = src + (size_t) splat * shCount;
+        float* d = dst + (size_t) group * groupSize * shCount + lane;
+        for (int i = 0; i != shCount; ++i) d[(size_t) i * groupSize] = s[i];
+    }
+}
+
+extern "C" void gs_camera_from_pose(const float position[3], const float rotationXYZW[4], int width, int height, GsCameraData* out)
+{
+    fillCamera(position, rotationXYZW, width, height, out);
+}
+
+extern "C" void gs_camera_from_bounds(const float bmin[3], const float bmax[3], int width, int height, GsCameraData* out)
+{
+    // CameraControls.cpp:132-146: look at the box centre from the (0,1,1) diagonal at a distance that fits it.
+    const float fov = 60.0f * 0.01745329251994329576923690768489f;
+    float size[3], center[3];
+    for (int k = 0; k != 3; ++k)
+    {
+        size[k] = bmax[k] - bmin[k];
+        center[k] = bmin[k] + size[k] * 0.5f;
+    }
+    const float maxSize = std::max(size[0], std::max(size[1], size[2]));
+    const float half = maxSize * 0.5f;
+    const float invLen = 1.0f / std::sqrt(half * half + half * half);
+    const float offset[3] = {0.0f, half * invLen, half * invLen};
+    const float dist = std::sqrt(2.0f) * maxSize * 0.5f / std::tan(fov * 0.5f);
+    const float position[3] = {center[0] + offset[0] * dist, center[1] + offset[1] * dist, center[2] + offset[2] * dist};
+
+    // quatLookAt(-offset, +Y): camera -Z looks along -offset. Basis columns: right, up, back(= offset).
+    const float back[3] = {offset[0], offset[1], offset[2]};
+    float right[3] = {1.0f * back[2] - back[1] * 0.0f, 0.0f * back[0] - back[2] * 0.0f, 0.0f * back[1] - back[0] * 1.0f}; // cross(up, back)
+    const float rl = 1.0f / std::sqrt(std::max(0.00001f, right[0] * right[0] + right[1] * right[1] + right[2] * right[2]));
+    for (float& v : right) v *= rl;
+    const float up[3] = {back[1] * right[2] - right[1] * back[2], back[2] * right[0] - right[2] * back[0],
+                         back[0] * right[1] - right[0] * back[1]}; // cross(back, right)
+    // rotation matrix -> quaternion (w largest is guaranteed for this pose family, but handle all branches)
+    const float m00 = right[0], m01 = right[1], m02 = right[2];
+    const float m10 = up[0], m11 = up[1], m12 = up[2];
+    const float m20 = back[0], m21 = back[1], m22 = back[2];
+    float q[4];
+    const float trace = m00 + m11 + m22;
+    if (trace > 0.0f)
+    {
+        const float s = std::sqrt(trace + 1.0f) * 2.0f;
+        q[3] = 0.25f * s;
+        q[0] = (m12 - m21) / s;
+        q[1] = (m20 - m02) / s;
+        q[2] = (m01 - m10) / s;
+    }
+    else if (m00 > m11 && m00 > m22)
+    {
+        const float s = std::sqrt(1.0f + m00 - m11 - m22) * 2.0f;
+        q[3] = (m12 - m21) / s;
+        q[0] = 0.25f * s;
+        q[1] = (m01 + m10) / s;
+        q[2] = (m20 + m02) / s;
+    }
+    else if (m11 > m22)
+    {
+        const float s = std::sqrt(1.0f + m11 - m00 - m22) * 2.0f;
+        q[3] = (m20 - m02) / s;
+        q[0] = (m01 + m10) / s;
+        q[1] = 0.25f * s;
+        q[2] = (m12 + m21) / s;
+    }
+    else
+    {
+        const float s = std::sqrt(1.0f + m22 - m00 - m11) * 2.0f;
+        q[3] = (m01 - m10) / s;
+        q[0] = (m20 + m02) / s;
+        q[1] = (m12 + m21) / s;
+        q[2] = 0.25f * s;
+    }
+    fillCamera(position, q, width, height, out);
+}
+
+extern "C" void gs_generate_random_gaussians(int32_t count, uint64_t seed, float minScale, float maxScale, const float minPosition[3],
+                                             const float maxPosition[3], float* position4, float* scaleAndRotation4, float* color4)
+{
+    // Distributions of Demo.cpp:119-143: position ~ U(box), rotation = angleAxis(U[0,pi], uniform axis),
+    // scale ~ U[min,max]^3, colour RGBA ~ U[0,1]^4 (alpha is the opacity used at SH degree 0), position.w = 1.
+    SplitMix64 rng{seed};
+    for (int32_t i = 0; i != count; ++i)
+    {
+        float* p = position4 + 4 * (size_t) i;
+        for (int k = 0; k != 3; ++k) p[k] = rng.uniform(minPosition[k], maxPosition[k]);
+        p[3] = 1.0f;
+        // uniform axis on the sphere: z ~ U[-1,1], phi ~ U[0,2pi)
+        const float z = rng.uniform(-1.0f, 1.0f);
+        const float phi = rng.uniform(0.0f, 6.28318530717958647692f);
+        const float rxy = std::sqrt(std::max(0.0f, 1.0f - z * z));
+        const float axis[3] = {rxy * std::cos(phi), rxy * std::sin(phi), z};
+        const float angle = rng.uniform(0.0f, 3.14159265358979323846f);
+        const float s = std::sin(angle * 0.5f);
+        const float quat[4] = {axis[0] * s, axis[1] * s, axis[2] * s, std::cos(angle * 0.5f)};
+        const float enc[4] = {(quat[0] + 1.0f) * 0.5f, (quat[1] + 1.0f) * 0.5f, (quat[2] + 1.0f) * 0.5f, (quat[3] + 1.0f) * 0.5f};
+        const uint32_t packed = gs_encode_vec4(enc);
+        float* sr = scaleAndRotation4 + 4 * (size_t) i;
+        for (int k = 0; k != 3; ++k) sr[k] = rng.uniform(minScale, maxScale);
+        std::memcpy(&sr[3], &packed, sizeof(float));
+        float* c = color4 + 4 * (size_t) i;
+        for (int k = 0; k != 4; ++k) c[k] = rng.uniform();
+    }
+}
+
+extern "C" int gs_parse_ply(const char* filePath, GsPly* out, char* err, size_t errLen)
+{
+    std::memset(out, 0, sizeof(*out));
+    try
+    {
+        std::ifstream in(filePath, std::ios_base::binary);
+        Header h = parseHeader(in);
+        const size_t n = (size_t) std::max(h.vertexCount, 0);
+        const size_t numProps = h.properties.size();
+
+        // Required attributes (PlyParser.cpp:182-196).
+        static const char* required[14] = {"x", "y", "z", "rot_0", "rot_1", "rot_2", "rot_3", "scale_0", "scale_1", "scale_2",
+                                           "f_dc_0", "f_dc_1", "f_dc_2", "opacity"};
+        int off[14];
+        for (int i = 0; i != 14; ++i) off[i] = findProperty(h.properties, required[i]);
+
+        // Optional f_rest_* and the degree they imply: 9->1, 24->2, 45->3, 72->4 (PlyParser.cpp:204-243).
+        std::vector<int> rest;
+        for (;;)
+        {
+            auto it = std::find(h.properties.begin(), h.properties.end(), "f_rest_" + std::to_string(rest.size()));
+            if (it == h.properties.end()) break;
+            rest.push_back((int) (it - h.properties.begin()));
+        }
+        const int extra = (int) rest.size();
+        int expected = 0, degree = 0;
+        while (expected < extra)
+        {
+            expected += (2 * (degree + 1) + 1) * 3;
+            ++degree;
+        }
+        if (expected != extra)
+            throw std::invalid_argument("Expected degree " + std::to_string(degree) + ", " + std::to_string(expected) +
+                                        " extra spherical harmonics. Found " + std::to_string(extra) + ".");
+        const int shCount = extra + 3;
+
+        // Body: [vertex][property] little-endian floats, read in one block. A short file leaves zeros.
+        std::vector<float> body(n * numProps, 0.0f);
+        in.clear();
+        in.seekg(h.bodyOffset);
+        in.read(reinterpret_cast<char*>(body.data()), (std::streamsize) (body.size() * sizeof(float)));
+
+        out->vertexCount = h.vertexCount;
+        out->sphericalHarmonicsDegree = degree;
+        out->sphericalHarmonicsCount = shCount;
+        out->position = allocFloats(n * 4);
+        out->scaleAndRotation = allocFloats(n * 4);
+        out->color = allocFloats(n * 4);
+        if (degree != 0) out->sphericalHarmonics = allocFloats(n * shCount);
+
+        // boundsMax starts at numeric_limits<float>::min() (smallest positive), a reference quirk kept (PlyParser.cpp:290).
+        float bmin[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
+        float bmax[3] = {std::numeric_limits<float>::min(), std::numeric_limits<float>::min(), std::numeric_limits<float>::min()};
+        const int perChannel = extra / 3;
+        for (size_t i = 0; i != n; ++i)
+        {
+            const float* row = body.data() + i * numProps;
+            float* p = out->position + 4 * i;
+            float* s = out->scaleAndRotation + 4 * i;
+            float* c = out->color + 4 * i;
+
+            // sigmoid, evaluated in double and rounded once (the reference's unqualified exp() is ::exp(double))
+            const float opacity = (float) (1.0 / (1.0 + std::exp(-(double) row[off[13]])));
+            for (int k = 0; k != 3; ++k)
+            {
+                p[k] = row[off[k]];
+                bmin[k] = std::min(bmin[k], p[k]);
+                bmax[k] = std::max(bmax[k], p[k]);
+                s[k] = std::exp(row[off[7 + k]]);
+                c[k] = row[off[10 + k]] * 0.28209479177387814f + 0.5f; // SH band 0 -> rgb, unclamped
+            }
+            p[3] = opacity;
+            c[3] = opacity;
+
+            // rot_0 is w. Normalise, map to [0,1], truncating 8-bit pack in (x,y,z,w) order.
+            float qw = row[off[3]], qx = row[off[4]], qy = row[off[5]], qz = row[off[6]];
+            const float len = std::sqrt((qw * qw + qx * qx) + (qy * qy + qz * qz));
+            if (len <= 0.0f)
+            {
+                qw = 1.0f;
+                qx = qy = qz = 0.0f;
+            }
+            else
+            {
+                const float inv = 1.0f / len;
+                qw *= inv;
+                qx *= inv;
+                qy *= inv;
+                qz *= inv;
+            }
+            const float enc[4] = {(qx + 1.0f) * 0.5f, (qy + 1.0f) * 0.5f, (qz + 1.0f) * 0.5f, (qw + 1.0f) * 0.5f};
+            const uint32_t packed = gs_encode_vec4(enc);
+            std::memcpy(&s[3], &packed, sizeof(float));
+
+            if (degree != 0)
+            {
+                // f_dc (rgb) then f_rest, which the file stores channel-major [c][k] -> [k][c] (PlyParser.cpp:269-286).
+                float* sh = out->sphericalHarmonics + i * (size_t) shCount;
+                for (int k = 0; k != 3; ++k) sh[k] = row[off[10 + k]];
+                for (int j = 0; j != perChannel; ++j)
+                    for (int ch = 0; ch != 3; ++ch) sh[3 + j * 3 + ch] = row[rest[ch * perChannel + j]];
+            }
+        }
+        for (int k = 0; k != 3; ++k)
+        {
+            out->boundsMin[k] = bmin[k];
+            out->boundsMax[k] = bmax[k];
+        }
+        return h.vertexCount;
+    }
+    catch (const std::exception& e)
+    {
+        if (err && errLen) std::snprintf(err, errLen, "%s", e.what());
+        gs_free_ply(out);
+        return -1;
+    }
+}
+
+extern "C" void gs_free_ply(GsPly* ply)
+{
+    std::free(ply->position);
+    std::free(ply->scaleAndRotation);
+    std::free(ply->color);
+    std::free(ply->sphericalHarmonics);
+    ply->position = ply->scaleAndRotation = ply->color = ply->sphericalHarmonics = nullptr;
+}

@@ -1,0 +1,94 @@
+// gs_internal.h -- declarations shared by the HIP translation units of libgsplat_hip.so.
+// Not installed; the public surface is include/gsplat_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#include "gsplat_hip.h"
+
+// src/CudaErrorCheck.cpp:2-11 -- print and exit on a failed runtime call.
+#define GS_CHECK(call)                                                                       \
+    do                                                                                       \
+    {                                                                                        \
+        hipError_t gsErr_ = (call);                                                          \
+        if (gsErr_ != hipSuccess)                                                            \
+        {                                                                                    \
+            printf("HIP error at %s %d: %s\n", __FILE__, __LINE__, hipGetErrorString(gsErr_)); \
+            exit(EXIT_FAILURE);                                                              \
+        }                                                                                    \
+    } while (0)
+
+namespace gs
+{
+
+constexpr int kTileSize = GS_TILE_SIZE;
+constexpr int kWave = 64;        // CDNA wavefront
+constexpr int kRasterChunk = 32; // GaussianRender.cu:439,950,995: termination is voted every 32 list entries
+
+// Everything the reference derives from the compile-time k_ScreenSize (Consts.h:4-8), per frame here.
+// Passed to kernels by value (kernarg segment -> SGPRs) instead of a __constant__ symbol.
+struct Screen
+{
+    int width, height;
+    int tilesX, tilesY, totalTiles;
+    int rowBegin, rowEnd;                   // tile-row band of this GPU
+    float tilesPerScreenX, tilesPerScreenY; // un-rounded W/16, H/16 (GaussianRender.cu:537)
+    float tileClipSizeX, tileClipSizeY;     // GaussianRender.cu:656-657
+    float pixelClipSizeX, pixelClipSizeY;   // GaussianRender.cu:939
+    float traceBump;                        // GaussianRender.cu:271-274
+};
+
+Screen makeScreen(int width, int height, int rowBegin, int rowEnd);
+
+// Camera fields the kernels read (the two projection matrices of CameraData are never used on device).
+struct ClipCamera
+{
+    float view[16];
+    float fovCotX, fovCotY;
+    float depthScale, depthBias;
+};
+
+// ---- launchers (one per stage); all enqueue on `stream` and return without synchronising --------
+void launchSphericalHarmonics(hipStream_t stream, int count, int degree, int shCount, const float4* position, const float* sh,
+                              float3 cameraPosition, float4* color);
+
+void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const ClipCamera& cam, const float4* position,
+                         const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic);
+
+// Scratch of the tile-list builder: per-wave pair counts, their exclusive scan, the total.
+struct TileListScratch
+{
+    int32_t* waveCounts = nullptr;  // [ceil(N/64)]
+    int32_t* waveOffsets = nullptr; // [ceil(N/64)]
+    int64_t* total = nullptr;       // device scalar
+    int64_t* totalHost = nullptr;   // pinned host mirror
+    int32_t capacityWaves = 0;
+};
+void ensureTileListScratch(TileListScratch& s, int count);
+void freeTileListScratch(TileListScratch& s);
+// Pass 1 + scan: leaves the demand (pairs with unlimited capacity) in *s.total (async copy to s.totalHost enqueued).
+void launchTileListCount(hipStream_t stream, int count, const Screen& scr, const float2* clipXY, const float4* screenEllipse,
+                         TileListScratch& s);
+// Pass 2: writes at most `capacity` pairs, in (splat, local tile) order.
+void launchTileListEmit(hipStream_t stream, int count, const Screen& scr, const float2* clipXY, const float* clipZ,
+                        const float4* screenEllipse, const TileListScratch& s, uint64_t* keys, int32_t* values, int capacity);
+
+// rocPRIM radix sort of (uint64 key, int32 value) pairs on bits [0, endBit).
+size_t sortTempBytes(int size, int endBit);
+// Returns the selector (0/1) of the buffer holding the sorted data.
+int launchSortPairs(hipStream_t stream, void* temp, size_t tempBytes, uint64_t* keys0, uint64_t* keys1, int32_t* values0,
+                    int32_t* values1, int selector, int size, int endBit);
+
+void launchTileRanges(hipStream_t stream, int size, const uint64_t* keys, int32_t* tileRange);
+
+void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileRange, const int32_t* values,
+                     const float2* clipXY, const float4* conic, const float4* color, uchar4* backBuffer,
+                     unsigned long long* consumedPairsOrNull);
+
+int sortEndBit(int totalTiles);
+
+} // namespace gs

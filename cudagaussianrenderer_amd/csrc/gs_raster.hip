@@ -1,0 +1,227 @@
+// gs_raster.hip -- 16x16-tile front-to-back alpha compositing.
+//
+// Replaces rasterizeTilesKernel (GaussianRender.cu:908-1016).  Same observable semantics:
+//   alpha = colour.a * saturate(exp(-0.5 * d^T Q d)), C += rgb * T * alpha, T *= 1 - alpha, every list
+//   entry contributes (no alpha cut-off), and a tile stops only when EVERY on-screen pixel has
+//   T <= 0.02, voted after each 32 list entries (the reference's chunk, :950,:995).
+//
+// CDNA4 mapping:
+//   * one workgroup per tile; each lane owns PPL horizontally adjacent pixels (PPL = 4 -> the tile is ONE
+//     64-lane wave, the termination vote is a single __ballot and there is no workgroup barrier cost;
+//     PPL = 1 -> four waves like the reference).  The dy-dependent half of the quadratic form is shared
+//     by a lane's pixels.
+//   * list entries are gathered 64 at a time (one entry per lane, 44 B: value -> centre, conic, colour),
+//     staged in LDS as two float4 + one float per entry with the -0.5*log2(e) factor folded into the
+//     conic, and read back as wave-uniform (broadcast) ds_read_b128;
+//   * the gather of batch b+1 is issued into registers before batch b is blended, so HBM/L2 latency is
+//     covered by the VALU work even with one wave per tile;
+//   * density uses the hardware exp2 (v_exp_f32) -- the reference is built with --use_fast_math/__expf;
+//   * blockIdx -> tile is XCD-aware: the 8 XCDs each take a contiguous run of tiles, so neighbouring
+//     tiles (which share splats) share an L2.
+// The kernel is VALU/transcendental-bound, not HBM-bound: per consumed entry it reads 44 B but does
+// ~11 VALU ops for each of 256 pixels ("Raster roofline").
+#include "gs_internal.h"
+
+namespace gs
+{
+namespace
+{
+
+constexpr int kBatch = 64; // entries staged per LDS fill; two vote chunks
+
+template <int THREADS>
+__device__ __forceinline__ bool anyInBlock(bool pred)
+{
+    if constexpr (THREADS == kWave) return __ballot(pred) != 0ull;
+    else return __syncthreads_or(pred ? 1 : 0) != 0;
+}
+
+__device__ __forceinline__ uint32_t quantize8(float c)
+{
+    // GaussianRender.cu:1007-1011: float -> uchar conversion (truncate, saturate, NaN -> 0).
+    const float v = c * 255.0f;
+    return (uint32_t) fminf(fmaxf(v, 0.0f), 255.0f); // fmaxf(NaN, 0) = 0
+}
+
+template <int PPL>
+__global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, int firstTile, int numTiles,
+                                                                  const int32_t* __restrict__ tileRange,
+                                                                  const int32_t* __restrict__ values,
+                                                                  const float2* __restrict__ clipXY,
+                                                                  const float4* __restrict__ conic,
+                                                                  const float4* __restrict__ color, uchar4* __restrict__ backBuffer,
+                                                                  unsigned long long* __restrict__ consumedPairs)
+{
+    constexpr int THREADS = 256 / PPL;
+    constexpr int GROUPS_X = kTileSize / PPL;
+    __shared__ float4 sA[kBatch];   // cx, cy, A', B'
+    __shared__ float4 sB[kBatch];   // C', r, g, b
+    __shared__ float sAlpha[kBatch];
+
+    // XCD-aware remap (bijective for any grid size): workgroups b, b+8, b+16, ... share an XCD and take
+    // consecutive tiles.
+    int wg = blockIdx.x;
+    {
+        const int nwg = numTiles, q = nwg / 8, r = nwg % 8, xcd = wg % 8, slot = wg / 8;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int tile = firstTile + wg;
+
+    // GaussianRender.cu:917-931 (wave-uniform: scalar loads)
+    int first = tileRange[tile * 2];
+    const int count = tileRange[tile * 2 + 1] - first;
+    if (count == 0) return;
+
+    const int t = threadIdx.x;
+    const int tileX = tile % scr.tilesX, tileY = tile / scr.tilesX;
+    const int px0 = tileX * kTileSize + (t % GROUPS_X) * PPL;
+    const int py = tileY * kTileSize + t / GROUPS_X;
+    // GaussianRender.cu:939 (no half-pixel offset)
+    float clipPx[PPL];
+    bool onScreen[PPL];
+#pragma unroll
+    for (int i = 0; i != PPL; ++i)
+    {
+        clipPx[i] = (float) (px0 + i) * scr.pixelClipSizeX - 1.0f;
+        onScreen[i] = (px0 + i) < scr.width && py < scr.height;
+    }
+    const float clipPy = (float) py * scr.pixelClipSizeY - 1.0f;
+
+    float cr[PPL], cg[PPL], cb[PPL], tr[PPL];
+#pragma unroll
+    for (int i = 0; i != PPL; ++i)
+    {
+        cr[i] = cg[i] = cb[i] = 0.0f;
+        tr[i] = 1.0f;
+    }
+
+    // Register-staged gather of one list entry per lane.
+    float2 gCentre = make_float2(0.f, 0.f);
+    float4 gConic = make_float4(0.f, 0.f, 0.f, 0.f), gColor = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto gather = [&](int base) {
+        if (t < kBatch && base + t < count)
+        {
+            const int src = values[first + base + t]; // GaussianRender.cu:957-960
+            gCentre = clipXY[src];
+            gConic = conic[src];
+            gColor = color[src];
+        }
+    };
+    gather(0);
+
+    constexpr float kHalfLog2e = -0.5f * 1.4426950408889634f; // exp(-q/2) = exp2(q * kHalfLog2e)
+    int base = 0, consumed = 0;
+    for (;;)
+    {
+        const int n = min(count - base, kBatch);
+        __syncthreads(); // every wave is done reading the previous batch
+        if (t < n)
+        {
+            sA[t] = make_float4(gCentre.x, gCentre.y, gConic.x * kHalfLog2e, gConic.y * (2.0f * kHalfLog2e));
+            sB[t] = make_float4(gConic.z * kHalfLog2e, gColor.x, gColor.y, gColor.z);
+            sAlpha[t] = gColor.w;
+        }
+        __syncthreads();
+        if (base + kBatch < count) gather(base + kBatch); // in flight while this batch is blended
+
+        bool stop = false;
+        for (int chunk = 0; chunk < n; chunk += kRasterChunk)
+        {
+            const int m = min(kRasterChunk, n - chunk);
+            for (int i = chunk; i != chunk + m; ++i)
+            {
+                const float4 a = sA[i];
+                const float4 b = sB[i];
+                const float opacity = sAlpha[i];
+                // GaussianRender.cu:972-984
+                const float dy = clipPy - a.y;
+                const float qy = b.x * dy * dy; // C' dy^2
+                const float by = a.w * dy;      // B' dy
+#pragma unroll
+                for (int p = 0; p != PPL; ++p)
+                {
+                    const float dx = clipPx[p] - a.x;
+                    const float power = fmaf(dx, fmaf(a.z, dx, by), qy);
+                    const float density = __saturatef(__builtin_amdgcn_exp2f(power));
+                    const float alpha = opacity * density;
+                    const float w = tr[p] * alpha;
+                    cr[p] = fmaf(b.y, w, cr[p]);
+                    cg[p] = fmaf(b.z, w, cg[p]);
+                    cb[p] = fmaf(b.w, w, cb[p]);
+                    tr[p] = fmaf(-tr[p], alpha, tr[p]);
+                }
+            }
+            consumed = base + chunk + m;
+            // GaussianRender.cu:995: stop when no pixel of the tile has T > 0.02 (off-screen pixels of a
+            // partial edge tile do not vote).
+            bool alive = false;
+#pragma unroll
+            for (int p = 0; p != PPL; ++p) alive |= onScreen[p] && tr[p] > 0.02f;
+            if (!anyInBlock<THREADS>(alive))
+            {
+                stop = true;
+                break;
+            }
+        }
+        base += n;
+        if (stop || base >= count) break;
+    }
+
+    if (consumedPairs != nullptr && t == 0) atomicAdd(consumedPairs, (unsigned long long) consumed);
+
+    // GaussianRender.cu:1007-1015: row 0 of the buffer is clip y = -1.
+    if (py < scr.height)
+    {
+        uchar4* row = backBuffer + (size_t) py * scr.width + px0;
+        if constexpr (PPL == 4)
+        {
+            if (px0 + 3 < scr.width && (scr.width & 3) == 0)
+            {
+                uint4 packed;
+                uint32_t* pk = &packed.x;
+#pragma unroll
+                for (int p = 0; p != 4; ++p)
+                    pk[p] = quantize8(cr[p]) | (quantize8(cg[p]) << 8) | (quantize8(cb[p]) << 16) | 0xFF000000u;
+                *reinterpret_cast<uint4*>(row) = packed;
+                return;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p != PPL; ++p)
+            if (onScreen[p]) row[p] = make_uchar4((unsigned char) quantize8(cr[p]), (unsigned char) quantize8(cg[p]),
+                                                  (unsigned char) quantize8(cb[p]), 255);
+    }
+}
+
+int g_rasterPixelsPerLane = 4;
+
+} // namespace
+
+void setRasterPixelsPerLane(int ppl) { g_rasterPixelsPerLane = (ppl == 1 || ppl == 2 || ppl == 4) ? ppl : 4; }
+int rasterPixelsPerLane() { return g_rasterPixelsPerLane; }
+
+void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileRange, const int32_t* values,
+                     const float2* clipXY, const float4* conic, const float4* color, uchar4* backBuffer,
+                     unsigned long long* consumedPairsOrNull)
+{
+    const int firstTile = scr.rowBegin * scr.tilesX;
+    const int numTiles = (scr.rowEnd - scr.rowBegin) * scr.tilesX;
+    if (numTiles <= 0) return;
+    switch (g_rasterPixelsPerLane)
+    {
+    case 1:
+        hipLaunchKernelGGL(rasterizeTilesKernel<1>, dim3(numTiles), dim3(256), 0, stream, scr, firstTile, numTiles, tileRange, values,
+                           clipXY, conic, color, backBuffer, consumedPairsOrNull);
+        break;
+    case 2:
+        hipLaunchKernelGGL(rasterizeTilesKernel<2>, dim3(numTiles), dim3(128), 0, stream, scr, firstTile, numTiles, tileRange, values,
+                           clipXY, conic, color, backBuffer, consumedPairsOrNull);
+        break;
+    default:
+        hipLaunchKernelGGL(rasterizeTilesKernel<4>, dim3(numTiles), dim3(64), 0, stream, scr, firstTile, numTiles, tileRange, values,
+                           clipXY, conic, color, backBuffer, consumedPairsOrNull);
+        break;
+    }
+}
+
+} // namespace gs

@@ -1,0 +1,223 @@
+/*
+ * gsplat_hip.h -- C ABI of libgsplat_hip.so, the MI355X (gfx950) 3D-Gaussian-splat rasterizer.
+ *
+ * Drop-in boundary for the per-frame pipeline of etienne-p/CUDAGaussianRenderer
+ * (src/GaussianRender.cuh:118-143 + the frame loop src/Demo.cpp:394-479) and its PLY ingest
+ * (src/PlyParser.h:11-21).  Plain pointers and sizes only; every function cites the reference
+ * interface it replaces.  A header-only C++ facade with the reference's own names
+ * (setGlobalArgs, evaluateSplatClipData, DoubleBuffer<T>, DeviceBuffer<T>, ...) is in
+ * GaussianRender.hpp; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions kept from the reference:
+ *   - the caller owns all device memory; the library keeps raw pointers until the next set-args call;
+ *   - not thread-safe (the reference keeps its args in file-scope __constant__ symbols);
+ *   - a failed HIP API call prints "HIP error at <file> <line>: <msg>" and exit(EXIT_FAILURE)
+ *     (src/CudaErrorCheck.cpp:2-11); a failed kernel launch prints "kernel error <stage>" and continues;
+ *   - tileRange must be pre-set to 0xFF and the back buffer zeroed by the caller each frame
+ *     (Demo.cpp:399,403); evaluateTileRange must be skipped when the list is empty (Demo.cpp:469).
+ * Additions (absent in the reference because they are compile-time there): width/height, the
+ * tile-row band used by the multi-GPU split, and the stream the stages are enqueued on.
+ *
+ * Matrices are glm layout: 16 floats, column-major, m[col*4+row].
+ */
+#ifndef GSPLAT_HIP_H
+#define GSPLAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS_TILE_SIZE 16            /* Consts.h:5  k_TileSize                                   */
+#define GS_DEFAULT_SCREEN_SIZE 1024 /* Consts.h:4  k_ScreenSize (used when width/height are 0) */
+#define GS_SH_GROUP_SIZE 256       /* Demo.cpp:294 / GaussianRender.cu:188: SH realign group   */
+
+/* ---- POD argument structs ------------------------------------------------------------------ */
+
+/* GaussianRender.cuh:17-26 CameraData, field for field (224 bytes). */
+typedef struct GsCameraData
+{
+    float viewProjection[16];
+    float projection[16];
+    float view[16];
+    float fovCotangent[2];
+    float depthScaleBias[2];
+    float position[3];
+    float aspect;
+} GsCameraData;
+
+/* GaussianRender.cuh:56-74 GlobalArgs, field for field, then the additions. Device pointers. */
+typedef struct GsGlobalArgs
+{
+    GsCameraData cameraData;
+    float* position;              /* float4[N]  xyz + opacity                                  */
+    float* scaleAndRotation;      /* float4[N]  scale xyz + 8-bit x4 packed quaternion         */
+    float* color;                 /* float4[N]  rgb + opacity                                  */
+    int32_t sphericalHarmonicsDegree;
+    int32_t sphericalHarmonicsCount;
+    float* sphericalHarmonics;    /* float[ceil(N/256)*256*shCount], realigned (Demo.cpp:160-194) */
+    float* positionClipSpaceXY;   /* float2[N]                                                 */
+    float* positionClipSpaceZ;    /* float[N]                                                  */
+    float* conic;                 /* float4[N]                                                 */
+    float* screenEllipse;         /* float4[N]  cos, sin, extent.x, extent.y                   */
+    int32_t splatCount;
+    uint8_t* backBuffer;          /* uchar4[width*height], row 0 = clip y -1                   */
+    int32_t* tileRange;           /* int32[2*tiles]                                            */
+    /* additions */
+    int32_t width;                /* 0 -> 1024                                                 */
+    int32_t height;               /* 0 -> 1024                                                 */
+    int32_t tileRowBegin;         /* multi-GPU band [begin,end) of tile rows; 0,0 -> all rows  */
+    int32_t tileRowEnd;
+} GsGlobalArgs;
+
+/* GaussianRender.cuh:77-83 TileListArgs. */
+typedef struct GsTileListArgs
+{
+    uint64_t* keys;
+    int32_t* values;
+    int32_t size;
+    int32_t capacity;
+} GsTileListArgs;
+
+/* GaussianRender.cuh:87-116 DoubleBuffer<T> as plain structs. */
+typedef struct GsDoubleBufferU64
+{
+    uint64_t* buffers[2];
+    int32_t selector;
+} GsDoubleBufferU64;
+
+typedef struct GsDoubleBufferI32
+{
+    int32_t* buffers[2];
+    int32_t selector;
+} GsDoubleBufferI32;
+
+/* Utilities.h:155-187 CudaTimer: event pair; stop() blocks until the stage has finished. */
+typedef struct GsTimer GsTimer;
+GsTimer* gs_timer_create(void);
+void gs_timer_destroy(GsTimer* timer);
+void gs_timer_start(GsTimer* timer);
+void gs_timer_stop(GsTimer* timer);
+float gs_timer_elapsed_ms(const GsTimer* timer);
+/* Addition: a non-blocking timer only records events; elapsed is read after gs_synchronize(). */
+void gs_timer_set_blocking(GsTimer* timer, int blocking);
+
+/* ---- the eight staged host functions (GaussianRender.cuh:118-143) ---------------------------- */
+
+void gs_set_global_args(const GsGlobalArgs* globalArgs);            /* setGlobalArgs      .cu:45-48   */
+void gs_set_tile_list_args(const GsTileListArgs* tileListArgs);     /* setTileListArgs    .cu:50-53   */
+void gs_evaluate_spherical_harmonics(GsTimer* timer, int32_t count); /* .cu:184-201                    */
+void gs_evaluate_splat_clip_data(GsTimer* timer, int32_t count);    /* .cu:331-348                    */
+/* buildTileList .cu:776-802: returns min(pairs emitted, capacity). numBlocks is accepted for
+ * signature compatibility and ignored (the grid is sized from the splat count). */
+int32_t gs_build_tile_list(GsTimer* timer, int32_t numBlocks, int32_t tileListCapacity);
+/* Addition: pairs the last gs_build_tile_list would have emitted with unlimited capacity. */
+int64_t gs_last_tile_list_demand(void);
+/* sortTileList .cu:806-855: rocPRIM radix sort on key bits [0, 32+ceil(log2(tiles))). May free and
+ * re-allocate *deviceTempStorage (hipFree/hipMalloc), as the reference does with cudaFree/cudaMalloc. */
+void gs_sort_tile_list(GsTimer* timer, int32_t tileListSize, void** deviceTempStorage, size_t* tempStorageSizeInBytes,
+                       GsDoubleBufferU64* keys, GsDoubleBufferI32* values);
+void gs_evaluate_tile_range(GsTimer* timer, int32_t tileListSize);  /* .cu:891-906                    */
+void gs_rasterize_tile(GsTimer* timer);                             /* .cu:1019-1034                  */
+/* Addition: number of list entries the last gs_rasterize_tile loaded before tile-wide termination
+ * (P_c of DESIGN.md); collected only when enabled, costs one atomic per tile. */
+void gs_set_collect_raster_stats(int enabled);
+int64_t gs_last_raster_consumed_pairs(void);
+/* Addition (tuning): pixels per lane of the raster kernel, 1, 2 or 4 (default 4 = one wave per tile). */
+void gs_set_raster_pixels_per_lane(int pixelsPerLane);
+int gs_get_raster_pixels_per_lane(void);
+
+/* ---- stream / device (additions) ------------------------------------------------------------- */
+void gs_set_device(int device);
+void gs_set_stream(void* hipStream); /* NULL = the null stream, as the reference */
+void* gs_get_stream(void);
+void gs_synchronize(void);           /* Demo.cpp:478 cudaDeviceSynchronize -> stream synchronize */
+int gs_device_info(char* name, size_t nameLen, int* computeUnits, size_t* totalMemBytes);
+
+/* ---- DeviceBuffer<T> (DeviceBuffer.cu:8-127) -------------------------------------------------- */
+void* gs_device_alloc(size_t bytes);
+void gs_device_free(void* ptr);
+void gs_device_upload(void* dst, const void* srcHost, size_t bytes);
+void gs_device_download(void* dstHost, const void* src, size_t bytes);
+void gs_device_memset(void* ptr, int value, size_t bytes); /* enqueued on the current stream */
+
+/* ---- host-side helpers of the path -------------------------------------------------------------- */
+uint32_t gs_encode_vec4(const float v[4]);                        /* PlyParser.cpp:155-165 */
+int gs_sort_end_bit(int width, int height);                       /* .cu:818-819 generalised */
+void gs_tile_counts(int width, int height, int* tilesX, int* tilesY);
+size_t gs_realigned_sh_size(int groupSize, int shCount, int splatCount);
+void gs_realign_spherical_harmonics(const float* src, float* dst, int groupSize, int shCount, int splatCount); /* Demo.cpp:160-194 */
+/* CameraControls.cpp:132-146 default pose + Demo.cpp:377-392 CameraData fill (near .1, far 100, fov 60 deg). */
+void gs_camera_from_bounds(const float boundsMin[3], const float boundsMax[3], int width, int height, GsCameraData* out);
+void gs_camera_from_pose(const float position[3], const float rotationXYZW[4], int width, int height, GsCameraData* out);
+/* Demo.cpp:119-143 generateRandomGaussians with a seeded PRNG (splitmix64) instead of std::rand. */
+void gs_generate_random_gaussians(int32_t count, uint64_t seed, float minScale, float maxScale, const float minPosition[3],
+                                  const float maxPosition[3], float* position4, float* scaleAndRotation4, float* color4);
+
+/* ---- PLY ingest (PlyParser.h:13-21 parsePly) ------------------------------------------------- */
+typedef struct GsPly
+{
+    int32_t vertexCount;
+    int32_t sphericalHarmonicsDegree;
+    int32_t sphericalHarmonicsCount;
+    float boundsMin[3];
+    float boundsMax[3];
+    float* position;            /* host, float4[N] */
+    float* scaleAndRotation;    /* host, float4[N] */
+    float* color;               /* host, float4[N] */
+    float* sphericalHarmonics;  /* host, [N][shCount] (not realigned), NULL at degree 0 */
+} GsPly;
+/* Returns the vertex count, or -1 and the reference's std::invalid_argument text in err. */
+int gs_parse_ply(const char* filePath, GsPly* out, char* err, size_t errLen);
+void gs_free_ply(GsPly* ply);
+
+/* ---- one-call renderer: the frame loop body Demo.cpp:352-479 as render(splats, camera) ------- */
+typedef struct GsRenderer GsRenderer;
+
+typedef struct GsFrameStats
+{
+    float msSphericalHarmonics, msClipData, msBuildTileList, msSortTileList, msTileRanges, msRasterize; /* Demo.cpp:149-157 */
+    float msFrame;            /* first enqueue -> last kernel done, GPU time */
+    int64_t tileListSize;     /* P   */
+    int64_t consumedPairs;    /* P_c (only with gs_set_collect_raster_stats) */
+    int32_t tileListCapacity;
+    int32_t grewTileList;     /* 1 when the list buffers were re-allocated this frame */
+} GsFrameStats;
+
+GsRenderer* gs_renderer_create(int width, int height);
+void gs_renderer_destroy(GsRenderer* r);
+/* Multi-GPU: this renderer only builds/sorts/rasterises tile rows [begin,end). 0,0 = all. */
+void gs_renderer_set_tile_rows(GsRenderer* r, int tileRowBegin, int tileRowEnd);
+/* Upload a scene from host arrays (Demo.cpp:314-331). sh is [N][shCount] un-aligned (as parsePly
+ * returns it) and is realigned here (Demo.cpp:291-296); may be NULL at degree 0. */
+int gs_renderer_set_scene(GsRenderer* r, int32_t splatCount, const float* position4, const float* scaleAndRotation4,
+                          const float* color4, const float* sh, int shDegree, int shCount);
+/* Render one frame into the renderer's device back buffer. per-stage timings are filled only when
+ * timed != 0 (that mode blocks after every stage like the reference's CudaTimer). */
+int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsFrameStats* statsOrNull);
+/* Device pointer of the uchar4 back buffer (width*height*4 bytes), valid until destroy. */
+uint8_t* gs_renderer_back_buffer(GsRenderer* r);
+/* Render into a caller-provided device buffer instead (e.g. a mapped interop buffer, Demo.cpp:396). */
+void gs_renderer_set_back_buffer(GsRenderer* r, uint8_t* deviceBackBufferOrNull);
+/* Copy the back buffer to host (blocking). */
+void gs_renderer_read_back_buffer(GsRenderer* r, uint8_t* hostRgba);
+/* Device pointers of the per-splat intermediates, for tests/inspection. */
+typedef struct GsRendererBuffers
+{
+    float *position, *scaleAndRotation, *color, *sphericalHarmonics;
+    float *positionClipSpaceXY, *positionClipSpaceZ, *conic, *screenEllipse;
+    int32_t* tileRange;
+    uint64_t* keys;
+    int32_t* values;
+    int32_t splatCount, tileListSize;
+} GsRendererBuffers;
+void gs_renderer_buffers(GsRenderer* r, GsRendererBuffers* out);
+
+const char* gs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
