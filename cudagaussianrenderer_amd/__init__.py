@@ -268,11 +268,19 @@ class Renderer:
         lib().gs_renderer_set_back_buffer(self.handle, device_ptr)
 
     def render(self, camera, timed=False, stats=False):
-        st = FrameStats() if (stats or timed) else None
-        rc = lib().gs_renderer_render(self.handle, C.byref(camera), 1 if timed else 0, C.byref(st) if st is not None else None)
+        """timed: False/0 none, True/1 blocking per-stage timers (reference style), 2 non-blocking stage events."""
+        mode = int(timed)
+        st = FrameStats() if (stats or mode == 1) else None
+        rc = lib().gs_renderer_render(self.handle, C.byref(camera), mode, C.byref(st) if st is not None else None)
         if rc != 0:
             raise RuntimeError(f"gs_renderer_render failed ({rc})")
         return st
+
+    def collect_stage_times(self):
+        """(frames, FrameStats of sums) over the frames rendered with timed=2 since the last call."""
+        st = FrameStats()
+        frames = lib().gs_renderer_collect_stage_times(self.handle, C.byref(st))
+        return frames, st
 
     def read_image(self):
         img = np.empty((self.height, self.width, 4), np.uint8)

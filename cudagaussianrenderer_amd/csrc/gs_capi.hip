@@ -304,6 +304,11 @@ struct GsRenderer
     size_t sortTempBytes = 0;
     GsTimer* timer = nullptr;
     hipEvent_t frameStart = nullptr, frameStop = nullptr;
+    // timed == 2: non-blocking per-stage event pairs, six per frame, read by gs_renderer_collect_stage_times
+    std::vector<GsTimer*> asyncTimers;
+    size_t asyncUsed = 0;
+    int64_t asyncPairs = 0, asyncConsumed = 0;
+    int asyncFrames = 0;
 };
 
 namespace
@@ -364,6 +369,7 @@ extern "C" void gs_renderer_destroy(GsRenderer* r)
     gs_device_free(r->backBufferOwned);
     gs_device_free(r->sortTemp);
     gs_timer_destroy(r->timer);
+    for (GsTimer* t : r->asyncTimers) gs_timer_destroy(t);
     (void) hipEventDestroy(r->frameStart);
     (void) hipEventDestroy(r->frameStop);
     delete r;
@@ -437,7 +443,31 @@ extern "C" void gs_renderer_buffers(GsRenderer* r, GsRendererBuffers* out)
 extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsFrameStats* stats)
 {
     const Screen scr = makeScreen(r->width, r->height, r->rowBegin, r->rowEnd);
-    GsTimer* timer = timed ? r->timer : nullptr;
+    // timed: 0 = no stage timers; 1 = the reference's blocking timer after every stage; 2 = one non-blocking
+    // event pair per stage, accumulated and read later with gs_renderer_collect_stage_times.
+    GsTimer* stageTimers[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (timed == 1)
+        for (GsTimer*& t : stageTimers) t = r->timer;
+    else if (timed == 2)
+    {
+        while (r->asyncTimers.size() < r->asyncUsed + 6)
+        {
+            GsTimer* t = gs_timer_create();
+            gs_timer_set_blocking(t, 0);
+            r->asyncTimers.push_back(t);
+        }
+        for (int i = 0; i != 6; ++i) stageTimers[i] = r->asyncTimers[r->asyncUsed + i];
+        // stages that do not run this frame must still hold a valid (zero-length) interval
+        for (int i = 0; i != 6; ++i)
+        {
+            gs_timer_start(stageTimers[i]);
+            gs_timer_stop(stageTimers[i]);
+        }
+        r->asyncUsed += 6;
+        r->asyncFrames += 1;
+    }
+    timed = (timed == 1) ? 1 : 0;
+    GsTimer* timer = nullptr;
     GsFrameStats st{};
     const int n = r->splatCount;
 
@@ -475,14 +505,17 @@ extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int
 
     if (r->shDegree != 0) // Demo.cpp:432
     {
+        timer = stageTimers[0];
         gs_evaluate_spherical_harmonics(timer, n);
         if (timed) st.msSphericalHarmonics = gs_timer_elapsed_ms(timer);
     }
+    timer = stageTimers[1];
     gs_evaluate_splat_clip_data(timer, n);
     if (timed) st.msClipData = gs_timer_elapsed_ms(timer);
 
     // Tile list: count first, grow if the demand exceeds the capacity (instead of rendering a truncated
     // frame and doubling for the next one, Demo.cpp:357-366,447), then emit.
+    timer = stageTimers[2];
     gs_timer_start(timer);
     launchTileListCount(g.stream, n, scr, (const float2*) r->clipXY, (const float4*) r->ellipse, g.scratch);
     GS_CHECK(hipStreamSynchronize(g.stream)); // pair count readback, as GaussianRender.cu:793
@@ -513,6 +546,7 @@ extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int
 
     GsDoubleBufferU64 keys{{r->keys[0], r->keys[1]}, 0};
     GsDoubleBufferI32 values{{r->values[0], r->values[1]}, 0};
+    timer = stageTimers[3];
     gs_sort_tile_list(timer, size, &r->sortTemp, &r->sortTempBytes, &keys, &values); // Demo.cpp:458
     if (timed) st.msSortTileList = gs_timer_elapsed_ms(timer);
     r->selector = keys.selector;
@@ -522,13 +556,16 @@ extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int
 
     if (size != 0) // Demo.cpp:469
     {
+        timer = stageTimers[4];
         gs_evaluate_tile_range(timer, size);
         if (timed) st.msTileRanges = gs_timer_elapsed_ms(timer);
     }
+    timer = stageTimers[5];
     gs_rasterize_tile(timer);
     if (timed) st.msRasterize = gs_timer_elapsed_ms(timer);
 
     GS_CHECK(hipEventRecord(r->frameStop, g.stream));
+    r->asyncPairs += (r->asyncFrames > 0) ? size : 0;
     if (stats)
     {
         GS_CHECK(hipEventSynchronize(r->frameStop));
@@ -537,6 +574,22 @@ extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int
         *stats = st;
     }
     return 0;
+}
+
+extern "C" int gs_renderer_collect_stage_times(GsRenderer* r, GsFrameStats* sums)
+{
+    // Sums over the frames rendered with timed == 2 since the last call; resets the accumulation.
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    GsFrameStats s{};
+    float* slots[6] = {&s.msSphericalHarmonics, &s.msClipData, &s.msBuildTileList, &s.msSortTileList, &s.msTileRanges, &s.msRasterize};
+    for (size_t i = 0; i != r->asyncUsed; ++i) *slots[i % 6] += gs_timer_elapsed_ms(r->asyncTimers[i]);
+    s.tileListSize = r->asyncPairs;
+    const int frames = r->asyncFrames;
+    r->asyncUsed = 0;
+    r->asyncFrames = 0;
+    r->asyncPairs = 0;
+    if (sums) *sums = s;
+    return frames;
 }
 
 extern "C" const char* gs_version(void) { return "gsplat_hip 0.1 (gfx950)"; }

@@ -194,9 +194,15 @@ void gs_renderer_set_tile_rows(GsRenderer* r, int tileRowBegin, int tileRowEnd);
  * returns it) and is realigned here (Demo.cpp:291-296); may be NULL at degree 0. */
 int gs_renderer_set_scene(GsRenderer* r, int32_t splatCount, const float* position4, const float* scaleAndRotation4,
                           const float* color4, const float* sh, int shDegree, int shCount);
-/* Render one frame into the renderer's device back buffer. per-stage timings are filled only when
- * timed != 0 (that mode blocks after every stage like the reference's CudaTimer). */
+/* Render one frame into the renderer's device back buffer.
+ *   timed == 0: no stage timers (throughput mode);
+ *   timed == 1: per-stage timings in *stats, blocking after every stage like the reference's CudaTimer;
+ *   timed == 2: one non-blocking event pair per stage on the stream; read the sums later with
+ *               gs_renderer_collect_stage_times (the frames are not slowed by host waits). */
 int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsFrameStats* statsOrNull);
+/* Sums of the per-stage times (ms) and of the list sizes over the timed==2 frames since the last call.
+ * Returns the number of frames summed. */
+int gs_renderer_collect_stage_times(GsRenderer* r, GsFrameStats* sums);
 /* Device pointer of the uchar4 back buffer (width*height*4 bytes), valid until destroy. */
 uint8_t* gs_renderer_back_buffer(GsRenderer* r);
 /* Render into a caller-provided device buffer instead (e.g. a mapped interop buffer, Demo.cpp:396). */
