@@ -14,6 +14,8 @@ from ._capi import CameraData, FrameStats, GlobalArgs, GsplatLibraryMissing, Til
 
 TILE_SIZE = 16
 SH_GROUP_SIZE = 256
+PIPELINE_REFERENCE = 0  # the reference's stage order: one 64-bit tile|depth radix sort of all pairs
+PIPELINE_TWO_LEVEL = 1  # default: depth-sort the splats, emit, stable-sort the pairs on the tile bits
 
 
 def lib():
@@ -248,11 +250,13 @@ def parse_ply(path):
 class Renderer:
     """The frame loop body of src/Demo.cpp:352-479 behind one call."""
 
-    def __init__(self, width, height, tile_rows=None):
+    def __init__(self, width, height, tile_rows=None, pipeline=None):
         self.width, self.height = width, height
         self.handle = lib().gs_renderer_create(width, height)
         if tile_rows is not None:
             lib().gs_renderer_set_tile_rows(self.handle, tile_rows[0], tile_rows[1])
+        if pipeline is not None:
+            lib().gs_renderer_set_pipeline(self.handle, pipeline)
         self.splat_count = 0
 
     def set_scene(self, position, scale_and_rotation, color, sh=None, sh_degree=0, sh_count=0):

@@ -200,7 +200,7 @@ extern "C" void gs_evaluate_splat_clip_data(GsTimer* timer, int32_t count)
     gs_timer_start(timer);
     launchSplatClipData(g.stream, count, currentScreen(), currentCamera(), (const float4*) g.global.position,
                         (const float4*) g.global.scaleAndRotation, (float2*) g.global.positionClipSpaceXY,
-                        g.global.positionClipSpaceZ, (float4*) g.global.screenEllipse, (float4*) g.global.conic);
+                        g.global.positionClipSpaceZ, (float4*) g.global.screenEllipse, (float4*) g.global.conic, nullptr, nullptr);
     gs_timer_stop(timer);
     reportLaunch("evaluateSplatsClipData");
 }
@@ -231,7 +231,7 @@ extern "C" void gs_sort_tile_list(GsTimer* timer, int32_t size, void** deviceTem
     if (size > 0)
     {
         const int endBit = sortEndBit(currentScreen().totalTiles);
-        const size_t required = sortTempBytes(size, endBit);
+        const size_t required = sortTempBytes(8, size, 0, endBit);
         if (required > *tempStorageSizeInBytes) // GaussianRender.cu:831-839
         {
             if (*deviceTempStorage != nullptr) GS_CHECK(hipFree(*deviceTempStorage));
@@ -239,8 +239,8 @@ extern "C" void gs_sort_tile_list(GsTimer* timer, int32_t size, void** deviceTem
             *tempStorageSizeInBytes = required;
         }
         // Keys and values may start on different selectors only if the caller mixed them up; follow keys.
-        const int sel = launchSortPairs(g.stream, *deviceTempStorage, *tempStorageSizeInBytes, keys->buffers[0], keys->buffers[1],
-                                        values->buffers[0], values->buffers[1], keys->selector, size, endBit);
+        const int sel = launchSortPairs(g.stream, *deviceTempStorage, *tempStorageSizeInBytes, 8, keys->buffers[0], keys->buffers[1],
+                                        values->buffers[0], values->buffers[1], keys->selector, size, 0, endBit);
         keys->selector = sel;
         values->selector = sel;
     }
@@ -251,7 +251,7 @@ extern "C" void gs_sort_tile_list(GsTimer* timer, int32_t size, void** deviceTem
 extern "C" void gs_evaluate_tile_range(GsTimer* timer, int32_t size)
 {
     gs_timer_start(timer);
-    launchTileRanges(g.stream, size, g.tileList.keys, g.global.tileRange);
+    launchTileRanges(g.stream, size, 8, g.tileList.keys, g.global.tileRange);
     gs_timer_stop(timer);
     reportLaunch("evaluateTileRanges");
 }
@@ -286,33 +286,48 @@ extern "C" void gs_rasterize_tile(GsTimer* timer)
 }
 
 // ---- one-call renderer (Demo.cpp:314-331 buffers, :352-479 frame) ---------------------------------
+//
+// Two pipelines produce the same frame:
+//   GS_PIPELINE_REFERENCE  the reference's stage order through the eight staged calls above: pairs keyed by
+//                          (tile << 32 | depth), one 64-bit radix sort over all pairs (44-47 key bits);
+//   GS_PIPELINE_TWO_LEVEL  (default) sort the SPLATS by the 32-bit depth key first (N elements), emit the
+//                          pairs in that order keyed by the tile index only, then one stable sort on the
+//                          13-15 tile bits.  The resulting value list is identical (same total order, ties by
+//                          splat index) while the radix-sort traffic drops from ~152 B to ~30 B per pair.
 struct GsRenderer
 {
     int width = 0, height = 0, rowBegin = 0, rowEnd = 0;
+    int pipeline = GS_PIPELINE_TWO_LEVEL;
     int32_t splatCount = 0, shDegree = 0, shCount = 0;
     float *position = nullptr, *scaleAndRotation = nullptr, *color = nullptr, *sh = nullptr;
     float *clipXY = nullptr, *clipZ = nullptr, *conic = nullptr, *ellipse = nullptr;
+    uint32_t* depthKey[2] = {nullptr, nullptr};
+    int32_t* order[2] = {nullptr, nullptr};
     int32_t* tileRange = nullptr;
     uint8_t* backBufferOwned = nullptr;
     uint8_t* backBuffer = nullptr;
     int32_t tileListCapacity = 0;
-    uint64_t* keys[2] = {nullptr, nullptr};
+    uint64_t* keys[2] = {nullptr, nullptr}; // 64-bit keys, or 16/32-bit tile indices in the same storage
     int32_t* values[2] = {nullptr, nullptr};
     int selector = 0;
+    int keyBytes = 8;
     int32_t tileListSize = 0;
     void* sortTemp = nullptr;
     size_t sortTempBytes = 0;
     GsTimer* timer = nullptr;
-    hipEvent_t frameStart = nullptr, frameStop = nullptr;
-    // timed == 2: non-blocking per-stage event pairs, six per frame, read by gs_renderer_collect_stage_times
+    hipEvent_t frameStart = nullptr, frameStop = nullptr, countReady = nullptr;
+    // timed == 2: non-blocking per-stage event pairs, kStageTimers per frame, read by gs_renderer_collect_stage_times
     std::vector<GsTimer*> asyncTimers;
     size_t asyncUsed = 0;
-    int64_t asyncPairs = 0, asyncConsumed = 0;
+    int64_t asyncPairs = 0;
     int asyncFrames = 0;
 };
 
 namespace
 {
+// sh, clip, tile list, pair sort, ranges, raster, depth sort (added to the sort total)
+constexpr int kStageTimers = 7;
+
 void freeTileList(GsRenderer* r)
 {
     for (int i = 0; i != 2; ++i)
@@ -341,6 +356,31 @@ void freeScene(GsRenderer* r)
         gs_device_free(*b);
         *b = nullptr;
     }
+    for (int i = 0; i != 2; ++i)
+    {
+        gs_device_free(r->depthKey[i]);
+        gs_device_free(r->order[i]);
+        r->depthKey[i] = nullptr;
+        r->order[i] = nullptr;
+    }
+}
+void ensureSortTemp(GsRenderer* r, size_t required)
+{
+    if (required > r->sortTempBytes)
+    {
+        gs_device_free(r->sortTemp);
+        r->sortTemp = gs_device_alloc(required);
+        r->sortTempBytes = required;
+    }
+}
+bool growTileListIfNeeded(GsRenderer* r, int64_t demand)
+{
+    if (demand <= r->tileListCapacity) return false;
+    int64_t cap = r->tileListCapacity > 0 ? r->tileListCapacity : 1;
+    while (cap < demand) cap <<= 1; // Demo.cpp:360
+    cap = std::min<int64_t>(cap, 0x7FFFFFFF);
+    allocTileList(r, (int32_t) cap);
+    return true;
 }
 } // namespace
 
@@ -356,6 +396,7 @@ extern "C" GsRenderer* gs_renderer_create(int width, int height)
     r->timer = gs_timer_create();
     GS_CHECK(hipEventCreate(&r->frameStart));
     GS_CHECK(hipEventCreate(&r->frameStop));
+    GS_CHECK(hipEventCreateWithFlags(&r->countReady, hipEventDisableTiming));
     return r;
 }
 
@@ -372,6 +413,7 @@ extern "C" void gs_renderer_destroy(GsRenderer* r)
     for (GsTimer* t : r->asyncTimers) gs_timer_destroy(t);
     (void) hipEventDestroy(r->frameStart);
     (void) hipEventDestroy(r->frameStop);
+    (void) hipEventDestroy(r->countReady);
     delete r;
 }
 
@@ -379,6 +421,11 @@ extern "C" void gs_renderer_set_tile_rows(GsRenderer* r, int begin, int end)
 {
     r->rowBegin = begin;
     r->rowEnd = end;
+}
+
+extern "C" void gs_renderer_set_pipeline(GsRenderer* r, int pipeline)
+{
+    r->pipeline = (pipeline == GS_PIPELINE_REFERENCE) ? GS_PIPELINE_REFERENCE : GS_PIPELINE_TWO_LEVEL;
 }
 
 extern "C" int gs_renderer_set_scene(GsRenderer* r, int32_t n, const float* position4, const float* scaleAndRotation4,
@@ -398,6 +445,11 @@ extern "C" int gs_renderer_set_scene(GsRenderer* r, int32_t n, const float* posi
     r->ellipse = (float*) gs_device_alloc(f4);
     r->clipXY = (float*) gs_device_alloc(sizeof(float) * 2 * (size_t) n);
     r->clipZ = (float*) gs_device_alloc(sizeof(float) * (size_t) n);
+    for (int i = 0; i != 2; ++i)
+    {
+        r->depthKey[i] = (uint32_t*) gs_device_alloc(sizeof(uint32_t) * (size_t) n);
+        r->order[i] = (int32_t*) gs_device_alloc(sizeof(int32_t) * (size_t) n);
+    }
     gs_device_upload(r->position, position4, f4);
     gs_device_upload(r->scaleAndRotation, scaleAndRotation4, f4);
     gs_device_upload(r->color, color4, f4);
@@ -438,6 +490,7 @@ extern "C" void gs_renderer_buffers(GsRenderer* r, GsRendererBuffers* out)
     out->values = r->values[r->selector];
     out->splatCount = r->splatCount;
     out->tileListSize = r->tileListSize;
+    out->keyBytes = r->keyBytes;
 }
 
 extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsFrameStats* stats)
@@ -445,35 +498,35 @@ extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int
     const Screen scr = makeScreen(r->width, r->height, r->rowBegin, r->rowEnd);
     // timed: 0 = no stage timers; 1 = the reference's blocking timer after every stage; 2 = one non-blocking
     // event pair per stage, accumulated and read later with gs_renderer_collect_stage_times.
-    GsTimer* stageTimers[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    GsTimer* stageTimers[kStageTimers] = {};
     if (timed == 1)
         for (GsTimer*& t : stageTimers) t = r->timer;
     else if (timed == 2)
     {
-        while (r->asyncTimers.size() < r->asyncUsed + 6)
+        while (r->asyncTimers.size() < r->asyncUsed + kStageTimers)
         {
             GsTimer* t = gs_timer_create();
             gs_timer_set_blocking(t, 0);
             r->asyncTimers.push_back(t);
         }
-        for (int i = 0; i != 6; ++i) stageTimers[i] = r->asyncTimers[r->asyncUsed + i];
+        for (int i = 0; i != kStageTimers; ++i) stageTimers[i] = r->asyncTimers[r->asyncUsed + i];
         // stages that do not run this frame must still hold a valid (zero-length) interval
-        for (int i = 0; i != 6; ++i)
+        for (int i = 0; i != kStageTimers; ++i)
         {
             gs_timer_start(stageTimers[i]);
             gs_timer_stop(stageTimers[i]);
         }
-        r->asyncUsed += 6;
+        r->asyncUsed += kStageTimers;
         r->asyncFrames += 1;
     }
-    timed = (timed == 1) ? 1 : 0;
-    GsTimer* timer = nullptr;
+    const bool blocking = timed == 1;
     GsFrameStats st{};
     const int n = r->splatCount;
+    const bool twoLevel = r->pipeline == GS_PIPELINE_TWO_LEVEL;
 
     GS_CHECK(hipEventRecord(r->frameStart, g.stream));
 
-    // Clears (Demo.cpp:399,403). Only this GPU's band of the back buffer and of the range table.
+    // Clears (Demo.cpp:399,403). Only this GPU's band of the back buffer; the whole range table.
     const size_t rowBytes = (size_t) r->width * 4;
     const int pixelRowBegin = scr.rowBegin * kTileSize;
     const int pixelRowEnd = std::min(scr.rowEnd * kTileSize, r->height);
@@ -505,64 +558,121 @@ extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int
 
     if (r->shDegree != 0) // Demo.cpp:432
     {
-        timer = stageTimers[0];
-        gs_evaluate_spherical_harmonics(timer, n);
-        if (timed) st.msSphericalHarmonics = gs_timer_elapsed_ms(timer);
+        gs_evaluate_spherical_harmonics(stageTimers[0], n);
+        if (blocking) st.msSphericalHarmonics = gs_timer_elapsed_ms(stageTimers[0]);
     }
-    timer = stageTimers[1];
-    gs_evaluate_splat_clip_data(timer, n);
-    if (timed) st.msClipData = gs_timer_elapsed_ms(timer);
 
-    // Tile list: count first, grow if the demand exceeds the capacity (instead of rendering a truncated
-    // frame and doubling for the next one, Demo.cpp:357-366,447), then emit.
-    timer = stageTimers[2];
-    gs_timer_start(timer);
-    launchTileListCount(g.stream, n, scr, (const float2*) r->clipXY, (const float4*) r->ellipse, g.scratch);
-    GS_CHECK(hipStreamSynchronize(g.stream)); // pair count readback, as GaussianRender.cu:793
-    const int64_t demand = *g.scratch.totalHost;
-    g.lastDemand = demand;
-    if (demand > 0x7FFFFFFF)
+    int32_t size = 0;
+    if (!twoLevel)
     {
-        printf("tile list demand %lld exceeds the int32 list size of the interface\n", (long long) demand);
-        return -2;
+        // ---- the reference's stage order, through the staged calls ---------------------------------
+        gs_evaluate_splat_clip_data(stageTimers[1], n);
+        if (blocking) st.msClipData = gs_timer_elapsed_ms(stageTimers[1]);
+
+        // Count first and grow if needed, instead of rendering a truncated frame and doubling for the next
+        // one (Demo.cpp:357-366,447).
+        gs_timer_start(stageTimers[2]);
+        launchTileListCount(g.stream, n, scr, (const float2*) r->clipXY, (const float4*) r->ellipse, g.scratch);
+        GS_CHECK(hipStreamSynchronize(g.stream)); // pair count readback, as GaussianRender.cu:793
+        const int64_t demand = *g.scratch.totalHost;
+        g.lastDemand = demand;
+        if (demand > 0x7FFFFFFF) return -2;
+        if (growTileListIfNeeded(r, demand)) st.grewTileList = 1;
+        size = (int32_t) demand;
+        launchTileListEmit(g.stream, n, scr, (const float2*) r->clipXY, r->clipZ, (const float4*) r->ellipse, g.scratch, r->keys[0],
+                           r->values[0], r->tileListCapacity);
+        gs_timer_stop(stageTimers[2]);
+        if (blocking) st.msBuildTileList = gs_timer_elapsed_ms(stageTimers[2]);
+
+        GsDoubleBufferU64 keys{{r->keys[0], r->keys[1]}, 0};
+        GsDoubleBufferI32 values{{r->values[0], r->values[1]}, 0};
+        gs_sort_tile_list(stageTimers[3], size, &r->sortTemp, &r->sortTempBytes, &keys, &values); // Demo.cpp:458
+        if (blocking) st.msSortTileList = gs_timer_elapsed_ms(stageTimers[3]);
+        r->selector = keys.selector;
+        r->keyBytes = 8;
+
+        GsTileListArgs tl{keys.buffers[keys.selector], values.buffers[values.selector], size, r->tileListCapacity};
+        gs_set_tile_list_args(&tl); // Demo.cpp:463-466
+        if (size != 0)              // Demo.cpp:469
+        {
+            gs_evaluate_tile_range(stageTimers[4], size);
+            if (blocking) st.msTileRanges = gs_timer_elapsed_ms(stageTimers[4]);
+        }
     }
-    if (demand > r->tileListCapacity)
+    else
     {
-        int64_t cap = r->tileListCapacity > 0 ? r->tileListCapacity : 1;
-        while (cap < demand) cap <<= 1; // Demo.cpp:360
-        cap = std::min<int64_t>(cap, 0x7FFFFFFF);
-        allocTileList(r, (int32_t) cap);
-        st.grewTileList = 1;
+        // ---- two-level sort ------------------------------------------------------------------------
+        const int tileKeyBytes = scr.totalTiles <= 65536 ? 2 : 4;
+        const int tBits = tileBits(scr.totalTiles);
+
+        gs_timer_start(stageTimers[1]);
+        launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation,
+                            (float2*) r->clipXY, r->clipZ, (float4*) r->ellipse, (float4*) r->conic, r->depthKey[0],
+                            (uint32_t*) r->order[0]);
+        gs_timer_stop(stageTimers[1]);
+        if (blocking) st.msClipData = gs_timer_elapsed_ms(stageTimers[1]);
+
+        // (1) splats by depth: 32-bit keys, N elements
+        int orderSel = 0;
+        gs_timer_start(stageTimers[6]);
+        if (n > 0)
+        {
+            ensureSortTemp(r, sortTempBytes(4, n, 0, 32));
+            orderSel = launchSortPairs(g.stream, r->sortTemp, r->sortTempBytes, 4, r->depthKey[0], r->depthKey[1], r->order[0],
+                                       r->order[1], 0, n, 0, 32);
+        }
+        gs_timer_stop(stageTimers[6]);
+        const uint32_t* order = (const uint32_t*) r->order[orderSel];
+
+        // (2) pairs in depth order, keyed by tile. The emit pass is launched with the current capacity while the
+        // pair count travels to the host, so the readback (GaussianRender.cu:793) costs no GPU idle time.
+        gs_timer_start(stageTimers[2]);
+        launchTileListFastCount(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, g.scratch);
+        GS_CHECK(hipEventRecord(r->countReady, g.stream));
+        launchTileListFastEmit(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, g.scratch, r->keys[0],
+                               tileKeyBytes, r->values[0], r->tileListCapacity);
+        GS_CHECK(hipEventSynchronize(r->countReady));
+        const int64_t demand = *g.scratch.totalHost;
+        g.lastDemand = demand;
+        if (demand > 0x7FFFFFFF) return -2;
+        if (growTileListIfNeeded(r, demand))
+        {
+            // the list did not fit: re-emit into the larger buffers (rare; the first frames of a scene)
+            st.grewTileList = 1;
+            launchTileListFastEmit(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, g.scratch,
+                                   r->keys[0], tileKeyBytes, r->values[0], r->tileListCapacity);
+        }
+        gs_timer_stop(stageTimers[2]);
+        if (blocking) st.msBuildTileList = gs_timer_elapsed_ms(stageTimers[2]);
+        size = (int32_t) demand;
+
+        // (3) stable sort of the pairs on the tile bits only
+        gs_timer_start(stageTimers[3]);
+        int sel = 0;
+        if (size > 0)
+        {
+            ensureSortTemp(r, sortTempBytes(tileKeyBytes, size, 0, tBits));
+            sel = launchSortPairs(g.stream, r->sortTemp, r->sortTempBytes, tileKeyBytes, r->keys[0], r->keys[1], r->values[0],
+                                  r->values[1], 0, size, 0, tBits);
+        }
+        gs_timer_stop(stageTimers[3]);
+        if (blocking) st.msSortTileList = gs_timer_elapsed_ms(stageTimers[3]) + gs_timer_elapsed_ms(stageTimers[6]);
+        r->selector = sel;
+        r->keyBytes = tileKeyBytes;
+
+        GsTileListArgs tl{r->keys[sel], r->values[sel], size, r->tileListCapacity};
+        gs_set_tile_list_args(&tl);
+        gs_timer_start(stageTimers[4]);
+        launchTileRanges(g.stream, size, tileKeyBytes, r->keys[sel], r->tileRange);
+        gs_timer_stop(stageTimers[4]);
+        if (blocking) st.msTileRanges = gs_timer_elapsed_ms(stageTimers[4]);
     }
-    r->selector = 0;
-    const int32_t size = (int32_t) demand;
-    launchTileListEmit(g.stream, n, scr, (const float2*) r->clipXY, r->clipZ, (const float4*) r->ellipse, g.scratch, r->keys[0],
-                       r->values[0], r->tileListCapacity);
-    gs_timer_stop(timer);
-    if (timed) st.msBuildTileList = gs_timer_elapsed_ms(timer);
     r->tileListSize = size;
     st.tileListSize = size;
     st.tileListCapacity = r->tileListCapacity;
 
-    GsDoubleBufferU64 keys{{r->keys[0], r->keys[1]}, 0};
-    GsDoubleBufferI32 values{{r->values[0], r->values[1]}, 0};
-    timer = stageTimers[3];
-    gs_sort_tile_list(timer, size, &r->sortTemp, &r->sortTempBytes, &keys, &values); // Demo.cpp:458
-    if (timed) st.msSortTileList = gs_timer_elapsed_ms(timer);
-    r->selector = keys.selector;
-
-    GsTileListArgs tl{keys.buffers[keys.selector], values.buffers[values.selector], size, r->tileListCapacity};
-    gs_set_tile_list_args(&tl); // Demo.cpp:463-466
-
-    if (size != 0) // Demo.cpp:469
-    {
-        timer = stageTimers[4];
-        gs_evaluate_tile_range(timer, size);
-        if (timed) st.msTileRanges = gs_timer_elapsed_ms(timer);
-    }
-    timer = stageTimers[5];
-    gs_rasterize_tile(timer);
-    if (timed) st.msRasterize = gs_timer_elapsed_ms(timer);
+    gs_rasterize_tile(stageTimers[5]);
+    if (blocking) st.msRasterize = gs_timer_elapsed_ms(stageTimers[5]);
 
     GS_CHECK(hipEventRecord(r->frameStop, g.stream));
     r->asyncPairs += (r->asyncFrames > 0) ? size : 0;
@@ -581,8 +691,9 @@ extern "C" int gs_renderer_collect_stage_times(GsRenderer* r, GsFrameStats* sums
     // Sums over the frames rendered with timed == 2 since the last call; resets the accumulation.
     GS_CHECK(hipStreamSynchronize(g.stream));
     GsFrameStats s{};
-    float* slots[6] = {&s.msSphericalHarmonics, &s.msClipData, &s.msBuildTileList, &s.msSortTileList, &s.msTileRanges, &s.msRasterize};
-    for (size_t i = 0; i != r->asyncUsed; ++i) *slots[i % 6] += gs_timer_elapsed_ms(r->asyncTimers[i]);
+    float* slots[kStageTimers] = {&s.msSphericalHarmonics, &s.msClipData, &s.msBuildTileList, &s.msSortTileList, &s.msTileRanges,
+                                  &s.msRasterize, &s.msSortTileList};
+    for (size_t i = 0; i != r->asyncUsed; ++i) *slots[i % kStageTimers] += gs_timer_elapsed_ms(r->asyncTimers[i]);
     s.tileListSize = r->asyncPairs;
     const int frames = r->asyncFrames;
     r->asyncUsed = 0;
@@ -592,4 +703,4 @@ extern "C" int gs_renderer_collect_stage_times(GsRenderer* r, GsFrameStats* sums
     return frames;
 }
 
-extern "C" const char* gs_version(void) { return "gsplat_hip 0.1 (gfx950)"; }
+extern "C" const char* gs_version(void) { return "gsplat_hip 0.2 (gfx950)"; }

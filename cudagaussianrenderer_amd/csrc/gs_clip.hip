@@ -23,7 +23,8 @@ struct Sym3
 __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr, ClipCamera cam, const float4* __restrict__ position,
                                                             const float4* __restrict__ scaleAndRotation,
                                                             float2* __restrict__ clipXY, float* __restrict__ clipZ,
-                                                            float4* __restrict__ screenEllipse, float4* __restrict__ conicOut)
+                                                            float4* __restrict__ screenEllipse, float4* __restrict__ conicOut,
+                                                            uint32_t* __restrict__ depthKey, uint32_t* __restrict__ splatOrder)
 {
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= count) return;
@@ -128,6 +129,15 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
     extentX *= isVisible;
     extentY *= isVisible;
 
+    if (depthKey != nullptr)
+    {
+        // Quantised depth of getKey() (GaussianRender.cu:446-454) as a 32-bit sort key of its own, plus the
+        // identity permutation: the one-call renderer sorts SPLATS by depth before expanding them to tiles.
+        const float n01 = fminf(fmaxf((clipDepth + 1.0f) * 0.5f, 0.0f), 1.0f);
+        const float scaled = n01 * 4294967296.0f;
+        depthKey[index] = (scaled >= 4294967296.0f) ? 0xFFFFFFFFu : (uint32_t) scaled;
+        splatOrder[index] = (uint32_t) index;
+    }
     clipXY[index] = make_float2(clipX, clipY);
     clipZ[index] = clipDepth;
     screenEllipse[index] = make_float4(cosA, sinA, extentX, extentY);
@@ -137,12 +147,13 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
 } // namespace
 
 void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const ClipCamera& cam, const float4* position,
-                         const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic)
+                         const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic,
+                         uint32_t* depthKey, uint32_t* splatOrder)
 {
     if (count <= 0) return;
     const dim3 grid((count + 255) / 256), block(256);
     hipLaunchKernelGGL(splatClipDataKernel, grid, block, 0, stream, count, scr, cam, position, scaleAndRotation, clipXY, clipZ,
-                       screenEllipse, conic);
+                       screenEllipse, conic, depthKey, splatOrder);
 }
 
 } // namespace gs

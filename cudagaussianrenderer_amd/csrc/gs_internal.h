@@ -57,7 +57,8 @@ void launchSphericalHarmonics(hipStream_t stream, int count, int degree, int shC
                               float3 cameraPosition, float4* color);
 
 void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const ClipCamera& cam, const float4* position,
-                         const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic);
+                         const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic,
+                         uint32_t* depthKeyOrNull, uint32_t* splatOrderOrNull);
 
 // Scratch of the tile-list builder: per-wave pair counts, their exclusive scan, the total.
 struct TileListScratch
@@ -77,18 +78,27 @@ void launchTileListCount(hipStream_t stream, int count, const Screen& scr, const
 void launchTileListEmit(hipStream_t stream, int count, const Screen& scr, const float2* clipXY, const float* clipZ,
                         const float4* screenEllipse, const TileListScratch& s, uint64_t* keys, int32_t* values, int capacity);
 
-// rocPRIM radix sort of (uint64 key, int32 value) pairs on bits [0, endBit).
-size_t sortTempBytes(int size, int endBit);
-// Returns the selector (0/1) of the buffer holding the sorted data.
-int launchSortPairs(hipStream_t stream, void* temp, size_t tempBytes, uint64_t* keys0, uint64_t* keys1, int32_t* values0,
-                    int32_t* values1, int selector, int size, int endBit);
+// Renderer-only builder (gs_tiles_fast.hip): splats visited in `order` (depth-sorted), key = tile index (2 or 4 bytes).
+void launchTileListFastCount(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
+                             const float4* screenEllipse, TileListScratch& s);
+void launchTileListFastEmit(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
+                            const float4* screenEllipse, const TileListScratch& s, void* tileKeys, int tileKeyBytes, int32_t* values,
+                            int capacity);
 
-void launchTileRanges(hipStream_t stream, int size, const uint64_t* keys, int32_t* tileRange);
+// rocPRIM radix sort of (key, int32 value) pairs on key bits [beginBit, endBit); keyBytes in {2, 4, 8}.
+size_t sortTempBytes(int keyBytes, int size, int beginBit, int endBit);
+// Returns the selector (0/1) of the buffer holding the sorted data.
+int launchSortPairs(hipStream_t stream, void* temp, size_t tempBytes, int keyBytes, void* keys0, void* keys1, int32_t* values0,
+                    int32_t* values1, int selector, int size, int beginBit, int endBit);
+
+// keyBytes 8: tile = key >> 32 (the reference's keys); 2 or 4: the key is the tile index.
+void launchTileRanges(hipStream_t stream, int size, int keyBytes, const void* keys, int32_t* tileRange);
 
 void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileRange, const int32_t* values,
                      const float2* clipXY, const float4* conic, const float4* color, uchar4* backBuffer,
                      unsigned long long* consumedPairsOrNull);
 
 int sortEndBit(int totalTiles);
+int tileBits(int totalTiles);
 
 } // namespace gs

@@ -2,8 +2,8 @@
 //
 // Replaces evaluateTileRangesKernel (GaussianRender.cu:857-888): tileRange[2t] = first index of tile
 // t, tileRange[2t+1] = one past its last; tiles that own no pair keep the caller's 0xFF fill (-1,-1)
-// and therefore count 0.  HBM streaming over the keys (8 B per pair): each lane reads two adjacent
-// keys with one 16-byte load and one extra neighbour key.
+// and therefore count 0.  HBM streaming over the keys: each lane owns 16 bytes of keys (two 64-bit
+// keys, four 32-bit or eight 16-bit tile indices) read with one load, plus one neighbour key.
 #include "gs_internal.h"
 
 namespace gs
@@ -11,50 +11,75 @@ namespace gs
 namespace
 {
 
-__global__ __launch_bounds__(256) void tileRangesKernel(int size, const uint64_t* __restrict__ keys, int32_t* __restrict__ tileRange)
+template <typename Key>
+__device__ __forceinline__ uint32_t tileOf(Key k)
 {
-    const int pairIndex = (blockIdx.x * blockDim.x + threadIdx.x) * 2; // this lane owns list entries pairIndex, pairIndex+1
-    if (pairIndex >= size) return;
+    if constexpr (sizeof(Key) == 8) return (uint32_t) (k >> 32); // GaussianRender.cu:865
+    else return (uint32_t) k;
+}
 
-    const ulonglong2 two = (pairIndex + 1 < size) ? *reinterpret_cast<const ulonglong2*>(keys + pairIndex)
-                                                  : make_ulonglong2(keys[pairIndex], 0ull);
-    const uint32_t tile0 = (uint32_t) (two.x >> 32);
-    if (pairIndex == 0)
+template <typename Key>
+__global__ __launch_bounds__(256) void tileRangesKernel(int size, const Key* __restrict__ keys, int32_t* __restrict__ tileRange)
+{
+    constexpr int PER = 16 / sizeof(Key);
+    const int first = (blockIdx.x * blockDim.x + threadIdx.x) * PER; // this lane owns list entries [first, first+PER)
+    if (first >= size) return;
+
+    Key local[PER];
+    if (first + PER <= size)
     {
-        tileRange[tile0 * 2] = 0; // GaussianRender.cu:864-866
+        const uint4 raw = *reinterpret_cast<const uint4*>(keys + first);
+        __builtin_memcpy(local, &raw, 16);
     }
     else
     {
-        const uint32_t prev = (uint32_t) (keys[pairIndex - 1] >> 32);
-        if (prev != tile0) // GaussianRender.cu:882-886
+#pragma unroll
+        for (int i = 0; i != PER; ++i) local[i] = (first + i < size) ? keys[first + i] : Key(0);
+    }
+    uint32_t prev;
+    if (first == 0)
+    {
+        prev = tileOf(local[0]);
+        tileRange[prev * 2] = 0; // GaussianRender.cu:864-866
+    }
+    else prev = tileOf(keys[first - 1]);
+#pragma unroll
+    for (int i = 0; i != PER; ++i)
+    {
+        const int index = first + i;
+        if (index < size)
         {
-            tileRange[prev * 2 + 1] = pairIndex;
-            tileRange[tile0 * 2] = pairIndex;
+            const uint32_t tile = tileOf(local[i]);
+            if (tile != prev) // GaussianRender.cu:882-886
+            {
+                tileRange[prev * 2 + 1] = index;
+                tileRange[tile * 2] = index;
+            }
+            if (index == size - 1) tileRange[tile * 2 + 1] = size; // GaussianRender.cu:868-870
+            prev = tile;
         }
     }
-    if (pairIndex + 1 < size)
-    {
-        const uint32_t tile1 = (uint32_t) (two.y >> 32);
-        if (tile1 != tile0)
-        {
-            tileRange[tile0 * 2 + 1] = pairIndex + 1;
-            tileRange[tile1 * 2] = pairIndex + 1;
-        }
-        if (pairIndex + 2 == size) tileRange[tile1 * 2 + 1] = size; // GaussianRender.cu:868-870
-    }
-    else
-    {
-        tileRange[tile0 * 2 + 1] = size;
-    }
+}
+
+template <typename Key>
+void launchT(hipStream_t stream, int size, const void* keys, int32_t* tileRange)
+{
+    constexpr int PER = 16 / sizeof(Key);
+    const int lanes = (size + PER - 1) / PER;
+    hipLaunchKernelGGL(tileRangesKernel<Key>, dim3((lanes + 255) / 256), dim3(256), 0, stream, size, (const Key*) keys, tileRange);
 }
 
 } // namespace
 
-void launchTileRanges(hipStream_t stream, int size, const uint64_t* keys, int32_t* tileRange)
+void launchTileRanges(hipStream_t stream, int size, int keyBytes, const void* keys, int32_t* tileRange)
 {
     if (size <= 0) return; // Demo.cpp:469
-    const int lanes = (size + 1) / 2;
-    hipLaunchKernelGGL(tileRangesKernel, dim3((lanes + 255) / 256), dim3(256), 0, stream, size, keys, tileRange);
+    switch (keyBytes)
+    {
+    case 2: launchT<uint16_t>(stream, size, keys, tileRange); break;
+    case 4: launchT<uint32_t>(stream, size, keys, tileRange); break;
+    default: launchT<uint64_t>(stream, size, keys, tileRange); break;
+    }
 }
 
 } // namespace gs

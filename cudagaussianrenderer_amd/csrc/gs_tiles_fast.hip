@@ -1,0 +1,353 @@
+// gs_tiles_fast.hip -- tile-list builder of the one-call renderer (gs_renderer_render).
+//
+// Same observable set as buildTileListKernel (GaussianRender.cu:456-770) and as gs_tiles.hip, but built
+// for the renderer's two-level sort: splats arrive ALREADY SORTED BY DEPTH (`order` is the permutation
+// produced by the 32-bit depth sort), pairs are emitted in that order, and the key is just the tile index
+// (16 or 32 bit).  A stable sort on the tile index then yields exactly the list the reference's 64-bit
+// (tile|depth) sort yields, at a fraction of the radix-sort traffic ("Two-level sort").
+//
+// Differences from the bit-exact builder in gs_tiles.hip:
+//   * work unit = (splat, 4 consecutive AABB tiles): one owner search and one LDS parameter fetch per
+//     four overlap tests; per-unit hit masks are compacted with four ballots, unit-major, so the emission
+//     order is (sorted splat, local tile) with no atomics;
+//   * the ellipse/rectangle predicate is evaluated in the ellipse's unit-circle space with the affine map
+//     hoisted per splat (reciprocals instead of the reference's 14 divisions per test).  It is the same
+//     predicate -- centre-in-rect OR rect-centre-in-ellipse OR an edge within the unit circle
+//     (GaussianRender.cu:375-405) -- evaluated in a different floating-point order, so a pair whose
+//     overlap margin is at rounding level may differ from the oracle's; tests check exactly that.
+#include "gs_internal.h"
+
+namespace gs
+{
+namespace
+{
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kTilesPerUnit = 4;
+
+__device__ __forceinline__ float gmin(float x, float y) { return (y < x) ? y : x; }
+__device__ __forceinline__ float gmax(float x, float y) { return (x < y) ? y : x; }
+__device__ __forceinline__ int f2iSat(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return -2147483647 - 1;
+    return (int) v;
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+struct WaveStage
+{
+    int excl[kWave];   // exclusive prefix of units
+    int area[kWave];   // AABB tiles
+    int origin[kWave]; // x0 | y0 << 16
+    int w[kWave];
+    float rcpW[kWave];
+    float4 centreM[kWave]; // cx, cy, m00, m01
+    float4 mInv[kWave];    // m10, m11, 1/|u|^2, 1/|v|^2
+    int splat[kWave];
+};
+
+// Does the segment q + t e, t in [0,1], come within the unit circle?  (GaussianRender.cu:361-372)
+__device__ __forceinline__ bool edgeHitsUnitCircle(float qx, float qy, float ex, float ey, float qe, float invEE)
+{
+    const float t = __saturatef(-qe * invEE);
+    const float rx = fmaf(t, ex, qx), ry = fmaf(t, ey, qy);
+    return fmaf(rx, rx, ry * ry) < 1.0f;
+}
+
+template <bool EMIT, typename TileKey>
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void tileListFastKernel(int count, Screen scr, const uint32_t* __restrict__ order,
+                                                                             const float2* __restrict__ clipXY,
+                                                                             const float4* __restrict__ screenEllipse,
+                                                                             int32_t* __restrict__ waveCounts,
+                                                                             const int32_t* __restrict__ waveOffsets,
+                                                                             TileKey* __restrict__ tileKeys, int32_t* __restrict__ values,
+                                                                             int capacity)
+{
+    __shared__ WaveStage stage[kWavesPerBlock];
+    const int waveInBlock = threadIdx.x >> 6;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int waveGlobal = blockIdx.x * kWavesPerBlock + waveInBlock;
+    if (waveGlobal * kWave >= count) return;
+    WaveStage& st = stage[waveInBlock];
+    const int sorted = waveGlobal * kWave + lane;
+
+    int area = 0, x0 = 0, y0 = 0, w = 0, splat = 0;
+    float cx = 0.f, cy = 0.f, m00 = 0.f, m01 = 0.f, m10 = 0.f, m11 = 0.f, invUU = 0.f, invVV = 0.f;
+    if (sorted < count)
+    {
+        splat = (int) order[sorted];
+        const float2 c = clipXY[splat];
+        const float4 se = screenEllipse[splat]; // cos, sin, extent.x, extent.y
+        cx = c.x;
+        cy = c.y;
+        // AABB in tiles, exactly as gs_tiles.hip / GaussianRender.cu:408-436,537-551.
+        {
+#pragma clang fp contract(off)
+            const float rightX = se.x * se.z, rightY = se.y * se.z;
+            const float upX = se.y * se.w, upY = -se.x * se.w;
+            float minX = 1e12f, minY = 1e12f, maxX = -1e12f, maxY = -1e12f;
+#pragma unroll
+            for (int j = 0; j != 4; ++j)
+            {
+                const int bottomBit = j & 1, topBit = j >> 1;
+                const float r = (float) (bottomBit ^ topBit) * 2.0f - 1.0f;
+                const float u = (float) topBit * 2.0f - 1.0f;
+                const float vx = rightX * r + upX * u, vy = rightY * r + upY * u;
+                minX = gmin(minX, vx);
+                minY = gmin(minY, vy);
+                maxX = gmax(maxX, vx);
+                maxY = gmax(maxY, vy);
+            }
+            minX += cx;
+            minY += cy;
+            maxX += cx;
+            maxY += cy;
+            x0 = clampi(f2iSat(floorf((minX + 1.0f) * 0.5f * scr.tilesPerScreenX)), 0, scr.tilesX);
+            y0 = clampi(f2iSat(floorf((minY + 1.0f) * 0.5f * scr.tilesPerScreenY)), 0, scr.tilesY);
+            const int x1 = clampi(f2iSat(ceilf((maxX + 1.0f) * 0.5f * scr.tilesPerScreenX)), 0, scr.tilesX);
+            int y1 = clampi(f2iSat(ceilf((maxY + 1.0f) * 0.5f * scr.tilesPerScreenY)), 0, scr.tilesY);
+            y0 = max(y0, scr.rowBegin);
+            y1 = min(y1, scr.rowEnd);
+            w = x1 - x0;
+            const int h = y1 - y0;
+            area = (w > 0 && h > 0) ? w * h : 0;
+        }
+        // Affine map clip space -> the ellipse's unit-circle space (GaussianRender.cu:351-358), hoisted:
+        //   l = M (p - c),  M = diag(1/ex, 1/ey) * [[cos, sin], [-sin, cos]]
+        const float invEx = 1.0f / se.z, invEy = 1.0f / se.w;
+        m00 = se.x * invEx;
+        m01 = se.y * invEx;
+        m10 = -se.y * invEy;
+        m11 = se.x * invEy;
+        // Images of the tile edges: u = M (sx, 0), v = M (0, sy).
+        const float ux = m00 * scr.tileClipSizeX, uy = m10 * scr.tileClipSizeX;
+        const float vx = m01 * scr.tileClipSizeY, vy = m11 * scr.tileClipSizeY;
+        invUU = 1.0f / fmaf(ux, ux, uy * uy);
+        invVV = 1.0f / fmaf(vx, vx, vy * vy);
+    }
+    const int units = (area + kTilesPerUnit - 1) / kTilesPerUnit;
+
+    int incl = units;
+#pragma unroll
+    for (int delta = 1; delta < kWave; delta <<= 1)
+    {
+        const int n = __shfl_up(incl, delta);
+        if (lane >= delta) incl += n;
+    }
+    const int totalUnits = __builtin_amdgcn_readfirstlane(__shfl(incl, kWave - 1));
+
+    st.excl[lane] = incl - units;
+    st.area[lane] = area;
+    st.origin[lane] = x0 | (y0 << 16);
+    st.w[lane] = max(w, 1);
+    st.rcpW[lane] = 1.0f / (float) max(w, 1);
+    st.centreM[lane] = make_float4(cx, cy, m00, m01);
+    st.mInv[lane] = make_float4(m10, m11, invUU, invVV);
+    st.splat[lane] = splat;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    int running = 0;
+    int outBase = 0;
+    if (EMIT) outBase = __builtin_amdgcn_readfirstlane(waveOffsets[waveGlobal]);
+    const unsigned long long lowerLanes = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
+    const float sx = scr.tileClipSizeX, sy = scr.tileClipSizeY;
+
+    for (int base = 0; base < totalUnits; base += kWave)
+    {
+        const int unit = base + lane;
+        const bool valid = unit < totalUnits;
+        int k = 0;
+#pragma unroll
+        for (int step = kWave / 2; step != 0; step >>= 1)
+        {
+            const int t = k + step;
+            if (st.excl[t] <= unit) k = t;
+        }
+        const int local0 = (unit - st.excl[k]) * kTilesPerUnit;
+        const int areaK = valid ? st.area[k] : 0;
+        const int wk = st.w[k];
+        const int origin = st.origin[k];
+        const float4 cm = st.centreM[k];
+        const float4 mi = st.mInv[k];
+        // local0 / wk through the reciprocal: the quotient's fractional part is at least 0.5/wk away from an
+        // integer, far above the float error for local0 < 2^16.
+        int ly = (int) (((float) local0 + 0.5f) * st.rcpW[k]);
+        int lx = local0 - ly * wk;
+
+        const float ux = cm.z * sx, uy = mi.x * sx; // u = M (sx, 0)
+        const float vx = cm.w * sy, vy = mi.y * sy; // v = M (0, sy)
+        const float uv = fmaf(ux, vx, uy * vy);
+        const float uu = fmaf(ux, ux, uy * uy), vv = fmaf(vx, vx, vy * vy);
+
+        unsigned hitMask = 0;
+        unsigned long long ballots[kTilesPerUnit];
+#pragma unroll
+        for (int t = 0; t != kTilesPerUnit; ++t)
+        {
+            bool hit = false;
+            if (local0 + t < areaK)
+            {
+                const int gx = (origin & 0xFFFF) + lx, gy = (origin >> 16) + ly;
+                const float minX = (float) gx * sx - 1.0f, minY = (float) gy * sy - 1.0f; // GaussianRender.cu:656-664
+                // centre inside the rectangle (strict, GaussianRender.cu:382-386)
+                hit = cm.x > minX && cm.x < minX + sx && cm.y > minY && cm.y < minY + sy;
+                // corner q0 = M (min - c); the other corners are q0 + u, q0 + v, q0 + u + v
+                const float dx = minX - cm.x, dy = minY - cm.y;
+                const float q0x = fmaf(cm.z, dx, cm.w * dy), q0y = fmaf(mi.x, dx, mi.y * dy);
+                const float qcx = fmaf(0.5f, ux + vx, q0x), qcy = fmaf(0.5f, uy + vy, q0y);
+                hit |= fmaf(qcx, qcx, qcy * qcy) < 1.0f; // rectangle centre inside the ellipse (:389)
+                const float q0u = fmaf(q0x, ux, q0y * uy), q0v = fmaf(q0x, vx, q0y * vy);
+                hit |= edgeHitsUnitCircle(q0x, q0y, ux, uy, q0u, mi.z);                     // bottom edge
+                hit |= edgeHitsUnitCircle(q0x + ux, q0y + uy, vx, vy, q0v + uv, mi.w);       // right edge
+                hit |= edgeHitsUnitCircle(q0x + vx, q0y + vy, ux, uy, q0u + uv, mi.z);       // top edge
+                hit |= edgeHitsUnitCircle(q0x, q0y, vx, vy, q0v, mi.w);                     // left edge
+                (void) uu;
+                (void) vv;
+            }
+            ballots[t] = __ballot(hit);
+            hitMask |= hit ? (1u << t) : 0u;
+            // next local tile
+            ++lx;
+            if (lx == wk)
+            {
+                lx = 0;
+                ++ly;
+            }
+        }
+
+        if (EMIT)
+        {
+            int pos = outBase + running;
+#pragma unroll
+            for (int t = 0; t != kTilesPerUnit; ++t) pos += __popcll(ballots[t] & lowerLanes);
+            // re-walk the unit's tiles to write the hits, unit-major
+            int wy = (int) (((float) local0 + 0.5f) * st.rcpW[k]);
+            int wx = local0 - wy * wk;
+            const int splatK = st.splat[k];
+#pragma unroll
+            for (int t = 0; t != kTilesPerUnit; ++t)
+            {
+                if (hitMask & (1u << t))
+                {
+                    if (pos < capacity)
+                    {
+                        const int gx = (origin & 0xFFFF) + wx, gy = (origin >> 16) + wy;
+                        tileKeys[pos] = (TileKey) (gy * scr.tilesX + gx);
+                        values[pos] = splatK;
+                    }
+                    ++pos;
+                }
+                ++wx;
+                if (wx == wk)
+                {
+                    wx = 0;
+                    ++wy;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t != kTilesPerUnit; ++t) running += __popcll(ballots[t]);
+    }
+
+    if (!EMIT && lane == 0) waveCounts[waveGlobal] = running;
+}
+
+// Exclusive scan of n ints by ONE workgroup (n = ceil(N/64)): 1024 lanes x 4 consecutive ints per pass
+// (16-byte coalesced loads), wave scans by shuffles, 16 wave totals through LDS, carry across passes.
+constexpr int kScanThreads = 1024;
+__global__ __launch_bounds__(kScanThreads) void scanFastKernel(int n, const int32_t* __restrict__ in, int32_t* __restrict__ out,
+                                                               int64_t* __restrict__ total)
+{
+    __shared__ long long waveTotals[kScanThreads / kWave];
+    __shared__ long long carryShared;
+    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
+    long long carry = 0;
+    for (int base = 0; base < n; base += kScanThreads * 4)
+    {
+        const int i = base + t * 4;
+        int4 v = make_int4(0, 0, 0, 0);
+        if (i + 3 < n) v = *reinterpret_cast<const int4*>(in + i);
+        else
+        {
+            if (i < n) v.x = in[i];
+            if (i + 1 < n) v.y = in[i + 1];
+            if (i + 2 < n) v.z = in[i + 2];
+        }
+        const long long own = (long long) v.x + v.y + v.z + v.w;
+        long long incl = own;
+#pragma unroll
+        for (int delta = 1; delta < kWave; delta <<= 1)
+        {
+            const long long o = __shfl_up(incl, delta);
+            if (lane >= delta) incl += o;
+        }
+        if (lane == kWave - 1) waveTotals[wave] = incl;
+        __syncthreads();
+        long long before = carry;
+        for (int wv = 0; wv < wave; ++wv) before += waveTotals[wv];
+        long long all = 0;
+        for (int wv = 0; wv < kScanThreads / kWave; ++wv) all += waveTotals[wv];
+        long long p = before + incl - own;
+        const long long cap = 0x7FFFFFFF;
+        if (i < n) out[i] = (int32_t) min(p, cap);
+        p += v.x;
+        if (i + 1 < n) out[i + 1] = (int32_t) min(p, cap);
+        p += v.y;
+        if (i + 2 < n) out[i + 2] = (int32_t) min(p, cap);
+        p += v.z;
+        if (i + 3 < n) out[i + 3] = (int32_t) min(p, cap);
+        carry += all;
+        __syncthreads();
+    }
+    if (t == 0)
+    {
+        carryShared = carry;
+        *total = carry;
+    }
+}
+
+template <typename TileKey>
+void launchEmit(hipStream_t stream, dim3 grid, dim3 block, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
+                const float4* screenEllipse, const TileListScratch& s, void* tileKeys, int32_t* values, int capacity)
+{
+    hipLaunchKernelGGL((tileListFastKernel<true, TileKey>), grid, block, 0, stream, count, scr, order, clipXY, screenEllipse,
+                       (int32_t*) nullptr, (const int32_t*) s.waveOffsets, (TileKey*) tileKeys, values, capacity);
+}
+
+} // namespace
+
+void launchTileListFastCount(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
+                             const float4* screenEllipse, TileListScratch& s)
+{
+    ensureTileListScratch(s, count);
+    const int waves = (count + kWave - 1) / kWave;
+    if (waves == 0)
+    {
+        GS_CHECK(hipMemsetAsync(s.total, 0, sizeof(int64_t), stream));
+    }
+    else
+    {
+        const dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
+        hipLaunchKernelGGL((tileListFastKernel<false, uint16_t>), grid, block, 0, stream, count, scr, order, clipXY, screenEllipse,
+                           s.waveCounts, (const int32_t*) nullptr, (uint16_t*) nullptr, (int32_t*) nullptr, 0);
+        hipLaunchKernelGGL(scanFastKernel, dim3(1), dim3(kScanThreads), 0, stream, waves, s.waveCounts, s.waveOffsets, s.total);
+    }
+    GS_CHECK(hipMemcpyAsync(s.totalHost, s.total, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+}
+
+void launchTileListFastEmit(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
+                            const float4* screenEllipse, const TileListScratch& s, void* tileKeys, int tileKeyBytes, int32_t* values,
+                            int capacity)
+{
+    const int waves = (count + kWave - 1) / kWave;
+    if (waves == 0 || capacity <= 0) return;
+    const dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
+    if (tileKeyBytes == 2) launchEmit<uint16_t>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, tileKeys, values, capacity);
+    else launchEmit<uint32_t>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, tileKeys, values, capacity);
+}
+
+} // namespace gs

@@ -246,6 +246,67 @@ def test_edge_cases(gs, gsref):
     _assert_image_close(got, want)
 
 
+def _overlap_margin(ell, xy, tile, w, h):
+    """float64 margin of the ellipse/tile predicate (GaussianRender.cu:375-405): < 0 overlap, > 0 none."""
+    tx, ty = tile % ((w + 15) // 16), tile // ((w + 15) // 16)
+    sx, sy = 32.0 / w, 32.0 / h
+    mn = np.array([tx * sx - 1.0, ty * sy - 1.0])
+    mx = mn + [sx, sy]
+    c, s_, ex, ey = [float(v) for v in ell]
+    ctr = np.array([float(xy[0]), float(xy[1])])
+
+    def to_e(p):
+        d = p - ctr
+        return np.array([(d[0] * c + d[1] * s_) / ex, (d[1] * c - d[0] * s_) / ey])
+
+    m = [-min(ctr[0] - mn[0], mx[0] - ctr[0], ctr[1] - mn[1], mx[1] - ctr[1]) / max(sx, sy)]
+    m.append(float(np.dot(to_e((mn + mx) / 2), to_e((mn + mx) / 2))) - 1.0)
+    pts = [to_e(np.array(p)) for p in [(mn[0], mn[1]), (mx[0], mn[1]), (mx[0], mx[1]), (mn[0], mx[1])]]
+    for i in range(4):
+        v0, v1 = pts[i], pts[(i + 1) % 4]
+        d = v1 - v0
+        t = min(max(float(np.dot(-v0, d) / np.dot(d, d)), 0.0), 1.0)
+        q = v0 + t * d
+        m.append(float(np.dot(q, q)) - 1.0)
+    return min(m)
+
+
+@pytest.mark.parametrize("w,h,n,scales", [(640, 360, 50000, (0.01, 0.3)), (1920, 1080, 200000, (0.005, 0.08)), (333, 177, 20000, (0.01, 1.0))])
+def test_two_level_pipeline_equals_reference_pipeline(gs, w, h, n, scales):
+    """The default two-level sort (depth-sort splats, emit, stable tile sort) must give the same sorted pair list
+    as the reference-shaped pipeline (64-bit tile|depth radix sort), except pairs whose overlap margin is at
+    float rounding level (the fast builder evaluates the predicate in the ellipse's space), and the same image."""
+    pos, sr, col = _procedural(gs, n, seed=11, min_scale=scales[0], max_scale=scales[1])
+    cam = gs.camera_from_bounds([-4] * 3, [4] * 3, w, h)
+    lists, images = [], []
+    for pipeline in [gs.PIPELINE_REFERENCE, gs.PIPELINE_TWO_LEVEL]:
+        r = gs.Renderer(w, h, pipeline=pipeline)
+        r.set_scene(pos, sr, col)
+        r.render(cam)
+        images.append(r.read_image())
+        b = r.buffers()
+        kd = {2: np.uint16, 4: np.uint32, 8: np.uint64}[b.keyBytes]
+        keys = r.download(b.keys, b.tileListSize, kd)
+        tiles = (keys >> np.uint64(32)).astype(np.int64) if b.keyBytes == 8 else keys.astype(np.int64)
+        values = r.download(b.values, b.tileListSize, np.int32).astype(np.int64)
+        ell = r.download(b.screenEllipse, 4 * n, np.float32).reshape(n, 4)
+        xy = r.download(b.positionClipSpaceXY, 2 * n, np.float32).reshape(n, 2)
+        lists.append(tiles * n + values)  # one integer per pair, list order preserved
+        r.close()
+    a, b_ = lists
+    if not np.array_equal(a, b_):
+        only_a = np.setdiff1d(a, b_)
+        only_b = np.setdiff1d(b_, a)
+        assert len(only_a) + len(only_b) <= max(4, 2e-5 * len(a)), (len(only_a), len(only_b), len(a))
+        for code in list(only_a) + list(only_b):
+            tile, splat = divmod(int(code), n)
+            assert abs(_overlap_margin(ell[splat], xy[splat], tile, w, h)) < 1e-4, (tile, splat)
+        common_a = a[~np.isin(a, only_a)]
+        common_b = b_[~np.isin(b_, only_b)]
+        assert np.array_equal(common_a, common_b)  # same order everywhere else
+    _assert_image_close(images[0], images[1])
+
+
 def test_band_renders_stitch_to_full_frame(gs):
     """Multi-GPU rule: rendering tile-row bands separately and stitching is byte-identical to one full render."""
     from cudagaussianrenderer_amd import scenes
@@ -288,25 +349,26 @@ def test_full_size_properties(gs, tmp_path):
     b = r.buffers()
     size = b.tileListSize
     assert size == st.tileListSize > n  # more than one tile per splat on average
-    keys = r.download(b.keys, size, np.uint64)
+    key_dtype = {2: np.uint16, 4: np.uint32, 8: np.uint64}[b.keyBytes]
+    keys = r.download(b.keys, size, key_dtype)
     values = r.download(b.values, size, np.int32)
     rng = r.download(b.tileRange, 2 * 120 * 68, np.int32).reshape(-1, 2)
     assert np.all(keys[1:] >= keys[:-1])
     assert values.min() >= 0 and values.max() < n
-    tiles = (keys >> np.uint64(32)).astype(np.int64)
+    tiles = (keys >> np.uint64(32)).astype(np.int64) if b.keyBytes == 8 else keys.astype(np.int64)
     assert tiles.max() < 120 * 68
     counts = np.bincount(tiles, minlength=120 * 68)
     assert np.array_equal(rng[:, 1] - rng[:, 0], counts)
     nonempty = counts > 0
     assert np.array_equal(rng[nonempty, 0], (np.cumsum(counts) - counts)[nonempty])
-    # equal keys keep ascending splat index (stable sort of a splat-ordered emission)
-    same = keys[1:] == keys[:-1]
-    assert np.all(values[1:][same] > values[:-1][same])
-    # depth order inside a tile follows clip z
+    # inside a tile the list is ordered by (quantised depth, splat index): the reference's 64-bit key order
     z = r.download(b.positionClipSpaceZ, n, np.float32)
-    t0 = int(np.argmax(counts))
-    seg = values[rng[t0, 0]:rng[t0, 1]]
-    assert np.all(np.diff(z[seg]) >= 0)
+    depth = np.floor(np.clip((z.astype(np.float64) + 1.0) * 0.5, 0.0, 1.0).astype(np.float32).astype(np.float64) * 2.0 ** 32)
+    depth = np.minimum(depth, 2.0 ** 32 - 1).astype(np.uint64)
+    full = (tiles.astype(np.uint64) << np.uint64(32)) | depth[values]
+    assert np.all(full[1:] >= full[:-1])
+    same = full[1:] == full[:-1]
+    assert np.all(values[1:][same] > values[:-1][same])
     # determinism
     r.render(cam)
     assert np.array_equal(r.read_image(), img1)
