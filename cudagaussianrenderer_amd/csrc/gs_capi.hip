@@ -47,6 +47,8 @@ struct State
     GsTileListArgs tileList{};
     hipStream_t stream = nullptr;
     TileListScratch scratch;
+    RadixScratch radix;
+    int sortBackend = GS_SORT_BACKEND_NATIVE;
     int64_t lastDemand = 0;
     bool collectRasterStats = false;
     unsigned long long* consumedDevice = nullptr;
@@ -269,6 +271,16 @@ extern "C" int64_t gs_last_raster_consumed_pairs(void)
     GS_CHECK(hipStreamSynchronize(g.stream));
     GS_CHECK(hipMemcpy(&v, g.consumedDevice, sizeof(v), hipMemcpyDeviceToHost));
     return (int64_t) v;
+}
+
+extern "C" void gs_set_sort_backend(int backend) { g.sortBackend = (backend == GS_SORT_BACKEND_ROCPRIM) ? backend : GS_SORT_BACKEND_NATIVE; }
+extern "C" int gs_get_sort_backend(void) { return g.sortBackend; }
+
+extern "C" int gs_radix_sort_pairs(int keyBytes, void* keys0, void* keys1, int32_t* values0, int32_t* values1, int32_t count, int beginBit,
+                                   int endBit)
+{
+    if (!radixSortSupported(keyBytes, count)) return -1;
+    return launchRadixSortPairs(g.stream, g.radix, keyBytes, keys0, keys1, values0, values1, count, beginBit, endBit);
 }
 
 extern "C" void gs_set_raster_pixels_per_lane(int ppl) { setRasterPixelsPerLane(ppl); }
@@ -615,11 +627,17 @@ extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int
         // (1) splats by depth: 32-bit keys, N elements
         int orderSel = 0;
         gs_timer_start(stageTimers[6]);
+        const bool native = g.sortBackend == GS_SORT_BACKEND_NATIVE;
         if (n > 0)
         {
-            ensureSortTemp(r, sortTempBytes(4, n, 0, 32));
-            orderSel = launchSortPairs(g.stream, r->sortTemp, r->sortTempBytes, 4, r->depthKey[0], r->depthKey[1], r->order[0],
-                                       r->order[1], 0, n, 0, 32);
+            if (native && radixSortSupported(4, n))
+                orderSel = launchRadixSortPairs(g.stream, g.radix, 4, r->depthKey[0], r->depthKey[1], r->order[0], r->order[1], n, 0, 32);
+            else
+            {
+                ensureSortTemp(r, sortTempBytes(4, n, 0, 32));
+                orderSel = launchSortPairs(g.stream, r->sortTemp, r->sortTempBytes, 4, r->depthKey[0], r->depthKey[1], r->order[0],
+                                           r->order[1], 0, n, 0, 32);
+            }
         }
         gs_timer_stop(stageTimers[6]);
         const uint32_t* order = (const uint32_t*) r->order[orderSel];
@@ -651,9 +669,15 @@ extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int
         int sel = 0;
         if (size > 0)
         {
-            ensureSortTemp(r, sortTempBytes(tileKeyBytes, size, 0, tBits));
-            sel = launchSortPairs(g.stream, r->sortTemp, r->sortTempBytes, tileKeyBytes, r->keys[0], r->keys[1], r->values[0],
-                                  r->values[1], 0, size, 0, tBits);
+            if (native && radixSortSupported(tileKeyBytes, size))
+                sel = launchRadixSortPairs(g.stream, g.radix, tileKeyBytes, r->keys[0], r->keys[1], r->values[0], r->values[1], size, 0,
+                                           tBits);
+            else
+            {
+                ensureSortTemp(r, sortTempBytes(tileKeyBytes, size, 0, tBits));
+                sel = launchSortPairs(g.stream, r->sortTemp, r->sortTempBytes, tileKeyBytes, r->keys[0], r->keys[1], r->values[0],
+                                      r->values[1], 0, size, 0, tBits);
+            }
         }
         gs_timer_stop(stageTimers[3]);
         if (blocking) st.msSortTileList = gs_timer_elapsed_ms(stageTimers[3]) + gs_timer_elapsed_ms(stageTimers[6]);

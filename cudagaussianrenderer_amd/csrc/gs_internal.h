@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -90,6 +91,21 @@ size_t sortTempBytes(int keyBytes, int size, int beginBit, int endBit);
 // Returns the selector (0/1) of the buffer holding the sorted data.
 int launchSortPairs(hipStream_t stream, void* temp, size_t tempBytes, int keyBytes, void* keys0, void* keys1, int32_t* values0,
                     int32_t* values1, int selector, int size, int beginBit, int endBit);
+
+// The renderer's own radix sort (gs_radix.hip): 2- or 4-byte keys, int32 values, stable, bits [beginBit, endBit).
+struct RadixScratch
+{
+    int32_t* table = nullptr;       // [256][tiles] digit histogram
+    int32_t* scanned = nullptr;     // chunk-local exclusive scan of the table
+    int32_t* chunkTotals = nullptr; // one total per 4096-entry chunk
+    int capacityEntries = 0;
+};
+bool radixSortSupported(int keyBytes, int n);
+void ensureRadixScratch(RadixScratch& s, int n);
+void freeRadixScratch(RadixScratch& s);
+// Returns the selector (0/1) of the buffer pair holding the sorted data (input is buffer 0).
+int launchRadixSortPairs(hipStream_t stream, RadixScratch& s, int keyBytes, void* keys0, void* keys1, int32_t* values0, int32_t* values1,
+                         int n, int beginBit, int endBit);
 
 // keyBytes 8: tile = key >> 32 (the reference's keys); 2 or 4: the key is the tile index.
 void launchTileRanges(hipStream_t stream, int size, int keyBytes, const void* keys, int32_t* tileRange);

@@ -125,6 +125,17 @@ void gs_rasterize_tile(GsTimer* timer);                             /* .cu:1019-
  * (P_c of DESIGN.md); collected only when enabled, costs one atomic per tile. */
 void gs_set_collect_raster_stats(int enabled);
 int64_t gs_last_raster_consumed_pairs(void);
+/* Addition: radix sort used by the one-call renderer for its two sorts (depth keys of the splats; tile index of
+ * the pairs). NATIVE = the three-kernel LSD sort of gs_radix.hip (default), ROCPRIM = rocPRIM's device sort. */
+#define GS_SORT_BACKEND_ROCPRIM 0
+#define GS_SORT_BACKEND_NATIVE 1
+void gs_set_sort_backend(int backend);
+int gs_get_sort_backend(void);
+/* The native sort on its own: stable LSD sort of (keyBytes in {2,4} key, int32 value) pairs on key bits
+ * [beginBit, endBit); input in buffers 0, returns the index (0/1) of the buffers holding the result, -1 if the
+ * size/key type is not supported. Device pointers, enqueued on the current stream. */
+int gs_radix_sort_pairs(int keyBytes, void* keys0, void* keys1, int32_t* values0, int32_t* values1, int32_t count, int beginBit,
+                        int endBit);
 /* Addition (tuning): pixels per lane of the raster kernel, 1, 2 or 4 (default 4 = one wave per tile). */
 void gs_set_raster_pixels_per_lane(int pixelsPerLane);
 int gs_get_raster_pixels_per_lane(void);
