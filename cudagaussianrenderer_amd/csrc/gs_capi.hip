@@ -614,7 +614,7 @@ extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int
     else
     {
         // ---- two-level sort ------------------------------------------------------------------------
-        const int tileKeyBytes = scr.totalTiles <= 65536 ? 2 : 4;
+        const int tileKeyBytes = (getenv("GS_TILEKEY4") || scr.totalTiles > 65536) ? 4 : 2;
         const int tBits = tileBits(scr.totalTiles);
 
         gs_timer_start(stageTimers[1]);

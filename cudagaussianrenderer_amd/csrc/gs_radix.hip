@@ -6,12 +6,11 @@
 // passes (merge-sort fallback at 1 M elements, two memsets + look-back state per onesweep pass), so the
 // renderer uses this plain three-kernel pass instead; every kernel is barrier-free across workgroups (no
 // look-back, no spinning), so there is nothing that can hang:
-//   1. histogram  -- one workgroup per 4096-element tile counts its 8-bit digits (wave-aggregated through
-//                    ballot matching, so a skewed digit does not serialise on one LDS word) -> table[digit][tile];
-//   2. chunk scan -- exclusive scan of the table in 4096-entry chunks + one total per chunk;
-//   3. scatter    -- the tile is re-read (keys and values in registers), ranked stably (ballot match + per-wave
-//                    running counters in LDS), reordered by digit in LDS, and written out as runs of consecutive
-//                    addresses (base = chunk prefix + scanned table entry).
+//   1. histogram   -- one workgroup per 1024/2048-element tile counts its 8-bit digits in LDS -> table[tile][digit];
+//   2. column scan -- one workgroup per digit: exclusive scan of that digit's column over the tiles + its total;
+//   3. scatter     -- the tile is re-read (keys and values in registers), ranked stably (ballot match + per-wave
+//                     running counters in LDS), reordered by digit in LDS, and written out as runs of consecutive
+//                     addresses (base = exclusive scan of the 256 digit totals + the scanned table entry).
 // HBM traffic per pass and element: key read twice, value read once, key + value written once.
 #include "gs_internal.h"
 
@@ -22,11 +21,12 @@ namespace
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / kWave;
-constexpr int kItems = 16;
-constexpr int kTile = kThreads * kItems; // 4096 elements per workgroup
+// Elements per lane: 8 (2048-element tiles) for long lists, 4 (1024-element tiles) for short ones so that a
+// 1 M-element sort still puts several workgroups on every CU.
+constexpr int kItemsLarge = 8;
+constexpr int kItemsSmall = 4;
+constexpr int kSmallLimit = 2 * 1024 * 1024;
 constexpr int kDigits = 256;
-constexpr int kScanChunk = 4096;         // table entries per scan workgroup (1024 lanes x 4)
-constexpr int kMaxChunks = 1024;
 
 // Lanes of the wave whose (valid) digit equals this lane's digit.
 template <int BITS>
@@ -43,148 +43,137 @@ __device__ __forceinline__ unsigned long long matchDigit(int digit, bool valid)
     return valid ? m : 0ull;
 }
 
-template <typename K, int BITS>
-__global__ __launch_bounds__(kThreads) void radixHistogramKernel(const K* __restrict__ keys, int n, int shift, int numTiles,
+template <typename K, int BITS, int ITEMS>
+__global__ __launch_bounds__(kThreads) void radixHistogramKernel(const K* __restrict__ keys, int n, int shift,
                                                                   int32_t* __restrict__ table)
 {
+    constexpr int kTile = kThreads * ITEMS;
     __shared__ int hist[kDigits];
-    const int t = threadIdx.x, lane = t & (kWave - 1);
+    const int t = threadIdx.x;
     hist[t] = 0;
     __syncthreads();
     const int base = blockIdx.x * kTile;
-    const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
-#pragma unroll 4
-    for (int r = 0; r != kItems; ++r)
+    K key[ITEMS];
+#pragma unroll
+    for (int r = 0; r != ITEMS; ++r) // all loads in flight before the first use
     {
         const int i = base + r * kThreads + t;
-        const bool valid = i < n;
-        const int digit = valid ? (int) ((keys[i] >> shift) & ((1 << BITS) - 1)) : 0;
-        const unsigned long long m = matchDigit<BITS>(digit, valid);
-        if (valid && (m & lower) == 0ull) atomicAdd(&hist[digit], __popcll(m)); // one add per distinct digit per wave
+        key[r] = (i < n) ? keys[i] : K(0);
     }
-    __syncthreads();
-    table[t * numTiles + blockIdx.x] = hist[t];
-}
-
-// Exclusive scan of `entries` ints in chunks of kScanChunk; chunk totals to chunkTotals.
-__global__ __launch_bounds__(1024) void radixChunkScanKernel(int entries, const int32_t* __restrict__ in, int32_t* __restrict__ out,
-                                                             int32_t* __restrict__ chunkTotals)
-{
-    __shared__ int waveTotals[16];
-    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
-    const int i = blockIdx.x * kScanChunk + t * 4;
-    int4 v = make_int4(0, 0, 0, 0);
-    if (i + 3 < entries) v = *reinterpret_cast<const int4*>(in + i);
-    else
-    {
-        if (i < entries) v.x = in[i];
-        if (i + 1 < entries) v.y = in[i + 1];
-        if (i + 2 < entries) v.z = in[i + 2];
-    }
-    const int own = v.x + v.y + v.z + v.w;
-    int incl = own;
 #pragma unroll
-    for (int delta = 1; delta < kWave; delta <<= 1)
+    for (int r = 0; r != ITEMS; ++r)
     {
-        const int o = __shfl_up(incl, delta);
-        if (lane >= delta) incl += o;
-    }
-    if (lane == kWave - 1) waveTotals[wave] = incl;
-    __syncthreads();
-    int before = 0, all = 0;
-#pragma unroll
-    for (int wv = 0; wv != 16; ++wv)
-    {
-        const int wt = waveTotals[wv];
-        before += (wv < wave) ? wt : 0;
-        all += wt;
-    }
-    int p = before + incl - own;
-    if (i + 3 < entries) *reinterpret_cast<int4*>(out + i) = make_int4(p, p + v.x, p + v.x + v.y, p + v.x + v.y + v.z);
-    else
-    {
-        if (i < entries) out[i] = p;
-        if (i + 1 < entries) out[i + 1] = p + v.x;
-        if (i + 2 < entries) out[i + 2] = p + v.x + v.y;
-    }
-    if (t == 0) chunkTotals[blockIdx.x] = all;
-}
-
-template <typename K, int BITS>
-__global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restrict__ keysIn, const int32_t* __restrict__ valuesIn,
-                                                                K* __restrict__ keysOut, int32_t* __restrict__ valuesOut, int n,
-                                                                int shift, int numTiles, const int32_t* __restrict__ scanned,
-                                                                const int32_t* __restrict__ chunkTotals, int numChunks)
-{
-    __shared__ int cnt[kWaves][kDigits];   // per-wave running digit counters, then per-wave exclusive prefixes
-    __shared__ int localBase[kDigits];     // first slot of each digit inside the tile
-    __shared__ int globalBase[kDigits];    // first output index of each digit for this tile
-    __shared__ int chunkPrefix[kMaxChunks];
-    __shared__ int waveSums[kWaves];
-    __shared__ uint32_t sKeys[kTile];
-    __shared__ int32_t sVals[kTile];
-
-    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
-    const int tile = blockIdx.x;
-    const int base = tile * kTile;
-    const int tileCount = min(kTile, n - base);
-    constexpr int kDigitMask = (1 << BITS) - 1;
-
-#pragma unroll
-    for (int w = 0; w != kWaves; ++w) cnt[w][t] = 0;
-    // exclusive prefix of the chunk totals (numChunks <= 1024): 4 per lane + workgroup scan
-    {
-        int c[4], s = 0;
-#pragma unroll
-        for (int j = 0; j != 4; ++j)
+        const bool valid = base + r * kThreads + t < n;
+        const int digit = (int) ((key[r] >> shift) & ((1 << BITS) - 1));
+        if constexpr (BITS == 8)
         {
-            const int idx = t * 4 + j;
-            c[j] = idx < numChunks ? chunkTotals[idx] : 0;
-            s += c[j];
+            // Full-width digits: plain LDS atomics (lanes sharing a digit serialise inside the LDS).
+            if (valid) atomicAdd(&hist[digit], 1);
         }
-        int incl = s;
+        else
+        {
+            // Short last digit (the high tile bits: few, heavily skewed values): one add per distinct digit per wave.
+            const int lane = t & (kWave - 1);
+            const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
+            const unsigned long long m = matchDigit<BITS>(digit, valid);
+            if (valid && (m & lower) == 0ull) atomicAdd(&hist[digit], __popcll(m));
+        }
+    }
+    __syncthreads();
+    table[blockIdx.x * kDigits + t] = hist[t]; // 1 KiB contiguous per tile
+}
+
+// One workgroup (1024 lanes) per digit: exclusive scan of column `digit` of table[tile][digit] over the tiles (the
+// table is L2-resident: 1 KiB per tile), column total to totals[digit].
+constexpr int kScanThreads = 1024;
+__global__ __launch_bounds__(kScanThreads) void radixColumnScanKernel(int numTiles, const int32_t* __restrict__ table,
+                                                                      int32_t* __restrict__ scanned, int32_t* __restrict__ totals)
+{
+    constexpr int kScanWaves = kScanThreads / kWave;
+    __shared__ int waveSums[2][kScanWaves];
+    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
+    const int digit = blockIdx.x;
+    int carry = 0, flip = 0;
+    for (int base = 0; base < numTiles; base += kScanThreads, flip ^= 1)
+    {
+        const int tile = base + t;
+        const int v = (tile < numTiles) ? table[tile * kDigits + digit] : 0;
+        int incl = v;
 #pragma unroll
         for (int delta = 1; delta < kWave; delta <<= 1)
         {
             const int o = __shfl_up(incl, delta);
             if (lane >= delta) incl += o;
         }
-        if (lane == kWave - 1) waveSums[wave] = incl;
-        __syncthreads();
-        int before = 0;
+        if (lane == kWave - 1) waveSums[flip][wave] = incl;
+        __syncthreads(); // the other half of waveSums is free for the next round: one barrier per round
+        int before = 0, all = 0;
 #pragma unroll
-        for (int w = 0; w != kWaves; ++w) before += (w < wave) ? waveSums[w] : 0;
-        int p = before + incl - s;
-#pragma unroll
-        for (int j = 0; j != 4; ++j)
+        for (int w = 0; w != kScanWaves; ++w)
         {
-            chunkPrefix[t * 4 + j] = p;
-            p += c[j];
+            const int ws = waveSums[flip][w];
+            before += (w < wave) ? ws : 0;
+            all += ws;
         }
+        if (tile < numTiles) scanned[tile * kDigits + digit] = carry + before + incl - v;
+        carry += all;
     }
-    __syncthreads();
+    if (t == 0) totals[digit] = carry;
+}
 
-    // ---- load the tile: element (wave, row, lane) is tile index wave*1024 + row*64 + lane ------------
-    K key[kItems];
-    int32_t val[kItems];
-    int rank[kItems];
-    const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
+template <typename K, int BITS, int ITEMS>
+__global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restrict__ keysIn, const int32_t* __restrict__ valuesIn,
+                                                                K* __restrict__ keysOut, int32_t* __restrict__ valuesOut, int n,
+                                                                int shift, const int32_t* __restrict__ scanned,
+                                                                const int32_t* __restrict__ totals)
+{
+    constexpr int kTile = kThreads * ITEMS;
+    constexpr int kDigitMask = (1 << BITS) - 1;
+    __shared__ int cnt[kWaves][kDigits]; // per-wave running digit counters, then per-wave exclusive prefixes
+    __shared__ int localBase[kDigits];   // first slot of each digit inside the tile
+    __shared__ int globalBase[kDigits];  // first output index of each digit for this tile
+    __shared__ int waveSums[2][kWaves];
+    __shared__ K sKeys[kTile];
+    __shared__ int32_t sVals[kTile];
+
+    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
+    const int tile = blockIdx.x;
+    const int base = tile * kTile;
+    const int tileCount = min(kTile, n - base);
+
+    // ---- load the tile: element (wave, row, lane) is tile index wave*64*ITEMS + row*64 + lane ---------
+    K key[ITEMS];
+    int32_t val[ITEMS];
 #pragma unroll
-    for (int r = 0; r != kItems; ++r)
+    for (int r = 0; r != ITEMS; ++r)
     {
-        const int i = base + wave * (kWave * kItems) + r * kWave + lane;
+        const int i = base + wave * (kWave * ITEMS) + r * kWave + lane;
         const bool valid = i < n;
         key[r] = valid ? keysIn[i] : K(0);
         val[r] = valid ? valuesIn[i] : 0;
     }
-    // ---- stable rank inside the wave: running per-digit counters -------------------------------------
+    const int digitTotal = totals[t];
+    const int tileEntry = scanned[tile * kDigits + t];
 #pragma unroll
-    for (int r = 0; r != kItems; ++r)
+    for (int w = 0; w != kWaves; ++w) cnt[w][t] = 0;
+    __syncthreads();
+
+    // ---- stable rank inside the wave: ballot match, then running per-digit counters ----------------------
+    const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
+    unsigned long long match[ITEMS];
+#pragma unroll
+    for (int r = 0; r != ITEMS; ++r) // independent of each other: issued back to back
     {
-        const int i = base + wave * (kWave * kItems) + r * kWave + lane;
-        const bool valid = i < n;
+        const bool valid = base + wave * (kWave * ITEMS) + r * kWave + lane < n;
+        match[r] = matchDigit<BITS>((int) ((key[r] >> shift) & kDigitMask), valid);
+    }
+    int rank[ITEMS];
+#pragma unroll
+    for (int r = 0; r != ITEMS; ++r)
+    {
+        const unsigned long long m = match[r];
         const int digit = (int) ((key[r] >> shift) & kDigitMask);
-        const unsigned long long m = matchDigit<BITS>(digit, valid);
+        const bool valid = m != 0ull;
         const int leader = valid ? (__ffsll((long long) m) - 1) : lane;
         int old = 0;
         if (valid && lane == leader)
@@ -208,62 +197,86 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
             cnt[w][t] = sum;
             sum += c;
         }
-        int incl = sum;
+        int inclLocal = sum, inclGlobal = digitTotal;
 #pragma unroll
         for (int delta = 1; delta < kWave; delta <<= 1)
         {
-            const int o = __shfl_up(incl, delta);
-            if (lane >= delta) incl += o;
+            const int a = __shfl_up(inclLocal, delta);
+            const int b = __shfl_up(inclGlobal, delta);
+            if (lane >= delta)
+            {
+                inclLocal += a;
+                inclGlobal += b;
+            }
         }
-        if (lane == kWave - 1) waveSums[wave] = incl;
+        if (lane == kWave - 1)
+        {
+            waveSums[0][wave] = inclLocal;
+            waveSums[1][wave] = inclGlobal;
+        }
         __syncthreads();
-        int before = 0;
+        int beforeLocal = 0, beforeGlobal = 0;
 #pragma unroll
-        for (int w = 0; w != kWaves; ++w) before += (w < wave) ? waveSums[w] : 0;
-        localBase[t] = before + incl - sum;
-        const int entry = t * numTiles + tile;
-        globalBase[t] = (t <= kDigitMask) ? scanned[entry] + chunkPrefix[entry / kScanChunk] : 0;
+        for (int w = 0; w != kWaves; ++w)
+        {
+            beforeLocal += (w < wave) ? waveSums[0][w] : 0;
+            beforeGlobal += (w < wave) ? waveSums[1][w] : 0;
+        }
+        localBase[t] = beforeLocal + inclLocal - sum;
+        globalBase[t] = beforeGlobal + inclGlobal - digitTotal + tileEntry;
     }
     __syncthreads();
 
     // ---- reorder by digit in LDS ----------------------------------------------------------------------
 #pragma unroll
-    for (int r = 0; r != kItems; ++r)
+    for (int r = 0; r != ITEMS; ++r)
     {
-        const int i = base + wave * (kWave * kItems) + r * kWave + lane;
-        if (i < n)
+        if (match[r] != 0ull)
         {
             const int digit = (int) ((key[r] >> shift) & kDigitMask);
             const int slot = localBase[digit] + cnt[wave][digit] + rank[r];
-            sKeys[slot] = (uint32_t) key[r];
+            sKeys[slot] = key[r];
             sVals[slot] = val[r];
         }
     }
     __syncthreads();
 
     // ---- write runs ---------------------------------------------------------------------------------
-#pragma unroll 4
-    for (int j = t; j < tileCount; j += kThreads)
+#pragma unroll
+    for (int r = 0; r != ITEMS; ++r)
     {
-        const uint32_t k = sKeys[j];
-        const int digit = (int) ((k >> shift) & kDigitMask);
-        const int pos = globalBase[digit] + (j - localBase[digit]);
-        keysOut[pos] = (K) k;
-        valuesOut[pos] = sVals[j];
+        const int j = r * kThreads + t;
+        if (j < tileCount)
+        {
+            const K k = sKeys[j];
+            const int digit = (int) ((k >> shift) & kDigitMask);
+            const int pos = globalBase[digit] + (j - localBase[digit]);
+            keysOut[pos] = k;
+            valuesOut[pos] = sVals[j];
+        }
     }
+}
+
+int itemsPerLane(int n) { return n <= kSmallLimit ? kItemsSmall : kItemsLarge; }
+
+template <typename K, int BITS, int ITEMS>
+void runPassItems(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, K* keysOut, int32_t* valuesOut, int n, int shift,
+                  RadixScratch& s)
+{
+    constexpr int kTile = kThreads * ITEMS;
+    const int numTiles = (n + kTile - 1) / kTile;
+    hipLaunchKernelGGL((radixHistogramKernel<K, BITS, ITEMS>), dim3(numTiles), dim3(kThreads), 0, stream, keysIn, n, shift, s.table);
+    hipLaunchKernelGGL(radixColumnScanKernel, dim3(kDigits), dim3(kScanThreads), 0, stream, numTiles, s.table, s.scanned, s.chunkTotals);
+    hipLaunchKernelGGL((radixScatterKernel<K, BITS, ITEMS>), dim3(numTiles), dim3(kThreads), 0, stream, keysIn, valuesIn, keysOut,
+                       valuesOut, n, shift, s.scanned, s.chunkTotals);
 }
 
 template <typename K, int BITS>
 void runPass(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, K* keysOut, int32_t* valuesOut, int n, int shift,
              RadixScratch& s)
 {
-    const int numTiles = (n + kTile - 1) / kTile;
-    const int entries = kDigits * numTiles;
-    const int numChunks = (entries + kScanChunk - 1) / kScanChunk;
-    hipLaunchKernelGGL((radixHistogramKernel<K, BITS>), dim3(numTiles), dim3(kThreads), 0, stream, keysIn, n, shift, numTiles, s.table);
-    hipLaunchKernelGGL(radixChunkScanKernel, dim3(numChunks), dim3(1024), 0, stream, entries, s.table, s.scanned, s.chunkTotals);
-    hipLaunchKernelGGL((radixScatterKernel<K, BITS>), dim3(numTiles), dim3(kThreads), 0, stream, keysIn, valuesIn, keysOut, valuesOut, n,
-                       shift, numTiles, s.scanned, s.chunkTotals, numChunks);
+    if (n <= kSmallLimit) runPassItems<K, BITS, kItemsSmall>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, s);
+    else runPassItems<K, BITS, kItemsLarge>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, s);
 }
 
 template <typename K>
@@ -302,15 +315,12 @@ int sortT(hipStream_t stream, K* keys0, K* keys1, int32_t* values0, int32_t* val
 
 } // namespace
 
-bool radixSortSupported(int keyBytes, int n)
-{
-    const long long numTiles = ((long long) n + kTile - 1) / kTile;
-    return (keyBytes == 2 || keyBytes == 4) && numTiles * kDigits <= (long long) kMaxChunks * kScanChunk;
-}
+bool radixSortSupported(int keyBytes, int n) { return (keyBytes == 2 || keyBytes == 4) && n >= 0; }
 
 void ensureRadixScratch(RadixScratch& s, int n)
 {
-    const int numTiles = (n + kTile - 1) / kTile;
+    const int tile = kThreads * itemsPerLane(n);
+    const int numTiles = (n + tile - 1) / tile;
     const int entries = kDigits * std::max(numTiles, 1);
     if (entries > s.capacityEntries)
     {
@@ -320,7 +330,7 @@ void ensureRadixScratch(RadixScratch& s, int n)
         GS_CHECK(hipMalloc((void**) &s.scanned, sizeof(int32_t) * (size_t) entries));
         s.capacityEntries = entries;
     }
-    if (s.chunkTotals == nullptr) GS_CHECK(hipMalloc((void**) &s.chunkTotals, sizeof(int32_t) * kMaxChunks));
+    if (s.chunkTotals == nullptr) GS_CHECK(hipMalloc((void**) &s.chunkTotals, sizeof(int32_t) * kDigits));
 }
 
 void freeRadixScratch(RadixScratch& s)

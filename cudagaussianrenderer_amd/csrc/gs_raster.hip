@@ -56,14 +56,17 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
     constexpr int GROUPS_X = kTileSize / PPL;
     __shared__ float4 sA[kBatch];   // cx, cy, A', B'
     __shared__ float4 sB[kBatch];   // C', r, g, b
-    __shared__ float sAlpha[kBatch];
+    __shared__ __attribute__((aligned(16))) float sAlpha[kBatch];
 
-    // XCD-aware remap (bijective for any grid size): workgroups b, b+8, b+16, ... share an XCD and take
-    // consecutive tiles.
+    // XCD-aware remap: workgroups b, b+8, b+16, ... share an XCD (round-robin dispatch). Inside every group of 64
+    // consecutive tiles each XCD takes a run of 8 neighbouring tiles (neighbours share splats -> shared L2), while
+    // the groups themselves interleave over the XCDs, so a dense screen region is spread over all eight of them.
+    // (Giving each XCD one contiguous eighth of the screen left the XCDs that own the empty top/bottom rows idle.)
     int wg = blockIdx.x;
     {
-        const int nwg = numTiles, q = nwg / 8, r = nwg % 8, xcd = wg % 8, slot = wg / 8;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        const int group = wg & ~63, inGroup = wg & 63;
+        const int remapped = group + (inGroup & 7) * 8 + (inGroup >> 3);
+        if (group + 64 <= numTiles) wg = remapped; // the ragged last group keeps the identity map
     }
     const int tile = firstTile + wg;
 
@@ -115,11 +118,15 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
     {
         const int n = min(count - base, kBatch);
         __syncthreads(); // every wave is done reading the previous batch
-        if (t < n)
+        if (t < kBatch)
         {
-            sA[t] = make_float4(gCentre.x, gCentre.y, gConic.x * kHalfLog2e, gConic.y * (2.0f * kHalfLog2e));
-            sB[t] = make_float4(gConic.z * kHalfLog2e, gColor.x, gColor.y, gColor.z);
-            sAlpha[t] = gColor.w;
+            // Entries past the end of the list are staged as all-zero records: opacity 0 makes them exact no-ops
+            // (w = T*0, C += c*0, T -= T*0), so the blend loop can always run whole groups of four.
+            const bool live = t < n;
+            sA[t] = live ? make_float4(gCentre.x, gCentre.y, gConic.x * kHalfLog2e, gConic.y * (2.0f * kHalfLog2e))
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+            sB[t] = live ? make_float4(gConic.z * kHalfLog2e, gColor.x, gColor.y, gColor.z) : make_float4(0.f, 0.f, 0.f, 0.f);
+            sAlpha[t] = live ? gColor.w : 0.0f;
         }
         __syncthreads();
         if (base + kBatch < count) gather(base + kBatch); // in flight while this batch is blended
@@ -128,27 +135,48 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
         for (int chunk = 0; chunk < n; chunk += kRasterChunk)
         {
             const int m = min(kRasterChunk, n - chunk);
-            for (int i = chunk; i != chunk + m; ++i)
+            // Four list entries per step: their LDS reads and their (mutually independent) densities are issued
+            // together, then the four order-dependent blends follow.
+            for (int i = chunk; i < chunk + m; i += 4)
             {
-                const float4 a = sA[i];
-                const float4 b = sB[i];
-                const float opacity = sAlpha[i];
-                // GaussianRender.cu:972-984
-                const float dy = clipPy - a.y;
-                const float qy = b.x * dy * dy; // C' dy^2
-                const float by = a.w * dy;      // B' dy
+                float4 a[4], b[4];
+                const float4 opacity4 = *reinterpret_cast<const float4*>(&sAlpha[i]);
+                const float opacity[4] = {opacity4.x, opacity4.y, opacity4.z, opacity4.w};
 #pragma unroll
-                for (int p = 0; p != PPL; ++p)
+                for (int e = 0; e != 4; ++e)
                 {
-                    const float dx = clipPx[p] - a.x;
-                    const float power = fmaf(dx, fmaf(a.z, dx, by), qy);
-                    const float density = __saturatef(__builtin_amdgcn_exp2f(power));
-                    const float alpha = opacity * density;
-                    const float w = tr[p] * alpha;
-                    cr[p] = fmaf(b.y, w, cr[p]);
-                    cg[p] = fmaf(b.z, w, cg[p]);
-                    cb[p] = fmaf(b.w, w, cb[p]);
-                    tr[p] = fmaf(-tr[p], alpha, tr[p]);
+                    a[e] = sA[i + e];
+                    b[e] = sB[i + e];
+                }
+                float alpha[4][PPL];
+#pragma unroll
+                for (int e = 0; e != 4; ++e)
+                {
+                    // GaussianRender.cu:972-982
+                    const float dy = clipPy - a[e].y;
+                    const float qy = b[e].x * dy * dy; // C' dy^2
+                    const float by = a[e].w * dy;      // B' dy
+#pragma unroll
+                    for (int p = 0; p != PPL; ++p)
+                    {
+                        const float dx = clipPx[p] - a[e].x;
+                        const float power = fmaf(dx, fmaf(a[e].z, dx, by), qy);
+                        alpha[e][p] = opacity[e] * __saturatef(__builtin_amdgcn_exp2f(power));
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e != 4; ++e)
+                {
+                    // GaussianRender.cu:983-984
+#pragma unroll
+                    for (int p = 0; p != PPL; ++p)
+                    {
+                        const float w = tr[p] * alpha[e][p];
+                        cr[p] = fmaf(b[e].y, w, cr[p]);
+                        cg[p] = fmaf(b[e].z, w, cg[p]);
+                        cb[p] = fmaf(b[e].w, w, cb[p]);
+                        tr[p] = fmaf(-tr[p], alpha[e][p], tr[p]);
+                    }
                 }
             }
             consumed = base + chunk + m;
@@ -193,11 +221,11 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
     }
 }
 
-int g_rasterPixelsPerLane = 4;
+int g_rasterPixelsPerLane = 2;
 
 } // namespace
 
-void setRasterPixelsPerLane(int ppl) { g_rasterPixelsPerLane = (ppl == 1 || ppl == 2 || ppl == 4) ? ppl : 4; }
+void setRasterPixelsPerLane(int ppl) { g_rasterPixelsPerLane = (ppl == 1 || ppl == 2 || ppl == 4) ? ppl : 2; }
 int rasterPixelsPerLane() { return g_rasterPixelsPerLane; }
 
 void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileRange, const int32_t* values,
@@ -217,6 +245,7 @@ void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileR
         hipLaunchKernelGGL(rasterizeTilesKernel<2>, dim3(numTiles), dim3(128), 0, stream, scr, firstTile, numTiles, tileRange, values,
                            clipXY, conic, color, backBuffer, consumedPairsOrNull);
         break;
+    case 4:
     default:
         hipLaunchKernelGGL(rasterizeTilesKernel<4>, dim3(numTiles), dim3(64), 0, stream, scr, firstTile, numTiles, tileRange, values,
                            clipXY, conic, color, backBuffer, consumedPairsOrNull);

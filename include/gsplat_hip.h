@@ -136,7 +136,8 @@ int gs_get_sort_backend(void);
  * size/key type is not supported. Device pointers, enqueued on the current stream. */
 int gs_radix_sort_pairs(int keyBytes, void* keys0, void* keys1, int32_t* values0, int32_t* values1, int32_t count, int beginBit,
                         int endBit);
-/* Addition (tuning): pixels per lane of the raster kernel, 1, 2 or 4 (default 4 = one wave per tile). */
+/* Addition (tuning): pixels per lane of the raster kernel: 1 (four waves per tile), 2 (two waves, default) or
+ * 4 (one wave per tile). */
 void gs_set_raster_pixels_per_lane(int pixelsPerLane);
 int gs_get_raster_pixels_per_lane(void);
 

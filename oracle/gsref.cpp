@@ -653,6 +653,10 @@ extern "C" void gsref_evaluate_tile_ranges(int64_t size, const uint64_t* keys, i
 // ----------------------------------------------------------------------------------------------
 // Raster (.cu:908-1016)
 // ----------------------------------------------------------------------------------------------
+// Optional diagnostics: list entries consumed per tile (caller-owned int32[tiles], zeroed by the caller).
+static int32_t* g_consumedPerTile = nullptr;
+extern "C" void gsref_set_consumed_per_tile_buffer(int32_t* buffer) { g_consumedPerTile = buffer; }
+
 extern "C" int64_t gsref_rasterize_tiles(int width, int height, int tileRowBegin, int tileRowEnd, const int32_t* tileRange,
                                          const int32_t* values, const float* clipXY2, const float* conic4,
                                          const float* color4, uint8_t* backBuffer)
@@ -690,6 +694,7 @@ extern "C" int64_t gsref_rasterize_tiles(int width, int height, int tileRowBegin
             {
                 int n = std::min(splatsCount, k_ChunkSize); // .cu:950
                 consumed += n;
+                if (g_consumedPerTile) g_consumedPerTile[tile] += n;
                 for (int i = 0; i != n; ++i)
                 {
                     // .cu:957-962

@@ -172,7 +172,7 @@ def test_raster_stage(gs, gsref, ppl, w, h):
         got = f.run_raster()
         got_consumed = gs.lib().gs_last_raster_consumed_pairs()
     finally:
-        gs.lib().gs_set_raster_pixels_per_lane(4)
+        gs.lib().gs_set_raster_pixels_per_lane(2)
         gs.lib().gs_set_collect_raster_stats(0)
     _assert_image_close(got, want, f"ppl={ppl}")
     assert np.array_equal(got[..., 3], want[..., 3])  # alpha: 255 where a tile had work, 0 elsewhere
