@@ -68,7 +68,7 @@ def main():
     import torch.distributed as dist
 
     import cudagaussianrenderer_amd as gs
-    from cudagaussianrenderer_amd import scenes
+    from cudagaussianrenderer_amd import multigpu, scenes
 
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -107,23 +107,11 @@ def main():
     cameras = [gs.camera_from_pose(p, q, W, H) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], args.views)]
 
     def pixel_rows(b):
-        return b[0] * gs.TILE_SIZE, min(b[1] * gs.TILE_SIZE, H)
+        return multigpu.pixel_rows(b, H)
 
     def gather_framebuffer():
         """Bands -> rank 0, one grouped RCCL send/recv set; receives land directly in the framebuffer rows."""
-        if world == 1:
-            return
-        if rank == 0:
-            ops = []
-            for src in range(1, world):
-                a, b = pixel_rows(bands[src])
-                if b > a:
-                    ops.append(dist.P2POp(dist.irecv, framebuffer[a:b], src))
-        else:
-            a, b = pixel_rows(band)
-            ops = [dist.P2POp(dist.isend, framebuffer[a:b], 0)] if b > a else []
-        for work in dist.batch_isend_irecv(ops) if ops else []:
-            work.wait()  # orders the current stream after the transfer; no host block
+        multigpu.gather_bands(framebuffer, bands, rank, world)
 
     def step(i, timed=0):
         renderer.render(cameras[i % len(cameras)], timed=timed)

@@ -1,0 +1,168 @@
+// gsplat_demo.cpp -- headless C++ host over GaussianRender.hpp: what the reference's Demo.cpp does per frame
+// (src/Demo.cpp:314-331 buffers, :352-479 frame, :541-562 per-stage averages), without the window.
+//
+//   gsplat_demo scene.ply [width height frames out.ppm]     render a 3DGS .ply from its default camera pose
+//   gsplat_demo --procedural N [width height frames out.ppm] N random splats (Demo.cpp:119-143, seeded)
+//
+// Build: make -C cudagaussianrenderer_amd/csrc demo
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "GaussianRender.hpp"
+
+int main(int argc, char** argv)
+{
+    if (argc < 2)
+    {
+        std::fprintf(stderr, "usage: %s scene.ply|--procedural N [width height frames out.ppm]\n", argv[0]);
+        return 2;
+    }
+    int arg = 1;
+    std::vector<gs::float4_t> position, scaleAndRotation, color;
+    std::vector<float> sphericalHarmonics;
+    int shDegree = 0, shCount = 0;
+    gs::vec3_t boundsMin{-4, -4, -4}, boundsMax{4, 4, 4};
+    if (std::strcmp(argv[arg], "--procedural") == 0)
+    {
+        const int n = std::atoi(argv[arg + 1]);
+        arg += 2;
+        position.resize(n);
+        scaleAndRotation.resize(n);
+        color.resize(n);
+        const float lo[3] = {-4, -4, -4}, hi[3] = {4, 4, 4};
+        gs::generateRandomGaussians(position, scaleAndRotation, color, 0.01f, 0.5f, lo, hi);
+    }
+    else
+    {
+        gs::parsePly(argv[arg++], position, scaleAndRotation, color, sphericalHarmonics, shDegree, shCount, boundsMin, boundsMax);
+        if (shDegree != 0)
+        {
+            std::vector<float> aligned;
+            gs::realignSphericalHarmonics(sphericalHarmonics, aligned, GS_SH_GROUP_SIZE, shCount, (int) position.size());
+            sphericalHarmonics.swap(aligned);
+        }
+    }
+    const int width = argc > arg ? std::atoi(argv[arg]) : 1024;
+    const int height = argc > arg + 1 ? std::atoi(argv[arg + 1]) : 1024;
+    const int frames = argc > arg + 2 ? std::atoi(argv[arg + 2]) : 100;
+    const char* outPath = argc > arg + 3 ? argv[arg + 3] : nullptr;
+    const int32_t splatCount = (int32_t) position.size();
+
+    int tilesX = 0, tilesY = 0;
+    gs_tile_counts(width, height, &tilesX, &tilesY);
+
+    // Device buffers, owned by the caller as in the reference.
+    gs::DeviceBuffer<gs::float4_t> positionBuffer(position), scaleAndRotationBuffer(scaleAndRotation), colorBuffer(color);
+    gs::DeviceBuffer<float> shBuffer(sphericalHarmonics);
+    gs::DeviceBuffer<gs::float4_t> conicBuffer(splatCount), ellipseBuffer(splatCount);
+    gs::DeviceBuffer<gs::float2_t> clipXYBuffer(splatCount);
+    gs::DeviceBuffer<float> clipZBuffer(splatCount);
+    gs::DeviceBuffer<int32_t> tileRangeBuffer((size_t) tilesX * tilesY * 2);
+    gs::DeviceBuffer<gs::uchar4_t> backBuffer((size_t) width * height);
+    int32_t capacity = splatCount * 8;
+    gs::DeviceBuffer<uint64_t> keysA(capacity), keysB(capacity);
+    gs::DeviceBuffer<int32_t> valuesA(capacity), valuesB(capacity);
+    void* sortTemp = nullptr;
+    size_t sortTempBytes = 0;
+
+    gs::CameraData camera;
+    gs_camera_from_bounds(&boundsMin.x, &boundsMax.x, width, height, &camera);
+
+    gs::GpuTimer timer;
+    double msSh = 0, msClip = 0, msBuild = 0, msSort = 0, msRanges = 0, msRaster = 0;
+    bool saturated = false;
+    for (int frame = 0; frame != frames; ++frame)
+    {
+        if (saturated) // grow the list when the previous frame filled it
+        {
+            capacity <<= 1;
+            keysA.resizeIfNeeded(capacity);
+            keysB.resizeIfNeeded(capacity);
+            valuesA.resizeIfNeeded(capacity);
+            valuesB.resizeIfNeeded(capacity);
+        }
+        backBuffer.clearMemory(0);
+        tileRangeBuffer.clearMemory(255);
+
+        gs::GlobalArgs args{};
+        args.cameraData = camera;
+        args.position = &positionBuffer.getPtr()->x;
+        args.scaleAndRotation = &scaleAndRotationBuffer.getPtr()->x;
+        args.color = &colorBuffer.getPtr()->x;
+        args.sphericalHarmonicsDegree = shDegree;
+        args.sphericalHarmonicsCount = shCount;
+        args.sphericalHarmonics = shBuffer.getPtr();
+        args.positionClipSpaceXY = &clipXYBuffer.getPtr()->x;
+        args.positionClipSpaceZ = clipZBuffer.getPtr();
+        args.conic = &conicBuffer.getPtr()->x;
+        args.screenEllipse = &ellipseBuffer.getPtr()->x;
+        args.splatCount = splatCount;
+        args.backBuffer = &backBuffer.getPtr()->x;
+        args.tileRange = tileRangeBuffer.getPtr();
+        args.width = width;
+        args.height = height;
+        gs::setGlobalArgs(&args);
+
+        gs::TileListArgs list{keysA.getPtr(), valuesA.getPtr(), 0, capacity};
+        gs::setTileListArgs(&list);
+
+        if (shDegree != 0)
+        {
+            gs::evaluateSphericalHarmonics(timer, splatCount);
+            msSh += timer.getElapseTimedMs();
+        }
+        gs::evaluateSplatClipData(timer, splatCount);
+        msClip += timer.getElapseTimedMs();
+
+        list.size = gs::buildTileList(timer, 256 * 8, capacity);
+        msBuild += timer.getElapseTimedMs();
+        saturated = list.size == capacity;
+        gs::setTileListArgs(&list);
+
+        gs::DoubleBuffer<uint64_t> keys(keysA.getPtr(), keysB.getPtr());
+        gs::DoubleBuffer<int32_t> values(valuesA.getPtr(), valuesB.getPtr());
+        gs::sortTileList(timer, list.size, sortTemp, sortTempBytes, keys, values);
+        msSort += timer.getElapseTimedMs();
+        list.keys = keys.current();
+        list.values = values.current();
+        gs::setTileListArgs(&list);
+
+        if (list.size != 0)
+        {
+            gs::evaluateTileRange(timer, list.size);
+            msRanges += timer.getElapseTimedMs();
+        }
+        gs::rasterizeTile(timer);
+        msRaster += timer.getElapseTimedMs();
+        gs_synchronize();
+    }
+    gs_device_free(sortTemp);
+
+    const double f = frames > 0 ? frames : 1;
+    std::printf("splats %d, %dx%d, %d frames (staged calls, blocking per-stage timers)\n", splatCount, width, height, frames);
+    std::printf("Evaluate Spherical Harmonics %.6f ms\nEvaluate Clip Data %.6f ms\nBuild Tile List %.6f ms\nSort Tile List %.6f ms\n"
+                "Evaluate Tile Ranges %.6f ms\nRasterize %.6f ms\nTotal %.6f ms\n",
+                msSh / f, msClip / f, msBuild / f, msSort / f, msRanges / f, msRaster / f,
+                (msSh + msClip + msBuild + msSort + msRanges + msRaster) / f);
+
+    if (outPath != nullptr)
+    {
+        std::vector<gs::uchar4_t> image;
+        backBuffer.copyTo(image, (size_t) width * height);
+        std::FILE* fp = std::fopen(outPath, "wb");
+        if (fp == nullptr) return 1;
+        std::fprintf(fp, "P6\n%d %d\n255\n", width, height);
+        for (int y = height - 1; y >= 0; --y) // row 0 of the buffer is the bottom of the image
+            for (int x = 0; x != width; ++x)
+            {
+                const gs::uchar4_t p = image[(size_t) y * width + x];
+                const unsigned char rgb[3] = {p.x, p.y, p.z};
+                std::fwrite(rgb, 1, 3, fp);
+            }
+        std::fclose(fp);
+    }
+    return 0;
+}
