@@ -250,13 +250,15 @@ def parse_ply(path):
 class Renderer:
     """The frame loop body of src/Demo.cpp:352-479 behind one call."""
 
-    def __init__(self, width, height, tile_rows=None, pipeline=None):
+    def __init__(self, width, height, tile_rows=None, pipeline=None, band_cull=None):
         self.width, self.height = width, height
         self.handle = lib().gs_renderer_create(width, height)
         if tile_rows is not None:
             lib().gs_renderer_set_tile_rows(self.handle, tile_rows[0], tile_rows[1])
         if pipeline is not None:
             lib().gs_renderer_set_pipeline(self.handle, pipeline)
+        if band_cull is not None:  # 0 auto (on for a strict sub-band of tile rows), 1 on, 2 off
+            lib().gs_renderer_set_band_cull(self.handle, band_cull)
         self.splat_count = 0
 
     def set_scene(self, position, scale_and_rotation, color, sh=None, sh_degree=0, sh_count=0):

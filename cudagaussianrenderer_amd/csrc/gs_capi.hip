@@ -315,6 +315,13 @@ struct GsRenderer
     float *clipXY = nullptr, *clipZ = nullptr, *conic = nullptr, *ellipse = nullptr;
     uint32_t* depthKey[2] = {nullptr, nullptr};
     int32_t* order[2] = {nullptr, nullptr};
+    // band cull (multi-GPU): per-splat coefficients in the [splat][shCount] layout for gathered SH evaluation,
+    // one keep-mask and count per 64 splats, their scan, and the kept-splat count (device scalar)
+    float* shPerSplat = nullptr;
+    unsigned long long* bandMask = nullptr;
+    int32_t *bandCounts = nullptr, *bandOffsets = nullptr;
+    int64_t* bandTotal = nullptr;
+    int bandCull = GS_BAND_CULL_AUTO;
     int32_t* tileRange = nullptr;
     uint8_t* backBufferOwned = nullptr;
     uint8_t* backBuffer = nullptr;
@@ -375,6 +382,15 @@ void freeScene(GsRenderer* r)
         r->depthKey[i] = nullptr;
         r->order[i] = nullptr;
     }
+    gs_device_free(r->shPerSplat);
+    gs_device_free(r->bandMask);
+    gs_device_free(r->bandCounts);
+    gs_device_free(r->bandOffsets);
+    gs_device_free(r->bandTotal);
+    r->shPerSplat = nullptr;
+    r->bandMask = nullptr;
+    r->bandCounts = r->bandOffsets = nullptr;
+    r->bandTotal = nullptr;
 }
 void ensureSortTemp(GsRenderer* r, size_t required)
 {
@@ -405,6 +421,7 @@ extern "C" GsRenderer* gs_renderer_create(int width, int height)
     r->tileRange = (int32_t*) gs_device_alloc(sizeof(int32_t) * 2 * (size_t) scr.totalTiles);
     r->backBufferOwned = (uint8_t*) gs_device_alloc((size_t) scr.width * scr.height * 4);
     r->backBuffer = r->backBufferOwned;
+    GS_CHECK(hipMemset(r->backBufferOwned, 0, (size_t) scr.width * scr.height * 4)); // rows outside a band stay zero
     r->timer = gs_timer_create();
     GS_CHECK(hipEventCreate(&r->frameStart));
     GS_CHECK(hipEventCreate(&r->frameStop));
@@ -440,6 +457,11 @@ extern "C" void gs_renderer_set_pipeline(GsRenderer* r, int pipeline)
     r->pipeline = (pipeline == GS_PIPELINE_REFERENCE) ? GS_PIPELINE_REFERENCE : GS_PIPELINE_TWO_LEVEL;
 }
 
+extern "C" void gs_renderer_set_band_cull(GsRenderer* r, int mode)
+{
+    r->bandCull = (mode == GS_BAND_CULL_ON || mode == GS_BAND_CULL_OFF) ? mode : GS_BAND_CULL_AUTO;
+}
+
 extern "C" int gs_renderer_set_scene(GsRenderer* r, int32_t n, const float* position4, const float* scaleAndRotation4,
                                      const float* color4, const float* sh, int shDegree, int shCount)
 {
@@ -465,6 +487,11 @@ extern "C" int gs_renderer_set_scene(GsRenderer* r, int32_t n, const float* posi
     gs_device_upload(r->position, position4, f4);
     gs_device_upload(r->scaleAndRotation, scaleAndRotation4, f4);
     gs_device_upload(r->color, color4, f4);
+    const size_t waves = ((size_t) n + kWave - 1) / kWave;
+    r->bandMask = (unsigned long long*) gs_device_alloc(sizeof(unsigned long long) * waves);
+    r->bandCounts = (int32_t*) gs_device_alloc(sizeof(int32_t) * waves);
+    r->bandOffsets = (int32_t*) gs_device_alloc(sizeof(int32_t) * waves);
+    r->bandTotal = (int64_t*) gs_device_alloc(sizeof(int64_t));
     if (shDegree != 0)
     {
         // Demo.cpp:291-296
@@ -473,6 +500,9 @@ extern "C" int gs_renderer_set_scene(GsRenderer* r, int32_t n, const float* posi
         gs_realign_spherical_harmonics(sh, aligned.data(), GS_SH_GROUP_SIZE, shCount, n);
         r->sh = (float*) gs_device_alloc(total * sizeof(float));
         gs_device_upload(r->sh, aligned.data(), total * sizeof(float));
+        // second copy in the file's [splat][shCount] layout for the band-culled (gathered) SH evaluation
+        r->shPerSplat = (float*) gs_device_alloc(sizeof(float) * (size_t) n * shCount);
+        gs_device_upload(r->shPerSplat, sh, sizeof(float) * (size_t) n * shCount);
     }
     // Demo.cpp:325: 8 pairs per splat to start with; grown on demand.
     if (r->tileListCapacity < std::max(n, 1) * 8) allocTileList(r, std::max(n, 1) * 8);
@@ -568,7 +598,13 @@ extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int
     args.tileRowEnd = scr.rowEnd;
     gs_set_global_args(&args);
 
-    if (r->shDegree != 0) // Demo.cpp:432
+    // Band cull: with a strict sub-band of tile rows (one rank of a multi-GPU split) only the splats whose tile AABB
+    // reaches the band go through SH evaluation, the depth sort and the tile-list passes.
+    const bool strictBand = scr.rowBegin > 0 || scr.rowEnd < scr.tilesY;
+    const bool cull = twoLevel && n > 0 && g.sortBackend == GS_SORT_BACKEND_NATIVE &&
+                      (r->bandCull == GS_BAND_CULL_ON || (r->bandCull == GS_BAND_CULL_AUTO && strictBand));
+
+    if (r->shDegree != 0 && !cull) // Demo.cpp:432
     {
         gs_evaluate_spherical_harmonics(stageTimers[0], n);
         if (blocking) st.msSphericalHarmonics = gs_timer_elapsed_ms(stageTimers[0]);
@@ -618,11 +654,37 @@ extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int
         const int tBits = tileBits(scr.totalTiles);
 
         gs_timer_start(stageTimers[1]);
-        launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation,
-                            (float2*) r->clipXY, r->clipZ, (float4*) r->ellipse, (float4*) r->conic, r->depthKey[0],
-                            (uint32_t*) r->order[0]);
+        const int* countDevice = nullptr;
+        if (!cull)
+        {
+            launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation,
+                                (float2*) r->clipXY, r->clipZ, (float4*) r->ellipse, (float4*) r->conic, r->depthKey[0],
+                                (uint32_t*) r->order[0]);
+        }
+        else
+        {
+            // clip data for every splat + keep-mask, then an order-preserving compaction of (depth key, index)
+            launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation,
+                                (float2*) r->clipXY, r->clipZ, (float4*) r->ellipse, (float4*) r->conic, nullptr, nullptr, r->bandMask,
+                                r->bandCounts);
+            launchScanInt32(g.stream, (n + kWave - 1) / kWave, r->bandCounts, r->bandOffsets, r->bandTotal);
+            launchCompactBand(g.stream, n, r->bandMask, r->bandOffsets, r->clipZ, r->depthKey[0], (uint32_t*) r->order[0]);
+            countDevice = (const int*) r->bandTotal; // low 32 bits of the little-endian int64 total
+        }
         gs_timer_stop(stageTimers[1]);
         if (blocking) st.msClipData = gs_timer_elapsed_ms(stageTimers[1]);
+        if (cull && r->shDegree != 0)
+        {
+            // SH colour of the kept splats only (list = the compacted, still index-ordered order[0])
+            gs_timer_start(stageTimers[0]);
+            const float* cp = camera->position;
+            launchSphericalHarmonicsGather(g.stream, n, countDevice, r->shDegree, r->shCount, r->order[0], (const float4*) r->position,
+                                           r->shPerSplat, make_float3(cp[0], cp[1], cp[2]), (float4*) r->color);
+            gs_timer_stop(stageTimers[0]);
+            if (blocking) st.msSphericalHarmonics = gs_timer_elapsed_ms(stageTimers[0]);
+        }
+        g.radix.countDevice = countDevice;
+        g.scratch.countDevice = countDevice;
 
         // (1) splats by depth: 32-bit keys, N elements
         int orderSel = 0;
@@ -663,6 +725,9 @@ extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int
         gs_timer_stop(stageTimers[2]);
         if (blocking) st.msBuildTileList = gs_timer_elapsed_ms(stageTimers[2]);
         size = (int32_t) demand;
+
+        g.radix.countDevice = nullptr;
+        g.scratch.countDevice = nullptr;
 
         // (3) stable sort of the pairs on the tile bits only
         gs_timer_start(stageTimers[3]);

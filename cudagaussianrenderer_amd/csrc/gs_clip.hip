@@ -8,6 +8,7 @@
 //
 // One deliberate simplification: the reference stores (cos(atan2(e.y,e.x)), sin(atan2(e.y,e.x)))
 // of the NORMALISED principal eigenvector e; that is e itself, which is what is stored here.
+#include "gs_aabb.h"
 #include "gs_internal.h"
 
 namespace gs
@@ -24,7 +25,9 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
                                                             const float4* __restrict__ scaleAndRotation,
                                                             float2* __restrict__ clipXY, float* __restrict__ clipZ,
                                                             float4* __restrict__ screenEllipse, float4* __restrict__ conicOut,
-                                                            uint32_t* __restrict__ depthKey, uint32_t* __restrict__ splatOrder)
+                                                            uint32_t* __restrict__ depthKey, uint32_t* __restrict__ splatOrder,
+                                                            unsigned long long* __restrict__ bandMask,
+                                                            int32_t* __restrict__ bandWaveCounts)
 {
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= count) return;
@@ -129,6 +132,18 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
     extentX *= isVisible;
     extentY *= isVisible;
 
+    if (bandMask != nullptr)
+    {
+        // Band cull for the multi-GPU split: does this splat's tile AABB reach the tile rows this GPU owns?  Same AABB
+        // routine as the tile-list builder, so nothing that would emit a pair is dropped. One 64-bit mask per wave.
+        const TileAabb box = splatTileAabb(clipX, clipY, cosA, sinA, extentX, extentY, scr);
+        const unsigned long long mask = __ballot(box.x1 > box.x0 && box.y1 > box.y0);
+        if ((threadIdx.x & (kWave - 1)) == 0)
+        {
+            bandMask[index >> 6] = mask;
+            bandWaveCounts[index >> 6] = __popcll(mask);
+        }
+    }
     if (depthKey != nullptr)
     {
         // Quantised depth of getKey() (GaussianRender.cu:446-454) as a 32-bit sort key of its own, plus the
@@ -144,16 +159,45 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
     conicOut[index] = make_float4(covC * invDet, -covB * invDet, covA * invDet, 0.0f);
 }
 
+// Order-preserving compaction of the splats flagged by the band cull: depth key + splat index of every kept splat at
+// waveOffsets[wave] + (kept lanes below it).
+__global__ __launch_bounds__(256) void compactBandKernel(int count, const unsigned long long* __restrict__ bandMask,
+                                                          const int32_t* __restrict__ waveOffsets, const float* __restrict__ clipZ,
+                                                          uint32_t* __restrict__ depthKey, uint32_t* __restrict__ splatOrder)
+{
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= count) return;
+    const int lane = index & (kWave - 1);
+    const unsigned long long mask = bandMask[index >> 6];
+    if ((mask >> lane) & 1ull)
+    {
+        const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
+        const int pos = waveOffsets[index >> 6] + __popcll(mask & lower);
+        const float n01 = fminf(fmaxf((clipZ[index] + 1.0f) * 0.5f, 0.0f), 1.0f);
+        const float scaled = n01 * 4294967296.0f;
+        depthKey[pos] = (scaled >= 4294967296.0f) ? 0xFFFFFFFFu : (uint32_t) scaled;
+        splatOrder[pos] = (uint32_t) index;
+    }
+}
+
 } // namespace
+
+void launchCompactBand(hipStream_t stream, int count, const unsigned long long* bandMask, const int32_t* waveOffsets, const float* clipZ,
+                       uint32_t* depthKey, uint32_t* splatOrder)
+{
+    if (count <= 0) return;
+    hipLaunchKernelGGL(compactBandKernel, dim3((count + 255) / 256), dim3(256), 0, stream, count, bandMask, waveOffsets, clipZ, depthKey,
+                       splatOrder);
+}
 
 void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const ClipCamera& cam, const float4* position,
                          const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic,
-                         uint32_t* depthKey, uint32_t* splatOrder)
+                         uint32_t* depthKey, uint32_t* splatOrder, unsigned long long* bandMask, int32_t* bandWaveCounts)
 {
     if (count <= 0) return;
     const dim3 grid((count + 255) / 256), block(256);
     hipLaunchKernelGGL(splatClipDataKernel, grid, block, 0, stream, count, scr, cam, position, scaleAndRotation, clipXY, clipZ,
-                       screenEllipse, conic, depthKey, splatOrder);
+                       screenEllipse, conic, depthKey, splatOrder, bandMask, bandWaveCounts);
 }
 
 } // namespace gs

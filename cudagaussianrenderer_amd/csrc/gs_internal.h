@@ -59,7 +59,19 @@ void launchSphericalHarmonics(hipStream_t stream, int count, int degree, int shC
 
 void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const ClipCamera& cam, const float4* position,
                          const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic,
-                         uint32_t* depthKeyOrNull, uint32_t* splatOrderOrNull);
+                         uint32_t* depthKeyOrNull, uint32_t* splatOrderOrNull, unsigned long long* bandMaskOrNull = nullptr,
+                         int32_t* bandWaveCountsOrNull = nullptr);
+// Band cull (multi-GPU): the clip kernel flags the splats whose tile AABB reaches this GPU's rows (one 64-bit mask and
+// one count per 64 splats); after an exclusive scan of the counts this writes the kept splats' depth keys and indices,
+// order preserved.
+void launchCompactBand(hipStream_t stream, int count, const unsigned long long* bandMask, const int32_t* waveOffsets, const float* clipZ,
+                       uint32_t* depthKey, uint32_t* splatOrder);
+// Exclusive scan of n int32 on the device (one workgroup), total as int64.
+void launchScanInt32(hipStream_t stream, int n, const int32_t* in, int32_t* out, int64_t* total);
+// SH colour for the splats of a device-side index list only; coefficients in the [splat][shCount] layout.
+void launchSphericalHarmonicsGather(hipStream_t stream, int countHost, const int* countDevice, int degree, int shCount,
+                                    const int32_t* indices, const float4* position, const float* shPerSplat, float3 cameraPosition,
+                                    float4* color);
 
 // Scratch of the tile-list builder: per-wave pair counts, their exclusive scan, the total.
 struct TileListScratch
@@ -69,6 +81,7 @@ struct TileListScratch
     int64_t* total = nullptr;       // device scalar
     int64_t* totalHost = nullptr;   // pinned host mirror
     int32_t capacityWaves = 0;
+    const int* countDevice = nullptr; // optional device-side splat count (renderer, culled list); nullptr = host count
 };
 void ensureTileListScratch(TileListScratch& s, int count);
 void freeTileListScratch(TileListScratch& s);
@@ -97,8 +110,11 @@ struct RadixScratch
 {
     int32_t* table = nullptr;       // [256][tiles] digit histogram
     int32_t* scanned = nullptr;     // chunk-local exclusive scan of the table
-    int32_t* chunkTotals = nullptr; // one total per 4096-entry chunk
+    int32_t* chunkTotals = nullptr; // the 256 digit totals of the current pass
     int capacityEntries = 0;
+    // Optional device-side element count (<= the host-side n the grids are sized for); set per call by the renderer
+    // when the splat list was culled on the device, nullptr otherwise.
+    const int* countDevice = nullptr;
 };
 bool radixSortSupported(int keyBytes, int n);
 void ensureRadixScratch(RadixScratch& s, int n);

@@ -44,15 +44,19 @@ __device__ __forceinline__ unsigned long long matchDigit(int digit, bool valid)
 }
 
 template <typename K, int BITS, int ITEMS>
-__global__ __launch_bounds__(kThreads) void radixHistogramKernel(const K* __restrict__ keys, int n, int shift,
+__global__ __launch_bounds__(kThreads) void radixHistogramKernel(const K* __restrict__ keys, int nHost, const int* __restrict__ nDevice, int shift,
                                                                   int32_t* __restrict__ table)
 {
     constexpr int kTile = kThreads * ITEMS;
     __shared__ int hist[kDigits];
     const int t = threadIdx.x;
+    // The element count may live on the device (the renderer's band-culled splat list): nHost is then only the
+    // upper bound the grid was sized for; tiles past the real count do nothing.
+    const int n = nDevice ? min(*nDevice, nHost) : nHost;
+    const int base = blockIdx.x * kTile;
+    if (base >= n) return;
     hist[t] = 0;
     __syncthreads();
-    const int base = blockIdx.x * kTile;
     K key[ITEMS];
 #pragma unroll
     for (int r = 0; r != ITEMS; ++r) // all loads in flight before the first use
@@ -86,13 +90,15 @@ __global__ __launch_bounds__(kThreads) void radixHistogramKernel(const K* __rest
 // One workgroup (1024 lanes) per digit: exclusive scan of column `digit` of table[tile][digit] over the tiles (the
 // table is L2-resident: 1 KiB per tile), column total to totals[digit].
 constexpr int kScanThreads = 1024;
-__global__ __launch_bounds__(kScanThreads) void radixColumnScanKernel(int numTiles, const int32_t* __restrict__ table,
+__global__ __launch_bounds__(kScanThreads) void radixColumnScanKernel(int nHost, const int* __restrict__ nDevice, int tileElements, const int32_t* __restrict__ table,
                                                                       int32_t* __restrict__ scanned, int32_t* __restrict__ totals)
 {
     constexpr int kScanWaves = kScanThreads / kWave;
     __shared__ int waveSums[2][kScanWaves];
     const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
     const int digit = blockIdx.x;
+    const int n = nDevice ? min(*nDevice, nHost) : nHost;
+    const int numTiles = (n + tileElements - 1) / tileElements;
     int carry = 0, flip = 0;
     for (int base = 0; base < numTiles; base += kScanThreads, flip ^= 1)
     {
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(kScanThreads) void radixColumnScanKernel(int numTil
 
 template <typename K, int BITS, int ITEMS>
 __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restrict__ keysIn, const int32_t* __restrict__ valuesIn,
-                                                                K* __restrict__ keysOut, int32_t* __restrict__ valuesOut, int n,
+                                                                K* __restrict__ keysOut, int32_t* __restrict__ valuesOut, int nHost, const int* __restrict__ nDevice,
                                                                 int shift, const int32_t* __restrict__ scanned,
                                                                 const int32_t* __restrict__ totals)
 {
@@ -139,6 +145,8 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
     const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
     const int tile = blockIdx.x;
     const int base = tile * kTile;
+    const int n = nDevice ? min(*nDevice, nHost) : nHost;
+    if (base >= n) return; // whole workgroup (uniform): the grid was sized for the host-side upper bound
     const int tileCount = min(kTile, n - base);
 
     // ---- load the tile: element (wave, row, lane) is tile index wave*64*ITEMS + row*64 + lane ---------
@@ -265,10 +273,10 @@ void runPassItems(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, 
 {
     constexpr int kTile = kThreads * ITEMS;
     const int numTiles = (n + kTile - 1) / kTile;
-    hipLaunchKernelGGL((radixHistogramKernel<K, BITS, ITEMS>), dim3(numTiles), dim3(kThreads), 0, stream, keysIn, n, shift, s.table);
-    hipLaunchKernelGGL(radixColumnScanKernel, dim3(kDigits), dim3(kScanThreads), 0, stream, numTiles, s.table, s.scanned, s.chunkTotals);
+    hipLaunchKernelGGL((radixHistogramKernel<K, BITS, ITEMS>), dim3(numTiles), dim3(kThreads), 0, stream, keysIn, n, s.countDevice, shift, s.table);
+    hipLaunchKernelGGL(radixColumnScanKernel, dim3(kDigits), dim3(kScanThreads), 0, stream, n, s.countDevice, kTile, s.table, s.scanned, s.chunkTotals);
     hipLaunchKernelGGL((radixScatterKernel<K, BITS, ITEMS>), dim3(numTiles), dim3(kThreads), 0, stream, keysIn, valuesIn, keysOut,
-                       valuesOut, n, shift, s.scanned, s.chunkTotals);
+                       valuesOut, n, s.countDevice, shift, s.scanned, s.chunkTotals);
 }
 
 template <typename K, int BITS>

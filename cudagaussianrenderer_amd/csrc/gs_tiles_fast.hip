@@ -15,6 +15,7 @@
 //     predicate -- centre-in-rect OR rect-centre-in-ellipse OR an edge within the unit circle
 //     (GaussianRender.cu:375-405) -- evaluated in a different floating-point order, so a pair whose
 //     overlap margin is at rounding level may differ from the oracle's; tests check exactly that.
+#include "gs_aabb.h"
 #include "gs_internal.h"
 
 namespace gs
@@ -24,17 +25,6 @@ namespace
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kTilesPerUnit = 4;
-
-__device__ __forceinline__ float gmin(float x, float y) { return (y < x) ? y : x; }
-__device__ __forceinline__ float gmax(float x, float y) { return (x < y) ? y : x; }
-__device__ __forceinline__ int f2iSat(float v)
-{
-    if (v != v) return 0;
-    if (v >= 2147483648.0f) return 2147483647;
-    if (v <= -2147483648.0f) return -2147483647 - 1;
-    return (int) v;
-}
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
 struct WaveStage
 {
@@ -57,7 +47,7 @@ __device__ __forceinline__ bool edgeHitsUnitCircle(float qx, float qy, float ex,
 }
 
 template <bool EMIT, typename TileKey>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void tileListFastKernel(int count, Screen scr, const uint32_t* __restrict__ order,
+__global__ __launch_bounds__(kWave* kWavesPerBlock) void tileListFastKernel(int countHost, const int* __restrict__ countDevice, Screen scr, const uint32_t* __restrict__ order,
                                                                              const float2* __restrict__ clipXY,
                                                                              const float4* __restrict__ screenEllipse,
                                                                              int32_t* __restrict__ waveCounts,
@@ -69,6 +59,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void tileListFastKernel(int 
     const int waveInBlock = threadIdx.x >> 6;
     const int lane = threadIdx.x & (kWave - 1);
     const int waveGlobal = blockIdx.x * kWavesPerBlock + waveInBlock;
+    const int count = countDevice ? min(*countDevice, countHost) : countHost; // device-side count: culled splat list
     if (waveGlobal * kWave >= count) return;
     WaveStage& st = stage[waveInBlock];
     const int sorted = waveGlobal * kWave + lane;
@@ -82,38 +73,13 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void tileListFastKernel(int 
         const float4 se = screenEllipse[splat]; // cos, sin, extent.x, extent.y
         cx = c.x;
         cy = c.y;
-        // AABB in tiles, exactly as gs_tiles.hip / GaussianRender.cu:408-436,537-551.
-        {
-#pragma clang fp contract(off)
-            const float rightX = se.x * se.z, rightY = se.y * se.z;
-            const float upX = se.y * se.w, upY = -se.x * se.w;
-            float minX = 1e12f, minY = 1e12f, maxX = -1e12f, maxY = -1e12f;
-#pragma unroll
-            for (int j = 0; j != 4; ++j)
-            {
-                const int bottomBit = j & 1, topBit = j >> 1;
-                const float r = (float) (bottomBit ^ topBit) * 2.0f - 1.0f;
-                const float u = (float) topBit * 2.0f - 1.0f;
-                const float vx = rightX * r + upX * u, vy = rightY * r + upY * u;
-                minX = gmin(minX, vx);
-                minY = gmin(minY, vy);
-                maxX = gmax(maxX, vx);
-                maxY = gmax(maxY, vy);
-            }
-            minX += cx;
-            minY += cy;
-            maxX += cx;
-            maxY += cy;
-            x0 = clampi(f2iSat(floorf((minX + 1.0f) * 0.5f * scr.tilesPerScreenX)), 0, scr.tilesX);
-            y0 = clampi(f2iSat(floorf((minY + 1.0f) * 0.5f * scr.tilesPerScreenY)), 0, scr.tilesY);
-            const int x1 = clampi(f2iSat(ceilf((maxX + 1.0f) * 0.5f * scr.tilesPerScreenX)), 0, scr.tilesX);
-            int y1 = clampi(f2iSat(ceilf((maxY + 1.0f) * 0.5f * scr.tilesPerScreenY)), 0, scr.tilesY);
-            y0 = max(y0, scr.rowBegin);
-            y1 = min(y1, scr.rowEnd);
-            w = x1 - x0;
-            const int h = y1 - y0;
-            area = (w > 0 && h > 0) ? w * h : 0;
-        }
+        // AABB in tiles, exactly as gs_tiles.hip / GaussianRender.cu:408-436,537-551 (shared with the band cull).
+        const TileAabb box = splatTileAabb(cx, cy, se.x, se.y, se.z, se.w, scr);
+        x0 = box.x0;
+        y0 = box.y0;
+        w = box.x1 - box.x0;
+        const int h = box.y1 - box.y0;
+        area = (w > 0 && h > 0) ? w * h : 0;
         // Affine map clip space -> the ellipse's unit-circle space (GaussianRender.cu:351-358), hoisted:
         //   l = M (p - c),  M = diag(1/ex, 1/ey) * [[cos, sin], [-sin, cos]]
         const float invEx = 1.0f / se.z, invEy = 1.0f / se.w;
@@ -259,12 +225,14 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void tileListFastKernel(int 
 // Exclusive scan of n ints by ONE workgroup (n = ceil(N/64)): 1024 lanes x 4 consecutive ints per pass
 // (16-byte coalesced loads), wave scans by shuffles, 16 wave totals through LDS, carry across passes.
 constexpr int kScanThreads = 1024;
-__global__ __launch_bounds__(kScanThreads) void scanFastKernel(int n, const int32_t* __restrict__ in, int32_t* __restrict__ out,
+__global__ __launch_bounds__(kScanThreads) void scanFastKernel(int nHost, const int* __restrict__ countDevice, const int32_t* __restrict__ in, int32_t* __restrict__ out,
                                                                int64_t* __restrict__ total)
 {
     __shared__ long long waveTotals[kScanThreads / kWave];
-    __shared__ long long carryShared;
     const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
+    // nHost = waves the grid of the count pass was sized for; with a device-side splat count only the first
+    // ceil(count/64) of them wrote their totals.
+    const int n = countDevice ? min((*countDevice + kWave - 1) / kWave, nHost) : nHost;
     long long carry = 0;
     for (int base = 0; base < n; base += kScanThreads * 4)
     {
@@ -303,22 +271,23 @@ __global__ __launch_bounds__(kScanThreads) void scanFastKernel(int n, const int3
         carry += all;
         __syncthreads();
     }
-    if (t == 0)
-    {
-        carryShared = carry;
-        *total = carry;
-    }
+    if (t == 0) *total = carry;
 }
 
 template <typename TileKey>
 void launchEmit(hipStream_t stream, dim3 grid, dim3 block, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
                 const float4* screenEllipse, const TileListScratch& s, void* tileKeys, int32_t* values, int capacity)
 {
-    hipLaunchKernelGGL((tileListFastKernel<true, TileKey>), grid, block, 0, stream, count, scr, order, clipXY, screenEllipse,
+    hipLaunchKernelGGL((tileListFastKernel<true, TileKey>), grid, block, 0, stream, count, s.countDevice, scr, order, clipXY, screenEllipse,
                        (int32_t*) nullptr, (const int32_t*) s.waveOffsets, (TileKey*) tileKeys, values, capacity);
 }
 
 } // namespace
+
+void launchScanInt32(hipStream_t stream, int n, const int32_t* in, int32_t* out, int64_t* total)
+{
+    hipLaunchKernelGGL(scanFastKernel, dim3(1), dim3(kScanThreads), 0, stream, n, (const int*) nullptr, in, out, total);
+}
 
 void launchTileListFastCount(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
                              const float4* screenEllipse, TileListScratch& s)
@@ -332,9 +301,9 @@ void launchTileListFastCount(hipStream_t stream, int count, const Screen& scr, c
     else
     {
         const dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
-        hipLaunchKernelGGL((tileListFastKernel<false, uint16_t>), grid, block, 0, stream, count, scr, order, clipXY, screenEllipse,
+        hipLaunchKernelGGL((tileListFastKernel<false, uint16_t>), grid, block, 0, stream, count, s.countDevice, scr, order, clipXY, screenEllipse,
                            s.waveCounts, (const int32_t*) nullptr, (uint16_t*) nullptr, (int32_t*) nullptr, 0);
-        hipLaunchKernelGGL(scanFastKernel, dim3(1), dim3(kScanThreads), 0, stream, waves, s.waveCounts, s.waveOffsets, s.total);
+        hipLaunchKernelGGL(scanFastKernel, dim3(1), dim3(kScanThreads), 0, stream, waves, s.countDevice, s.waveCounts, s.waveOffsets, s.total);
     }
     GS_CHECK(hipMemcpyAsync(s.totalHost, s.total, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
 }

@@ -206,6 +206,12 @@ void gs_renderer_set_tile_rows(GsRenderer* r, int tileRowBegin, int tileRowEnd);
  * radix sort of all pairs on the 64-bit tile|depth key). TWO_LEVEL (default) sorts the splats by the 32-bit
  * depth key, emits the pairs in that order keyed by tile index, and sorts them stably on the tile bits only:
  * same list order (ties by splat index), ~5x less radix-sort traffic. */
+/* Band cull (TWO_LEVEL pipeline): when the renderer owns a strict sub-band of tile rows, only the splats whose tile
+ * AABB reaches the band are SH-evaluated, depth-sorted and expanded. AUTO = on exactly then; ON/OFF force it. */
+#define GS_BAND_CULL_AUTO 0
+#define GS_BAND_CULL_ON 1
+#define GS_BAND_CULL_OFF 2
+void gs_renderer_set_band_cull(GsRenderer* r, int mode);
 #define GS_PIPELINE_REFERENCE 0
 #define GS_PIPELINE_TWO_LEVEL 1
 void gs_renderer_set_pipeline(GsRenderer* r, int pipeline);

@@ -415,3 +415,31 @@ def test_sort_backends_give_identical_frames(gs):
         r.close()
     gs.lib().gs_set_sort_backend(1)
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
+
+
+@pytest.mark.parametrize("degree", [0, 3])
+def test_band_cull_is_invisible(gs, tmp_path, degree):
+    """Band cull (compacted splat list, gathered SH, device-side counts) on/off: same pair list, same image; and a
+    culled sub-band render equals the same rows of the full frame."""
+    w, h = 960, 544
+    ply = _ply_scene(gs, tmp_path, 60000, degree, log_scale_mean=-3.2)
+    cam = gs.camera_from_bounds(ply["boundsMin"], ply["boundsMax"], w, h)
+    out = []
+    for mode in (2, 1):  # off, on
+        r = gs.Renderer(w, h, band_cull=mode)
+        r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+        r.render(cam)
+        b = r.buffers()
+        out.append((r.read_image(), r.download(b.values, b.tileListSize, np.int32)))
+        r.close()
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
+    tx, ty = gs.tile_counts(w, h)
+    for band in [(0, 5), (11, 23), (ty - 3, ty)]:
+        r = gs.Renderer(w, h, tile_rows=band)  # auto: cull on
+        r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+        r.render(cam)
+        img = r.read_image()
+        r.close()
+        a, b_ = band[0] * 16, min(band[1] * 16, h)
+        assert np.array_equal(img[a:b_], out[0][0][a:b_])
+        assert not img[:a].any() and not img[b_:].any()
