@@ -45,8 +45,8 @@ def algorithmic_bytes(n, p, pc, tiles, nonempty_tiles, w, h, sh_degree, sort_pas
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--splats", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--opacity-mean", type=float, default=1.0, help="raw (pre-sigmoid) opacity mean of the synthetic scene")
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU oracle timed as cpu_baseline (0 = skip)")
     ap.add_argument("--ppl", type=int, default=0, help="raster pixels per lane override (1,2,4)")
+    ap.add_argument("--inflight", type=int, default=3, help="frames in flight per GPU (renderers on separate HIP streams)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,22 +101,47 @@ def main():
     tiles_x, tiles_y = gs.tile_counts(W, H)
     bands = scenes.tile_row_bands(tiles_y, world)
     band = bands[rank]
-    renderer = gs.Renderer(W, H, tile_rows=band if world > 1 else None)
-    renderer.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
-    framebuffer = torch.zeros((H, W, 4), dtype=torch.uint8, device=device)
-    renderer.set_back_buffer(framebuffer.data_ptr())
+    # D frames in flight: D renderers, each with its own stream, intermediates and framebuffer (the scene is uploaded
+    # to each; 0.43 GB apiece). One host thread drives them: begin(frame i+D-1) is issued before finish(frame i), so
+    # the latency-bound stages of one frame overlap the others' and the pair-count readback never idles the GPU.
+    depth = max(1, args.inflight)
+    streams = [torch.cuda.Stream(device) for _ in range(depth)]
+    renderers, framebuffers = [], []
+    for d in range(depth):
+        r = gs.Renderer(W, H, tile_rows=band if world > 1 else None)
+        r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+        fb = torch.zeros((H, W, 4), dtype=torch.uint8, device=device)
+        r.set_back_buffer(fb.data_ptr())
+        r.set_stream(streams[d].cuda_stream)
+        renderers.append(r)
+        framebuffers.append(fb)
+    renderer, framebuffer = renderers[0], framebuffers[0]
     cameras = [gs.camera_from_pose(p, q, W, H) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], args.views)]
+    torch.cuda.synchronize(device)
 
     def pixel_rows(b):
         return multigpu.pixel_rows(b, H)
 
-    def gather_framebuffer():
-        """Bands -> rank 0, one grouped RCCL send/recv set; receives land directly in the framebuffer rows."""
-        multigpu.gather_bands(framebuffer, bands, rank, world)
+    def issue(i, timed=0):
+        d = i % depth
+        with torch.cuda.stream(streams[d]):
+            renderers[d].begin(cameras[i % len(cameras)], timed=timed)
 
-    def step(i, timed=0):
-        renderer.render(cameras[i % len(cameras)], timed=timed)
-        gather_framebuffer()
+    def complete(i):
+        """Second half of frame i, then its bands -> rank 0 (one grouped RCCL send/recv set, receives land directly
+        in the framebuffer rows); ordered on the frame's own stream, so the next use of that renderer waits for it."""
+        d = i % depth
+        with torch.cuda.stream(streams[d]):
+            renderers[d].finish()
+            multigpu.gather_bands(framebuffers[d], bands, rank, world)
+
+    def run_frames(count, first=0, timed=0):
+        for i in range(first, first + count + depth - 1):
+            if i < first + count:
+                issue(i, timed)
+            j = i - (depth - 1)
+            if j >= first:
+                complete(j)
 
     def sync_all():
         torch.cuda.synchronize(device)
@@ -124,12 +150,10 @@ def main():
         torch.cuda.synchronize(device)
 
     # ---- warmup, then EXACTLY --steps timed frames ----------------------------------------------------
-    for i in range(args.warmup):
-        step(i)
+    run_frames(args.warmup)
     sync_all()
     t_start = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    run_frames(args.steps, first=args.warmup)
     sync_all()
     elapsed = time.perf_counter() - t_start
     if world > 1:
@@ -138,9 +162,12 @@ def main():
         elapsed = float(t.item())
 
     # ---- per-stage GPU times: the same frames again with one non-blocking event pair per stage --------
-    for i in range(args.steps):
-        step(i, timed=2)
-    frames, sums = renderer.collect_stage_times()
+    # (one renderer, frames back to back, so the stage intervals do not overlap another frame's kernels)
+    with torch.cuda.stream(streams[0]):
+        for i in range(args.steps):
+            renderer.render(cameras[i % len(cameras)], timed=2)
+            multigpu.gather_bands(framebuffer, bands, rank, world)
+        frames, sums = renderer.collect_stage_times()
     stage_ms = {
         "sh": sums.msSphericalHarmonics / frames, "clip": sums.msClipData / frames, "tile_list": sums.msBuildTileList / frames,
         "sort": sums.msSortTileList / frames, "ranges": sums.msTileRanges / frames, "raster": sums.msRasterize / frames,
@@ -148,10 +175,11 @@ def main():
     # list sizes per view (deterministic), P_c from the raster kernel's own counter
     lib.gs_set_collect_raster_stats(1)
     p_sum = pc_sum = 0
-    for i in range(len(cameras)):
-        st = renderer.render(cameras[i], stats=True)
-        p_sum += st.tileListSize
-        pc_sum += st.consumedPairs
+    with torch.cuda.stream(streams[0]):
+        for i in range(len(cameras)):
+            st = renderer.render(cameras[i], stats=True)
+            p_sum += st.tileListSize
+            pc_sum += st.consumedPairs
     lib.gs_set_collect_raster_stats(0)
     views = len(cameras)
     p_mean, pc_mean = p_sum / views, pc_sum / views
@@ -187,7 +215,7 @@ def main():
                             f"{views}-view orbit, tile-row bands over {world} GPU(s)",
                 "splats": N, "width": W, "height": H, "sh_degree": args.sh_degree, "views": views,
                 "pairs_per_frame": round(p_mean), "consumed_pairs_per_frame": round(pc_mean),
-                "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": name,
+                "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": name, "frames_in_flight": depth,
                 "opacity_mean_raw": args.opacity_mean, "ingest_s": round(t_ingest, 2),
             },
             "roofline": {
@@ -207,7 +235,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    renderer.close()
+    for r in renderers:
+        r.close()
     if rank == 0:
         print(json.dumps(result))
 

@@ -282,6 +282,24 @@ class Renderer:
             raise RuntimeError(f"gs_renderer_render failed ({rc})")
         return st
 
+    def set_stream(self, hip_stream):
+        """Give this renderer its own stream (e.g. torch.cuda.Stream().cuda_stream) so frames can overlap."""
+        lib().gs_renderer_set_stream(self.handle, hip_stream)
+
+    def begin(self, camera, timed=0):
+        """First half of a frame (up to the pair emission); returns immediately."""
+        rc = lib().gs_renderer_begin(self.handle, C.byref(camera), int(timed))
+        if rc != 0:
+            raise RuntimeError(f"gs_renderer_begin failed ({rc})")
+
+    def finish(self, stats=False):
+        """Second half (tile sort, ranges, raster); picks up the pair count of begin()."""
+        st = FrameStats() if stats else None
+        rc = lib().gs_renderer_finish(self.handle, C.byref(st) if st is not None else None)
+        if rc != 0:
+            raise RuntimeError(f"gs_renderer_finish failed ({rc})")
+        return st
+
     def collect_stage_times(self):
         """(frames, FrameStats of sums) over the frames rendered with timed=2 since the last call."""
         st = FrameStats()

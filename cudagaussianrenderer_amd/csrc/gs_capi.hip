@@ -306,6 +306,22 @@ extern "C" void gs_rasterize_tile(GsTimer* timer)
 //                          pairs in that order keyed by the tile index only, then one stable sort on the
 //                          13-15 tile bits.  The resulting value list is identical (same total order, ties by
 //                          splat index) while the radix-sort traffic drops from ~152 B to ~30 B per pair.
+namespace
+{
+constexpr int kStageTimers = 7; // sh, clip, tile list, pair sort, ranges, raster, depth sort (added to the sort total)
+// What begin() leaves for finish().
+struct FrameState
+{
+    Screen scr{};
+    GsTimer* stageTimers[kStageTimers] = {};
+    bool blocking = false;
+    bool listDone = false; // reference pipeline: the sorted list and ranges were produced in begin()
+    int orderSel = 0, tileKeyBytes = 2;
+    int32_t size = 0;
+    GsFrameStats st{};
+};
+} // namespace
+
 struct GsRenderer
 {
     int width = 0, height = 0, rowBegin = 0, rowEnd = 0;
@@ -318,6 +334,14 @@ struct GsRenderer
     // band cull (multi-GPU): per-splat coefficients in the [splat][shCount] layout for gathered SH evaluation,
     // one keep-mask and count per 64 splats, their scan, and the kept-splat count (device scalar)
     float* shPerSplat = nullptr;
+    // per-renderer stream and scratch, so that several renderers can have frames in flight at once
+    hipStream_t stream = nullptr;
+    bool hasStream = false;
+    TileListScratch scratch;
+    RadixScratch radix;
+    unsigned long long* consumed = nullptr;
+    bool pending = false; // begin() issued, finish() not yet
+    FrameState frame;
     unsigned long long* bandMask = nullptr;
     int32_t *bandCounts = nullptr, *bandOffsets = nullptr;
     int64_t* bandTotal = nullptr;
@@ -344,9 +368,22 @@ struct GsRenderer
 
 namespace
 {
-// sh, clip, tile list, pair sort, ranges, raster, depth sort (added to the sort total)
-constexpr int kStageTimers = 7;
+// The launchers enqueue on g.stream; a renderer that was given its own stream borrows the slot for the call, so that
+// several renderers (frames in flight) can be driven from one host thread on different streams.
+struct StreamScope
+{
+    hipStream_t saved;
+    explicit StreamScope(GsRenderer* r) : saved(g.stream)
+    {
+        if (r->hasStream) g.stream = r->stream;
+    }
+    ~StreamScope() { g.stream = saved; }
+};
+} // namespace
 
+
+namespace
+{
 void freeTileList(GsRenderer* r)
 {
     for (int i = 0; i != 2; ++i)
@@ -432,12 +469,18 @@ extern "C" GsRenderer* gs_renderer_create(int width, int height)
 extern "C" void gs_renderer_destroy(GsRenderer* r)
 {
     if (!r) return;
-    GS_CHECK(hipStreamSynchronize(g.stream));
+    {
+        StreamScope scope(r);
+        GS_CHECK(hipStreamSynchronize(g.stream));
+    }
     freeScene(r);
     freeTileList(r);
     gs_device_free(r->tileRange);
     gs_device_free(r->backBufferOwned);
     gs_device_free(r->sortTemp);
+    freeTileListScratch(r->scratch);
+    freeRadixScratch(r->radix);
+    if (r->consumed) (void) hipFree(r->consumed);
     gs_timer_destroy(r->timer);
     for (GsTimer* t : r->asyncTimers) gs_timer_destroy(t);
     (void) hipEventDestroy(r->frameStart);
@@ -466,6 +509,7 @@ extern "C" int gs_renderer_set_scene(GsRenderer* r, int32_t n, const float* posi
                                      const float* color4, const float* sh, int shDegree, int shCount)
 {
     if (n < 0 || (shDegree != 0 && sh == nullptr)) return -1;
+    StreamScope scope(r);
     GS_CHECK(hipStreamSynchronize(g.stream));
     freeScene(r);
     r->splatCount = n;
@@ -514,6 +558,7 @@ extern "C" void gs_renderer_set_back_buffer(GsRenderer* r, uint8_t* p) { r->back
 
 extern "C" void gs_renderer_read_back_buffer(GsRenderer* r, uint8_t* hostRgba)
 {
+    StreamScope scope(r);
     gs_device_download(hostRgba, r->backBuffer, (size_t) r->width * r->height * 4);
 }
 
@@ -535,14 +580,27 @@ extern "C" void gs_renderer_buffers(GsRenderer* r, GsRendererBuffers* out)
     out->keyBytes = r->keyBytes;
 }
 
-extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsFrameStats* stats)
+extern "C" void gs_renderer_set_stream(GsRenderer* r, void* stream)
 {
-    const Screen scr = makeScreen(r->width, r->height, r->rowBegin, r->rowEnd);
+    r->stream = (hipStream_t) stream;
+    r->hasStream = true;
+}
+
+// First half of a frame: clears, SH, clip data, (band cull,) depth sort of the splats, pair count + scan, and the
+// emit pass launched with the current list capacity. Returns without waiting for anything.
+extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int timed)
+{
+    if (r->pending) return -3;
+    StreamScope scope(r);
+    FrameState& f = r->frame;
+    f = FrameState{};
+    f.scr = makeScreen(r->width, r->height, r->rowBegin, r->rowEnd);
+    const Screen& scr = f.scr;
     // timed: 0 = no stage timers; 1 = the reference's blocking timer after every stage; 2 = one non-blocking
     // event pair per stage, accumulated and read later with gs_renderer_collect_stage_times.
-    GsTimer* stageTimers[kStageTimers] = {};
+    GsTimer** stageTimers = f.stageTimers;
     if (timed == 1)
-        for (GsTimer*& t : stageTimers) t = r->timer;
+        for (int i = 0; i != kStageTimers; ++i) stageTimers[i] = r->timer;
     else if (timed == 2)
     {
         while (r->asyncTimers.size() < r->asyncUsed + kStageTimers)
@@ -561,8 +619,9 @@ extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int
         r->asyncUsed += kStageTimers;
         r->asyncFrames += 1;
     }
-    const bool blocking = timed == 1;
-    GsFrameStats st{};
+    f.blocking = timed == 1;
+    const bool blocking = f.blocking;
+    GsFrameStats& st = f.st;
     const int n = r->splatCount;
     const bool twoLevel = r->pipeline == GS_PIPELINE_TWO_LEVEL;
 
@@ -610,24 +669,23 @@ extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int
         if (blocking) st.msSphericalHarmonics = gs_timer_elapsed_ms(stageTimers[0]);
     }
 
-    int32_t size = 0;
     if (!twoLevel)
     {
-        // ---- the reference's stage order, through the staged calls ---------------------------------
+        // ---- the reference's stage order, through the staged calls (whole frame here; finish() only reports) ----
         gs_evaluate_splat_clip_data(stageTimers[1], n);
         if (blocking) st.msClipData = gs_timer_elapsed_ms(stageTimers[1]);
 
         // Count first and grow if needed, instead of rendering a truncated frame and doubling for the next
         // one (Demo.cpp:357-366,447).
         gs_timer_start(stageTimers[2]);
-        launchTileListCount(g.stream, n, scr, (const float2*) r->clipXY, (const float4*) r->ellipse, g.scratch);
+        launchTileListCount(g.stream, n, scr, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch);
         GS_CHECK(hipStreamSynchronize(g.stream)); // pair count readback, as GaussianRender.cu:793
-        const int64_t demand = *g.scratch.totalHost;
+        const int64_t demand = *r->scratch.totalHost;
         g.lastDemand = demand;
         if (demand > 0x7FFFFFFF) return -2;
         if (growTileListIfNeeded(r, demand)) st.grewTileList = 1;
-        size = (int32_t) demand;
-        launchTileListEmit(g.stream, n, scr, (const float2*) r->clipXY, r->clipZ, (const float4*) r->ellipse, g.scratch, r->keys[0],
+        const int32_t size = (int32_t) demand;
+        launchTileListEmit(g.stream, n, scr, (const float2*) r->clipXY, r->clipZ, (const float4*) r->ellipse, r->scratch, r->keys[0],
                            r->values[0], r->tileListCapacity);
         gs_timer_stop(stageTimers[2]);
         if (blocking) st.msBuildTileList = gs_timer_elapsed_ms(stageTimers[2]);
@@ -646,12 +704,13 @@ extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int
             gs_evaluate_tile_range(stageTimers[4], size);
             if (blocking) st.msTileRanges = gs_timer_elapsed_ms(stageTimers[4]);
         }
+        f.size = size;
+        f.listDone = true;
     }
     else
     {
         // ---- two-level sort ------------------------------------------------------------------------
-        const int tileKeyBytes = (getenv("GS_TILEKEY4") || scr.totalTiles > 65536) ? 4 : 2;
-        const int tBits = tileBits(scr.totalTiles);
+        f.tileKeyBytes = (getenv("GS_TILEKEY4") || scr.totalTiles > 65536) ? 4 : 2;
 
         gs_timer_start(stageTimers[1]);
         const int* countDevice = nullptr;
@@ -683,8 +742,8 @@ extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int
             gs_timer_stop(stageTimers[0]);
             if (blocking) st.msSphericalHarmonics = gs_timer_elapsed_ms(stageTimers[0]);
         }
-        g.radix.countDevice = countDevice;
-        g.scratch.countDevice = countDevice;
+        r->radix.countDevice = countDevice;
+        r->scratch.countDevice = countDevice;
 
         // (1) splats by depth: 32-bit keys, N elements
         int orderSel = 0;
@@ -693,7 +752,7 @@ extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int
         if (n > 0)
         {
             if (native && radixSortSupported(4, n))
-                orderSel = launchRadixSortPairs(g.stream, g.radix, 4, r->depthKey[0], r->depthKey[1], r->order[0], r->order[1], n, 0, 32);
+                orderSel = launchRadixSortPairs(g.stream, r->radix, 4, r->depthKey[0], r->depthKey[1], r->order[0], r->order[1], n, 0, 32);
             else
             {
                 ensureSortTemp(r, sortTempBytes(4, n, 0, 32));
@@ -702,65 +761,101 @@ extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int
             }
         }
         gs_timer_stop(stageTimers[6]);
+        f.orderSel = orderSel;
         const uint32_t* order = (const uint32_t*) r->order[orderSel];
 
         // (2) pairs in depth order, keyed by tile. The emit pass is launched with the current capacity while the
         // pair count travels to the host, so the readback (GaussianRender.cu:793) costs no GPU idle time.
         gs_timer_start(stageTimers[2]);
-        launchTileListFastCount(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, g.scratch);
+        launchTileListFastCount(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch);
         GS_CHECK(hipEventRecord(r->countReady, g.stream));
-        launchTileListFastEmit(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, g.scratch, r->keys[0],
-                               tileKeyBytes, r->values[0], r->tileListCapacity);
+        launchTileListFastEmit(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],
+                               f.tileKeyBytes, r->values[0], r->tileListCapacity);
+        gs_timer_stop(stageTimers[2]);
+    }
+    r->pending = true;
+    return 0;
+}
+
+// Second half: wait for the pair count (long since on the host), grow and re-emit in the rare overflow case, tile
+// sort, ranges, raster.
+extern "C" int gs_renderer_finish(GsRenderer* r, GsFrameStats* stats)
+{
+    if (!r->pending) return -3;
+    StreamScope scope(r);
+    FrameState& f = r->frame;
+    const Screen& scr = f.scr;
+    GsTimer** stageTimers = f.stageTimers;
+    const bool blocking = f.blocking;
+    GsFrameStats& st = f.st;
+    const int n = r->splatCount;
+    r->pending = false;
+
+    if (!f.listDone)
+    {
+        const int tBits = tileBits(scr.totalTiles);
+        const uint32_t* order = (const uint32_t*) r->order[f.orderSel];
         GS_CHECK(hipEventSynchronize(r->countReady));
-        const int64_t demand = *g.scratch.totalHost;
+        const int64_t demand = *r->scratch.totalHost;
         g.lastDemand = demand;
         if (demand > 0x7FFFFFFF) return -2;
         if (growTileListIfNeeded(r, demand))
         {
             // the list did not fit: re-emit into the larger buffers (rare; the first frames of a scene)
             st.grewTileList = 1;
-            launchTileListFastEmit(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, g.scratch,
-                                   r->keys[0], tileKeyBytes, r->values[0], r->tileListCapacity);
+            launchTileListFastEmit(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch,
+                                   r->keys[0], f.tileKeyBytes, r->values[0], r->tileListCapacity);
         }
-        gs_timer_stop(stageTimers[2]);
         if (blocking) st.msBuildTileList = gs_timer_elapsed_ms(stageTimers[2]);
-        size = (int32_t) demand;
-
-        g.radix.countDevice = nullptr;
-        g.scratch.countDevice = nullptr;
+        r->radix.countDevice = nullptr;
+        r->scratch.countDevice = nullptr;
+        const int32_t size = (int32_t) demand;
 
         // (3) stable sort of the pairs on the tile bits only
+        const bool native = g.sortBackend == GS_SORT_BACKEND_NATIVE;
         gs_timer_start(stageTimers[3]);
         int sel = 0;
         if (size > 0)
         {
-            if (native && radixSortSupported(tileKeyBytes, size))
-                sel = launchRadixSortPairs(g.stream, g.radix, tileKeyBytes, r->keys[0], r->keys[1], r->values[0], r->values[1], size, 0,
+            if (native && radixSortSupported(f.tileKeyBytes, size))
+                sel = launchRadixSortPairs(g.stream, r->radix, f.tileKeyBytes, r->keys[0], r->keys[1], r->values[0], r->values[1], size, 0,
                                            tBits);
             else
             {
-                ensureSortTemp(r, sortTempBytes(tileKeyBytes, size, 0, tBits));
-                sel = launchSortPairs(g.stream, r->sortTemp, r->sortTempBytes, tileKeyBytes, r->keys[0], r->keys[1], r->values[0],
+                ensureSortTemp(r, sortTempBytes(f.tileKeyBytes, size, 0, tBits));
+                sel = launchSortPairs(g.stream, r->sortTemp, r->sortTempBytes, f.tileKeyBytes, r->keys[0], r->keys[1], r->values[0],
                                       r->values[1], 0, size, 0, tBits);
             }
         }
         gs_timer_stop(stageTimers[3]);
         if (blocking) st.msSortTileList = gs_timer_elapsed_ms(stageTimers[3]) + gs_timer_elapsed_ms(stageTimers[6]);
         r->selector = sel;
-        r->keyBytes = tileKeyBytes;
+        r->keyBytes = f.tileKeyBytes;
 
-        GsTileListArgs tl{r->keys[sel], r->values[sel], size, r->tileListCapacity};
-        gs_set_tile_list_args(&tl);
         gs_timer_start(stageTimers[4]);
-        launchTileRanges(g.stream, size, tileKeyBytes, r->keys[sel], r->tileRange);
+        launchTileRanges(g.stream, size, f.tileKeyBytes, r->keys[sel], r->tileRange);
         gs_timer_stop(stageTimers[4]);
         if (blocking) st.msTileRanges = gs_timer_elapsed_ms(stageTimers[4]);
+        f.size = size;
     }
+    const int32_t size = f.size;
     r->tileListSize = size;
     st.tileListSize = size;
     st.tileListCapacity = r->tileListCapacity;
 
-    gs_rasterize_tile(stageTimers[5]);
+    // raster (direct launch: no global argument state, so renderers can interleave their halves)
+    unsigned long long* consumed = nullptr;
+    if (g.collectRasterStats)
+    {
+        if (r->consumed == nullptr) GS_CHECK(hipMalloc((void**) &r->consumed, sizeof(unsigned long long)));
+        consumed = r->consumed;
+        GS_CHECK(hipMemsetAsync(consumed, 0, sizeof(unsigned long long), g.stream));
+    }
+    gs_timer_start(stageTimers[5]);
+    launchRasterize(g.stream, scr, r->tileRange, r->values[r->selector], (const float2*) r->clipXY, (const float4*) r->conic,
+                    (const float4*) r->color, (uchar4*) r->backBuffer, consumed);
+    gs_timer_stop(stageTimers[5]);
+    if (hipGetLastError() != hipSuccess) printf("kernel error renderDepthBuffer\n");
     if (blocking) st.msRasterize = gs_timer_elapsed_ms(stageTimers[5]);
 
     GS_CHECK(hipEventRecord(r->frameStop, g.stream));
@@ -769,15 +864,28 @@ extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int
     {
         GS_CHECK(hipEventSynchronize(r->frameStop));
         GS_CHECK(hipEventElapsedTime(&st.msFrame, r->frameStart, r->frameStop));
-        if (g.collectRasterStats) st.consumedPairs = gs_last_raster_consumed_pairs();
+        if (consumed != nullptr)
+        {
+            unsigned long long v = 0;
+            GS_CHECK(hipMemcpy(&v, consumed, sizeof(v), hipMemcpyDeviceToHost));
+            st.consumedPairs = (int64_t) v;
+        }
         *stats = st;
     }
     return 0;
 }
 
+extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsFrameStats* stats)
+{
+    const int rc = gs_renderer_begin(r, camera, timed);
+    if (rc != 0) return rc;
+    return gs_renderer_finish(r, stats);
+}
+
 extern "C" int gs_renderer_collect_stage_times(GsRenderer* r, GsFrameStats* sums)
 {
     // Sums over the frames rendered with timed == 2 since the last call; resets the accumulation.
+    StreamScope scope(r);
     GS_CHECK(hipStreamSynchronize(g.stream));
     GsFrameStats s{};
     float* slots[kStageTimers] = {&s.msSphericalHarmonics, &s.msClipData, &s.msBuildTileList, &s.msSortTileList, &s.msTileRanges,

@@ -225,6 +225,12 @@ int gs_renderer_set_scene(GsRenderer* r, int32_t splatCount, const float* positi
  *   timed == 2: one non-blocking event pair per stage on the stream; read the sums later with
  *               gs_renderer_collect_stage_times (the frames are not slowed by host waits). */
 int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsFrameStats* statsOrNull);
+/* The same frame in two halves, so that one host thread can keep several renderers (each with its own stream and
+ * buffers, gs_renderer_set_stream) busy: begin() enqueues everything up to the pair emission and returns; finish()
+ * picks up the pair count -- by then on the host -- and enqueues tile sort, ranges and raster. render() = begin + finish. */
+void gs_renderer_set_stream(GsRenderer* r, void* hipStream);
+int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int timed);
+int gs_renderer_finish(GsRenderer* r, GsFrameStats* statsOrNull);
 /* Sums of the per-stage times (ms) and of the list sizes over the timed==2 frames since the last call.
  * Returns the number of frames summed. */
 int gs_renderer_collect_stage_times(GsRenderer* r, GsFrameStats* sums);
