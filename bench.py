@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--opacity-mean", type=float, default=1.0, help="raw (pre-sigmoid) opacity mean of the synthetic scene")
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU oracle timed as cpu_baseline (0 = skip)")
     ap.add_argument("--ppl", type=int, default=0, help="raster pixels per lane override (1,2,4)")
+    ap.add_argument("--even-bands", action="store_true", help="multi-GPU: equal-height bands instead of cost-balanced ones")
     ap.add_argument("--inflight", type=int, default=3, help="frames in flight per GPU (renderers on separate HIP streams)")
     args = ap.parse_args()
 
@@ -99,7 +100,23 @@ def main():
     assert ply["vertexCount"] == N
 
     tiles_x, tiles_y = gs.tile_counts(W, H)
+    cameras = [gs.camera_from_pose(p, q, W, H) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], args.views)]
     bands = scenes.tile_row_bands(tiles_y, world)
+    if world > 1 and not args.even_bands:
+        # Cost-balanced contiguous bands: every rank renders the orbit once full-frame (a calibration pass outside the
+        # timed region) and sums a per-tile-row cost -- pairs in the row, plus the entries a raster tile can consume
+        # before it saturates -- then cuts the rows so the summed cost per band is even. Same scene, same numbers on
+        # every rank, so all ranks derive the same bands without talking to each other.
+        cal = gs.Renderer(W, H)
+        cal.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+        row_cost = np.zeros(tiles_y, np.float64)
+        for cam in cameras:
+            cal.render(cam)
+            rng = cal.download(cal.buffers().tileRange, 2 * tiles_x * tiles_y, np.int32).reshape(tiles_y, tiles_x, 2)
+            counts = (rng[..., 1] - rng[..., 0]).astype(np.float64)
+            row_cost += counts.sum(1) + 6.0 * np.minimum(counts, 256.0).sum(1)
+        cal.close()
+        bands = scenes.balanced_tile_row_bands(row_cost, world)
     band = bands[rank]
     # D frames in flight: D renderers, each with its own stream, intermediates and framebuffer (the scene is uploaded
     # to each; 0.43 GB apiece). One host thread drives them: begin(frame i+D-1) is issued before finish(frame i), so
@@ -116,32 +133,42 @@ def main():
         renderers.append(r)
         framebuffers.append(fb)
     renderer, framebuffer = renderers[0], framebuffers[0]
-    cameras = [gs.camera_from_pose(p, q, W, H) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], args.views)]
     torch.cuda.synchronize(device)
 
     def pixel_rows(b):
         return multigpu.pixel_rows(b, H)
 
-    def issue(i, timed=0):
-        d = i % depth
-        with torch.cuda.stream(streams[d]):
-            renderers[d].begin(cameras[i % len(cameras)], timed=timed)
+    # One host thread per frame in flight: each drives its renderer's whole frame (it blocks on its own pair-count
+    # readback only), so kernel launches of different frames are issued in parallel; the main thread collects the
+    # frames in order and enqueues the band gather (RCCL calls stay on one thread, in the same order on every rank).
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
 
-    def complete(i):
-        """Second half of frame i, then its bands -> rank 0 (one grouped RCCL send/recv set, receives land directly
-        in the framebuffer rows); ordered on the frame's own stream, so the next use of that renderer waits for it."""
-        d = i % depth
+    def init_worker():
+        torch.cuda.set_device(local_rank)
+        lib.gs_set_device(local_rank)
+
+    pools = [ThreadPoolExecutor(1, initializer=init_worker) for _ in range(depth)]
+
+    def render_frame(d, i, timed):
+        renderers[d].render(cameras[i % len(cameras)], timed=timed)
+
+    def collect(j, future):
+        """Frame j is enqueued: its bands -> rank 0 (one grouped RCCL send/recv set, receives land directly in the
+        framebuffer rows), ordered on the frame's own stream so the next use of that renderer waits for it."""
+        future.result()
+        d = j % depth
         with torch.cuda.stream(streams[d]):
-            renderers[d].finish()
             multigpu.gather_bands(framebuffers[d], bands, rank, world)
 
     def run_frames(count, first=0, timed=0):
-        for i in range(first, first + count + depth - 1):
-            if i < first + count:
-                issue(i, timed)
-            j = i - (depth - 1)
-            if j >= first:
-                complete(j)
+        inflight = deque()
+        for i in range(first, first + count):
+            if len(inflight) == depth:
+                collect(*inflight.popleft())
+            inflight.append((i, pools[i % depth].submit(render_frame, i % depth, i, timed)))
+        while inflight:
+            collect(*inflight.popleft())
 
     def sync_all():
         torch.cuda.synchronize(device)
@@ -215,7 +242,7 @@ def main():
                             f"{views}-view orbit, tile-row bands over {world} GPU(s)",
                 "splats": N, "width": W, "height": H, "sh_degree": args.sh_degree, "views": views,
                 "pairs_per_frame": round(p_mean), "consumed_pairs_per_frame": round(pc_mean),
-                "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": name, "frames_in_flight": depth,
+                "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": name, "frames_in_flight": depth, "tile_row_bands": [list(b) for b in bands],
                 "opacity_mean_raw": args.opacity_mean, "ingest_s": round(t_ingest, 2),
             },
             "roofline": {
@@ -235,6 +262,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    for pool in pools:
+        pool.shutdown()
     for r in renderers:
         r.close()
     if rank == 0:

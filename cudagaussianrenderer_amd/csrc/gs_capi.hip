@@ -48,13 +48,20 @@ struct State
     hipStream_t stream = nullptr;
     TileListScratch scratch;
     RadixScratch radix;
-    int sortBackend = GS_SORT_BACKEND_NATIVE;
     int64_t lastDemand = 0;
-    bool collectRasterStats = false;
-    unsigned long long* consumedDevice = nullptr;
-    int64_t lastConsumed = 0;
 };
-State g;
+// One state per host thread: like the reference, the staged calls are not re-entrant, but each host thread may drive
+// its own renderer / staged sequence on its own stream (bench.py runs one thread per frame in flight).
+thread_local State g;
+
+// Process-wide settings.
+struct Settings
+{
+    int sortBackend = GS_SORT_BACKEND_NATIVE;
+    bool collectRasterStats = false;
+    unsigned long long* consumedDevice = nullptr; // counter of the staged gs_rasterize_tile
+};
+Settings cfg;
 
 Screen currentScreen() { return makeScreen(g.global.width, g.global.height, g.global.tileRowBegin, g.global.tileRowEnd); }
 
@@ -260,21 +267,21 @@ extern "C" void gs_evaluate_tile_range(GsTimer* timer, int32_t size)
 
 extern "C" void gs_set_collect_raster_stats(int enabled)
 {
-    g.collectRasterStats = enabled != 0;
-    if (enabled && g.consumedDevice == nullptr) GS_CHECK(hipMalloc((void**) &g.consumedDevice, sizeof(unsigned long long)));
+    cfg.collectRasterStats = enabled != 0;
+    if (enabled && cfg.consumedDevice == nullptr) GS_CHECK(hipMalloc((void**) &cfg.consumedDevice, sizeof(unsigned long long)));
 }
 
 extern "C" int64_t gs_last_raster_consumed_pairs(void)
 {
-    if (g.consumedDevice == nullptr) return 0;
+    if (cfg.consumedDevice == nullptr) return 0;
     unsigned long long v = 0;
     GS_CHECK(hipStreamSynchronize(g.stream));
-    GS_CHECK(hipMemcpy(&v, g.consumedDevice, sizeof(v), hipMemcpyDeviceToHost));
+    GS_CHECK(hipMemcpy(&v, cfg.consumedDevice, sizeof(v), hipMemcpyDeviceToHost));
     return (int64_t) v;
 }
 
-extern "C" void gs_set_sort_backend(int backend) { g.sortBackend = (backend == GS_SORT_BACKEND_ROCPRIM) ? backend : GS_SORT_BACKEND_NATIVE; }
-extern "C" int gs_get_sort_backend(void) { return g.sortBackend; }
+extern "C" void gs_set_sort_backend(int backend) { cfg.sortBackend = (backend == GS_SORT_BACKEND_ROCPRIM) ? backend : GS_SORT_BACKEND_NATIVE; }
+extern "C" int gs_get_sort_backend(void) { return cfg.sortBackend; }
 
 extern "C" int gs_radix_sort_pairs(int keyBytes, void* keys0, void* keys1, int32_t* values0, int32_t* values1, int32_t count, int beginBit,
                                    int endBit)
@@ -288,7 +295,7 @@ extern "C" int gs_get_raster_pixels_per_lane(void) { return rasterPixelsPerLane(
 
 extern "C" void gs_rasterize_tile(GsTimer* timer)
 {
-    unsigned long long* consumed = g.collectRasterStats ? g.consumedDevice : nullptr;
+    unsigned long long* consumed = cfg.collectRasterStats ? cfg.consumedDevice : nullptr;
     if (consumed) GS_CHECK(hipMemsetAsync(consumed, 0, sizeof(unsigned long long), g.stream));
     gs_timer_start(timer);
     launchRasterize(g.stream, currentScreen(), g.global.tileRange, g.tileList.values, (const float2*) g.global.positionClipSpaceXY,
@@ -631,7 +638,8 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
     const size_t rowBytes = (size_t) r->width * 4;
     const int pixelRowBegin = scr.rowBegin * kTileSize;
     const int pixelRowEnd = std::min(scr.rowEnd * kTileSize, r->height);
-    if (pixelRowEnd > pixelRowBegin)
+    // (two-level pipeline: the raster kernel zeroes the tiles that have no work itself, no 8 MB memset)
+    if (pixelRowEnd > pixelRowBegin && !twoLevel)
         gs_device_memset(r->backBuffer + rowBytes * pixelRowBegin, 0, rowBytes * (size_t) (pixelRowEnd - pixelRowBegin));
     gs_device_memset(r->tileRange, 0xFF, sizeof(int32_t) * 2 * (size_t) scr.totalTiles);
 
@@ -660,7 +668,7 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
     // Band cull: with a strict sub-band of tile rows (one rank of a multi-GPU split) only the splats whose tile AABB
     // reaches the band go through SH evaluation, the depth sort and the tile-list passes.
     const bool strictBand = scr.rowBegin > 0 || scr.rowEnd < scr.tilesY;
-    const bool cull = twoLevel && n > 0 && g.sortBackend == GS_SORT_BACKEND_NATIVE &&
+    const bool cull = twoLevel && n > 0 && cfg.sortBackend == GS_SORT_BACKEND_NATIVE &&
                       (r->bandCull == GS_BAND_CULL_ON || (r->bandCull == GS_BAND_CULL_AUTO && strictBand));
 
     if (r->shDegree != 0 && !cull) // Demo.cpp:432
@@ -748,7 +756,7 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         // (1) splats by depth: 32-bit keys, N elements
         int orderSel = 0;
         gs_timer_start(stageTimers[6]);
-        const bool native = g.sortBackend == GS_SORT_BACKEND_NATIVE;
+        const bool native = cfg.sortBackend == GS_SORT_BACKEND_NATIVE;
         if (n > 0)
         {
             if (native && radixSortSupported(4, n))
@@ -812,7 +820,7 @@ extern "C" int gs_renderer_finish(GsRenderer* r, GsFrameStats* stats)
         const int32_t size = (int32_t) demand;
 
         // (3) stable sort of the pairs on the tile bits only
-        const bool native = g.sortBackend == GS_SORT_BACKEND_NATIVE;
+        const bool native = cfg.sortBackend == GS_SORT_BACKEND_NATIVE;
         gs_timer_start(stageTimers[3]);
         int sel = 0;
         if (size > 0)
@@ -845,7 +853,7 @@ extern "C" int gs_renderer_finish(GsRenderer* r, GsFrameStats* stats)
 
     // raster (direct launch: no global argument state, so renderers can interleave their halves)
     unsigned long long* consumed = nullptr;
-    if (g.collectRasterStats)
+    if (cfg.collectRasterStats)
     {
         if (r->consumed == nullptr) GS_CHECK(hipMalloc((void**) &r->consumed, sizeof(unsigned long long)));
         consumed = r->consumed;
@@ -853,7 +861,7 @@ extern "C" int gs_renderer_finish(GsRenderer* r, GsFrameStats* stats)
     }
     gs_timer_start(stageTimers[5]);
     launchRasterize(g.stream, scr, r->tileRange, r->values[r->selector], (const float2*) r->clipXY, (const float4*) r->conic,
-                    (const float4*) r->color, (uchar4*) r->backBuffer, consumed);
+                    (const float4*) r->color, (uchar4*) r->backBuffer, consumed, r->pipeline == GS_PIPELINE_TWO_LEVEL);
     gs_timer_stop(stageTimers[5]);
     if (hipGetLastError() != hipSuccess) printf("kernel error renderDepthBuffer\n");
     if (blocking) st.msRasterize = gs_timer_elapsed_ms(stageTimers[5]);

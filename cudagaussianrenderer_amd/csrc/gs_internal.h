@@ -80,6 +80,7 @@ struct TileListScratch
     int32_t* waveOffsets = nullptr; // [ceil(N/64)]
     int64_t* total = nullptr;       // device scalar
     int64_t* totalHost = nullptr;   // pinned host mirror
+    int64_t* totalHostMapped = nullptr; // device address of the same word (written directly by the renderer's scan)
     int32_t capacityWaves = 0;
     const int* countDevice = nullptr; // optional device-side splat count (renderer, culled list); nullptr = host count
 };
@@ -128,7 +129,7 @@ void launchTileRanges(hipStream_t stream, int size, int keyBytes, const void* ke
 
 void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileRange, const int32_t* values,
                      const float2* clipXY, const float4* conic, const float4* color, uchar4* backBuffer,
-                     unsigned long long* consumedPairsOrNull);
+                     unsigned long long* consumedPairsOrNull, bool clearEmptyTiles = false);
 
 int sortEndBit(int totalTiles);
 int tileBits(int totalTiles);

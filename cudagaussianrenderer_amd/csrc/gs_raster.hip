@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
                                                                   const float2* __restrict__ clipXY,
                                                                   const float4* __restrict__ conic,
                                                                   const float4* __restrict__ color, uchar4* __restrict__ backBuffer,
-                                                                  unsigned long long* __restrict__ consumedPairs)
+                                                                  unsigned long long* __restrict__ consumedPairs, int clearEmptyTiles)
 {
     constexpr int THREADS = 256 / PPL;
     constexpr int GROUPS_X = kTileSize / PPL;
@@ -73,12 +73,24 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
     // GaussianRender.cu:917-931 (wave-uniform: scalar loads)
     int first = tileRange[tile * 2];
     const int count = tileRange[tile * 2 + 1] - first;
-    if (count == 0) return;
+    if (count == 0 && !clearEmptyTiles) return;
 
     const int t = threadIdx.x;
     const int tileX = tile % scr.tilesX, tileY = tile / scr.tilesX;
     const int px0 = tileX * kTileSize + (t % GROUPS_X) * PPL;
     const int py = tileY * kTileSize + t / GROUPS_X;
+    if (count == 0)
+    {
+        // The reference leaves tiles without work at the caller's memset value (0,0,0,0) (Demo.cpp:399); the renderer
+        // skips that 8 MB memset and has the empty tiles write their zeros here instead.
+        if (py < scr.height)
+        {
+#pragma unroll
+            for (int p = 0; p != PPL; ++p)
+                if (px0 + p < scr.width) backBuffer[(size_t) py * scr.width + px0 + p] = make_uchar4(0, 0, 0, 0);
+        }
+        return;
+    }
     // GaussianRender.cu:939 (no half-pixel offset)
     float clipPx[PPL];
     bool onScreen[PPL];
@@ -230,7 +242,7 @@ int rasterPixelsPerLane() { return g_rasterPixelsPerLane; }
 
 void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileRange, const int32_t* values,
                      const float2* clipXY, const float4* conic, const float4* color, uchar4* backBuffer,
-                     unsigned long long* consumedPairsOrNull)
+                     unsigned long long* consumedPairsOrNull, bool clearEmptyTiles)
 {
     const int firstTile = scr.rowBegin * scr.tilesX;
     const int numTiles = (scr.rowEnd - scr.rowBegin) * scr.tilesX;
@@ -239,16 +251,16 @@ void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileR
     {
     case 1:
         hipLaunchKernelGGL(rasterizeTilesKernel<1>, dim3(numTiles), dim3(256), 0, stream, scr, firstTile, numTiles, tileRange, values,
-                           clipXY, conic, color, backBuffer, consumedPairsOrNull);
+                           clipXY, conic, color, backBuffer, consumedPairsOrNull, clearEmptyTiles ? 1 : 0);
         break;
     case 2:
         hipLaunchKernelGGL(rasterizeTilesKernel<2>, dim3(numTiles), dim3(128), 0, stream, scr, firstTile, numTiles, tileRange, values,
-                           clipXY, conic, color, backBuffer, consumedPairsOrNull);
+                           clipXY, conic, color, backBuffer, consumedPairsOrNull, clearEmptyTiles ? 1 : 0);
         break;
     case 4:
     default:
         hipLaunchKernelGGL(rasterizeTilesKernel<4>, dim3(numTiles), dim3(64), 0, stream, scr, firstTile, numTiles, tileRange, values,
-                           clipXY, conic, color, backBuffer, consumedPairsOrNull);
+                           clipXY, conic, color, backBuffer, consumedPairsOrNull, clearEmptyTiles ? 1 : 0);
         break;
     }
 }

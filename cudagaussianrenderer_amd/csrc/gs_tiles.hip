@@ -286,8 +286,9 @@ void ensureTileListScratch(TileListScratch& s, int count)
     if (s.total == nullptr)
     {
         GS_CHECK(hipMalloc((void**) &s.total, sizeof(int64_t)));
-        GS_CHECK(hipHostMalloc((void**) &s.totalHost, sizeof(int64_t), hipHostMallocDefault));
+        GS_CHECK(hipHostMalloc((void**) &s.totalHost, sizeof(int64_t), hipHostMallocMapped));
         *s.totalHost = 0;
+        if (hipHostGetDevicePointer((void**) &s.totalHostMapped, s.totalHost, 0) != hipSuccess) s.totalHostMapped = nullptr;
     }
     if (waves > s.capacityWaves)
     {

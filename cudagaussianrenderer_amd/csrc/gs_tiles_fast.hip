@@ -226,7 +226,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void tileListFastKernel(int 
 // (16-byte coalesced loads), wave scans by shuffles, 16 wave totals through LDS, carry across passes.
 constexpr int kScanThreads = 1024;
 __global__ __launch_bounds__(kScanThreads) void scanFastKernel(int nHost, const int* __restrict__ countDevice, const int32_t* __restrict__ in, int32_t* __restrict__ out,
-                                                               int64_t* __restrict__ total)
+                                                               int64_t* __restrict__ total, int64_t* __restrict__ totalHostMapped)
 {
     __shared__ long long waveTotals[kScanThreads / kWave];
     const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
@@ -271,7 +271,12 @@ __global__ __launch_bounds__(kScanThreads) void scanFastKernel(int nHost, const 
         carry += all;
         __syncthreads();
     }
-    if (t == 0) *total = carry;
+    if (t == 0)
+    {
+        *total = carry;
+        // pinned, device-mapped host word: the host reads it after the event that follows this kernel (no copy kernel)
+        if (totalHostMapped != nullptr) *totalHostMapped = carry;
+    }
 }
 
 template <typename TileKey>
@@ -286,7 +291,7 @@ void launchEmit(hipStream_t stream, dim3 grid, dim3 block, int count, const Scre
 
 void launchScanInt32(hipStream_t stream, int n, const int32_t* in, int32_t* out, int64_t* total)
 {
-    hipLaunchKernelGGL(scanFastKernel, dim3(1), dim3(kScanThreads), 0, stream, n, (const int*) nullptr, in, out, total);
+    hipLaunchKernelGGL(scanFastKernel, dim3(1), dim3(kScanThreads), 0, stream, n, (const int*) nullptr, in, out, total, (int64_t*) nullptr);
 }
 
 void launchTileListFastCount(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
@@ -303,9 +308,11 @@ void launchTileListFastCount(hipStream_t stream, int count, const Screen& scr, c
         const dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
         hipLaunchKernelGGL((tileListFastKernel<false, uint16_t>), grid, block, 0, stream, count, s.countDevice, scr, order, clipXY, screenEllipse,
                            s.waveCounts, (const int32_t*) nullptr, (uint16_t*) nullptr, (int32_t*) nullptr, 0);
-        hipLaunchKernelGGL(scanFastKernel, dim3(1), dim3(kScanThreads), 0, stream, waves, s.countDevice, s.waveCounts, s.waveOffsets, s.total);
+        hipLaunchKernelGGL(scanFastKernel, dim3(1), dim3(kScanThreads), 0, stream, waves, s.countDevice, s.waveCounts, s.waveOffsets, s.total,
+                           s.totalHostMapped);
     }
-    GS_CHECK(hipMemcpyAsync(s.totalHost, s.total, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    if (waves == 0 || s.totalHostMapped == nullptr)
+        GS_CHECK(hipMemcpyAsync(s.totalHost, s.total, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
 }
 
 void launchTileListFastEmit(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,

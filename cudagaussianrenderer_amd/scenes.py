@@ -133,3 +133,53 @@ def tile_row_bands(tiles_y, world_size):
         bands.append((begin, begin + rows))
         begin += rows
     return bands
+
+
+def balanced_tile_row_bands(row_costs, world_size):
+    """Contiguous tile-row bands whose summed cost is as even as a prefix partition allows.
+
+    `row_costs[y]` is the estimated work of tile row y (e.g. pairs in that row from a calibration frame). Every rank
+    calls this with the same numbers, so all ranks agree on the bands without communicating. Each band gets at least
+    one row while rows remain. Minimises the maximum band cost (binary search on the cap + greedy packing).
+    """
+    costs = [float(c) for c in row_costs]
+    rows = len(costs)
+    world_size = max(1, int(world_size))
+    if world_size == 1:
+        return [(0, rows)]
+    if rows <= world_size:
+        return [(min(r, rows), min(r + 1, rows)) for r in range(world_size)]
+
+    def pack(cap):
+        bands, begin, acc = [], 0, 0.0
+        for y in range(rows):
+            remaining_bands = world_size - len(bands) - 1
+            must_close = rows - y <= remaining_bands  # keep one row for every later band
+            if y > begin and (acc + costs[y] > cap or must_close):
+                bands.append((begin, y))
+                begin, acc = y, 0.0
+                if len(bands) == world_size - 1:
+                    break
+            acc += costs[y]
+        bands.append((begin, rows))
+        return bands
+
+    lo, hi = max(costs), sum(costs)
+    for _ in range(40):
+        mid = 0.5 * (lo + hi)
+        b = pack(mid)
+        worst = max(sum(costs[a:e]) for a, e in b)
+        if len(b) == world_size and worst <= mid * (1 + 1e-9):
+            hi = mid
+        else:
+            lo = mid
+    bands = pack(hi)
+    while len(bands) < world_size:  # degenerate inputs: split the largest band
+        i = max(range(len(bands)), key=lambda k: bands[k][1] - bands[k][0])
+        a, e = bands[i]
+        if e - a < 2:
+            bands.append((rows, rows))
+            continue
+        m = (a + e) // 2
+        bands[i:i + 1] = [(a, m), (m, e)]
+    return bands

@@ -3,6 +3,7 @@
 report the per-band frame time; the N-GPU frame time is the slowest band (+ the framebuffer gather)."""
 import argparse, os, sys, tempfile, time
 import numpy as np
+import torch  # before the library: both must share one HIP runtime (torch ships its own libamdhip64)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cudagaussianrenderer_amd as gs
 from cudagaussianrenderer_amd import scenes
@@ -10,8 +11,10 @@ from cudagaussianrenderer_amd import scenes
 ap = argparse.ArgumentParser()
 ap.add_argument("--splats", type=int, default=1_000_000)
 ap.add_argument("--worlds", type=str, default="1,2,4,8")
-ap.add_argument("--frames", type=int, default=32)
+ap.add_argument("--frames", type=int, default=256)
 ap.add_argument("--cull", type=int, default=0)
+ap.add_argument("--inflight", type=int, default=3)
+ap.add_argument("--balanced", type=int, default=1)
 args = ap.parse_args()
 W, H = 1920, 1080
 with tempfile.TemporaryDirectory() as tmp:
@@ -21,20 +24,48 @@ with tempfile.TemporaryDirectory() as tmp:
 cams = [gs.camera_from_pose(p, q, W, H) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 8)]
 tx, ty = gs.tile_counts(W, H)
 base = None
+row_cost = np.zeros(ty)
+cal = gs.Renderer(W, H)
+cal.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+for cam in cams:
+    cal.render(cam)
+    rng = cal.download(cal.buffers().tileRange, 2 * tx * ty, np.int32).reshape(ty, tx, 2)
+    counts = (rng[..., 1] - rng[..., 0]).astype(np.float64)
+    row_cost += counts.sum(1) + 6.0 * np.minimum(counts, 256.0).sum(1)
+cal.close()
 for world in [int(x) for x in args.worlds.split(",")]:
     times = []
-    for band in scenes.tile_row_bands(ty, world):
-        r = gs.Renderer(W, H, tile_rows=band if world > 1 else None, band_cull=args.cull)
-        r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
-        for i in range(8):
-            r.render(cams[i % 8])
-        gs.synchronize()
+
+    D = args.inflight
+    bands = scenes.balanced_tile_row_bands(row_cost, world) if args.balanced else scenes.tile_row_bands(ty, world)
+    print('bands', bands)
+    for band in bands:
+        streams = [torch.cuda.Stream() for _ in range(D)]
+        rs = []
+        for d in range(D):
+            r = gs.Renderer(W, H, tile_rows=band if world > 1 else None, band_cull=args.cull)
+            r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+            r.set_stream(streams[d].cuda_stream)
+            rs.append(r)
+        from concurrent.futures import ThreadPoolExecutor
+        from collections import deque
+        pools = [ThreadPoolExecutor(1) for _ in range(D)]
+        def run(count, first=0):
+            q = deque()
+            for i in range(first, first + count):
+                if len(q) == D:
+                    q.popleft().result()
+                q.append(pools[i % D].submit(rs[i % D].render, cams[i % 8]))
+            while q:
+                q.popleft().result()
+        run(16)
+        torch.cuda.synchronize()
         t = time.perf_counter()
-        for i in range(args.frames):
-            r.render(cams[i % 8])
-        gs.synchronize()
+        run(args.frames, 16)
+        torch.cuda.synchronize()
         times.append(1e3 * (time.perf_counter() - t) / args.frames)
-        r.close()
+        for r in rs:
+            r.close()
     worst = max(times)
     base = base or worst
     print(f"world {world}: per-band ms {[round(x, 3) for x in times]} -> slowest {worst:.3f} ms, speed-up vs 1 GPU {base / worst:.2f}x (gather not included)")
