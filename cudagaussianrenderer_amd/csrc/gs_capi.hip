@@ -58,6 +58,7 @@ thread_local State g;
 struct Settings
 {
     int sortBackend = GS_SORT_BACKEND_NATIVE;
+    bool onesweep = false; // NATIVE with single-kernel (look-back) passes
     bool collectRasterStats = false;
     unsigned long long* consumedDevice = nullptr; // counter of the staged gs_rasterize_tile
 };
@@ -280,13 +281,18 @@ extern "C" int64_t gs_last_raster_consumed_pairs(void)
     return (int64_t) v;
 }
 
-extern "C" void gs_set_sort_backend(int backend) { cfg.sortBackend = (backend == GS_SORT_BACKEND_ROCPRIM) ? backend : GS_SORT_BACKEND_NATIVE; }
-extern "C" int gs_get_sort_backend(void) { return cfg.sortBackend; }
+extern "C" void gs_set_sort_backend(int backend)
+{
+    cfg.onesweep = backend == GS_SORT_BACKEND_ONESWEEP;
+    cfg.sortBackend = (backend == GS_SORT_BACKEND_ROCPRIM) ? GS_SORT_BACKEND_ROCPRIM : GS_SORT_BACKEND_NATIVE;
+}
+extern "C" int gs_get_sort_backend(void) { return cfg.onesweep ? GS_SORT_BACKEND_ONESWEEP : cfg.sortBackend; }
 
 extern "C" int gs_radix_sort_pairs(int keyBytes, void* keys0, void* keys1, int32_t* values0, int32_t* values1, int32_t count, int beginBit,
                                    int endBit)
 {
     if (!radixSortSupported(keyBytes, count)) return -1;
+    g.radix.onesweep = cfg.onesweep;
     return launchRadixSortPairs(g.stream, g.radix, keyBytes, keys0, keys1, values0, values1, count, beginBit, endBit);
 }
 
@@ -751,6 +757,7 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
             if (blocking) st.msSphericalHarmonics = gs_timer_elapsed_ms(stageTimers[0]);
         }
         r->radix.countDevice = countDevice;
+        r->radix.onesweep = cfg.onesweep;
         r->scratch.countDevice = countDevice;
 
         // (1) splats by depth: 32-bit keys, N elements

@@ -116,6 +116,15 @@ struct RadixScratch
     // Optional device-side element count (<= the host-side n the grids are sized for); set per call by the renderer
     // when the splat list was culled on the device, nullptr otherwise.
     const int* countDevice = nullptr;
+    // single-kernel passes (decoupled look-back): per-pass digit totals, one status granule per (tile, digit), the
+    // ticket counter and its running base, the launch epoch, and a device word set when a bounded spin gave up
+    bool onesweep = false; // measured slower than the three-kernel pass on MI355X; kept selectable
+    unsigned* digitCounts = nullptr;
+    unsigned long long* status = nullptr;
+    unsigned* ticket = nullptr;
+    unsigned* error = nullptr;
+    unsigned ticketBase = 0, epoch = 0;
+    int capacityStatusTiles = 0;
 };
 bool radixSortSupported(int keyBytes, int n);
 void ensureRadixScratch(RadixScratch& s, int n);

@@ -129,6 +129,7 @@ int64_t gs_last_raster_consumed_pairs(void);
  * the pairs). NATIVE = the three-kernel LSD sort of gs_radix.hip (default), ROCPRIM = rocPRIM's device sort. */
 #define GS_SORT_BACKEND_ROCPRIM 0
 #define GS_SORT_BACKEND_NATIVE 1
+#define GS_SORT_BACKEND_ONESWEEP 2 /* NATIVE with one kernel per pass (decoupled look-back); slower on MI355X, kept for comparison */
 void gs_set_sort_backend(int backend);
 int gs_get_sort_backend(void);
 /* The native sort on its own: stable LSD sort of (keyBytes in {2,4} key, int32 value) pairs on key bits

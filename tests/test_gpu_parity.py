@@ -378,9 +378,13 @@ def test_full_size_properties(gs, tmp_path):
 
 @pytest.mark.parametrize("key_bytes,n,begin,end,skew", [(4, 1_000_003, 0, 32, False), (4, 4096, 0, 32, True), (4, 1, 0, 32, False),
                                                       (2, 5_000_017, 0, 13, False), (2, 70_001, 0, 15, True), (4, 300_000, 8, 21, False)])
-def test_native_radix_sort_bit_exact(gs, key_bytes, n, begin, end, skew):
-    """The renderer's own LSD radix sort: stable, bit-exact against numpy's stable argsort on the masked key."""
+@pytest.mark.parametrize("backend", [1, 2])
+def test_native_radix_sort_bit_exact(gs, key_bytes, n, begin, end, skew, backend):
+    """The renderer's own LSD radix sort (three-kernel passes, and the single-kernel look-back variant): stable,
+    bit-exact against numpy's stable argsort on the masked key."""
     import ctypes as C
+
+    gs.lib().gs_set_sort_backend(backend)
 
     rng = np.random.default_rng(n)
     dt = np.uint16 if key_bytes == 2 else np.uint32
@@ -393,6 +397,7 @@ def test_native_radix_sort_bit_exact(gs, key_bytes, n, begin, end, skew):
     bufs = [gs.DeviceBuffer(keys), gs.DeviceBuffer(nbytes=keys.nbytes, dtype=dt)]
     vals = [gs.DeviceBuffer(values), gs.DeviceBuffer(nbytes=values.nbytes, dtype=np.int32)]
     sel = gs.lib().gs_radix_sort_pairs(key_bytes, bufs[0].ptr, bufs[1].ptr, vals[0].ptr, vals[1].ptr, n, begin, end)
+    gs.lib().gs_set_sort_backend(1)
     assert sel in (0, 1)
     got_k = bufs[sel].copy_to(count=n, dtype=dt)
     got_v = vals[sel].copy_to(count=n, dtype=np.int32)
@@ -405,7 +410,7 @@ def test_sort_backends_give_identical_frames(gs):
     pos, sr, col = _procedural(gs, 100000, seed=21, min_scale=0.005, max_scale=0.1)
     cam = gs.camera_from_bounds([-4] * 3, [4] * 3, 1280, 720)
     out = []
-    for backend in (0, 1):  # rocPRIM, native
+    for backend in (0, 1, 2):  # rocPRIM, native, native with look-back passes
         gs.lib().gs_set_sort_backend(backend)
         r = gs.Renderer(1280, 720)
         r.set_scene(pos, sr, col)
@@ -414,7 +419,8 @@ def test_sort_backends_give_identical_frames(gs):
         out.append((r.read_image(), r.download(b.values, b.tileListSize, np.int32)))
         r.close()
     gs.lib().gs_set_sort_backend(1)
-    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
+    for other in out[1:]:
+        assert np.array_equal(out[0][1], other[1]) and np.array_equal(out[0][0], other[0])
 
 
 @pytest.mark.parametrize("degree", [0, 3])
