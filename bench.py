@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--opacity-mean", type=float, default=1.0, help="raw (pre-sigmoid) opacity mean of the synthetic scene")
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the CPU oracle timed as cpu_baseline (0 = skip)")
     ap.add_argument("--ppl", type=int, default=0, help="raster pixels per lane override (1,2,4)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel individually instead of replaying a captured frame")
     ap.add_argument("--even-bands", action="store_true", help="multi-GPU: equal-height bands instead of cost-balanced ones")
     ap.add_argument("--inflight", type=int, default=3, help="frames in flight per GPU (renderers on separate HIP streams)")
     args = ap.parse_args()
@@ -130,6 +131,7 @@ def main():
         fb = torch.zeros((H, W, 4), dtype=torch.uint8, device=device)
         r.set_back_buffer(fb.data_ptr())
         r.set_stream(streams[d].cuda_stream)
+        r.set_graph(not args.no_graph)
         renderers.append(r)
         framebuffers.append(fb)
     renderer, framebuffer = renderers[0], framebuffers[0]
@@ -242,7 +244,7 @@ def main():
                             f"{views}-view orbit, tile-row bands over {world} GPU(s)",
                 "splats": N, "width": W, "height": H, "sh_degree": args.sh_degree, "views": views,
                 "pairs_per_frame": round(p_mean), "consumed_pairs_per_frame": round(pc_mean),
-                "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": name, "frames_in_flight": depth, "tile_row_bands": [list(b) for b in bands],
+                "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": name, "frames_in_flight": depth, "captured_frames": not args.no_graph, "tile_row_bands": [list(b) for b in bands],
                 "opacity_mean_raw": args.opacity_mean, "ingest_s": round(t_ingest, 2),
             },
             "roofline": {

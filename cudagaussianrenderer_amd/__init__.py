@@ -282,6 +282,10 @@ class Renderer:
             raise RuntimeError(f"gs_renderer_render failed ({rc})")
         return st
 
+    def set_graph(self, enabled=True):
+        """Replay plain frames (render(camera) without timers/stats) as one captured hipGraph launch."""
+        lib().gs_renderer_set_graph(self.handle, 1 if enabled else 0)
+
     def set_stream(self, hip_stream):
         """Give this renderer its own stream (e.g. torch.cuda.Stream().cuda_stream) so frames can overlap."""
         lib().gs_renderer_set_stream(self.handle, hip_stream)

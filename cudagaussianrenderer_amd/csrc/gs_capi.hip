@@ -2,6 +2,7 @@
 // staged host functions (GaussianRender.cuh:118-143) and the one-call renderer (Demo.cpp:352-479).
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "gs_internal.h"
@@ -353,6 +354,13 @@ struct GsRenderer
     TileListScratch scratch;
     RadixScratch radix;
     unsigned long long* consumed = nullptr;
+    // captured frame (hipGraph): the whole two-level frame as one graph launch, list sizes kept on the device
+    bool useGraph = false, graphValid = false, ownsStream = false;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graphExec = nullptr;
+    FrameParams* paramsDevice = nullptr;
+    FrameParams* paramsHost = nullptr; // pinned
+    int graphCapacity = 0, graphSplats = 0, graphRowBegin = -1, graphRowEnd = -1, graphCull = -1, graphSelector = 0, graphKeyBytes = 2;
     bool pending = false; // begin() issued, finish() not yet
     FrameState frame;
     unsigned long long* bandMask = nullptr;
@@ -493,6 +501,11 @@ extern "C" void gs_renderer_destroy(GsRenderer* r)
     gs_device_free(r->sortTemp);
     freeTileListScratch(r->scratch);
     freeRadixScratch(r->radix);
+    if (r->graphExec) (void) hipGraphExecDestroy(r->graphExec);
+    if (r->graph) (void) hipGraphDestroy(r->graph);
+    if (r->ownsStream) (void) hipStreamDestroy(r->stream);
+    if (r->paramsDevice) (void) hipFree(r->paramsDevice);
+    if (r->paramsHost) (void) hipHostFree(r->paramsHost);
     if (r->consumed) (void) hipFree(r->consumed);
     gs_timer_destroy(r->timer);
     for (GsTimer* t : r->asyncTimers) gs_timer_destroy(t);
@@ -525,6 +538,7 @@ extern "C" int gs_renderer_set_scene(GsRenderer* r, int32_t n, const float* posi
     StreamScope scope(r);
     GS_CHECK(hipStreamSynchronize(g.stream));
     freeScene(r);
+    r->graphValid = false;
     r->splatCount = n;
     r->shDegree = shDegree;
     r->shCount = shCount;
@@ -588,6 +602,15 @@ extern "C" void gs_renderer_buffers(GsRenderer* r, GsRendererBuffers* out)
     out->tileRange = r->tileRange;
     out->keys = r->keys[r->selector];
     out->values = r->values[r->selector];
+    if (r->useGraph && r->graphValid && r->scratch.totalHost != nullptr)
+    {
+        // captured frames keep the pair count on the device; fetch the last frame's for the caller
+        StreamScope scope(r);
+        GS_CHECK(hipStreamSynchronize(g.stream));
+        r->tileListSize = (int32_t) std::min<int64_t>(*r->scratch.totalHost, r->tileListCapacity);
+        out->keys = r->keys[r->selector];
+        out->values = r->values[r->selector];
+    }
     out->splatCount = r->splatCount;
     out->tileListSize = r->tileListSize;
     out->keyBytes = r->keyBytes;
@@ -890,8 +913,181 @@ extern "C" int gs_renderer_finish(GsRenderer* r, GsFrameStats* stats)
     return 0;
 }
 
+// ---- captured frame ------------------------------------------------------------------------------------------------
+// The two-level frame with every list size left on the device (the pair count feeds the tile sort and the range kernel
+// through pointers, grids are sized for the list capacity), so the frame has no host round trip and can be captured once
+// and replayed as ONE graph launch per frame.  The camera travels in a small device struct that a memcpy node refreshes.
+// Overflow follows the reference (Demo.cpp:357-366,447): a frame whose demand exceeds the capacity is truncated, the
+// next frame runs with a doubled list.
+namespace
+{
+// Allocation / legacy-stream work of one host thread must not overlap another thread's stream capture: set-up and capture
+// are serialised process-wide (they happen once per renderer; replays take no lock).
+std::mutex g_captureMutex;
+
+int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull)
+{
+    const int n = r->splatCount;
+    const int tileKeyBytes = scr.totalTiles > 65536 ? 4 : 2;
+    const int tBits = tileBits(scr.totalTiles);
+    const char* stopEnv = getenv("GS_GRAPH_STOP"); // debugging aid: enqueue only the first k stages
+    const int stopAfter = stopEnv ? atoi(stopEnv) : 99;
+    const float3 unused = make_float3(0.f, 0.f, 0.f);
+    ClipCamera unusedCamera{};
+
+    GS_CHECK(hipMemcpyAsync(r->paramsDevice, r->paramsHost, sizeof(FrameParams), hipMemcpyHostToDevice, g.stream));
+    launchFillInt32(g.stream, r->tileRange, -1, 2 * scr.totalTiles); // not a memset node: see gs_ranges.hip
+    if (r->shDegree != 0 && !cull)
+        launchSphericalHarmonics(g.stream, n, r->shDegree, r->shCount, (const float4*) r->position, r->sh, unused, (float4*) r->color,
+                                 r->paramsDevice);
+    const int* countDevice = nullptr;
+    if (!cull)
+        launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
+                            (float2*) r->clipXY, r->clipZ, (float4*) r->ellipse, (float4*) r->conic, r->depthKey[0],
+                            (uint32_t*) r->order[0], nullptr, nullptr, r->paramsDevice);
+    else
+    {
+        launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
+                            (float2*) r->clipXY, r->clipZ, (float4*) r->ellipse, (float4*) r->conic, nullptr, nullptr, r->bandMask,
+                            r->bandCounts, r->paramsDevice);
+        launchScanInt32(g.stream, (n + kWave - 1) / kWave, r->bandCounts, r->bandOffsets, r->bandTotal);
+        launchCompactBand(g.stream, n, r->bandMask, r->bandOffsets, r->clipZ, r->depthKey[0], (uint32_t*) r->order[0]);
+        countDevice = (const int*) r->bandTotal;
+        if (stopAfter < 2) return 0;
+        if (r->shDegree != 0)
+            launchSphericalHarmonicsGather(g.stream, n, countDevice, r->shDegree, r->shCount, r->order[0], (const float4*) r->position,
+                                           r->shPerSplat, unused, (float4*) r->color, r->paramsDevice);
+    }
+    if (stopAfter < 3) return 0;
+    r->radix.onesweep = false; // its ticket base / epoch are host-side launch arguments: not replayable
+    r->radix.countDevice = countDevice;
+    r->scratch.countDevice = countDevice;
+    const int orderSel = launchRadixSortPairs(g.stream, r->radix, 4, r->depthKey[0], r->depthKey[1], r->order[0], r->order[1], n, 0, 32);
+    const uint32_t* order = (const uint32_t*) r->order[orderSel];
+    if (stopAfter < 4)
+    {
+        r->radix.countDevice = nullptr;
+        r->scratch.countDevice = nullptr;
+        return 0;
+    }
+    launchTileListFastCount(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch);
+    launchTileListFastEmit(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],
+                           tileKeyBytes, r->values[0], r->tileListCapacity);
+    // tile sort + ranges on the device-side pair count (low word of the int64 total), grids sized for the capacity
+    const int* pairCount = (const int*) r->scratch.total;
+    r->radix.countDevice = pairCount;
+    r->scratch.countDevice = nullptr;
+    if (stopAfter < 5)
+    {
+        r->radix.countDevice = nullptr;
+        return 0;
+    }
+    const int sel = launchRadixSortPairs(g.stream, r->radix, tileKeyBytes, r->keys[0], r->keys[1], r->values[0], r->values[1],
+                                         r->tileListCapacity, 0, tBits);
+    r->radix.countDevice = nullptr;
+    if (stopAfter < 6) return 0;
+    launchTileRanges(g.stream, r->tileListCapacity, tileKeyBytes, r->keys[sel], r->tileRange, pairCount);
+    if (stopAfter < 7) return 0;
+    launchRasterize(g.stream, scr, r->tileRange, r->values[sel], (const float2*) r->clipXY, (const float4*) r->conic,
+                    (const float4*) r->color, (uchar4*) r->backBuffer, nullptr, true);
+    r->graphSelector = sel;
+    r->graphKeyBytes = tileKeyBytes;
+    return 0;
+}
+
+int renderCaptured(GsRenderer* r, const GsCameraData* camera)
+{
+    if (!r->hasStream && g.stream == nullptr)
+    {
+        // the null stream cannot be captured: a renderer without a stream of its own gets one
+        GS_CHECK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+        r->hasStream = true;
+        r->ownsStream = true;
+        GS_CHECK(hipDeviceSynchronize()); // uploads and earlier frames issued on the null stream
+    }
+    StreamScope scope(r);
+    const Screen scr = makeScreen(r->width, r->height, r->rowBegin, r->rowEnd);
+    const int n = r->splatCount;
+    const bool strictBand = scr.rowBegin > 0 || scr.rowEnd < scr.tilesY;
+    const bool cull = n > 0 && (r->bandCull == GS_BAND_CULL_ON || (r->bandCull == GS_BAND_CULL_AUTO && strictBand));
+
+    // The previous frame of this renderer is complete before its parameter block is overwritten; its pair count is on
+    // the host by then, so an overflow is noticed here and the list doubled for this frame.
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    if (r->paramsDevice == nullptr)
+    {
+        std::lock_guard<std::mutex> lock(g_captureMutex);
+        GS_CHECK(hipMalloc((void**) &r->paramsDevice, sizeof(FrameParams)));
+        GS_CHECK(hipHostMalloc((void**) &r->paramsHost, sizeof(FrameParams), hipHostMallocDefault));
+    }
+    if (r->graphValid && r->scratch.totalHost != nullptr)
+    {
+        const int64_t demand = *r->scratch.totalHost;
+        g.lastDemand = demand;
+        r->tileListSize = (int32_t) std::min<int64_t>(demand, r->tileListCapacity);
+        bool grew = false;
+        if (demand > r->tileListCapacity)
+        {
+            std::lock_guard<std::mutex> lock(g_captureMutex);
+            grew = growTileListIfNeeded(r, demand);
+        }
+        if (grew) r->graphValid = false;
+    }
+    if (r->graphValid && (r->graphCapacity != r->tileListCapacity || r->graphSplats != n || r->graphRowBegin != scr.rowBegin ||
+                          r->graphRowEnd != scr.rowEnd || r->graphCull != (int) cull))
+        r->graphValid = false;
+
+    FrameParams fp{};
+    std::memcpy(fp.camera.view, camera->view, sizeof(fp.camera.view));
+    fp.camera.fovCotX = camera->fovCotangent[0];
+    fp.camera.fovCotY = camera->fovCotangent[1];
+    fp.camera.depthScale = camera->depthScaleBias[0];
+    fp.camera.depthBias = camera->depthScaleBias[1];
+    for (int k = 0; k != 3; ++k) fp.cameraPosition[k] = camera->position[k];
+    *r->paramsHost = fp;
+
+    if (!r->graphValid)
+    {
+        std::lock_guard<std::mutex> lock(g_captureMutex);
+        // allocate everything the frame needs BEFORE capturing (no allocation may happen inside a capture)
+        ensureTileListScratch(r->scratch, n);
+        ensureRadixScratch(r->radix, n);
+        ensureRadixScratch(r->radix, r->tileListCapacity);
+        if (r->graphExec) (void) hipGraphExecDestroy(r->graphExec);
+        if (r->graph) (void) hipGraphDestroy(r->graph);
+        r->graphExec = nullptr;
+        r->graph = nullptr;
+        GS_CHECK(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+        enqueueCapturableFrame(r, scr, cull);
+        GS_CHECK(hipStreamEndCapture(g.stream, &r->graph));
+        GS_CHECK(hipGraphInstantiate(&r->graphExec, r->graph, nullptr, nullptr, 0));
+        r->graphValid = true;
+        r->graphCapacity = r->tileListCapacity;
+        r->graphSplats = n;
+        r->graphRowBegin = scr.rowBegin;
+        r->graphRowEnd = scr.rowEnd;
+        r->graphCull = (int) cull;
+    }
+    GS_CHECK(hipGraphLaunch(r->graphExec, g.stream));
+    r->selector = r->graphSelector;
+    r->keyBytes = r->graphKeyBytes;
+    return 0;
+}
+} // namespace
+
+extern "C" void gs_renderer_set_graph(GsRenderer* r, int enabled)
+{
+    r->useGraph = enabled != 0;
+    r->graphValid = false;
+}
+
 extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsFrameStats* stats)
 {
+    // Captured path: plain frames (no stage timers, no stats) of the two-level pipeline on the native sort.
+    if (r->useGraph && timed == 0 && stats == nullptr && r->pipeline == GS_PIPELINE_TWO_LEVEL &&
+        cfg.sortBackend == GS_SORT_BACKEND_NATIVE && !cfg.collectRasterStats && r->splatCount > 0)
+        return renderCaptured(r, camera);
+    r->graphValid = false; // the regular path re-sizes scratch as it likes
     const int rc = gs_renderer_begin(r, camera, timed);
     if (rc != 0) return rc;
     return gs_renderer_finish(r, stats);

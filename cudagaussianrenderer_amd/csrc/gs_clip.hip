@@ -21,7 +21,8 @@ struct Sym3
     float xx, xy, xz, yy, yz, zz;
 };
 
-__global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr, ClipCamera cam, const float4* __restrict__ position,
+__global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr, ClipCamera camArg, const FrameParams* __restrict__ params,
+                                                            const float4* __restrict__ position,
                                                             const float4* __restrict__ scaleAndRotation,
                                                             float2* __restrict__ clipXY, float* __restrict__ clipZ,
                                                             float4* __restrict__ screenEllipse, float4* __restrict__ conicOut,
@@ -31,6 +32,7 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
 {
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= count) return;
+    const ClipCamera cam = params ? params->camera : camArg; // device-resident when the frame is a captured graph
 
     const float4 pd = position[index];
     const float4 sr = scaleAndRotation[index];
@@ -192,11 +194,12 @@ void launchCompactBand(hipStream_t stream, int count, const unsigned long long* 
 
 void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const ClipCamera& cam, const float4* position,
                          const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic,
-                         uint32_t* depthKey, uint32_t* splatOrder, unsigned long long* bandMask, int32_t* bandWaveCounts)
+                         uint32_t* depthKey, uint32_t* splatOrder, unsigned long long* bandMask, int32_t* bandWaveCounts,
+                         const FrameParams* paramsDevice)
 {
     if (count <= 0) return;
     const dim3 grid((count + 255) / 256), block(256);
-    hipLaunchKernelGGL(splatClipDataKernel, grid, block, 0, stream, count, scr, cam, position, scaleAndRotation, clipXY, clipZ,
+    hipLaunchKernelGGL(splatClipDataKernel, grid, block, 0, stream, count, scr, cam, paramsDevice, position, scaleAndRotation, clipXY, clipZ,
                        screenEllipse, conic, depthKey, splatOrder, bandMask, bandWaveCounts);
 }
 

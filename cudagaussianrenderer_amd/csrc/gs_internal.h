@@ -53,14 +53,23 @@ struct ClipCamera
     float depthScale, depthBias;
 };
 
+// Per-frame parameters in device memory: with a captured frame (hipGraph) the kernel arguments are frozen, so the
+// camera is read through a pointer that a memcpy node refreshes at the head of every replay.
+struct FrameParams
+{
+    ClipCamera camera;
+    float cameraPosition[3];
+    float pad;
+};
+
 // ---- launchers (one per stage); all enqueue on `stream` and return without synchronising --------
 void launchSphericalHarmonics(hipStream_t stream, int count, int degree, int shCount, const float4* position, const float* sh,
-                              float3 cameraPosition, float4* color);
+                              float3 cameraPosition, float4* color, const FrameParams* paramsDeviceOrNull = nullptr);
 
 void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const ClipCamera& cam, const float4* position,
                          const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic,
                          uint32_t* depthKeyOrNull, uint32_t* splatOrderOrNull, unsigned long long* bandMaskOrNull = nullptr,
-                         int32_t* bandWaveCountsOrNull = nullptr);
+                         int32_t* bandWaveCountsOrNull = nullptr, const FrameParams* paramsDeviceOrNull = nullptr);
 // Band cull (multi-GPU): the clip kernel flags the splats whose tile AABB reaches this GPU's rows (one 64-bit mask and
 // one count per 64 splats); after an exclusive scan of the counts this writes the kept splats' depth keys and indices,
 // order preserved.
@@ -71,7 +80,7 @@ void launchScanInt32(hipStream_t stream, int n, const int32_t* in, int32_t* out,
 // SH colour for the splats of a device-side index list only; coefficients in the [splat][shCount] layout.
 void launchSphericalHarmonicsGather(hipStream_t stream, int countHost, const int* countDevice, int degree, int shCount,
                                     const int32_t* indices, const float4* position, const float* shPerSplat, float3 cameraPosition,
-                                    float4* color);
+                                    float4* color, const FrameParams* paramsDeviceOrNull = nullptr);
 
 // Scratch of the tile-list builder: per-wave pair counts, their exclusive scan, the total.
 struct TileListScratch
@@ -134,7 +143,11 @@ int launchRadixSortPairs(hipStream_t stream, RadixScratch& s, int keyBytes, void
                          int n, int beginBit, int endBit);
 
 // keyBytes 8: tile = key >> 32 (the reference's keys); 2 or 4: the key is the tile index.
-void launchTileRanges(hipStream_t stream, int size, int keyBytes, const void* keys, int32_t* tileRange);
+// sizeDevice (optional): the list length lives on the device (captured frame); `size` is then the upper bound the grid covers.
+void launchTileRanges(hipStream_t stream, int size, int keyBytes, const void* keys, int32_t* tileRange,
+                      const int* sizeDevice = nullptr);
+
+void launchFillInt32(hipStream_t stream, int32_t* p, int32_t value, int n);
 
 void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileRange, const int32_t* values,
                      const float2* clipXY, const float4* conic, const float4* color, uchar4* backBuffer,

@@ -19,8 +19,10 @@ __device__ __forceinline__ uint32_t tileOf(Key k)
 }
 
 template <typename Key>
-__global__ __launch_bounds__(256) void tileRangesKernel(int size, const Key* __restrict__ keys, int32_t* __restrict__ tileRange)
+__global__ __launch_bounds__(256) void tileRangesKernel(int sizeHost, const int* __restrict__ sizeDevice, const Key* __restrict__ keys,
+                                                        int32_t* __restrict__ tileRange)
 {
+    const int size = sizeDevice ? min(*sizeDevice, sizeHost) : sizeHost;
     constexpr int PER = 16 / sizeof(Key);
     const int first = (blockIdx.x * blockDim.x + threadIdx.x) * PER; // this lane owns list entries [first, first+PER)
     if (first >= size) return;
@@ -62,23 +64,36 @@ __global__ __launch_bounds__(256) void tileRangesKernel(int size, const Key* __r
 }
 
 template <typename Key>
-void launchT(hipStream_t stream, int size, const void* keys, int32_t* tileRange)
+void launchT(hipStream_t stream, int size, const void* keys, int32_t* tileRange, const int* sizeDevice)
 {
     constexpr int PER = 16 / sizeof(Key);
     const int lanes = (size + PER - 1) / PER;
-    hipLaunchKernelGGL(tileRangesKernel<Key>, dim3((lanes + 255) / 256), dim3(256), 0, stream, size, (const Key*) keys, tileRange);
+    hipLaunchKernelGGL(tileRangesKernel<Key>, dim3((lanes + 255) / 256), dim3(256), 0, stream, size, sizeDevice, (const Key*) keys, tileRange);
+}
+
+// Plain fill kernel for the range table. Used instead of hipMemsetAsync inside captured frames: on ROCm 7.2 a memset
+// node replayed from a hipGraph wrote stale kernarg bytes instead of the fill value once the graph held more nodes.
+__global__ __launch_bounds__(256) void fillInt32Kernel(int32_t* __restrict__ p, int32_t value, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = value;
 }
 
 } // namespace
 
-void launchTileRanges(hipStream_t stream, int size, int keyBytes, const void* keys, int32_t* tileRange)
+void launchFillInt32(hipStream_t stream, int32_t* p, int32_t value, int n)
+{
+    if (n > 0) hipLaunchKernelGGL(fillInt32Kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, value, n);
+}
+
+void launchTileRanges(hipStream_t stream, int size, int keyBytes, const void* keys, int32_t* tileRange, const int* sizeDevice)
 {
     if (size <= 0) return; // Demo.cpp:469
     switch (keyBytes)
     {
-    case 2: launchT<uint16_t>(stream, size, keys, tileRange); break;
-    case 4: launchT<uint32_t>(stream, size, keys, tileRange); break;
-    default: launchT<uint64_t>(stream, size, keys, tileRange); break;
+    case 2: launchT<uint16_t>(stream, size, keys, tileRange, sizeDevice); break;
+    case 4: launchT<uint32_t>(stream, size, keys, tileRange, sizeDevice); break;
+    default: launchT<uint64_t>(stream, size, keys, tileRange, sizeDevice); break;
     }
 }
 

@@ -226,6 +226,10 @@ int gs_renderer_set_scene(GsRenderer* r, int32_t splatCount, const float* positi
  *   timed == 2: one non-blocking event pair per stage on the stream; read the sums later with
  *               gs_renderer_collect_stage_times (the frames are not slowed by host waits). */
 int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsFrameStats* statsOrNull);
+/* Captured frames: gs_renderer_render (timed == 0, stats == NULL, TWO_LEVEL pipeline, native sort) replays the whole frame
+ * as ONE hipGraph launch; list sizes stay on the device, the camera is refreshed by a memcpy node. Overflow then follows
+ * the reference (a frame whose demand exceeds the list capacity is truncated and the list is doubled for the next one). */
+void gs_renderer_set_graph(GsRenderer* r, int enabled);
 /* The same frame in two halves, so that one host thread can keep several renderers (each with its own stream and
  * buffers, gs_renderer_set_stream) busy: begin() enqueues everything up to the pair emission and returns; finish()
  * picks up the pair count -- by then on the host -- and enqueues tile sort, ranges and raster. render() = begin + finish. */

@@ -15,8 +15,13 @@ ap.add_argument("--frames", type=int, default=256)
 ap.add_argument("--cull", type=int, default=0)
 ap.add_argument("--inflight", type=int, default=3)
 ap.add_argument("--balanced", type=int, default=1)
+ap.add_argument("--graph", type=int, default=1)
+ap.add_argument("--sort-backend", type=int, default=1, help="0 rocPRIM, 1 native, 2 onesweep")
+ap.add_argument("--ppl", type=int, default=2, help="raster pixels per lane")
 args = ap.parse_args()
 W, H = 1920, 1080
+gs.lib().gs_set_sort_backend(args.sort_backend)
+gs.lib().gs_set_raster_pixels_per_lane(args.ppl)
 with tempfile.TemporaryDirectory() as tmp:
     path = os.path.join(tmp, "s.ply")
     scenes.write_synthetic_ply(path, args.splats, sh_degree=3, seed=1234)
@@ -46,6 +51,7 @@ for world in [int(x) for x in args.worlds.split(",")]:
             r = gs.Renderer(W, H, tile_rows=band if world > 1 else None, band_cull=args.cull)
             r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
             r.set_stream(streams[d].cuda_stream)
+            r.set_graph(bool(args.graph))
             rs.append(r)
         from concurrent.futures import ThreadPoolExecutor
         from collections import deque
