@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--ppl", type=int, default=0, help="raster pixels per lane override (1,2,4)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel individually instead of replaying a captured frame")
     ap.add_argument("--even-bands", action="store_true", help="multi-GPU: equal-height bands instead of cost-balanced ones")
+    ap.add_argument("--band-cull", type=int, default=0, help="0 auto (compact the visible splats on strict bands only), 1 always, 2 never")
     ap.add_argument("--inflight", type=int, default=3, help="frames in flight per GPU (renderers on separate HIP streams)")
     args = ap.parse_args()
 
@@ -126,7 +127,7 @@ def main():
     streams = [torch.cuda.Stream(device) for _ in range(depth)]
     renderers, framebuffers = [], []
     for d in range(depth):
-        r = gs.Renderer(W, H, tile_rows=band if world > 1 else None)
+        r = gs.Renderer(W, H, tile_rows=band if world > 1 else None, band_cull=args.band_cull)
         r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
         fb = torch.zeros((H, W, 4), dtype=torch.uint8, device=device)
         r.set_back_buffer(fb.data_ptr())
@@ -176,6 +177,14 @@ def main():
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
+        torch.cuda.synchronize(device)
+
+    # ---- set-up outside the measured steps: one frame per renderer, one at a time (frame capture, scratch sizing,
+    # RCCL channel set-up for the gather), so the pipelined loop below starts from a steady state -------------------
+    for d in range(depth):
+        pools[d].submit(render_frame, d, d, 0).result()
+        with torch.cuda.stream(streams[d]):
+            multigpu.gather_bands(framebuffers[d], bands, rank, world)
         torch.cuda.synchronize(device)
 
     # ---- warmup, then EXACTLY --steps timed frames ----------------------------------------------------

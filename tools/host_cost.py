@@ -12,6 +12,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--splats", type=int, default=1_000_000)
 ap.add_argument("--band", type=str, default="29,34")
 ap.add_argument("--frames", type=int, default=512)
+ap.add_argument("--depths", type=str, default="1,2,3,4")
+ap.add_argument("--graphs", type=str, default="1,0")
 args = ap.parse_args()
 W, H = 1920, 1080
 with tempfile.TemporaryDirectory() as tmp:
@@ -20,8 +22,8 @@ with tempfile.TemporaryDirectory() as tmp:
     ply = gs.parse_ply(path)
 cams = [gs.camera_from_pose(p, q, W, H) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 8)]
 band = tuple(int(x) for x in args.band.split(",")) if args.band != "full" else None
-for graph in (1, 0):
-    for D in (1, 2, 3, 4):
+for graph in [int(x) for x in args.graphs.split(',')]:
+    for D in [int(x) for x in args.depths.split(',')]:
         rs = []
         for d in range(D):
             r = gs.Renderer(W, H, tile_rows=band)
