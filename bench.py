@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--ppl", type=int, default=0, help="raster pixels per lane override (1,2,4)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel individually instead of replaying a captured frame")
     ap.add_argument("--even-bands", action="store_true", help="multi-GPU: equal-height bands instead of cost-balanced ones")
+    ap.add_argument("--pipeline", type=int, default=1, help="1 two-level sort (default, fastest at C3), 2 binned tile lists (no pair sort)")
     ap.add_argument("--band-cull", type=int, default=0, help="0 auto (compact the visible splats on strict bands only), 1 always, 2 never")
     ap.add_argument("--inflight", type=int, default=3, help="frames in flight per GPU (renderers on separate HIP streams)")
     args = ap.parse_args()
@@ -127,7 +128,7 @@ def main():
     streams = [torch.cuda.Stream(device) for _ in range(depth)]
     renderers, framebuffers = [], []
     for d in range(depth):
-        r = gs.Renderer(W, H, tile_rows=band if world > 1 else None, band_cull=args.band_cull)
+        r = gs.Renderer(W, H, tile_rows=band if world > 1 else None, band_cull=args.band_cull, pipeline=args.pipeline)
         r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
         fb = torch.zeros((H, W, 4), dtype=torch.uint8, device=device)
         r.set_back_buffer(fb.data_ptr())
@@ -253,7 +254,7 @@ def main():
                             f"{views}-view orbit, tile-row bands over {world} GPU(s)",
                 "splats": N, "width": W, "height": H, "sh_degree": args.sh_degree, "views": views,
                 "pairs_per_frame": round(p_mean), "consumed_pairs_per_frame": round(pc_mean),
-                "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": name, "frames_in_flight": depth, "captured_frames": not args.no_graph, "tile_row_bands": [list(b) for b in bands],
+                "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": name, "frames_in_flight": depth, "captured_frames": not args.no_graph, "pipeline": {1: "two_level", 2: "binned"}.get(args.pipeline, str(args.pipeline)), "tile_row_bands": [list(b) for b in bands],
                 "opacity_mean_raw": args.opacity_mean, "ingest_s": round(t_ingest, 2),
             },
             "roofline": {

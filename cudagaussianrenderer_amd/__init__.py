@@ -16,6 +16,7 @@ TILE_SIZE = 16
 SH_GROUP_SIZE = 256
 PIPELINE_REFERENCE = 0  # the reference's stage order: one 64-bit tile|depth radix sort of all pairs
 PIPELINE_TWO_LEVEL = 1  # default: depth-sort the splats, emit, stable-sort the pairs on the tile bits
+PIPELINE_BINNED = 2     # depth-sort the splats, then write every hit straight to its slot of the per-tile lists (no pair sort)
 
 
 def lib():

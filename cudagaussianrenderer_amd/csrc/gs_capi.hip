@@ -331,6 +331,9 @@ struct FrameState
     bool blocking = false;
     bool listDone = false; // reference pipeline: the sorted list and ranges were produced in begin()
     int orderSel = 0, tileKeyBytes = 2;
+    bool binned = false; // binned pipeline: lists and ranges are on their way, only the pair total is awaited
+    int binBatches = 0;
+    const int* binCountDevice = nullptr;
     int32_t size = 0;
     GsFrameStats st{};
 };
@@ -353,6 +356,7 @@ struct GsRenderer
     bool hasStream = false;
     TileListScratch scratch;
     RadixScratch radix;
+    BinScratch bins;
     unsigned long long* consumed = nullptr;
     // captured frame (hipGraph): the whole two-level frame as one graph launch, list sizes kept on the device
     bool useGraph = false, graphValid = false, ownsStream = false;
@@ -360,7 +364,7 @@ struct GsRenderer
     hipGraphExec_t graphExec = nullptr;
     FrameParams* paramsDevice = nullptr;
     FrameParams* paramsHost = nullptr; // pinned
-    int graphCapacity = 0, graphSplats = 0, graphRowBegin = -1, graphRowEnd = -1, graphCull = -1, graphSelector = 0, graphKeyBytes = 2;
+    int graphCapacity = 0, graphSplats = 0, graphRowBegin = -1, graphRowEnd = -1, graphCull = -1, graphBinned = -1, graphSelector = 0, graphKeyBytes = 2;
     bool pending = false; // begin() issued, finish() not yet
     FrameState frame;
     unsigned long long* bandMask = nullptr;
@@ -477,6 +481,7 @@ extern "C" GsRenderer* gs_renderer_create(int width, int height)
     r->width = scr.width;
     r->height = scr.height;
     r->tileRange = (int32_t*) gs_device_alloc(sizeof(int32_t) * 2 * (size_t) scr.totalTiles);
+    GS_CHECK(hipMemset(r->tileRange, 0xFF, sizeof(int32_t) * 2 * (size_t) scr.totalTiles)); // binned frames rewrite their band only
     r->backBufferOwned = (uint8_t*) gs_device_alloc((size_t) scr.width * scr.height * 4);
     r->backBuffer = r->backBufferOwned;
     GS_CHECK(hipMemset(r->backBufferOwned, 0, (size_t) scr.width * scr.height * 4)); // rows outside a band stay zero
@@ -501,6 +506,7 @@ extern "C" void gs_renderer_destroy(GsRenderer* r)
     gs_device_free(r->sortTemp);
     freeTileListScratch(r->scratch);
     freeRadixScratch(r->radix);
+    freeBinScratch(r->bins);
     if (r->graphExec) (void) hipGraphExecDestroy(r->graphExec);
     if (r->graph) (void) hipGraphDestroy(r->graph);
     if (r->ownsStream) (void) hipStreamDestroy(r->stream);
@@ -517,13 +523,22 @@ extern "C" void gs_renderer_destroy(GsRenderer* r)
 
 extern "C" void gs_renderer_set_tile_rows(GsRenderer* r, int begin, int end)
 {
+    if (begin != r->rowBegin || end != r->rowEnd)
+    {
+        // ranges of tiles that leave the band must not linger (the binned pipeline rewrites its own rows only)
+        StreamScope scope(r);
+        GS_CHECK(hipStreamSynchronize(g.stream));
+        const Screen scr = makeScreen(r->width, r->height, 0, 0);
+        GS_CHECK(hipMemset(r->tileRange, 0xFF, sizeof(int32_t) * 2 * (size_t) scr.totalTiles));
+    }
     r->rowBegin = begin;
     r->rowEnd = end;
 }
 
 extern "C" void gs_renderer_set_pipeline(GsRenderer* r, int pipeline)
 {
-    r->pipeline = (pipeline == GS_PIPELINE_REFERENCE) ? GS_PIPELINE_REFERENCE : GS_PIPELINE_TWO_LEVEL;
+    r->pipeline = (pipeline == GS_PIPELINE_REFERENCE || pipeline == GS_PIPELINE_BINNED) ? pipeline : GS_PIPELINE_TWO_LEVEL;
+    r->graphValid = false;
 }
 
 extern "C" void gs_renderer_set_band_cull(GsRenderer* r, int mode)
@@ -659,7 +674,11 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
     const bool blocking = f.blocking;
     GsFrameStats& st = f.st;
     const int n = r->splatCount;
-    const bool twoLevel = r->pipeline == GS_PIPELINE_TWO_LEVEL;
+    // The binned pipeline shares the front half (clip data, band cull, depth sort) with the two-level one; it needs the
+    // native sort (device-side counts) and a band whose cursor table fits the LDS, else the frame runs two-level.
+    const bool binned = r->pipeline == GS_PIPELINE_BINNED && n > 0 && cfg.sortBackend == GS_SORT_BACKEND_NATIVE && binsSupported(scr) &&
+                        radixSortSupported(4, n);
+    const bool twoLevel = r->pipeline != GS_PIPELINE_REFERENCE;
 
     GS_CHECK(hipEventRecord(r->frameStart, g.stream));
 
@@ -670,7 +689,7 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
     // (two-level pipeline: the raster kernel zeroes the tiles that have no work itself, no 8 MB memset)
     if (pixelRowEnd > pixelRowBegin && !twoLevel)
         gs_device_memset(r->backBuffer + rowBytes * pixelRowBegin, 0, rowBytes * (size_t) (pixelRowEnd - pixelRowBegin));
-    gs_device_memset(r->tileRange, 0xFF, sizeof(int32_t) * 2 * (size_t) scr.totalTiles);
+    if (!binned) gs_device_memset(r->tileRange, 0xFF, sizeof(int32_t) * 2 * (size_t) scr.totalTiles);
 
     // Demo.cpp:406-430
     GsGlobalArgs args{};
@@ -805,10 +824,30 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         // (2) pairs in depth order, keyed by tile. The emit pass is launched with the current capacity while the
         // pair count travels to the host, so the readback (GaussianRender.cu:793) costs no GPU idle time.
         gs_timer_start(stageTimers[2]);
-        launchTileListFastCount(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch);
-        GS_CHECK(hipEventRecord(r->countReady, g.stream));
-        launchTileListFastEmit(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],
-                               f.tileKeyBytes, r->values[0], r->tileListCapacity);
+        if (binned)
+        {
+            // (2b) straight into the final per-tile lists: count per (row of sorted splats, tile), column scan, emit
+            const int bandTiles = (scr.rowEnd - scr.rowBegin) * scr.tilesX;
+            f.binned = true;
+            f.binBatches = binBatchesFor(bandTiles);
+            f.binCountDevice = countDevice;
+            ensureTileListScratch(r->scratch, n); // the pair total and its host mirror live there
+            ensureBinScratch(r->bins, n, bandTiles, f.binBatches);
+            launchBinCountScan(g.stream, n, countDevice, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->bins,
+                               f.binBatches);
+            launchBinEmit(g.stream, n, countDevice, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->bins, f.binBatches,
+                          r->values[0], r->tileListCapacity, r->tileRange, r->scratch.total, r->scratch.totalHostMapped);
+            if (r->scratch.totalHostMapped == nullptr)
+                GS_CHECK(hipMemcpyAsync(r->scratch.totalHost, r->scratch.total, sizeof(int64_t), hipMemcpyDeviceToHost, g.stream));
+            GS_CHECK(hipEventRecord(r->countReady, g.stream));
+        }
+        else
+        {
+            launchTileListFastCount(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch);
+            GS_CHECK(hipEventRecord(r->countReady, g.stream));
+            launchTileListFastEmit(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],
+                                   f.tileKeyBytes, r->values[0], r->tileListCapacity);
+        }
         gs_timer_stop(stageTimers[2]);
     }
     r->pending = true;
@@ -829,7 +868,32 @@ extern "C" int gs_renderer_finish(GsRenderer* r, GsFrameStats* stats)
     const int n = r->splatCount;
     r->pending = false;
 
-    if (!f.listDone)
+    if (f.binned)
+    {
+        const uint32_t* order = (const uint32_t*) r->order[f.orderSel];
+        GS_CHECK(hipEventSynchronize(r->countReady));
+        const int64_t demand = *r->scratch.totalHost;
+        g.lastDemand = demand;
+        if (demand > 0x7FFFFFFF) return -2;
+        if (growTileListIfNeeded(r, demand))
+        {
+            // the lists did not fit: emit again into the larger buffer (counts and offsets are still valid)
+            st.grewTileList = 1;
+            launchBinEmit(g.stream, n, f.binCountDevice, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->bins,
+                          f.binBatches, r->values[0], r->tileListCapacity, r->tileRange, r->scratch.total, r->scratch.totalHostMapped);
+        }
+        if (blocking)
+        {
+            st.msBuildTileList = gs_timer_elapsed_ms(stageTimers[2]);
+            st.msSortTileList = gs_timer_elapsed_ms(stageTimers[6]);
+        }
+        r->radix.countDevice = nullptr;
+        r->scratch.countDevice = nullptr;
+        r->selector = 0;
+        r->keyBytes = 0; // no keys: the lists are addressed through tileRange only
+        f.size = (int32_t) demand;
+    }
+    else if (!f.listDone)
     {
         const int tBits = tileBits(scr.totalTiles);
         const uint32_t* order = (const uint32_t*) r->order[f.orderSel];
@@ -891,7 +955,7 @@ extern "C" int gs_renderer_finish(GsRenderer* r, GsFrameStats* stats)
     }
     gs_timer_start(stageTimers[5]);
     launchRasterize(g.stream, scr, r->tileRange, r->values[r->selector], (const float2*) r->clipXY, (const float4*) r->conic,
-                    (const float4*) r->color, (uchar4*) r->backBuffer, consumed, r->pipeline == GS_PIPELINE_TWO_LEVEL);
+                    (const float4*) r->color, (uchar4*) r->backBuffer, consumed, r->pipeline != GS_PIPELINE_REFERENCE);
     gs_timer_stop(stageTimers[5]);
     if (hipGetLastError() != hipSuccess) printf("kernel error renderDepthBuffer\n");
     if (blocking) st.msRasterize = gs_timer_elapsed_ms(stageTimers[5]);
@@ -925,7 +989,7 @@ namespace
 // are serialised process-wide (they happen once per renderer; replays take no lock).
 std::mutex g_captureMutex;
 
-int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull)
+int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool binned)
 {
     const int n = r->splatCount;
     const int tileKeyBytes = scr.totalTiles > 65536 ? 4 : 2;
@@ -936,7 +1000,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull)
     ClipCamera unusedCamera{};
 
     GS_CHECK(hipMemcpyAsync(r->paramsDevice, r->paramsHost, sizeof(FrameParams), hipMemcpyHostToDevice, g.stream));
-    launchFillInt32(g.stream, r->tileRange, -1, 2 * scr.totalTiles); // not a memset node: see gs_ranges.hip
+    if (!binned) launchFillInt32(g.stream, r->tileRange, -1, 2 * scr.totalTiles); // not a memset node: see gs_ranges.hip
     if (r->shDegree != 0 && !cull)
         launchSphericalHarmonics(g.stream, n, r->shDegree, r->shCount, (const float4*) r->position, r->sh, unused, (float4*) r->color,
                                  r->paramsDevice);
@@ -968,6 +1032,21 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull)
     {
         r->radix.countDevice = nullptr;
         r->scratch.countDevice = nullptr;
+        return 0;
+    }
+    if (binned)
+    {
+        const int bandTiles = (scr.rowEnd - scr.rowBegin) * scr.tilesX;
+        const int batches = binBatchesFor(bandTiles);
+        launchBinCountScan(g.stream, n, countDevice, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->bins, batches);
+        launchBinEmit(g.stream, n, countDevice, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->bins, batches,
+                      r->values[0], r->tileListCapacity, r->tileRange, r->scratch.total, r->scratch.totalHostMapped);
+        r->radix.countDevice = nullptr;
+        r->scratch.countDevice = nullptr;
+        launchRasterize(g.stream, scr, r->tileRange, r->values[0], (const float2*) r->clipXY, (const float4*) r->conic,
+                        (const float4*) r->color, (uchar4*) r->backBuffer, nullptr, true);
+        r->graphSelector = 0;
+        r->graphKeyBytes = 0;
         return 0;
     }
     launchTileListFastCount(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch);
@@ -1033,8 +1112,10 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
         }
         if (grew) r->graphValid = false;
     }
+    const bool binned = r->pipeline == GS_PIPELINE_BINNED && binsSupported(scr) && radixSortSupported(4, n) &&
+                        r->scratch.totalHostMapped != nullptr;
     if (r->graphValid && (r->graphCapacity != r->tileListCapacity || r->graphSplats != n || r->graphRowBegin != scr.rowBegin ||
-                          r->graphRowEnd != scr.rowEnd || r->graphCull != (int) cull))
+                          r->graphRowEnd != scr.rowEnd || r->graphCull != (int) cull || r->graphBinned != (int) binned))
         r->graphValid = false;
 
     FrameParams fp{};
@@ -1053,12 +1134,13 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
         ensureTileListScratch(r->scratch, n);
         ensureRadixScratch(r->radix, n);
         ensureRadixScratch(r->radix, r->tileListCapacity);
+        if (binned) ensureBinScratch(r->bins, n, (scr.rowEnd - scr.rowBegin) * scr.tilesX, binBatchesFor((scr.rowEnd - scr.rowBegin) * scr.tilesX));
         if (r->graphExec) (void) hipGraphExecDestroy(r->graphExec);
         if (r->graph) (void) hipGraphDestroy(r->graph);
         r->graphExec = nullptr;
         r->graph = nullptr;
         GS_CHECK(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
-        enqueueCapturableFrame(r, scr, cull);
+        enqueueCapturableFrame(r, scr, cull, binned);
         GS_CHECK(hipStreamEndCapture(g.stream, &r->graph));
         GS_CHECK(hipGraphInstantiate(&r->graphExec, r->graph, nullptr, nullptr, 0));
         r->graphValid = true;
@@ -1067,6 +1149,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
         r->graphRowBegin = scr.rowBegin;
         r->graphRowEnd = scr.rowEnd;
         r->graphCull = (int) cull;
+        r->graphBinned = (int) binned;
     }
     GS_CHECK(hipGraphLaunch(r->graphExec, g.stream));
     r->selector = r->graphSelector;
@@ -1084,7 +1167,7 @@ extern "C" void gs_renderer_set_graph(GsRenderer* r, int enabled)
 extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsFrameStats* stats)
 {
     // Captured path: plain frames (no stage timers, no stats) of the two-level pipeline on the native sort.
-    if (r->useGraph && timed == 0 && stats == nullptr && r->pipeline == GS_PIPELINE_TWO_LEVEL &&
+    if (r->useGraph && timed == 0 && stats == nullptr && r->pipeline != GS_PIPELINE_REFERENCE &&
         cfg.sortBackend == GS_SORT_BACKEND_NATIVE && !cfg.collectRasterStats && r->splatCount > 0)
         return renderCaptured(r, camera);
     r->graphValid = false; // the regular path re-sizes scratch as it likes

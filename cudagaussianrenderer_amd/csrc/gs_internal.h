@@ -149,6 +149,28 @@ void launchTileRanges(hipStream_t stream, int size, int keyBytes, const void* ke
 
 void launchFillInt32(hipStream_t stream, int32_t* p, int32_t value, int n);
 
+// Binned tile lists (gs_bins.hip): depth-sorted splats -> final per-tile lists + ranges, no pair sort.
+constexpr int kBinMaxTiles = 8192; // LDS cursor table: 4 bytes per band tile and wave
+struct BinScratch
+{
+    uint16_t* counts = nullptr;    // [rows][stride] hits of a row of sorted splats per tile
+    uint32_t* offsets = nullptr;   // [rows][stride] exclusive scan of counts over the rows
+    int32_t* rowFlags = nullptr;   // [rows]
+    int32_t* tileTotals = nullptr; // [stride]
+    uint32_t* tileStart = nullptr; // [stride]
+    int rowsCapacity = 0, strideCapacity = 0;
+};
+bool binsSupported(const Screen& scr);
+int binBatchesFor(int bandTiles);
+void ensureBinScratch(BinScratch& s, int splats, int bandTiles, int batches);
+void freeBinScratch(BinScratch& s);
+void launchBinCountScan(hipStream_t stream, int count, const int* countDevice, const Screen& scr, const uint32_t* order,
+                        const float2* clipXY, const float4* screenEllipse, const BinScratch& s, int batches);
+// Writes values (at most `capacity`), the band's rows of tileRange, *total (+ the host-mapped copy when given).
+void launchBinEmit(hipStream_t stream, int count, const int* countDevice, const Screen& scr, const uint32_t* order, const float2* clipXY,
+                   const float4* screenEllipse, const BinScratch& s, int batches, int32_t* values, int capacity, int32_t* tileRange,
+                   int64_t* total, int64_t* totalHostMapped);
+
 void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileRange, const int32_t* values,
                      const float2* clipXY, const float4* conic, const float4* color, uchar4* backBuffer,
                      unsigned long long* consumedPairsOrNull, bool clearEmptyTiles = false);

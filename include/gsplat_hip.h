@@ -215,6 +215,11 @@ void gs_renderer_set_tile_rows(GsRenderer* r, int tileRowBegin, int tileRowEnd);
 void gs_renderer_set_band_cull(GsRenderer* r, int mode);
 #define GS_PIPELINE_REFERENCE 0
 #define GS_PIPELINE_TWO_LEVEL 1
+/* BINNED: same depth sort of the splats, then every (splat, tile) hit is written straight to its final slot of the
+ * per-tile lists (count per row of sorted splats and tile, column scan, emit through per-tile LDS cursors): no pair
+ * sort and no range search; values and tileRange are identical to the other two pipelines, there is no key array
+ * (GsRendererBuffers.keys is meaningless, keyBytes 0).  Bands of more than 8192 tiles fall back to TWO_LEVEL. */
+#define GS_PIPELINE_BINNED 2
 void gs_renderer_set_pipeline(GsRenderer* r, int pipeline);
 /* Upload a scene from host arrays (Demo.cpp:314-331). sh is [N][shCount] un-aligned (as parsePly
  * returns it) and is realigned here (Demo.cpp:291-296); may be NULL at degree 0. */

@@ -18,6 +18,7 @@ ap.add_argument("--balanced", type=int, default=1)
 ap.add_argument("--graph", type=int, default=1)
 ap.add_argument("--sort-backend", type=int, default=1, help="0 rocPRIM, 1 native, 2 onesweep")
 ap.add_argument("--ppl", type=int, default=2, help="raster pixels per lane")
+ap.add_argument("--pipeline", type=int, default=1)
 args = ap.parse_args()
 W, H = 1920, 1080
 gs.lib().gs_set_sort_backend(args.sort_backend)
@@ -48,7 +49,7 @@ for world in [int(x) for x in args.worlds.split(",")]:
         streams = [torch.cuda.Stream() for _ in range(D)]
         rs = []
         for d in range(D):
-            r = gs.Renderer(W, H, tile_rows=band if world > 1 else None, band_cull=args.cull)
+            r = gs.Renderer(W, H, tile_rows=band if world > 1 else None, band_cull=args.cull, pipeline=args.pipeline)
             r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
             r.set_stream(streams[d].cuda_stream)
             r.set_graph(bool(args.graph))
