@@ -259,7 +259,7 @@ def main():
             },
             "roofline": {
                 "kernel": "rasterizeTilesKernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), **pmc_traffic(world, N, W, H, args),
                 "note": "VALU/exp-bound kernel (44 B vs ~2800 VALU lane-ops per consumed pair); see DESIGN.md",
                 "dominant_stage": dominant,
                 "dominant_stage_GBps": stages[dominant]["GBps"],
@@ -280,6 +280,22 @@ def main():
         r.close()
     if rank == 0:
         print(json.dumps(result))
+
+
+def pmc_traffic(world, n, w, h, args):
+    """HBM bytes per raster launch from the committed PMC passes (profiles/r01_pmc_raster.json: rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE of this very workload). Counters cannot be collected from inside the timed run, so the figure is only
+    attached when the run IS that workload (default scene, full frame on one GPU); otherwise traffic is null."""
+    default_scene = (world == 1 and n == 1_000_000 and (w, h) == (1920, 1080) and args.sh_degree == 3 and args.seed == 1234
+                     and args.opacity_mean == 1.0)
+    path = os.path.join(ROOT, "profiles", "r01_pmc_raster.json")
+    if not default_scene or not os.path.exists(path):
+        return {"traffic": None}
+    with open(path) as f:
+        d = json.load(f)
+    return {"traffic": round(d["traffic_bytes_per_launch_low"]), "traffic_unit": "bytes per launch",
+            "traffic_source": "profiles/r01_pmc_raster.json (FETCH_SIZE raw + WRITE_SIZE; gather widths are uncalibrated, "
+                              "upper bound %d with the wide-read 2x correction)" % round(d["traffic_bytes_per_launch_high"])}
 
 
 def ctypes_name(lib):

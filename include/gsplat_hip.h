@@ -10,7 +10,9 @@
  *
  * Conventions kept from the reference:
  *   - the caller owns all device memory; the library keeps raw pointers until the next set-args call;
- *   - not thread-safe (the reference keeps its args in file-scope __constant__ symbols);
+ *   - the staged calls keep their arguments in per-host-thread state (the reference keeps them in file-scope __constant__
+ *     symbols): one host thread runs one frame at a time, exactly as in the reference; different threads may each drive
+ *     their own GsRenderer concurrently (device, stream and global/tile-list args are thread-local, tuning knobs are global);
  *   - a failed HIP API call prints "HIP error at <file> <line>: <msg>" and exit(EXIT_FAILURE)
  *     (src/CudaErrorCheck.cpp:2-11); a failed kernel launch prints "kernel error <stage>" and continues;
  *   - tileRange must be pre-set to 0xFF and the back buffer zeroed by the caller each frame
