@@ -331,17 +331,19 @@ def test_band_renders_stitch_to_full_frame(gs):
     assert np.array_equal(stitched, want)
 
 
-def test_full_size_properties(gs, tmp_path):
-    """BASELINE.json configs[2] (1 M splats, SH degree 3, 1920x1080) is too slow for the serial oracle inside
-    a test; check size-independent properties instead: sortedness, range/key consistency, determinism."""
+@pytest.mark.parametrize("n,w,h", [(1_000_000, 1920, 1080), (5_000_000, 3840, 2160)])
+def test_full_size_properties(gs, tmp_path, n, w, h):
+    """BASELINE.json configs[2] (1 M splats, SH degree 3, 1920x1080) and configs[4] (5 M splats, SH degree 3, 3840x2160)
+    are too slow for the serial oracle inside a test; check size-independent properties instead: sortedness,
+    range/key consistency, determinism, and that a tile-row band rendered alone equals the same rows of the full frame."""
     from cudagaussianrenderer_amd import scenes
 
-    n, w, h = 1_000_000, 1920, 1080
-    path = str(tmp_path / "c3.ply")
+    path = str(tmp_path / "scene.ply")
     scenes.write_synthetic_ply(path, n, sh_degree=3, seed=1234)
     ply = gs.parse_ply(path)
     assert ply["vertexCount"] == n and ply["shDegree"] == 3 and ply["shCount"] == 48
     cam = gs.camera_from_bounds(ply["boundsMin"], ply["boundsMax"], w, h)
+    tx, ty = gs.tile_counts(w, h)
     r = gs.Renderer(w, h)
     r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], 3, 48)
     st = r.render(cam, stats=True)
@@ -352,12 +354,12 @@ def test_full_size_properties(gs, tmp_path):
     key_dtype = {2: np.uint16, 4: np.uint32, 8: np.uint64}[b.keyBytes]
     keys = r.download(b.keys, size, key_dtype)
     values = r.download(b.values, size, np.int32)
-    rng = r.download(b.tileRange, 2 * 120 * 68, np.int32).reshape(-1, 2)
+    rng = r.download(b.tileRange, 2 * tx * ty, np.int32).reshape(-1, 2)
     assert np.all(keys[1:] >= keys[:-1])
     assert values.min() >= 0 and values.max() < n
     tiles = (keys >> np.uint64(32)).astype(np.int64) if b.keyBytes == 8 else keys.astype(np.int64)
-    assert tiles.max() < 120 * 68
-    counts = np.bincount(tiles, minlength=120 * 68)
+    assert tiles.max() < tx * ty
+    counts = np.bincount(tiles, minlength=tx * ty)
     assert np.array_equal(rng[:, 1] - rng[:, 0], counts)
     nonempty = counts > 0
     assert np.array_equal(rng[nonempty, 0], (np.cumsum(counts) - counts)[nonempty])
@@ -374,6 +376,15 @@ def test_full_size_properties(gs, tmp_path):
     assert np.array_equal(r.read_image(), img1)
     assert (img1[..., 3] == 255).mean() > 0.3
     r.close()
+    # one rank's band of an 8-way split (culled splat list, device-side counts) = the same rows of the full frame
+    band = scenes.tile_row_bands(ty, 8)[3]
+    rb = gs.Renderer(w, h, tile_rows=band)
+    rb.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], 3, 48)
+    rb.render(cam)
+    part = rb.read_image()
+    rb.close()
+    a, e = band[0] * 16, min(band[1] * 16, h)
+    assert np.array_equal(part[a:e], img1[a:e])
 
 
 @pytest.mark.parametrize("key_bytes,n,begin,end,skew", [(4, 1_000_003, 0, 32, False), (4, 4096, 0, 32, True), (4, 1, 0, 32, False),
