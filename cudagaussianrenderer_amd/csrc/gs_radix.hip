@@ -45,7 +45,7 @@ __device__ __forceinline__ unsigned long long matchDigit(int digit, bool valid)
 
 template <typename K, int BITS, int ITEMS>
 __global__ __launch_bounds__(kThreads) void radixHistogramKernel(const K* __restrict__ keys, int nHost, const int* __restrict__ nDevice, int shift,
-                                                                  int32_t* __restrict__ table)
+                                                                  int skewed, int32_t* __restrict__ table)
 {
     constexpr int kTile = kThreads * ITEMS;
     __shared__ int hist[kDigits];
@@ -58,29 +58,68 @@ __global__ __launch_bounds__(kThreads) void radixHistogramKernel(const K* __rest
     hist[t] = 0;
     __syncthreads();
     K key[ITEMS];
-#pragma unroll
-    for (int r = 0; r != ITEMS; ++r) // all loads in flight before the first use
+    // Counting does not care which lane sees which key: full tiles are read 16 bytes per lane (ITEMS consecutive keys
+    // when they fill a multiple of 16 bytes), the ragged last tile element by element.
+    constexpr bool kWide = (sizeof(K) * ITEMS) % 16 == 0;
+    const bool wide = kWide && base + kTile <= n;
+    if constexpr (kWide)
     {
-        const int i = base + r * kThreads + t;
-        key[r] = (i < n) ? keys[i] : K(0);
-    }
-#pragma unroll
-    for (int r = 0; r != ITEMS; ++r)
-    {
-        const bool valid = base + r * kThreads + t < n;
-        const int digit = (int) ((key[r] >> shift) & ((1 << BITS) - 1));
-        if constexpr (BITS == 8)
+        if (wide)
         {
-            // Full-width digits: plain LDS atomics (lanes sharing a digit serialise inside the LDS).
-            if (valid) atomicAdd(&hist[digit], 1);
+        constexpr int kVecs = (int) (sizeof(K) * ITEMS / 16);
+        const uint4* src = reinterpret_cast<const uint4*>(keys + base) + t * kVecs;
+        uint4 v[kVecs];
+#pragma unroll
+        for (int q = 0; q != kVecs; ++q) v[q] = src[q];
+        __builtin_memcpy(key, v, sizeof(key));
         }
-        else
+    }
+    if (!wide)
+    {
+#pragma unroll
+        for (int r = 0; r != ITEMS; ++r) // all loads in flight before the first use
         {
-            // Short last digit (the high tile bits: few, heavily skewed values): one add per distinct digit per wave.
-            const int lane = t & (kWave - 1);
-            const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
-            const unsigned long long m = matchDigit<BITS>(digit, valid);
-            if (valid && (m & lower) == 0ull) atomicAdd(&hist[digit], __popcll(m));
+            const int i = base + r * kThreads + t;
+            key[r] = (i < n) ? keys[i] : K(0);
+        }
+    }
+    if (skewed && wide)
+    {
+        // Top digit of a multi-pass tile sort: the lane's ITEMS consecutive keys mostly share it -- one add per run.
+        int run = 1;
+#pragma unroll
+        for (int r = 0; r != ITEMS; ++r)
+        {
+            const int digit = (int) ((key[r] >> shift) & ((1 << BITS) - 1));
+            const int next = (r + 1 != ITEMS) ? (int) ((key[(r + 1) % ITEMS] >> shift) & ((1 << BITS) - 1)) : -1;
+            if (next == digit) ++run;
+            else
+            {
+                atomicAdd(&hist[digit], run);
+                run = 1;
+            }
+        }
+    }
+    else
+    {
+#pragma unroll
+        for (int r = 0; r != ITEMS; ++r)
+        {
+            const bool valid = wide || base + r * kThreads + t < n;
+            const int digit = (int) ((key[r] >> shift) & ((1 << BITS) - 1));
+            if (BITS == 8 || !skewed)
+            {
+                // Well-spread digits: plain LDS atomics (lanes sharing a digit serialise inside the LDS).
+                if (valid) atomicAdd(&hist[digit], 1);
+            }
+            else
+            {
+                // skewed digit, ragged tile: one add per distinct digit per wave
+                const int lane = t & (kWave - 1);
+                const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
+                const unsigned long long m = matchDigit<BITS>(digit, valid);
+                if (valid && (m & lower) == 0ull) atomicAdd(&hist[digit], __popcll(m));
+            }
         }
     }
     __syncthreads();
@@ -131,7 +170,7 @@ template <typename K, int BITS, int ITEMS>
 __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restrict__ keysIn, const int32_t* __restrict__ valuesIn,
                                                                 K* __restrict__ keysOut, int32_t* __restrict__ valuesOut, int nHost, const int* __restrict__ nDevice,
                                                                 int shift, const int32_t* __restrict__ scanned,
-                                                                const int32_t* __restrict__ totals)
+                                                                const int32_t* __restrict__ totals, int debug)
 {
     constexpr int kTile = kThreads * ITEMS;
     constexpr int kDigitMask = (1 << BITS) - 1;
@@ -143,10 +182,16 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
     __shared__ int32_t sVals[kTile];
 
     const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
-    const int tile = blockIdx.x;
-    const int base = tile * kTile;
     const int n = nDevice ? min(*nDevice, nHost) : nHost;
-    if (base >= n) return; // whole workgroup (uniform): the grid was sized for the host-side upper bound
+    // Workgroups are dealt to the 8 XCDs round-robin; give every XCD a CONTIGUOUS eighth of the tiles, so that the
+    // output runs of neighbouring tiles (adjacent addresses, often the two halves of one 64-byte sector) meet in the
+    // same L2 instead of leaving two partial lines in two L2s.  Any bijection works: the tables are indexed by tile.
+    const int numTiles = (n + kTile - 1) / kTile;
+    const int perXcd = (numTiles + 7) >> 3;
+    const int slot = (int) blockIdx.x >> 3;
+    const int tile = ((int) blockIdx.x & 7) * perXcd + slot;
+    const int base = tile * kTile;
+    if (slot >= perXcd || base >= n) return; // whole workgroup (uniform): the grid was sized for the host-side upper bound
     const int tileCount = min(kTile, n - base);
 
     // ---- load the tile: element (wave, row, lane) is tile index wave*64*ITEMS + row*64 + lane ---------
@@ -183,13 +228,10 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
         const int digit = (int) ((key[r] >> shift) & kDigitMask);
         const bool valid = m != 0ull;
         const int leader = valid ? (__ffsll((long long) m) - 1) : lane;
-        int old = 0;
-        if (valid && lane == leader)
-        {
-            old = cnt[wave][digit];
-            cnt[wave][digit] = old + __popcll(m);
-        }
-        old = __shfl(old, leader);
+        // every lane of a digit group reads the running count (one broadcast read), then the group's first lane
+        // bumps it: LDS instructions of a wave execute in order, so the next row sees the bumped value
+        const int old = valid ? cnt[wave][digit] : 0;
+        if (valid && lane == leader) cnt[wave][digit] = old + __popcll(m);
         rank[r] = old + __popcll(m & lower);
         __builtin_amdgcn_wave_barrier();
     }
@@ -259,6 +301,7 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
             const K k = sKeys[j];
             const int digit = (int) ((k >> shift) & kDigitMask);
             const int pos = globalBase[digit] + (j - localBase[digit]);
+            if (debug & 1) continue;
             keysOut[pos] = k;
             valuesOut[pos] = sVals[j];
         }
@@ -546,57 +589,71 @@ int sortOnesweepT(hipStream_t stream, K* keys0, K* keys1, int32_t* values0, int3
     return sortOnesweepItems<K, kItemsLarge>(stream, keys0, keys1, values0, values1, n, beginBit, endBit, s);
 }
 
+int scatterDebug()
+{
+    static const int v = getenv("GS_RADIX_DEBUG") ? atoi(getenv("GS_RADIX_DEBUG")) : 0; // timing experiments only
+    return v;
+}
+
 int itemsPerLane(int n) { return n <= kSmallLimit ? kItemsSmall : kItemsLarge; }
 
 template <typename K, int BITS, int ITEMS>
 void runPassItems(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, K* keysOut, int32_t* valuesOut, int n, int shift,
-                  RadixScratch& s)
+                  bool skewed, RadixScratch& s)
 {
     constexpr int kTile = kThreads * ITEMS;
     const int numTiles = (n + kTile - 1) / kTile;
-    hipLaunchKernelGGL((radixHistogramKernel<K, BITS, ITEMS>), dim3(numTiles), dim3(kThreads), 0, stream, keysIn, n, s.countDevice, shift, s.table);
+    hipLaunchKernelGGL((radixHistogramKernel<K, BITS, ITEMS>), dim3(numTiles), dim3(kThreads), 0, stream, keysIn, n, s.countDevice, shift, skewed ? 1 : 0, s.table);
     hipLaunchKernelGGL(radixColumnScanKernel, dim3(kDigits), dim3(kScanThreads), 0, stream, n, s.countDevice, kTile, s.table, s.scanned, s.chunkTotals);
-    hipLaunchKernelGGL((radixScatterKernel<K, BITS, ITEMS>), dim3(numTiles), dim3(kThreads), 0, stream, keysIn, valuesIn, keysOut,
-                       valuesOut, n, s.countDevice, shift, s.scanned, s.chunkTotals);
+    hipLaunchKernelGGL((radixScatterKernel<K, BITS, ITEMS>), dim3(8 * ((numTiles + 7) / 8)), dim3(kThreads), 0, stream, keysIn, valuesIn, keysOut,
+                       valuesOut, n, s.countDevice, shift, s.scanned, s.chunkTotals, scatterDebug());
 }
 
 template <typename K, int BITS>
 void runPass(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, K* keysOut, int32_t* valuesOut, int n, int shift,
-             RadixScratch& s)
+             bool skewed, RadixScratch& s)
 {
-    if (n <= kSmallLimit) runPassItems<K, BITS, kItemsSmall>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, s);
-    else runPassItems<K, BITS, kItemsLarge>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, s);
+    if (n <= kSmallLimit) runPassItems<K, BITS, kItemsSmall>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s);
+    else runPassItems<K, BITS, kItemsLarge>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s);
 }
 
 template <typename K>
 void runPassBits(hipStream_t stream, int bits, const K* keysIn, const int32_t* valuesIn, K* keysOut, int32_t* valuesOut, int n,
-                 int shift, RadixScratch& s)
+                 int shift, bool skewed, RadixScratch& s)
 {
     switch (bits)
     {
-    case 1: runPass<K, 1>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, s); break;
-    case 2: runPass<K, 2>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, s); break;
-    case 3: runPass<K, 3>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, s); break;
-    case 4: runPass<K, 4>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, s); break;
-    case 5: runPass<K, 5>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, s); break;
-    case 6: runPass<K, 6>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, s); break;
-    case 7: runPass<K, 7>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, s); break;
-    default: runPass<K, 8>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, s); break;
+    case 1: runPass<K, 1>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
+    case 2: runPass<K, 2>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
+    case 3: runPass<K, 3>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
+    case 4: runPass<K, 4>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
+    case 5: runPass<K, 5>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
+    case 6: runPass<K, 6>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
+    case 7: runPass<K, 7>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
+    default: runPass<K, 8>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
     }
 }
 
 template <typename K>
 int sortT(hipStream_t stream, K* keys0, K* keys1, int32_t* values0, int32_t* values1, int n, int beginBit, int endBit, RadixScratch& s)
 {
-    int sel = 0;
-    for (int shift = beginBit; shift < endBit; shift += 8)
+    // As few passes as 8-bit digits allow, the bits spread evenly over them (13 tile bits -> 7 + 6, not 8 + 5): fewer
+    // digits per pass means longer runs of consecutive output addresses per workgroup in BOTH passes.
+    const int totalBits = endBit - beginBit;
+    const int passes = (totalBits + 7) / 8;
+    int sel = 0, shift = beginBit;
+    for (int pass = 0; pass != passes; ++pass)
     {
-        const int bits = std::min(8, endBit - shift);
+        const int left = endBit - shift;
+        const int bits = (left + (passes - pass) - 1) / (passes - pass);
         K* kin = sel ? keys1 : keys0;
         K* kout = sel ? keys0 : keys1;
         int32_t* vin = sel ? values1 : values0;
         int32_t* vout = sel ? values0 : values1;
-        runPassBits<K>(stream, bits, kin, vin, kout, vout, n, shift, s);
+        // the top digit of a multi-pass sort of tile indices is shared by most neighbours: count it through ballots
+        const bool skewed = sizeof(K) == 2 && passes > 1 && pass == passes - 1 && bits < 8;
+        runPassBits<K>(stream, bits, kin, vin, kout, vout, n, shift, skewed, s);
+        shift += bits;
         sel ^= 1;
     }
     return sel;
