@@ -45,7 +45,7 @@ __device__ __forceinline__ unsigned long long matchDigit(int digit, bool valid)
 
 template <typename K, int BITS, int ITEMS>
 __global__ __launch_bounds__(kThreads) void radixHistogramKernel(const K* __restrict__ keys, int nHost, const int* __restrict__ nDevice, int shift,
-                                                                  int skewed, int32_t* __restrict__ table)
+                                                                  int skewed, int32_t* __restrict__ table, int stride)
 {
     constexpr int kTile = kThreads * ITEMS;
     __shared__ int hist[kDigits];
@@ -123,14 +123,15 @@ __global__ __launch_bounds__(kThreads) void radixHistogramKernel(const K* __rest
         }
     }
     __syncthreads();
-    table[blockIdx.x * kDigits + t] = hist[t]; // 1 KiB contiguous per tile
+    table[t * stride + blockIdx.x] = hist[t]; // [digit][tile]: every digit's column is contiguous for the scan
 }
 
-// One workgroup (1024 lanes) per digit: exclusive scan of column `digit` of table[tile][digit] over the tiles (the
-// table is L2-resident: 1 KiB per tile), column total to totals[digit].
+// One workgroup (1024 lanes) per digit: exclusive scan of that digit's row of table[digit][tile] over the tiles
+// (contiguous: 16 bytes per lane and round), row total to totals[digit].
 constexpr int kScanThreads = 1024;
-__global__ __launch_bounds__(kScanThreads) void radixColumnScanKernel(int nHost, const int* __restrict__ nDevice, int tileElements, const int32_t* __restrict__ table,
-                                                                      int32_t* __restrict__ scanned, int32_t* __restrict__ totals)
+__global__ __launch_bounds__(kScanThreads) void radixColumnScanKernel(int nHost, const int* __restrict__ nDevice, int tileElements, int stride,
+                                                                      const int32_t* __restrict__ table, int32_t* __restrict__ scanned,
+                                                                      int32_t* __restrict__ totals)
 {
     constexpr int kScanWaves = kScanThreads / kWave;
     __shared__ int waveSums[2][kScanWaves];
@@ -138,12 +139,19 @@ __global__ __launch_bounds__(kScanThreads) void radixColumnScanKernel(int nHost,
     const int digit = blockIdx.x;
     const int n = nDevice ? min(*nDevice, nHost) : nHost;
     const int numTiles = (n + tileElements - 1) / tileElements;
+    const int32_t* in = table + (size_t) digit * stride;
+    int32_t* out = scanned + (size_t) digit * stride;
     int carry = 0, flip = 0;
-    for (int base = 0; base < numTiles; base += kScanThreads, flip ^= 1)
+    for (int base = 0; base < numTiles; base += kScanThreads * 4, flip ^= 1)
     {
-        const int tile = base + t;
-        const int v = (tile < numTiles) ? table[tile * kDigits + digit] : 0;
-        int incl = v;
+        const int tile = base + t * 4; // stride is a multiple of 4: a quad never leaves the row
+        int4 v = make_int4(0, 0, 0, 0);
+        if (tile < numTiles) v = *reinterpret_cast<const int4*>(in + tile);
+        if (tile + 1 >= numTiles) v.y = 0; // entries past the live tiles hold stale counts
+        if (tile + 2 >= numTiles) v.z = 0;
+        if (tile + 3 >= numTiles) v.w = 0;
+        const int own = v.x + v.y + v.z + v.w;
+        int incl = own;
 #pragma unroll
         for (int delta = 1; delta < kWave; delta <<= 1)
         {
@@ -160,7 +168,8 @@ __global__ __launch_bounds__(kScanThreads) void radixColumnScanKernel(int nHost,
             before += (w < wave) ? ws : 0;
             all += ws;
         }
-        if (tile < numTiles) scanned[tile * kDigits + digit] = carry + before + incl - v;
+        const int p0 = carry + before + incl - own;
+        if (tile < numTiles) *reinterpret_cast<int4*>(out + tile) = make_int4(p0, p0 + v.x, p0 + v.x + v.y, p0 + v.x + v.y + v.z);
         carry += all;
     }
     if (t == 0) totals[digit] = carry;
@@ -170,7 +179,7 @@ template <typename K, int BITS, int ITEMS>
 __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restrict__ keysIn, const int32_t* __restrict__ valuesIn,
                                                                 K* __restrict__ keysOut, int32_t* __restrict__ valuesOut, int nHost, const int* __restrict__ nDevice,
                                                                 int shift, const int32_t* __restrict__ scanned,
-                                                                const int32_t* __restrict__ totals, int debug)
+                                                                const int32_t* __restrict__ totals, int stride, int debug)
 {
     constexpr int kTile = kThreads * ITEMS;
     constexpr int kDigitMask = (1 << BITS) - 1;
@@ -206,7 +215,7 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
         val[r] = valid ? valuesIn[i] : 0;
     }
     const int digitTotal = totals[t];
-    const int tileEntry = scanned[tile * kDigits + t];
+    const int tileEntry = scanned[t * stride + tile];
 #pragma unroll
     for (int w = 0; w != kWaves; ++w) cnt[w][t] = 0;
     __syncthreads();
@@ -603,10 +612,11 @@ void runPassItems(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, 
 {
     constexpr int kTile = kThreads * ITEMS;
     const int numTiles = (n + kTile - 1) / kTile;
-    hipLaunchKernelGGL((radixHistogramKernel<K, BITS, ITEMS>), dim3(numTiles), dim3(kThreads), 0, stream, keysIn, n, s.countDevice, shift, skewed ? 1 : 0, s.table);
-    hipLaunchKernelGGL(radixColumnScanKernel, dim3(kDigits), dim3(kScanThreads), 0, stream, n, s.countDevice, kTile, s.table, s.scanned, s.chunkTotals);
+    const int stride = (numTiles + 3) & ~3; // tiles per digit row of the tables
+    hipLaunchKernelGGL((radixHistogramKernel<K, BITS, ITEMS>), dim3(numTiles), dim3(kThreads), 0, stream, keysIn, n, s.countDevice, shift, skewed ? 1 : 0, s.table, stride);
+    hipLaunchKernelGGL(radixColumnScanKernel, dim3(kDigits), dim3(kScanThreads), 0, stream, n, s.countDevice, kTile, stride, s.table, s.scanned, s.chunkTotals);
     hipLaunchKernelGGL((radixScatterKernel<K, BITS, ITEMS>), dim3(8 * ((numTiles + 7) / 8)), dim3(kThreads), 0, stream, keysIn, valuesIn, keysOut,
-                       valuesOut, n, s.countDevice, shift, s.scanned, s.chunkTotals, scatterDebug());
+                       valuesOut, n, s.countDevice, shift, s.scanned, s.chunkTotals, stride, scatterDebug());
 }
 
 template <typename K, int BITS>
@@ -667,7 +677,7 @@ void ensureRadixScratch(RadixScratch& s, int n)
 {
     const int tile = kThreads * itemsPerLane(n);
     const int numTiles = (n + tile - 1) / tile;
-    const int entries = kDigits * std::max(numTiles, 1);
+    const int entries = kDigits * ((std::max(numTiles, 1) + 3) & ~3);
     if (entries > s.capacityEntries)
     {
         if (s.table) GS_CHECK(hipFree(s.table));
