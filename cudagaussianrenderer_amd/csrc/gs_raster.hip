@@ -29,6 +29,23 @@ namespace
 
 constexpr int kBatch = 64; // entries staged per LDS fill; two vote chunks
 
+// A lane's PPL pixels as one vector value: the per-pixel multiplies and fmas then compile to packed FP32 instructions
+// (v_pk_fma_f32 / v_pk_mul_f32: two pixels per issue slot); the results are the same IEEE operations as scalar code.
+template <int N>
+struct PixelVec
+{
+    typedef float type __attribute__((ext_vector_type(N)));
+    static __device__ __forceinline__ float get(const type& v, int i) { return v[i]; }
+    static __device__ __forceinline__ void set(type& v, int i, float x) { v[i] = x; }
+};
+template <>
+struct PixelVec<1>
+{
+    typedef float type;
+    static __device__ __forceinline__ float get(const type& v, int) { return v; }
+    static __device__ __forceinline__ void set(type& v, int, float x) { v = x; }
+};
+
 template <int THREADS>
 __device__ __forceinline__ bool anyInBlock(bool pred)
 {
@@ -92,23 +109,19 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
         return;
     }
     // GaussianRender.cu:939 (no half-pixel offset)
-    float clipPx[PPL];
+    using PV = PixelVec<PPL>;
+    using V = typename PV::type;
+    V clipPx;
     bool onScreen[PPL];
 #pragma unroll
     for (int i = 0; i != PPL; ++i)
     {
-        clipPx[i] = (float) (px0 + i) * scr.pixelClipSizeX - 1.0f;
+        PV::set(clipPx, i, (float) (px0 + i) * scr.pixelClipSizeX - 1.0f);
         onScreen[i] = (px0 + i) < scr.width && py < scr.height;
     }
     const float clipPy = (float) py * scr.pixelClipSizeY - 1.0f;
 
-    float cr[PPL], cg[PPL], cb[PPL], tr[PPL];
-#pragma unroll
-    for (int i = 0; i != PPL; ++i)
-    {
-        cr[i] = cg[i] = cb[i] = 0.0f;
-        tr[i] = 1.0f;
-    }
+    V cr = V(0.0f), cg = V(0.0f), cb = V(0.0f), tr = V(1.0f);
 
     // Register-staged gather of one list entry per lane.
     float2 gCentre = make_float2(0.f, 0.f);
@@ -160,7 +173,7 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
                     a[e] = sA[i + e];
                     b[e] = sB[i + e];
                 }
-                float alpha[4][PPL];
+                V alpha[4];
 #pragma unroll
                 for (int e = 0; e != 4; ++e)
                 {
@@ -168,27 +181,22 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
                     const float dy = clipPy - a[e].y;
                     const float qy = b[e].x * dy * dy; // C' dy^2
                     const float by = a[e].w * dy;      // B' dy
+                    const V dx = clipPx - V(a[e].x);
+                    const V power = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(V(a[e].z), dx, V(by)), V(qy));
+                    V density;
 #pragma unroll
-                    for (int p = 0; p != PPL; ++p)
-                    {
-                        const float dx = clipPx[p] - a[e].x;
-                        const float power = fmaf(dx, fmaf(a[e].z, dx, by), qy);
-                        alpha[e][p] = opacity[e] * __saturatef(__builtin_amdgcn_exp2f(power));
-                    }
+                    for (int p = 0; p != PPL; ++p) PV::set(density, p, __saturatef(__builtin_amdgcn_exp2f(PV::get(power, p))));
+                    alpha[e] = V(opacity[e]) * density;
                 }
 #pragma unroll
                 for (int e = 0; e != 4; ++e)
                 {
                     // GaussianRender.cu:983-984
-#pragma unroll
-                    for (int p = 0; p != PPL; ++p)
-                    {
-                        const float w = tr[p] * alpha[e][p];
-                        cr[p] = fmaf(b[e].y, w, cr[p]);
-                        cg[p] = fmaf(b[e].z, w, cg[p]);
-                        cb[p] = fmaf(b[e].w, w, cb[p]);
-                        tr[p] = fmaf(-tr[p], alpha[e][p], tr[p]);
-                    }
+                    const V w = tr * alpha[e];
+                    cr = __builtin_elementwise_fma(V(b[e].y), w, cr);
+                    cg = __builtin_elementwise_fma(V(b[e].z), w, cg);
+                    cb = __builtin_elementwise_fma(V(b[e].w), w, cb);
+                    tr = __builtin_elementwise_fma(-tr, alpha[e], tr);
                 }
             }
             consumed = base + chunk + m;
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
             // partial edge tile do not vote).
             bool alive = false;
 #pragma unroll
-            for (int p = 0; p != PPL; ++p) alive |= onScreen[p] && tr[p] > 0.02f;
+            for (int p = 0; p != PPL; ++p) alive |= onScreen[p] && PV::get(tr, p) > 0.02f;
             if (!anyInBlock<THREADS>(alive))
             {
                 stop = true;
@@ -221,15 +229,15 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
                 uint32_t* pk = &packed.x;
 #pragma unroll
                 for (int p = 0; p != 4; ++p)
-                    pk[p] = quantize8(cr[p]) | (quantize8(cg[p]) << 8) | (quantize8(cb[p]) << 16) | 0xFF000000u;
+                    pk[p] = quantize8(PV::get(cr, p)) | (quantize8(PV::get(cg, p)) << 8) | (quantize8(PV::get(cb, p)) << 16) | 0xFF000000u;
                 *reinterpret_cast<uint4*>(row) = packed;
                 return;
             }
         }
 #pragma unroll
         for (int p = 0; p != PPL; ++p)
-            if (onScreen[p]) row[p] = make_uchar4((unsigned char) quantize8(cr[p]), (unsigned char) quantize8(cg[p]),
-                                                  (unsigned char) quantize8(cb[p]), 255);
+            if (onScreen[p]) row[p] = make_uchar4((unsigned char) quantize8(PV::get(cr, p)), (unsigned char) quantize8(PV::get(cg, p)),
+                                                  (unsigned char) quantize8(PV::get(cb, p)), 255);
     }
 }
 
