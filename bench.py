@@ -60,12 +60,13 @@ def main():
     ap.add_argument("--even-bands", action="store_true", help="multi-GPU: equal-height bands instead of cost-balanced ones")
     ap.add_argument("--pipeline", type=int, default=1, help="1 two-level sort (default, fastest at C3), 2 binned tile lists (no pair sort)")
     ap.add_argument("--band-cull", type=int, default=0, help="0 auto (compact the visible splats on strict bands only), 1 always, 2 never")
+    ap.add_argument("--rehearse", action="store_true", help="multi-rank control flow on ONE GPU: every rank on cuda:0, gloo instead of RCCL (not a measurement)")
     ap.add_argument("--inflight", type=int, default=3, help="frames in flight per GPU (renderers on separate HIP streams)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.rehearse else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
@@ -80,7 +81,10 @@ def main():
     lib = gs.lib()  # fails loudly if libgsplat_hip.so is missing
     lib.gs_set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     stream = torch.cuda.current_stream(device)
     lib.gs_set_stream(stream.cuda_stream)
     if args.ppl:
@@ -196,9 +200,25 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t_start
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=("cpu" if args.rehearse else device))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- N > 1: one more frame through the same path, compared on rank 0 with a full-frame render of its own --------
+    gathered_ok = None
+    if world > 1:
+        check_view = 1 % len(cameras)
+        with torch.cuda.stream(streams[0]):
+            renderers[0].render(cameras[check_view])
+            multigpu.gather_bands(framebuffers[0], bands, rank, world)
+        torch.cuda.synchronize(device)
+        if rank == 0:
+            whole = gs.Renderer(W, H)
+            whole.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+            whole.render(cameras[check_view])
+            gathered_ok = bool(np.array_equal(whole.read_image(), framebuffers[0].cpu().numpy()))
+            whole.close()
+        dist.barrier()
 
     # ---- per-stage GPU times: the same frames again with one non-blocking event pair per stage --------
     # (one renderer, frames back to back, so the stage intervals do not overlap another frame's kernels)
@@ -256,6 +276,7 @@ def main():
                 "pairs_per_frame": round(p_mean), "consumed_pairs_per_frame": round(pc_mean),
                 "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": name, "frames_in_flight": depth, "captured_frames": not args.no_graph, "pipeline": {1: "two_level", 2: "binned"}.get(args.pipeline, str(args.pipeline)), "tile_row_bands": [list(b) for b in bands],
                 "opacity_mean_raw": args.opacity_mean, "ingest_s": round(t_ingest, 2),
+                "gathered_frame_equals_single_gpu_frame": gathered_ok,
             },
             "roofline": {
                 "kernel": "rasterizeTilesKernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

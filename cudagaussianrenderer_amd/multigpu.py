@@ -26,6 +26,21 @@ def gather_bands(framebuffer, bands, rank, world, root=0):
     if world == 1:
         return
     height = framebuffer.shape[0]
+    if framebuffer.is_cuda and dist.get_backend() == "gloo":
+        # Rehearsal of the multi-rank flow without RCCL (several ranks sharing one GPU): gloo moves host tensors only,
+        # so the band goes through a host copy.  Never the measured path.
+        if rank == root:
+            for src in range(world):
+                a, b = pixel_rows(bands[src], height)
+                if src != root and b > a:
+                    staging = framebuffer[a:b].cpu()
+                    dist.recv(staging, src)
+                    framebuffer[a:b].copy_(staging)
+        else:
+            a, b = pixel_rows(bands[rank], height)
+            if b > a:
+                dist.send(framebuffer[a:b].cpu(), root)
+        return
     ops = []
     if rank == root:
         for src in range(world):
