@@ -689,7 +689,8 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
     // (two-level pipeline: the raster kernel zeroes the tiles that have no work itself, no 8 MB memset)
     if (pixelRowEnd > pixelRowBegin && !twoLevel)
         gs_device_memset(r->backBuffer + rowBytes * pixelRowBegin, 0, rowBytes * (size_t) (pixelRowEnd - pixelRowBegin));
-    if (!binned) gs_device_memset(r->tileRange, 0xFF, sizeof(int32_t) * 2 * (size_t) scr.totalTiles);
+    // (two-level pipeline: the clip kernel resets the range table on the side; binned: every range of the band is written)
+    if (!twoLevel || n <= 0) gs_device_memset(r->tileRange, 0xFF, sizeof(int32_t) * 2 * (size_t) scr.totalTiles);
 
     // Demo.cpp:406-430
     GsGlobalArgs args{};
@@ -774,14 +775,14 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         {
             launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation,
                                 (float2*) r->clipXY, r->clipZ, (float4*) r->ellipse, (float4*) r->conic, r->depthKey[0],
-                                (uint32_t*) r->order[0]);
+                                (uint32_t*) r->order[0], nullptr, nullptr, nullptr, binned ? nullptr : r->tileRange, 2 * scr.totalTiles);
         }
         else
         {
             // clip data for every splat + keep-mask, then an order-preserving compaction of (depth key, index)
             launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation,
                                 (float2*) r->clipXY, r->clipZ, (float4*) r->ellipse, (float4*) r->conic, nullptr, nullptr, r->bandMask,
-                                r->bandCounts);
+                                r->bandCounts, nullptr, binned ? nullptr : r->tileRange, 2 * scr.totalTiles);
             launchScanInt32(g.stream, (n + kWave - 1) / kWave, r->bandCounts, r->bandOffsets, r->bandTotal);
             launchCompactBand(g.stream, n, r->bandMask, r->bandOffsets, r->clipZ, r->depthKey[0], (uint32_t*) r->order[0]);
             countDevice = (const int*) r->bandTotal; // low 32 bits of the little-endian int64 total
@@ -1000,7 +1001,9 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
     ClipCamera unusedCamera{};
 
     GS_CHECK(hipMemcpyAsync(r->paramsDevice, r->paramsHost, sizeof(FrameParams), hipMemcpyHostToDevice, g.stream));
-    if (!binned) launchFillInt32(g.stream, r->tileRange, -1, 2 * scr.totalTiles); // not a memset node: see gs_ranges.hip
+    // the range table is reset to -1 by the clip kernel (not a memset node: see gs_ranges.hip); binned frames write every range
+    int32_t* clearTable = binned ? nullptr : r->tileRange;
+    const int clearEntries = 2 * scr.totalTiles;
     if (r->shDegree != 0 && !cull)
         launchSphericalHarmonics(g.stream, n, r->shDegree, r->shCount, (const float4*) r->position, r->sh, unused, (float4*) r->color,
                                  r->paramsDevice);
@@ -1008,12 +1011,12 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
     if (!cull)
         launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
                             (float2*) r->clipXY, r->clipZ, (float4*) r->ellipse, (float4*) r->conic, r->depthKey[0],
-                            (uint32_t*) r->order[0], nullptr, nullptr, r->paramsDevice);
+                            (uint32_t*) r->order[0], nullptr, nullptr, r->paramsDevice, clearTable, clearEntries);
     else
     {
         launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
                             (float2*) r->clipXY, r->clipZ, (float4*) r->ellipse, (float4*) r->conic, nullptr, nullptr, r->bandMask,
-                            r->bandCounts, r->paramsDevice);
+                            r->bandCounts, r->paramsDevice, clearTable, clearEntries);
         launchScanInt32(g.stream, (n + kWave - 1) / kWave, r->bandCounts, r->bandOffsets, r->bandTotal);
         launchCompactBand(g.stream, n, r->bandMask, r->bandOffsets, r->clipZ, r->depthKey[0], (uint32_t*) r->order[0]);
         countDevice = (const int*) r->bandTotal;

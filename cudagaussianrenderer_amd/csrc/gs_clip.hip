@@ -28,9 +28,14 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
                                                             float4* __restrict__ screenEllipse, float4* __restrict__ conicOut,
                                                             uint32_t* __restrict__ depthKey, uint32_t* __restrict__ splatOrder,
                                                             unsigned long long* __restrict__ bandMask,
-                                                            int32_t* __restrict__ bandWaveCounts)
+                                                            int32_t* __restrict__ bandWaveCounts, int32_t* __restrict__ rangeTable,
+                                                            int rangeEntries)
 {
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    // The renderer has this kernel reset the tile range table to -1 (Demo.cpp:403) on the side: it is the first kernel
+    // of the frame and nothing reads the table before the range search, so the frame needs no separate clear.
+    if (rangeTable != nullptr)
+        for (int i = index; i < rangeEntries; i += (int) (gridDim.x * blockDim.x)) rangeTable[i] = -1;
     if (index >= count) return;
     const ClipCamera cam = params ? params->camera : camArg; // device-resident when the frame is a captured graph
 
@@ -195,12 +200,12 @@ void launchCompactBand(hipStream_t stream, int count, const unsigned long long* 
 void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const ClipCamera& cam, const float4* position,
                          const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic,
                          uint32_t* depthKey, uint32_t* splatOrder, unsigned long long* bandMask, int32_t* bandWaveCounts,
-                         const FrameParams* paramsDevice)
+                         const FrameParams* paramsDevice, int32_t* rangeTableToClear, int rangeEntries)
 {
     if (count <= 0) return;
     const dim3 grid((count + 255) / 256), block(256);
     hipLaunchKernelGGL(splatClipDataKernel, grid, block, 0, stream, count, scr, cam, paramsDevice, position, scaleAndRotation, clipXY, clipZ,
-                       screenEllipse, conic, depthKey, splatOrder, bandMask, bandWaveCounts);
+                       screenEllipse, conic, depthKey, splatOrder, bandMask, bandWaveCounts, rangeTableToClear, rangeEntries);
 }
 
 } // namespace gs

@@ -69,7 +69,8 @@ void launchSphericalHarmonics(hipStream_t stream, int count, int degree, int shC
 void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const ClipCamera& cam, const float4* position,
                          const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic,
                          uint32_t* depthKeyOrNull, uint32_t* splatOrderOrNull, unsigned long long* bandMaskOrNull = nullptr,
-                         int32_t* bandWaveCountsOrNull = nullptr, const FrameParams* paramsDeviceOrNull = nullptr);
+                         int32_t* bandWaveCountsOrNull = nullptr, const FrameParams* paramsDeviceOrNull = nullptr,
+                         int32_t* rangeTableToClearOrNull = nullptr, int rangeEntries = 0);
 // Band cull (multi-GPU): the clip kernel flags the splats whose tile AABB reaches this GPU's rows (one 64-bit mask and
 // one count per 64 splats); after an exclusive scan of the counts this writes the kept splats' depth keys and indices,
 // order preserved.
