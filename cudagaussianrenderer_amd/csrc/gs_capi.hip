@@ -995,8 +995,6 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
     const int n = r->splatCount;
     const int tileKeyBytes = scr.totalTiles > 65536 ? 4 : 2;
     const int tBits = tileBits(scr.totalTiles);
-    const char* stopEnv = getenv("GS_GRAPH_STOP"); // debugging aid: enqueue only the first k stages
-    const int stopAfter = stopEnv ? atoi(stopEnv) : 99;
     const float3 unused = make_float3(0.f, 0.f, 0.f);
     ClipCamera unusedCamera{};
 
@@ -1020,23 +1018,15 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
         launchScanInt32(g.stream, (n + kWave - 1) / kWave, r->bandCounts, r->bandOffsets, r->bandTotal);
         launchCompactBand(g.stream, n, r->bandMask, r->bandOffsets, r->clipZ, r->depthKey[0], (uint32_t*) r->order[0]);
         countDevice = (const int*) r->bandTotal;
-        if (stopAfter < 2) return 0;
         if (r->shDegree != 0)
             launchSphericalHarmonicsGather(g.stream, n, countDevice, r->shDegree, r->shCount, r->order[0], (const float4*) r->position,
                                            r->shPerSplat, unused, (float4*) r->color, r->paramsDevice);
     }
-    if (stopAfter < 3) return 0;
     r->radix.onesweep = false; // its ticket base / epoch are host-side launch arguments: not replayable
     r->radix.countDevice = countDevice;
     r->scratch.countDevice = countDevice;
     const int orderSel = launchRadixSortPairs(g.stream, r->radix, 4, r->depthKey[0], r->depthKey[1], r->order[0], r->order[1], n, 0, 32);
     const uint32_t* order = (const uint32_t*) r->order[orderSel];
-    if (stopAfter < 4)
-    {
-        r->radix.countDevice = nullptr;
-        r->scratch.countDevice = nullptr;
-        return 0;
-    }
     if (binned)
     {
         const int bandTiles = (scr.rowEnd - scr.rowBegin) * scr.tilesX;
@@ -1059,17 +1049,10 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
     const int* pairCount = (const int*) r->scratch.total;
     r->radix.countDevice = pairCount;
     r->scratch.countDevice = nullptr;
-    if (stopAfter < 5)
-    {
-        r->radix.countDevice = nullptr;
-        return 0;
-    }
     const int sel = launchRadixSortPairs(g.stream, r->radix, tileKeyBytes, r->keys[0], r->keys[1], r->values[0], r->values[1],
                                          r->tileListCapacity, 0, tBits);
     r->radix.countDevice = nullptr;
-    if (stopAfter < 6) return 0;
     launchTileRanges(g.stream, r->tileListCapacity, tileKeyBytes, r->keys[sel], r->tileRange, pairCount);
-    if (stopAfter < 7) return 0;
     launchRasterize(g.stream, scr, r->tileRange, r->values[sel], (const float2*) r->clipXY, (const float4*) r->conic,
                     (const float4*) r->color, (uchar4*) r->backBuffer, nullptr, true);
     r->graphSelector = sel;

@@ -179,7 +179,7 @@ template <typename K, int BITS, int ITEMS>
 __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restrict__ keysIn, const int32_t* __restrict__ valuesIn,
                                                                 K* __restrict__ keysOut, int32_t* __restrict__ valuesOut, int nHost, const int* __restrict__ nDevice,
                                                                 int shift, const int32_t* __restrict__ scanned,
-                                                                const int32_t* __restrict__ totals, int stride, int debug)
+                                                                const int32_t* __restrict__ totals, int stride)
 {
     constexpr int kTile = kThreads * ITEMS;
     constexpr int kDigitMask = (1 << BITS) - 1;
@@ -310,7 +310,6 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
             const K k = sKeys[j];
             const int digit = (int) ((k >> shift) & kDigitMask);
             const int pos = globalBase[digit] + (j - localBase[digit]);
-            if (debug & 1) continue;
             keysOut[pos] = k;
             valuesOut[pos] = sVals[j];
         }
@@ -598,12 +597,6 @@ int sortOnesweepT(hipStream_t stream, K* keys0, K* keys1, int32_t* values0, int3
     return sortOnesweepItems<K, kItemsLarge>(stream, keys0, keys1, values0, values1, n, beginBit, endBit, s);
 }
 
-int scatterDebug()
-{
-    static const int v = getenv("GS_RADIX_DEBUG") ? atoi(getenv("GS_RADIX_DEBUG")) : 0; // timing experiments only
-    return v;
-}
-
 int itemsPerLane(int n) { return n <= kSmallLimit ? kItemsSmall : kItemsLarge; }
 
 template <typename K, int BITS, int ITEMS>
@@ -616,7 +609,7 @@ void runPassItems(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, 
     hipLaunchKernelGGL((radixHistogramKernel<K, BITS, ITEMS>), dim3(numTiles), dim3(kThreads), 0, stream, keysIn, n, s.countDevice, shift, skewed ? 1 : 0, s.table, stride);
     hipLaunchKernelGGL(radixColumnScanKernel, dim3(kDigits), dim3(kScanThreads), 0, stream, n, s.countDevice, kTile, stride, s.table, s.scanned, s.chunkTotals);
     hipLaunchKernelGGL((radixScatterKernel<K, BITS, ITEMS>), dim3(8 * ((numTiles + 7) / 8)), dim3(kThreads), 0, stream, keysIn, valuesIn, keysOut,
-                       valuesOut, n, s.countDevice, shift, s.scanned, s.chunkTotals, stride, scatterDebug());
+                       valuesOut, n, s.countDevice, shift, s.scanned, s.chunkTotals, stride);
 }
 
 template <typename K, int BITS>
