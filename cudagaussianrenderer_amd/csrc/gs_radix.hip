@@ -43,87 +43,99 @@ __device__ __forceinline__ unsigned long long matchDigit(int digit, bool valid)
     return valid ? m : 0ull;
 }
 
+// Tiles counted by one histogram workgroup: its four counts of a digit are one 16-byte store into the digit's row of
+// table[digit][tile] (a single tile per workgroup would scatter 256 four-byte stores a row apart).
+constexpr int kHistTiles = 4;
+
 template <typename K, int BITS, int ITEMS>
 __global__ __launch_bounds__(kThreads) void radixHistogramKernel(const K* __restrict__ keys, int nHost, const int* __restrict__ nDevice, int shift,
                                                                   int skewed, int32_t* __restrict__ table, int stride)
 {
     constexpr int kTile = kThreads * ITEMS;
-    __shared__ int hist[kDigits];
+    __shared__ int hist[kHistTiles][kDigits];
     const int t = threadIdx.x;
     // The element count may live on the device (the renderer's band-culled splat list): nHost is then only the
     // upper bound the grid was sized for; tiles past the real count do nothing.
     const int n = nDevice ? min(*nDevice, nHost) : nHost;
-    const int base = blockIdx.x * kTile;
-    if (base >= n) return;
-    hist[t] = 0;
+    const int firstTile = blockIdx.x * kHistTiles;
+    if (firstTile * kTile >= n) return;
+#pragma unroll
+    for (int j = 0; j != kHistTiles; ++j) hist[j][t] = 0;
     __syncthreads();
-    K key[ITEMS];
-    // Counting does not care which lane sees which key: full tiles are read 16 bytes per lane (ITEMS consecutive keys
-    // when they fill a multiple of 16 bytes), the ragged last tile element by element.
-    constexpr bool kWide = (sizeof(K) * ITEMS) % 16 == 0;
-    const bool wide = kWide && base + kTile <= n;
-    if constexpr (kWide)
+    for (int j = 0; j != kHistTiles; ++j)
     {
-        if (wide)
+        const int base = (firstTile + j) * kTile;
+        if (base >= n) break;
+        int* h = hist[j];
+        K key[ITEMS];
+        // Counting does not care which lane sees which key: full tiles are read 16 bytes per lane (ITEMS consecutive keys
+        // when they fill a multiple of 16 bytes), the ragged last tile element by element.
+        constexpr bool kWide = (sizeof(K) * ITEMS) % 16 == 0;
+        const bool wide = kWide && base + kTile <= n;
+        if constexpr (kWide)
         {
-        constexpr int kVecs = (int) (sizeof(K) * ITEMS / 16);
-        const uint4* src = reinterpret_cast<const uint4*>(keys + base) + t * kVecs;
-        uint4 v[kVecs];
-#pragma unroll
-        for (int q = 0; q != kVecs; ++q) v[q] = src[q];
-        __builtin_memcpy(key, v, sizeof(key));
-        }
-    }
-    if (!wide)
-    {
-#pragma unroll
-        for (int r = 0; r != ITEMS; ++r) // all loads in flight before the first use
-        {
-            const int i = base + r * kThreads + t;
-            key[r] = (i < n) ? keys[i] : K(0);
-        }
-    }
-    if (skewed && wide)
-    {
-        // Top digit of a multi-pass tile sort: the lane's ITEMS consecutive keys mostly share it -- one add per run.
-        int run = 1;
-#pragma unroll
-        for (int r = 0; r != ITEMS; ++r)
-        {
-            const int digit = (int) ((key[r] >> shift) & ((1 << BITS) - 1));
-            const int next = (r + 1 != ITEMS) ? (int) ((key[(r + 1) % ITEMS] >> shift) & ((1 << BITS) - 1)) : -1;
-            if (next == digit) ++run;
-            else
+            if (wide)
             {
-                atomicAdd(&hist[digit], run);
-                run = 1;
+                constexpr int kVecs = (int) (sizeof(K) * ITEMS / 16);
+                const uint4* src = reinterpret_cast<const uint4*>(keys + base) + t * kVecs;
+                uint4 v[kVecs];
+#pragma unroll
+                for (int q = 0; q != kVecs; ++q) v[q] = src[q];
+                __builtin_memcpy(key, v, sizeof(key));
             }
         }
-    }
-    else
-    {
-#pragma unroll
-        for (int r = 0; r != ITEMS; ++r)
+        if (!wide)
         {
-            const bool valid = wide || base + r * kThreads + t < n;
-            const int digit = (int) ((key[r] >> shift) & ((1 << BITS) - 1));
-            if (BITS == 8 || !skewed)
+#pragma unroll
+            for (int r = 0; r != ITEMS; ++r) // all loads in flight before the first use
             {
-                // Well-spread digits: plain LDS atomics (lanes sharing a digit serialise inside the LDS).
-                if (valid) atomicAdd(&hist[digit], 1);
+                const int i = base + r * kThreads + t;
+                key[r] = (i < n) ? keys[i] : K(0);
             }
-            else
+        }
+        if (skewed && wide)
+        {
+            // Top digit of a multi-pass tile sort: the lane's ITEMS consecutive keys mostly share it -- one add per run.
+            int run = 1;
+#pragma unroll
+            for (int r = 0; r != ITEMS; ++r)
             {
-                // skewed digit, ragged tile: one add per distinct digit per wave
-                const int lane = t & (kWave - 1);
-                const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
-                const unsigned long long m = matchDigit<BITS>(digit, valid);
-                if (valid && (m & lower) == 0ull) atomicAdd(&hist[digit], __popcll(m));
+                const int digit = (int) ((key[r] >> shift) & ((1 << BITS) - 1));
+                const int next = (r + 1 != ITEMS) ? (int) ((key[(r + 1) % ITEMS] >> shift) & ((1 << BITS) - 1)) : -1;
+                if (next == digit) ++run;
+                else
+                {
+                    atomicAdd(&h[digit], run);
+                    run = 1;
+                }
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int r = 0; r != ITEMS; ++r)
+            {
+                const bool valid = wide || base + r * kThreads + t < n;
+                const int digit = (int) ((key[r] >> shift) & ((1 << BITS) - 1));
+                if (BITS == 8 || !skewed)
+                {
+                    // Well-spread digits: plain LDS atomics (lanes sharing a digit serialise inside the LDS).
+                    if (valid) atomicAdd(&h[digit], 1);
+                }
+                else
+                {
+                    // skewed digit, ragged tile: one add per distinct digit per wave
+                    const int lane = t & (kWave - 1);
+                    const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
+                    const unsigned long long m = matchDigit<BITS>(digit, valid);
+                    if (valid && (m & lower) == 0ull) atomicAdd(&h[digit], __popcll(m));
+                }
             }
         }
     }
     __syncthreads();
-    table[t * stride + blockIdx.x] = hist[t]; // [digit][tile]: every digit's column is contiguous for the scan
+    // [digit][tile]: every digit's row is contiguous for the scan; stride is a multiple of 4, so the quad is aligned
+    *reinterpret_cast<int4*>(table + (size_t) t * stride + firstTile) = make_int4(hist[0][t], hist[1][t], hist[2][t], hist[3][t]);
 }
 
 // One workgroup (1024 lanes) per digit: exclusive scan of that digit's row of table[digit][tile] over the tiles
@@ -606,7 +618,7 @@ void runPassItems(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, 
     constexpr int kTile = kThreads * ITEMS;
     const int numTiles = (n + kTile - 1) / kTile;
     const int stride = (numTiles + 3) & ~3; // tiles per digit row of the tables
-    hipLaunchKernelGGL((radixHistogramKernel<K, BITS, ITEMS>), dim3(numTiles), dim3(kThreads), 0, stream, keysIn, n, s.countDevice, shift, skewed ? 1 : 0, s.table, stride);
+    hipLaunchKernelGGL((radixHistogramKernel<K, BITS, ITEMS>), dim3((numTiles + kHistTiles - 1) / kHistTiles), dim3(kThreads), 0, stream, keysIn, n, s.countDevice, shift, skewed ? 1 : 0, s.table, stride);
     hipLaunchKernelGGL(radixColumnScanKernel, dim3(kDigits), dim3(kScanThreads), 0, stream, n, s.countDevice, kTile, stride, s.table, s.scanned, s.chunkTotals);
     hipLaunchKernelGGL((radixScatterKernel<K, BITS, ITEMS>), dim3(8 * ((numTiles + 7) / 8)), dim3(kThreads), 0, stream, keysIn, valuesIn, keysOut,
                        valuesOut, n, s.countDevice, shift, s.scanned, s.chunkTotals, stride);

@@ -222,30 +222,45 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void tileListFastKernel(int 
     if (!EMIT && lane == 0) waveCounts[waveGlobal] = running;
 }
 
-// Exclusive scan of n ints by ONE workgroup (n = ceil(N/64)): 1024 lanes x 4 consecutive ints per pass
-// (16-byte coalesced loads), wave scans by shuffles, 16 wave totals through LDS, carry across passes.
+// Exclusive scan of n ints by ONE workgroup (n = ceil(N/64)): 1024 lanes x 16 consecutive ints per pass (four 16-byte
+// loads in flight per lane), one wave scan of the lane sums by shuffles, 16 wave totals through LDS, carry across passes
+// (one pass up to 16 Ki entries = 1 M splats).
 constexpr int kScanThreads = 1024;
+constexpr int kScanItems = 16;
 __global__ __launch_bounds__(kScanThreads) void scanFastKernel(int nHost, const int* __restrict__ countDevice, const int32_t* __restrict__ in, int32_t* __restrict__ out,
                                                                int64_t* __restrict__ total, int64_t* __restrict__ totalHostMapped)
 {
-    __shared__ long long waveTotals[kScanThreads / kWave];
+    __shared__ long long waveTotals[2][kScanThreads / kWave];
     const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
     // nHost = waves the grid of the count pass was sized for; with a device-side splat count only the first
     // ceil(count/64) of them wrote their totals.
     const int n = countDevice ? min((*countDevice + kWave - 1) / kWave, nHost) : nHost;
     long long carry = 0;
-    for (int base = 0; base < n; base += kScanThreads * 4)
+    int flip = 0;
+    for (int base = 0; base < n; base += kScanThreads * kScanItems, flip ^= 1)
     {
-        const int i = base + t * 4;
-        int4 v = make_int4(0, 0, 0, 0);
-        if (i + 3 < n) v = *reinterpret_cast<const int4*>(in + i);
+        const int i = base + t * kScanItems;
+        int v[kScanItems];
+        if (i + kScanItems <= n)
+        {
+#pragma unroll
+            for (int q = 0; q != kScanItems / 4; ++q)
+            {
+                const int4 w = *reinterpret_cast<const int4*>(in + i + 4 * q);
+                v[4 * q] = w.x;
+                v[4 * q + 1] = w.y;
+                v[4 * q + 2] = w.z;
+                v[4 * q + 3] = w.w;
+            }
+        }
         else
         {
-            if (i < n) v.x = in[i];
-            if (i + 1 < n) v.y = in[i + 1];
-            if (i + 2 < n) v.z = in[i + 2];
+#pragma unroll
+            for (int k = 0; k != kScanItems; ++k) v[k] = (i + k < n) ? in[i + k] : 0;
         }
-        const long long own = (long long) v.x + v.y + v.z + v.w;
+        long long own = 0;
+#pragma unroll
+        for (int k = 0; k != kScanItems; ++k) own += v[k];
         long long incl = own;
 #pragma unroll
         for (int delta = 1; delta < kWave; delta <<= 1)
@@ -253,23 +268,45 @@ __global__ __launch_bounds__(kScanThreads) void scanFastKernel(int nHost, const 
             const long long o = __shfl_up(incl, delta);
             if (lane >= delta) incl += o;
         }
-        if (lane == kWave - 1) waveTotals[wave] = incl;
-        __syncthreads();
-        long long before = carry;
-        for (int wv = 0; wv < wave; ++wv) before += waveTotals[wv];
-        long long all = 0;
-        for (int wv = 0; wv < kScanThreads / kWave; ++wv) all += waveTotals[wv];
+        if (lane == kWave - 1) waveTotals[flip][wave] = incl;
+        __syncthreads(); // the other half of waveTotals is free for the next pass: one barrier per pass
+        long long before = carry, all = 0;
+#pragma unroll
+        for (int wv = 0; wv != kScanThreads / kWave; ++wv)
+        {
+            const long long ws = waveTotals[flip][wv];
+            before += (wv < wave) ? ws : 0;
+            all += ws;
+        }
         long long p = before + incl - own;
         const long long cap = 0x7FFFFFFF;
-        if (i < n) out[i] = (int32_t) min(p, cap);
-        p += v.x;
-        if (i + 1 < n) out[i + 1] = (int32_t) min(p, cap);
-        p += v.y;
-        if (i + 2 < n) out[i + 2] = (int32_t) min(p, cap);
-        p += v.z;
-        if (i + 3 < n) out[i + 3] = (int32_t) min(p, cap);
+        if (i + kScanItems <= n)
+        {
+#pragma unroll
+            for (int q = 0; q != kScanItems / 4; ++q)
+            {
+                int4 w;
+                w.x = (int32_t) min(p, cap);
+                p += v[4 * q];
+                w.y = (int32_t) min(p, cap);
+                p += v[4 * q + 1];
+                w.z = (int32_t) min(p, cap);
+                p += v[4 * q + 2];
+                w.w = (int32_t) min(p, cap);
+                p += v[4 * q + 3];
+                *reinterpret_cast<int4*>(out + i + 4 * q) = w;
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int k = 0; k != kScanItems; ++k)
+            {
+                if (i + k < n) out[i + k] = (int32_t) min(p, cap);
+                p += v[k];
+            }
+        }
         carry += all;
-        __syncthreads();
     }
     if (t == 0)
     {
