@@ -14,6 +14,8 @@ from ._capi import CameraData, FrameStats, GlobalArgs, GsplatLibraryMissing, Til
 
 TILE_SIZE = 16
 SH_GROUP_SIZE = 256
+FOOTPRINT_GAUSSIAN = 0      # exp(-q/2), 3 sigma extent
+FOOTPRINT_EPANECHNIKOV = 1  # the reference's EPANECHNIKOV_KERNEL option: 1 - q/7, sqrt(7) sigma extent
 PIPELINE_REFERENCE = 0  # the reference's stage order: one 64-bit tile|depth radix sort of all pairs
 PIPELINE_TWO_LEVEL = 1  # default: depth-sort the splats, emit, stable-sort the pairs on the tile bits
 PIPELINE_BINNED = 2     # depth-sort the splats, then write every hit straight to its slot of the per-tile lists (no pair sort)
@@ -163,6 +165,11 @@ def evaluate_tile_range(timer, size):
 
 def rasterize_tile(timer):
     lib().gs_rasterize_tile(_t(timer))
+
+
+def set_footprint(footprint):
+    """GaussianRender.cu:8-9 (EPANECHNIKOV_KERNEL) as a process-wide run-time switch."""
+    lib().gs_set_footprint(int(footprint))
 
 
 def synchronize():

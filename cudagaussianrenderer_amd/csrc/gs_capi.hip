@@ -13,6 +13,11 @@ namespace gs
 void setRasterPixelsPerLane(int ppl);
 int rasterPixelsPerLane();
 
+namespace
+{
+int g_footprint = GS_FOOTPRINT_GAUSSIAN; // process-wide, like the reference's #define
+}
+
 Screen makeScreen(int width, int height, int rowBegin, int rowEnd)
 {
     if (width <= 0) width = GS_DEFAULT_SCREEN_SIZE;
@@ -34,6 +39,8 @@ Screen makeScreen(int width, int height, int rowBegin, int rowEnd)
     s.pixelClipSizeY = 2.0f / (float) height;
     const float pi = 3.14159265359f;
     s.traceBump = (1.0f / pi) * s.pixelClipSizeX * s.pixelClipSizeY;
+    s.epanechnikov = g_footprint == GS_FOOTPRINT_EPANECHNIKOV ? 1 : 0;
+    s.extentFactor = s.epanechnikov ? sqrtf(7.0f) : 3.0f;
     return s;
 }
 
@@ -282,6 +289,12 @@ extern "C" int64_t gs_last_raster_consumed_pairs(void)
     return (int64_t) v;
 }
 
+extern "C" void gs_set_footprint(int footprint)
+{
+    g_footprint = footprint == GS_FOOTPRINT_EPANECHNIKOV ? GS_FOOTPRINT_EPANECHNIKOV : GS_FOOTPRINT_GAUSSIAN;
+}
+extern "C" int gs_get_footprint(void) { return g_footprint; }
+
 extern "C" void gs_set_sort_backend(int backend)
 {
     cfg.onesweep = backend == GS_SORT_BACKEND_ONESWEEP;
@@ -364,7 +377,7 @@ struct GsRenderer
     hipGraphExec_t graphExec = nullptr;
     FrameParams* paramsDevice = nullptr;
     FrameParams* paramsHost = nullptr; // pinned
-    int graphCapacity = 0, graphSplats = 0, graphRowBegin = -1, graphRowEnd = -1, graphCull = -1, graphBinned = -1, graphSelector = 0, graphKeyBytes = 2;
+    int graphCapacity = 0, graphSplats = 0, graphRowBegin = -1, graphRowEnd = -1, graphCull = -1, graphBinned = -1, graphFootprint = -1, graphSelector = 0, graphKeyBytes = 2;
     bool pending = false; // begin() issued, finish() not yet
     FrameState frame;
     unsigned long long* bandMask = nullptr;
@@ -1101,7 +1114,8 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
     const bool binned = r->pipeline == GS_PIPELINE_BINNED && binsSupported(scr) && radixSortSupported(4, n) &&
                         r->scratch.totalHostMapped != nullptr;
     if (r->graphValid && (r->graphCapacity != r->tileListCapacity || r->graphSplats != n || r->graphRowBegin != scr.rowBegin ||
-                          r->graphRowEnd != scr.rowEnd || r->graphCull != (int) cull || r->graphBinned != (int) binned))
+                          r->graphRowEnd != scr.rowEnd || r->graphCull != (int) cull || r->graphBinned != (int) binned ||
+                          r->graphFootprint != scr.epanechnikov))
         r->graphValid = false;
 
     FrameParams fp{};
@@ -1136,6 +1150,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
         r->graphRowEnd = scr.rowEnd;
         r->graphCull = (int) cull;
         r->graphBinned = (int) binned;
+        r->graphFootprint = scr.epanechnikov;
     }
     GS_CHECK(hipGraphLaunch(r->graphExec, g.stream));
     r->selector = r->graphSelector;

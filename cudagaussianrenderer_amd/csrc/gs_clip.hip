@@ -122,8 +122,8 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
     const float ex = covB, ey = lambda0 - covA;
     const float invLen = 1.0f / sqrtf(ex * ex + ey * ey);
     const float cosA = ex * invLen, sinA = ey * invLen;
-    float extentX = sqrtf(lambda0) * 3.0f;
-    float extentY = sqrtf(lambda1) * 3.0f;
+    float extentX = sqrtf(lambda0) * scr.extentFactor; // GaussianRender.cu:298-302
+    float extentY = sqrtf(lambda1) * scr.extentFactor;
 
     // Conic (GaussianRender.cu:305-307).
     const float invDet = 1.0f / fmaxf(epsilon, det);

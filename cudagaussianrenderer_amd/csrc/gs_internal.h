@@ -41,6 +41,8 @@ struct Screen
     float tileClipSizeX, tileClipSizeY;     // GaussianRender.cu:656-657
     float pixelClipSizeX, pixelClipSizeY;   // GaussianRender.cu:939
     float traceBump;                        // GaussianRender.cu:271-274
+    float extentFactor;                     // 3 sigma, or sqrt(7) with the Epanechnikov footprint (GaussianRender.cu:298-302)
+    int epanechnikov;                       // GaussianRender.cu:8-9 as a run-time switch
 };
 
 Screen makeScreen(int width, int height, int rowBegin, int rowEnd);

@@ -60,7 +60,8 @@ __device__ __forceinline__ uint32_t quantize8(float c)
     return (uint32_t) fminf(fmaxf(v, 0.0f), 255.0f); // fmaxf(NaN, 0) = 0
 }
 
-template <int PPL>
+// EPAN: the reference's EPANECHNIKOV_KERNEL option (GaussianRender.cu:977-981): density 1 - q/7 instead of exp(-q/2).
+template <int PPL, bool EPAN>
 __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, int firstTile, int numTiles,
                                                                   const int32_t* __restrict__ tileRange,
                                                                   const int32_t* __restrict__ values,
@@ -137,7 +138,8 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
     };
     gather(0);
 
-    constexpr float kHalfLog2e = -0.5f * 1.4426950408889634f; // exp(-q/2) = exp2(q * kHalfLog2e)
+    // the conic is staged pre-scaled: exp(-q/2) = exp2(q * -0.5 log2 e); Epanechnikov: 1 - q/7 = 1 + q * (-1/7)
+    constexpr float kHalfLog2e = EPAN ? (-1.0f / 7.0f) : (-0.5f * 1.4426950408889634f);
     int base = 0, consumed = 0;
     for (;;)
     {
@@ -185,7 +187,8 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
                     const V power = __builtin_elementwise_fma(dx, __builtin_elementwise_fma(V(a[e].z), dx, V(by)), V(qy));
                     V density;
 #pragma unroll
-                    for (int p = 0; p != PPL; ++p) PV::set(density, p, __saturatef(__builtin_amdgcn_exp2f(PV::get(power, p))));
+                    for (int p = 0; p != PPL; ++p)
+                        PV::set(density, p, EPAN ? __saturatef(1.0f + PV::get(power, p)) : __saturatef(__builtin_amdgcn_exp2f(PV::get(power, p))));
                     alpha[e] = V(opacity[e]) * density;
                 }
 #pragma unroll
@@ -255,22 +258,27 @@ void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileR
     const int firstTile = scr.rowBegin * scr.tilesX;
     const int numTiles = (scr.rowEnd - scr.rowBegin) * scr.tilesX;
     if (numTiles <= 0) return;
+#define GS_LAUNCH_RASTER(PPL, EPAN)                                                                                                   \
+    hipLaunchKernelGGL((rasterizeTilesKernel<PPL, EPAN>), dim3(numTiles), dim3(256 / PPL), 0, stream, scr, firstTile, numTiles, tileRange, \
+                       values, clipXY, conic, color, backBuffer, consumedPairsOrNull, clearEmptyTiles ? 1 : 0)
+    const bool epan = scr.epanechnikov != 0;
     switch (g_rasterPixelsPerLane)
     {
     case 1:
-        hipLaunchKernelGGL(rasterizeTilesKernel<1>, dim3(numTiles), dim3(256), 0, stream, scr, firstTile, numTiles, tileRange, values,
-                           clipXY, conic, color, backBuffer, consumedPairsOrNull, clearEmptyTiles ? 1 : 0);
+        if (epan) GS_LAUNCH_RASTER(1, true);
+        else GS_LAUNCH_RASTER(1, false);
         break;
     case 2:
-        hipLaunchKernelGGL(rasterizeTilesKernel<2>, dim3(numTiles), dim3(128), 0, stream, scr, firstTile, numTiles, tileRange, values,
-                           clipXY, conic, color, backBuffer, consumedPairsOrNull, clearEmptyTiles ? 1 : 0);
+        if (epan) GS_LAUNCH_RASTER(2, true);
+        else GS_LAUNCH_RASTER(2, false);
         break;
     case 4:
     default:
-        hipLaunchKernelGGL(rasterizeTilesKernel<4>, dim3(numTiles), dim3(64), 0, stream, scr, firstTile, numTiles, tileRange, values,
-                           clipXY, conic, color, backBuffer, consumedPairsOrNull, clearEmptyTiles ? 1 : 0);
+        if (epan) GS_LAUNCH_RASTER(4, true);
+        else GS_LAUNCH_RASTER(4, false);
         break;
     }
+#undef GS_LAUNCH_RASTER
 }
 
 } // namespace gs

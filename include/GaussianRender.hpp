@@ -123,6 +123,8 @@ struct DoubleBuffer
 };
 
 // GaussianRender.cuh:118-143
+// GaussianRender.cu:8-9: `#define EPANECHNIKOV_KERNEL`, a build option of the reference, is a run-time switch here.
+inline void setEpanechnikovKernel(bool enabled) { gs_set_footprint(enabled ? GS_FOOTPRINT_EPANECHNIKOV : GS_FOOTPRINT_GAUSSIAN); }
 inline void setGlobalArgs(GlobalArgs* globalArgs) { gs_set_global_args(globalArgs); }
 inline void setTileListArgs(TileListArgs* tileListArgs) { gs_set_tile_list_args(tileListArgs); }
 inline void evaluateSphericalHarmonics(GpuTimer& timer, int32_t count) { gs_evaluate_spherical_harmonics(timer.handle, count); }

@@ -133,6 +133,13 @@ int64_t gs_last_raster_consumed_pairs(void);
 #define GS_SORT_BACKEND_NATIVE 1
 #define GS_SORT_BACKEND_ONESWEEP 2 /* NATIVE with one kernel per pass (decoupled look-back); slower on MI355X, kept for comparison */
 void gs_set_sort_backend(int backend);
+/* The reference's compile-time option `#define EPANECHNIKOV_KERNEL` (GaussianRender.cu:8-9, README.md:133-136) as a
+ * run-time switch: footprint extent sqrt(7) sigma instead of 3 sigma (.cu:298-302), density 1 - q/7 instead of exp(-q/2)
+ * (.cu:977-981).  Process-wide, like the reference's #define; applies to the staged calls and to every renderer. */
+#define GS_FOOTPRINT_GAUSSIAN 0
+#define GS_FOOTPRINT_EPANECHNIKOV 1
+void gs_set_footprint(int footprint);
+int gs_get_footprint(void);
 int gs_get_sort_backend(void);
 /* The native sort on its own: stable LSD sort of (keyBytes in {2,4} key, int32 value) pairs on key bits
  * [beginBit, endBit); input in buffers 0, returns the index (0/1) of the buffers holding the result, -1 if the

@@ -24,6 +24,12 @@
 #include <thread>
 #include <vector>
 
+// The reference's compile-time switch `#define EPANECHNIKOV_KERNEL` (GaussianRender.cu:8-9): footprint extent sqrt(7) sigma
+// instead of 3 sigma (.cu:298-302) and density 1 - q/7 instead of exp(-q/2) (.cu:977-981).  A run-time switch here.
+static int g_epanechnikov = 0;
+extern "C" void gsref_set_footprint(int epanechnikov) { g_epanechnikov = epanechnikov ? 1 : 0; }
+extern "C" int gsref_get_footprint(void) { return g_epanechnikov; }
+
 namespace
 {
 
@@ -503,7 +509,9 @@ extern "C" void gsref_evaluate_splat_clip_data(int32_t count, const float* posit
 
         // .cu:295-301
         float angle = std::atan2(eigenVector0.y, eigenVector0.x);
-        V2 extent{std::sqrt(lambda0) * 3.0f, std::sqrt(lambda1) * 3.0f};
+        // .cu:298-302: 3 sigma for the Gaussian footprint, sqrt(7) with EPANECHNIKOV_KERNEL
+        const float extentFactor = g_epanechnikov ? std::sqrt(7.0f) : 3.0f;
+        V2 extent{std::sqrt(lambda0) * extentFactor, std::sqrt(lambda1) * extentFactor};
 
         // .cu:305-307
         float invDet = 1.0f / gmax(epsilon, det);
@@ -708,7 +716,8 @@ extern "C" int64_t gsref_rasterize_tiles(int width, int height, int tileRowBegin
                         float dx_ = clipX[t] - cx;
                         float dy_ = clipY[t] - cy;
                         float q = cn[0] * dx_ * dx_ + cn[2] * dy_ * dy_ + 2.0f * cn[1] * dx_ * dy_;
-                        float density = std::exp(-0.5f * q);
+                        // .cu:977-981
+                        float density = g_epanechnikov ? 1.0f - q / 7.0f : std::exp(-0.5f * q);
                         float alpha = sc[3] * saturatef(density);
                         colR[t] += sc[0] * trans[t] * alpha;
                         colG[t] += sc[1] * trans[t] * alpha;

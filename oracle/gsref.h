@@ -134,6 +134,10 @@ void gsref_free_ply(GsRefPly* ply);
 
 int gsref_hardware_concurrency(void);
 
+/* GaussianRender.cu:8-9 EPANECHNIKOV_KERNEL as a run-time switch (0 = Gaussian footprint, the default). */
+void gsref_set_footprint(int epanechnikov);
+int gsref_get_footprint(void);
+
 #ifdef __cplusplus
 }
 #endif

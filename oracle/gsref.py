@@ -192,6 +192,11 @@ def rasterize_tiles(width, height, tile_range, values, clip_xy, conic, color, ro
     return img, int(consumed)
 
 
+def set_footprint(epanechnikov):
+    """GaussianRender.cu:8-9: the EPANECHNIKOV_KERNEL build option as a switch (False = Gaussian, the default)."""
+    lib().gsref_set_footprint(1 if epanechnikov else 0)
+
+
 def render(position, scale_and_rotation, color, sh_aligned, sh_degree, sh_count, camera, width, height):
     """Demo.cpp:394-479 on the CPU. Returns (image HxWx4 uint8, FrameStats, colour actually used)."""
     pos, pp = _f(position)

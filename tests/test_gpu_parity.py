@@ -507,3 +507,49 @@ def test_captured_frames_overflow_then_recover(gs):
     assert r.buffers().tileListSize == st.tileListSize
     assert np.array_equal(r.read_image(), want)
     r.close()
+
+
+def test_epanechnikov_footprint(gs, gsref, tmp_path):
+    """The reference's EPANECHNIKOV_KERNEL option as a run-time switch: clip extents, pair lists and image against the
+    oracle run with the same switch; the renderer's pipelines agree with each other; captured frames re-capture."""
+    w, h = 640, 360
+    ply = _ply_scene(gs, tmp_path, 30000, 2, log_scale_mean=-3.0)
+    n = ply["vertexCount"]
+    cam = gs.camera_from_bounds(ply["boundsMin"], ply["boundsMax"], w, h)
+    scene = (ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+    sh_al = gs.realign_spherical_harmonics(ply["sh"], ply["shCount"], n)
+    images = {}
+    try:
+        captured = gs.Renderer(w, h)
+        captured.set_graph(True)
+        captured.set_scene(*scene)
+        for footprint in (gs.FOOTPRINT_GAUSSIAN, gs.FOOTPRINT_EPANECHNIKOV, gs.FOOTPRINT_GAUSSIAN):
+            gs.set_footprint(footprint)
+            gsref.set_footprint(footprint == gs.FOOTPRINT_EPANECHNIKOV)
+            want, rst, _ = gsref.render(*scene[:3], sh_al, ply["shDegree"], ply["shCount"], cam, w, h)
+            per_pipeline = []
+            for pipeline in (gs.PIPELINE_REFERENCE, gs.PIPELINE_TWO_LEVEL, gs.PIPELINE_BINNED):
+                r = gs.Renderer(w, h, pipeline=pipeline)
+                r.set_scene(*scene)
+                st = r.render(cam, stats=True)
+                b = r.buffers()
+                ell = r.download(b.screenEllipse, 4 * n, np.float32).reshape(n, 4)
+                per_pipeline.append((r.read_image(), st.tileListSize, r.download(b.values, b.tileListSize, np.int32)))
+                r.close()
+            for img, size, values in per_pipeline:
+                _assert_image_close(img, want, f"footprint={footprint}")
+                assert abs(size - rst.tileListSize) <= max(4, 2e-5 * rst.tileListSize)
+            assert np.array_equal(per_pipeline[1][2], per_pipeline[2][2])  # two-level and binned lists: identical
+            assert np.array_equal(per_pipeline[1][0], per_pipeline[2][0])
+            captured.render(cam)  # the footprint is part of the captured kernels' arguments: must re-capture
+            assert np.array_equal(captured.read_image(), per_pipeline[1][0])
+            images[footprint] = (per_pipeline[1][0], ell.copy())
+        captured.close()
+    finally:
+        gs.set_footprint(gs.FOOTPRINT_GAUSSIAN)
+        gsref.set_footprint(False)
+    img_g, ell_g = images[gs.FOOTPRINT_GAUSSIAN]
+    img_e, ell_e = images[gs.FOOTPRINT_EPANECHNIKOV]
+    assert not np.array_equal(img_g, img_e)
+    vis = ell_g[:, 2] > 0
+    assert np.allclose(ell_e[vis, 2:] / ell_g[vis, 2:], np.sqrt(7.0) / 3.0, rtol=1e-5)

@@ -96,3 +96,45 @@ def test_realign_spherical_harmonics_layout(gsref):
         for i in [0, 5, 11]:
             assert dst[g * 256 * s + i * 256 + lane] == src[splat, i]
     assert dst[1 * 256 * s + 0 * 256 + 44] == 0.0  # padded tail of the last group
+
+
+def test_epanechnikov_footprint_known_answers(gsref):
+    """GaussianRender.cu:8-9 EPANECHNIKOV_KERNEL as a switch: extent sqrt(7) sigma instead of 3 sigma (.cu:298-302), density
+    1 - q/7 instead of exp(-q/2) (.cu:977-981).  One splat, so a pixel's colour is opacity * density * rgb, from float64."""
+    w = h = 64
+    pos = np.array([[0.1, -0.2, 0.3, 0.8]], np.float32)  # xyz + opacity
+    sr = np.array([[0.9, 0.5, 0.7, 0.0]], np.float32)
+    sr[0, 3] = np.array([gsref.encode_vec4([0.2, -0.3, 0.1, 0.9])], np.uint32).view(np.float32)[0]
+    col = np.array([[0.9, 0.5, 0.25, 0.8]], np.float32)
+    cam = gsref.camera_from_bounds([-2, -2, -2], [2, 2, 2], w, h)
+    out = {}
+    try:
+        for epan in (False, True):
+            gsref.set_footprint(epan)
+            xy, z, ell, con = gsref.evaluate_splat_clip_data(pos, sr, cam, w, h)
+            img, st, _ = gsref.render(pos, sr, col, None, 0, 0, cam, w, h)
+            out[epan] = (xy, ell, con, img)
+    finally:
+        gsref.set_footprint(False)
+    (xy_g, ell_g, con_g, img_g), (xy_e, ell_e, con_e, img_e) = out[False], out[True]
+    assert np.array_equal(xy_g, xy_e) and np.array_equal(con_g, con_e)
+    assert np.allclose(ell_e[:, 2:] / ell_g[:, 2:], np.sqrt(7.0) / 3.0, rtol=1e-6)  # extents only; same axis
+    assert np.array_equal(ell_g[:, :2], ell_e[:, :2])
+    px = np.arange(w, dtype=np.float64) * (2.0 / w) - 1.0
+    py = np.arange(h, dtype=np.float64) * (2.0 / h) - 1.0
+    dx = px[None, :] - float(xy_g[0, 0])
+    dy = py[:, None] - float(xy_g[0, 1])
+    a, b, c = [float(v) for v in con_g[0, :3]]
+    q = a * dx * dx + c * dy * dy + 2.0 * b * dx * dy
+    for img, density in ((img_g, np.exp(-0.5 * q)), (img_e, 1.0 - q / 7.0)):
+        alpha = 0.8 * np.clip(density, 0.0, 1.0)
+        touched = img[..., 3] == 255  # tiles that had work
+        assert touched.any()
+        for ch, rgb in enumerate([0.9, 0.5, 0.25]):
+            want = np.floor(np.clip(rgb * alpha, 0, 1) * 255.0)
+            diff = np.abs(img[..., ch].astype(np.int64) - want.astype(np.int64))[touched]
+            assert diff.max() <= 1
+    # compact support: outside q >= 7 the Epanechnikov splat contributes nothing, the Gaussian still does
+    far = (q > 7.5) & (img_g[..., 3] == 255) & (img_e[..., 3] == 255)
+    if far.any():
+        assert img_e[..., 0][far].max() == 0
