@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--even-bands", action="store_true", help="multi-GPU: equal-height bands instead of cost-balanced ones")
     ap.add_argument("--pipeline", type=int, default=1, help="1 two-level sort (default, fastest at C3), 2 binned tile lists (no pair sort)")
     ap.add_argument("--band-cull", type=int, default=0, help="0 auto (compact the visible splats on strict bands only), 1 always, 2 never")
+    ap.add_argument("--epanechnikov", action="store_true", help="the reference's EPANECHNIKOV_KERNEL option (footprint sqrt(7) sigma, density 1 - q/7)")
     ap.add_argument("--rehearse", action="store_true", help="multi-rank control flow on ONE GPU: every rank on cuda:0, gloo instead of RCCL (not a measurement)")
     ap.add_argument("--inflight", type=int, default=3, help="frames in flight per GPU (renderers on separate HIP streams)")
     args = ap.parse_args()
@@ -89,6 +90,8 @@ def main():
     lib.gs_set_stream(stream.cuda_stream)
     if args.ppl:
         lib.gs_set_raster_pixels_per_lane(args.ppl)
+    if args.epanechnikov:
+        gs.set_footprint(gs.FOOTPRINT_EPANECHNIKOV)
 
     W, H, N = args.width, args.height, args.splats
 
@@ -274,7 +277,7 @@ def main():
                             f"{views}-view orbit, tile-row bands over {world} GPU(s)",
                 "splats": N, "width": W, "height": H, "sh_degree": args.sh_degree, "views": views,
                 "pairs_per_frame": round(p_mean), "consumed_pairs_per_frame": round(pc_mean),
-                "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": name, "frames_in_flight": depth, "captured_frames": not args.no_graph, "pipeline": {1: "two_level", 2: "binned"}.get(args.pipeline, str(args.pipeline)), "tile_row_bands": [list(b) for b in bands],
+                "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": name, "frames_in_flight": depth, "captured_frames": not args.no_graph, "footprint": "epanechnikov" if args.epanechnikov else "gaussian", "pipeline": {1: "two_level", 2: "binned"}.get(args.pipeline, str(args.pipeline)), "tile_row_bands": [list(b) for b in bands],
                 "opacity_mean_raw": args.opacity_mean, "ingest_s": round(t_ingest, 2),
                 "gathered_frame_equals_single_gpu_frame": gathered_ok,
             },
@@ -290,7 +293,7 @@ def main():
             "gpu_ms_sum_of_stages": round(sum(stage_ms.values()), 4),
         }
         if args.cpu_frames > 0 and world == 1:
-            result["cpu_baseline"] = cpu_baseline(ply, cameras, W, H, args.cpu_frames)
+            result["cpu_baseline"] = cpu_baseline(ply, cameras, W, H, args.cpu_frames, args.epanechnikov)
 
     if world > 1:
         dist.barrier()
@@ -329,13 +332,14 @@ def ctypes_name(lib):
     return f"{buf.value.decode()} {cus.value} CUs"
 
 
-def cpu_baseline(ply, cameras, W, H, frames):
+def cpu_baseline(ply, cameras, W, H, frames, epanechnikov=False):
     """The CPU oracle (serial restatement of the reference pipeline, kind 'port') on the same workload:
     `frames` frames of the same scene/views on ONE host thread. Checker code: never part of the product."""
     import cudagaussianrenderer_amd as gs
     from oracle import gsref
 
     sh = gs.realign_spherical_harmonics(ply["sh"], ply["shCount"], ply["vertexCount"])
+    gsref.set_footprint(epanechnikov)
     t = time.perf_counter()
     done = 0
     per_stage = {}
