@@ -553,3 +553,34 @@ def test_epanechnikov_footprint(gs, gsref, tmp_path):
     assert not np.array_equal(img_g, img_e)
     vis = ell_g[:, 2] > 0
     assert np.allclose(ell_e[vis, 2:] / ell_g[vis, 2:], np.sqrt(7.0) / 3.0, rtol=1e-5)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_renderer_empty_scene_and_scene_swap(gs, graph):
+    """Zero splats render a cleared frame in every pipeline; replacing the scene (other size) on a live renderer, captured
+    or not, gives the same frame as a fresh renderer."""
+    w, h = 320, 200
+    cam = gs.camera_from_bounds([-4] * 3, [4] * 3, w, h)
+    empty = np.zeros((0, 4), np.float32)
+    for pipeline in (gs.PIPELINE_REFERENCE, gs.PIPELINE_TWO_LEVEL, gs.PIPELINE_BINNED):
+        r = gs.Renderer(w, h, pipeline=pipeline)
+        r.set_graph(graph)
+        r.set_scene(empty, empty, empty)
+        r.render(cam)
+        assert not r.read_image().any()
+        assert r.buffers().tileListSize == 0
+        images = []
+        for n, seed in ((5000, 3), (1200, 4), (9000, 5)):
+            pos, sr, col = _procedural(gs, n, seed=seed)
+            r.set_scene(pos, sr, col)
+            r.render(cam)
+            r.render(cam)
+            fresh = gs.Renderer(w, h, pipeline=pipeline)
+            fresh.set_scene(pos, sr, col)
+            fresh.render(cam)
+            assert np.array_equal(r.read_image(), fresh.read_image()), (pipeline, n)
+            fresh.close()
+        r.set_scene(empty, empty, empty)
+        r.render(cam)
+        assert not r.read_image().any()
+        r.close()
