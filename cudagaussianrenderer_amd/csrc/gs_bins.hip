@@ -73,12 +73,13 @@ struct BinArgs
     int64_t* totalHostMapped;
 };
 
-// Does the segment q + t e, t in [0,1], come within the unit circle?  (GaussianRender.cu:361-372)
-__device__ __forceinline__ bool edgeHitsUnitCircle(float qx, float qy, float ex, float ey, float qe, float invEE)
+// Squared distance of the origin to the segment q + t e, t in [0,1]: the edge comes within the unit circle when it is
+// below 1 (GaussianRender.cu:361-372).
+__device__ __forceinline__ float edgeDistanceSquared(float qx, float qy, float ex, float ey, float qe, float invEE)
 {
     const float t = __builtin_amdgcn_fmed3f(-qe * invEE, 0.0f, 1.0f); // saturate in one instruction (v_med3_f32)
     const float rx = fmaf(t, ex, qx), ry = fmaf(t, ey, qy);
-    return fmaf(rx, rx, ry * ry) < 1.0f;
+    return fmaf(rx, rx, ry * ry);
 }
 
 // One row of sorted splats -> per-tile hit counts (EMIT = false) or list entries (EMIT = true).
@@ -246,12 +247,13 @@ __global__ __launch_bounds__(kWave) void binRowsKernel(BinArgs a)
                     const float dx = minX - cm.x, dy = minY - cm.y;
                     const float q0x = fmaf(cm.z, dx, cm.w * dy), q0y = fmaf(mi.x, dx, mi.y * dy);
                     const float qcx = fmaf(0.5f, ux + vx, q0x), qcy = fmaf(0.5f, uy + vy, q0y);
-                    hit |= fmaf(qcx, qcx, qcy * qcy) < 1.0f;
+                    const float centre2 = fmaf(qcx, qcx, qcy * qcy);
                     const float q0u = fmaf(q0x, ux, q0y * uy), q0v = fmaf(q0x, vx, q0y * vy);
-                    hit |= edgeHitsUnitCircle(q0x, q0y, ux, uy, q0u, mi.z);
-                    hit |= edgeHitsUnitCircle(q0x + ux, q0y + uy, vx, vy, q0v + uv, mi.w);
-                    hit |= edgeHitsUnitCircle(q0x + vx, q0y + vy, ux, uy, q0u + uv, mi.z);
-                    hit |= edgeHitsUnitCircle(q0x, q0y, vx, vy, q0v, mi.w);
+                    const float bottom2 = edgeDistanceSquared(q0x, q0y, ux, uy, q0u, mi.z);
+                    const float right2 = edgeDistanceSquared(q0x + ux, q0y + uy, vx, vy, q0v + uv, mi.w);
+                    const float top2 = edgeDistanceSquared(q0x + vx, q0y + vy, ux, uy, q0u + uv, mi.z);
+                    const float left2 = edgeDistanceSquared(q0x, q0y, vx, vy, q0v, mi.w);
+                    hit |= fminf(fminf(fminf(bottom2, right2), fminf(top2, left2)), centre2) < 1.0f;
                 }
                 hitMask |= hit ? (1u << t) : 0u;
                 ++lx;
