@@ -1131,7 +1131,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
     {
         std::lock_guard<std::mutex> lock(g_captureMutex);
         // allocate everything the frame needs BEFORE capturing (no allocation may happen inside a capture)
-        ensureTileListScratch(r->scratch, n);
+        ensureTileListFastScratch(r->scratch, n);
         ensureRadixScratch(r->radix, n);
         ensureRadixScratch(r->radix, r->tileListCapacity);
         if (binned) ensureBinScratch(r->bins, n, (scr.rowEnd - scr.rowBegin) * scr.tilesX, binBatchesFor((scr.rowEnd - scr.rowBegin) * scr.tilesX));

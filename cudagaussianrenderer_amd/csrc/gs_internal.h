@@ -94,6 +94,10 @@ struct TileListScratch
     int64_t* totalHost = nullptr;   // pinned host mirror
     int64_t* totalHostMapped = nullptr; // device address of the same word (written directly by the renderer's scan)
     int32_t capacityWaves = 0;
+    // renderer's builder: hit masks of the count pass (one byte per lane and round, the first rounds of every group of
+    // 256 splats), replayed by the emit pass instead of repeating the overlap tests
+    uint8_t* hitMasks = nullptr;
+    int32_t capacityMaskGroups = 0;
     const int* countDevice = nullptr; // optional device-side splat count (renderer, culled list); nullptr = host count
 };
 void ensureTileListScratch(TileListScratch& s, int count);
@@ -105,6 +109,9 @@ void launchTileListCount(hipStream_t stream, int count, const Screen& scr, const
 void launchTileListEmit(hipStream_t stream, int count, const Screen& scr, const float2* clipXY, const float* clipZ,
                         const float4* screenEllipse, const TileListScratch& s, uint64_t* keys, int32_t* values, int capacity);
 
+// Sizes everything the renderer's builder needs for `count` splats (call before capturing a frame: no allocation may happen
+// inside a capture).
+void ensureTileListFastScratch(TileListScratch& s, int count);
 // Renderer-only builder (gs_tiles_fast.hip): splats visited in `order` (depth-sorted), key = tile index (2 or 4 bytes).
 void launchTileListFastCount(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
                              const float4* screenEllipse, TileListScratch& s);

@@ -304,6 +304,7 @@ void freeTileListScratch(TileListScratch& s)
 {
     if (s.waveCounts) (void) hipFree(s.waveCounts);
     if (s.waveOffsets) (void) hipFree(s.waveOffsets);
+    if (s.hitMasks) (void) hipFree(s.hitMasks);
     if (s.total) (void) hipFree(s.total);
     if (s.totalHost) (void) hipHostFree(s.totalHost);
     s = TileListScratch{};

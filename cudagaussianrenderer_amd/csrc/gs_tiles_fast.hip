@@ -7,9 +7,14 @@
 // (tile|depth) sort yields, at a fraction of the radix-sort traffic ("Two-level sort").
 //
 // Differences from the bit-exact builder in gs_tiles.hip:
+//   * a workgroup (4 waves) owns 256 consecutive sorted splats and walks ALL their work units together, 256 units per
+//     round: the nearest splats come first in the depth order and have by far the largest AABBs, so a wave that owned 64
+//     of them alone (an earlier version) set the kernel's duration;
 //   * work unit = (splat, 4 consecutive AABB tiles): one owner search and one LDS parameter fetch per
-//     four overlap tests; per-unit hit masks are compacted with four ballots, unit-major, so the emission
+//     four overlap tests; per-unit hit masks are compacted with ballots, unit-major, so the emission
 //     order is (sorted splat, local tile) with no atomics;
+//   * the count pass leaves each lane's four hit bits of its first 16 rounds in memory; the emit pass replays them instead
+//     of repeating the overlap tests (later rounds are tested again);
 //   * the ellipse/rectangle predicate is evaluated in the ellipse's unit-circle space with the affine map
 //     hoisted per splat (reciprocals instead of the reference's 14 divisions per test).  It is the same
 //     predicate -- centre-in-rect OR rect-centre-in-ellipse OR an edge within the unit circle
@@ -24,18 +29,20 @@ namespace
 {
 
 constexpr int kWavesPerBlock = 4;
+constexpr int kGroup = kWave * kWavesPerBlock; // splats (and lanes) per workgroup
 constexpr int kTilesPerUnit = 4;
+constexpr int kMaskRounds = 16;                // rounds of a workgroup whose hit masks are kept for the emit pass
 
-struct WaveStage
+struct GroupStage
 {
-    int excl[kWave];   // exclusive prefix of units
-    int area[kWave];   // AABB tiles
-    int origin[kWave]; // x0 | y0 << 16
-    int w[kWave];
-    float rcpW[kWave];
-    float4 centreM[kWave]; // cx, cy, m00, m01
-    float4 mInv[kWave];    // m10, m11, 1/|u|^2, 1/|v|^2
-    int splat[kWave];
+    int excl[kGroup];   // exclusive prefix of units
+    int area[kGroup];   // AABB tiles
+    int origin[kGroup]; // x0 | y0 << 16
+    int w[kGroup];
+    float rcpW[kGroup];
+    float4 centreM[kGroup]; // cx, cy, m00, m01
+    float4 mInv[kGroup];    // m10, m11, 1/|u|^2, 1/|v|^2
+    int splat[kGroup];
 };
 
 // Squared distance of the origin to the segment q + t e, t in [0,1]: the edge comes within the unit circle when it is
@@ -48,22 +55,21 @@ __device__ __forceinline__ float edgeDistanceSquared(float qx, float qy, float e
 }
 
 template <bool EMIT, typename TileKey>
-__global__ __launch_bounds__(kWave* kWavesPerBlock) void tileListFastKernel(int countHost, const int* __restrict__ countDevice, Screen scr, const uint32_t* __restrict__ order,
-                                                                             const float2* __restrict__ clipXY,
-                                                                             const float4* __restrict__ screenEllipse,
-                                                                             int32_t* __restrict__ waveCounts,
-                                                                             const int32_t* __restrict__ waveOffsets,
-                                                                             TileKey* __restrict__ tileKeys, int32_t* __restrict__ values,
-                                                                             int capacity)
+__global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, const int* __restrict__ countDevice, Screen scr, const uint32_t* __restrict__ order,
+                                                             const float2* __restrict__ clipXY, const float4* __restrict__ screenEllipse,
+                                                             int32_t* __restrict__ groupCounts, const int32_t* __restrict__ groupOffsets,
+                                                             TileKey* __restrict__ tileKeys, int32_t* __restrict__ values, int capacity,
+                                                             uint8_t* __restrict__ hitMasks)
 {
-    __shared__ WaveStage stage[kWavesPerBlock];
-    const int waveInBlock = threadIdx.x >> 6;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int waveGlobal = blockIdx.x * kWavesPerBlock + waveInBlock;
+    __shared__ GroupStage st;
+    __shared__ int waveTotals[kWavesPerBlock];
+    __shared__ int roundHits[2][kWavesPerBlock];
+    const int t = threadIdx.x;
+    const int wave = t >> 6, lane = t & (kWave - 1);
+    const int group = blockIdx.x;
     const int count = countDevice ? min(*countDevice, countHost) : countHost; // device-side count: culled splat list
-    if (waveGlobal * kWave >= count) return;
-    WaveStage& st = stage[waveInBlock];
-    const int sorted = waveGlobal * kWave + lane;
+    if (group * kGroup >= count) return; // whole workgroup
+    const int sorted = group * kGroup + t;
 
     int area = 0, x0 = 0, y0 = 0, w = 0, splat = 0;
     float cx = 0.f, cy = 0.f, m00 = 0.f, m01 = 0.f, m10 = 0.f, m11 = 0.f, invUU = 0.f, invVV = 0.f;
@@ -96,6 +102,7 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void tileListFastKernel(int 
     }
     const int units = (area + kTilesPerUnit - 1) / kTilesPerUnit;
 
+    // exclusive prefix of the units over the workgroup's 256 splats
     int incl = units;
 #pragma unroll
     for (int delta = 1; delta < kWave; delta <<= 1)
@@ -103,105 +110,140 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void tileListFastKernel(int 
         const int n = __shfl_up(incl, delta);
         if (lane >= delta) incl += n;
     }
-    const int totalUnits = __builtin_amdgcn_readfirstlane(__shfl(incl, kWave - 1));
+    if (lane == kWave - 1) waveTotals[wave] = incl;
+    __syncthreads();
+    int unitsBefore = 0, totalUnits = 0;
+#pragma unroll
+    for (int wv = 0; wv != kWavesPerBlock; ++wv)
+    {
+        const int v = waveTotals[wv];
+        unitsBefore += (wv < wave) ? v : 0;
+        totalUnits += v;
+    }
+    if (totalUnits == 0) // nothing on screen (e.g. the culled splats, which sort first): uniform exit
+    {
+        if (!EMIT && t == 0) groupCounts[group] = 0;
+        return;
+    }
 
-    st.excl[lane] = incl - units;
-    st.area[lane] = area;
-    st.origin[lane] = x0 | (y0 << 16);
-    st.w[lane] = max(w, 1);
-    st.rcpW[lane] = 1.0f / (float) max(w, 1);
-    st.centreM[lane] = make_float4(cx, cy, m00, m01);
-    st.mInv[lane] = make_float4(m10, m11, invUU, invVV);
-    st.splat[lane] = splat;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    st.excl[t] = unitsBefore + incl - units;
+    st.area[t] = area;
+    st.origin[t] = x0 | (y0 << 16);
+    st.w[t] = max(w, 1);
+    st.rcpW[t] = 1.0f / (float) max(w, 1);
+    st.centreM[t] = make_float4(cx, cy, m00, m01);
+    st.mInv[t] = make_float4(m10, m11, invUU, invVV);
+    st.splat[t] = splat;
+    __syncthreads();
 
-    int running = 0;
+    int running = 0; // COUNT: hits of this wave so far; EMIT: hits of the whole workgroup in the rounds before this one
     int outBase = 0;
-    if (EMIT) outBase = __builtin_amdgcn_readfirstlane(waveOffsets[waveGlobal]);
+    if (EMIT) outBase = groupOffsets[group];
     const unsigned long long lowerLanes = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
     const float sx = scr.tileClipSizeX, sy = scr.tileClipSizeY;
 
-    for (int base = 0; base < totalUnits; base += kWave)
+    for (int base = 0, round = 0; base < totalUnits; base += kGroup, ++round)
     {
-        const int unit = base + lane;
+        const int unit = base + t;
         const bool valid = unit < totalUnits;
         int k = 0;
 #pragma unroll
-        for (int step = kWave / 2; step != 0; step >>= 1)
+        for (int step = kGroup / 2; step != 0; step >>= 1)
         {
-            const int t = k + step;
-            if (st.excl[t] <= unit) k = t;
+            const int probe = k + step;
+            if (st.excl[probe] <= unit) k = probe;
         }
         const int local0 = (unit - st.excl[k]) * kTilesPerUnit;
         const int areaK = valid ? st.area[k] : 0;
         const int wk = st.w[k];
         const int origin = st.origin[k];
-        const float4 cm = st.centreM[k];
-        const float4 mi = st.mInv[k];
         // local0 / wk through the reciprocal: the quotient's fractional part is at least 0.5/wk away from an
         // integer, far above the float error for local0 < 2^16.
-        int ly = (int) (((float) local0 + 0.5f) * st.rcpW[k]);
-        int lx = local0 - ly * wk;
+        const int ly0 = (int) (((float) local0 + 0.5f) * st.rcpW[k]);
+        const int lx0 = local0 - ly0 * wk;
 
-        const float ux = cm.z * sx, uy = mi.x * sx; // u = M (sx, 0)
-        const float vx = cm.w * sy, vy = mi.y * sy; // v = M (0, sy)
-        const float uv = fmaf(ux, vx, uy * vy);
-        const float uu = fmaf(ux, ux, uy * uy), vv = fmaf(vx, vx, vy * vy);
-
+        // The count pass leaves the four hit bits of every lane for its first kMaskRounds rounds; the emit pass replays
+        // them instead of repeating the overlap tests (rounds past that are simply tested again). Uniform branches.
+        const bool recorded = round < kMaskRounds;
+        uint8_t* maskSlot = hitMasks + ((size_t) group * kMaskRounds + (size_t) (recorded ? round : 0)) * kGroup + t;
         unsigned hitMask = 0;
-        unsigned long long ballots[kTilesPerUnit];
-#pragma unroll
-        for (int t = 0; t != kTilesPerUnit; ++t)
+        if (EMIT && recorded) hitMask = *maskSlot;
+        else
         {
-            bool hit = false;
-            if (local0 + t < areaK)
+            const float4 cm = st.centreM[k];
+            const float4 mi = st.mInv[k];
+            const float ux = cm.z * sx, uy = mi.x * sx; // u = M (sx, 0)
+            const float vx = cm.w * sy, vy = mi.y * sy; // v = M (0, sy)
+            const float uv = fmaf(ux, vx, uy * vy);
+            int lx = lx0, ly = ly0;
+#pragma unroll
+            for (int e = 0; e != kTilesPerUnit; ++e)
             {
-                const int gx = (origin & 0xFFFF) + lx, gy = (origin >> 16) + ly;
-                const float minX = (float) gx * sx - 1.0f, minY = (float) gy * sy - 1.0f; // GaussianRender.cu:656-664
-                // centre inside the rectangle (strict, GaussianRender.cu:382-386)
-                hit = cm.x > minX && cm.x < minX + sx && cm.y > minY && cm.y < minY + sy;
-                // corner q0 = M (min - c); the other corners are q0 + u, q0 + v, q0 + u + v
-                const float dx = minX - cm.x, dy = minY - cm.y;
-                const float q0x = fmaf(cm.z, dx, cm.w * dy), q0y = fmaf(mi.x, dx, mi.y * dy);
-                const float qcx = fmaf(0.5f, ux + vx, q0x), qcy = fmaf(0.5f, uy + vy, q0y);
-                // rectangle centre inside the ellipse (:389), or an edge within the unit circle (:392-402): the smallest of
-                // the five squared distances decides (a NaN distance never wins a min, as it never passed the comparison)
-                const float centre2 = fmaf(qcx, qcx, qcy * qcy);
-                const float q0u = fmaf(q0x, ux, q0y * uy), q0v = fmaf(q0x, vx, q0y * vy);
-                const float bottom2 = edgeDistanceSquared(q0x, q0y, ux, uy, q0u, mi.z);
-                const float right2 = edgeDistanceSquared(q0x + ux, q0y + uy, vx, vy, q0v + uv, mi.w);
-                const float top2 = edgeDistanceSquared(q0x + vx, q0y + vy, ux, uy, q0u + uv, mi.z);
-                const float left2 = edgeDistanceSquared(q0x, q0y, vx, vy, q0v, mi.w);
-                hit |= fminf(fminf(fminf(bottom2, right2), fminf(top2, left2)), centre2) < 1.0f;
-                (void) uu;
-                (void) vv;
+                bool hit = false;
+                if (local0 + e < areaK)
+                {
+                    const int gx = (origin & 0xFFFF) + lx, gy = (origin >> 16) + ly;
+                    const float minX = (float) gx * sx - 1.0f, minY = (float) gy * sy - 1.0f; // GaussianRender.cu:656-664
+                    // centre inside the rectangle (strict, GaussianRender.cu:382-386)
+                    hit = cm.x > minX && cm.x < minX + sx && cm.y > minY && cm.y < minY + sy;
+                    // corner q0 = M (min - c); the other corners are q0 + u, q0 + v, q0 + u + v
+                    const float dx = minX - cm.x, dy = minY - cm.y;
+                    const float q0x = fmaf(cm.z, dx, cm.w * dy), q0y = fmaf(mi.x, dx, mi.y * dy);
+                    const float qcx = fmaf(0.5f, ux + vx, q0x), qcy = fmaf(0.5f, uy + vy, q0y);
+                    // rectangle centre inside the ellipse (:389), or an edge within the unit circle (:392-402): the smallest of
+                    // the five squared distances decides (a NaN distance never wins a min, as it never passed the comparison)
+                    const float centre2 = fmaf(qcx, qcx, qcy * qcy);
+                    const float q0u = fmaf(q0x, ux, q0y * uy), q0v = fmaf(q0x, vx, q0y * vy);
+                    const float bottom2 = edgeDistanceSquared(q0x, q0y, ux, uy, q0u, mi.z);
+                    const float right2 = edgeDistanceSquared(q0x + ux, q0y + uy, vx, vy, q0v + uv, mi.w);
+                    const float top2 = edgeDistanceSquared(q0x + vx, q0y + vy, ux, uy, q0u + uv, mi.z);
+                    const float left2 = edgeDistanceSquared(q0x, q0y, vx, vy, q0v, mi.w);
+                    hit |= fminf(fminf(fminf(bottom2, right2), fminf(top2, left2)), centre2) < 1.0f;
+                }
+                hitMask |= hit ? (1u << e) : 0u;
+                // next local tile
+                ++lx;
+                if (lx == wk)
+                {
+                    lx = 0;
+                    ++ly;
+                }
             }
-            ballots[t] = __ballot(hit);
-            hitMask |= hit ? (1u << t) : 0u;
-            // next local tile
-            ++lx;
-            if (lx == wk)
-            {
-                lx = 0;
-                ++ly;
-            }
+            if (!EMIT && recorded) *maskSlot = (uint8_t) hitMask;
+        }
+        unsigned long long ballots[kTilesPerUnit];
+        int waveHits = 0;
+#pragma unroll
+        for (int e = 0; e != kTilesPerUnit; ++e)
+        {
+            ballots[e] = __ballot((hitMask & (1u << e)) != 0u);
+            waveHits += __popcll(ballots[e]);
         }
 
-        if (EMIT)
+        if (!EMIT) running += waveHits;
+        else
         {
-            int pos = outBase + running;
+            // this round's hits of the waves before this one (order = unit order: round, wave, lane, tile)
+            if (lane == 0) roundHits[round & 1][wave] = waveHits;
+            __syncthreads(); // one barrier per round: the other half of roundHits belongs to the next round
+            int before = 0, all = 0;
 #pragma unroll
-            for (int t = 0; t != kTilesPerUnit; ++t) pos += __popcll(ballots[t] & lowerLanes);
+            for (int wv = 0; wv != kWavesPerBlock; ++wv)
+            {
+                const int v = roundHits[round & 1][wv];
+                before += (wv < wave) ? v : 0;
+                all += v;
+            }
+            int pos = outBase + running + before;
+#pragma unroll
+            for (int e = 0; e != kTilesPerUnit; ++e) pos += __popcll(ballots[e] & lowerLanes);
             // re-walk the unit's tiles to write the hits, unit-major
-            int wy = (int) (((float) local0 + 0.5f) * st.rcpW[k]);
-            int wx = local0 - wy * wk;
+            int wx = lx0, wy = ly0;
             const int splatK = st.splat[k];
 #pragma unroll
-            for (int t = 0; t != kTilesPerUnit; ++t)
+            for (int e = 0; e != kTilesPerUnit; ++e)
             {
-                if (hitMask & (1u << t))
+                if (hitMask & (1u << e))
                 {
                     if (pos < capacity)
                     {
@@ -218,12 +260,17 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void tileListFastKernel(int 
                     ++wy;
                 }
             }
+            running += all;
         }
-#pragma unroll
-        for (int t = 0; t != kTilesPerUnit; ++t) running += __popcll(ballots[t]);
     }
 
-    if (!EMIT && lane == 0) waveCounts[waveGlobal] = running;
+    if (!EMIT)
+    {
+        __syncthreads(); // waveTotals: everybody is past the prologue's reads
+        if (lane == 0) waveTotals[wave] = running;
+        __syncthreads();
+        if (t == 0) groupCounts[group] = waveTotals[0] + waveTotals[1] + waveTotals[2] + waveTotals[3];
+    }
 }
 
 // Exclusive scan of n ints by ONE workgroup (n = ceil(N/64)): 1024 lanes x 16 consecutive ints per pass (four 16-byte
@@ -231,14 +278,14 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void tileListFastKernel(int 
 // (one pass up to 16 Ki entries = 1 M splats).
 constexpr int kScanThreads = 1024;
 constexpr int kScanItems = 16;
-__global__ __launch_bounds__(kScanThreads) void scanFastKernel(int nHost, const int* __restrict__ countDevice, const int32_t* __restrict__ in, int32_t* __restrict__ out,
-                                                               int64_t* __restrict__ total, int64_t* __restrict__ totalHostMapped)
+__global__ __launch_bounds__(kScanThreads) void scanFastKernel(int nHost, const int* __restrict__ countDevice, int groupSize, const int32_t* __restrict__ in,
+                                                               int32_t* __restrict__ out, int64_t* __restrict__ total, int64_t* __restrict__ totalHostMapped)
 {
     __shared__ long long waveTotals[2][kScanThreads / kWave];
     const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
-    // nHost = waves the grid of the count pass was sized for; with a device-side splat count only the first
-    // ceil(count/64) of them wrote their totals.
-    const int n = countDevice ? min((*countDevice + kWave - 1) / kWave, nHost) : nHost;
+    // nHost = groups (of groupSize splats) the grid of the count pass was sized for; with a device-side splat count only
+    // the first ceil(count/groupSize) of them wrote their totals.
+    const int n = countDevice ? min((*countDevice + groupSize - 1) / groupSize, nHost) : nHost;
     long long carry = 0;
     int flip = 0;
     for (int base = 0; base < n; base += kScanThreads * kScanItems, flip ^= 1)
@@ -325,34 +372,46 @@ void launchEmit(hipStream_t stream, dim3 grid, dim3 block, int count, const Scre
                 const float4* screenEllipse, const TileListScratch& s, void* tileKeys, int32_t* values, int capacity)
 {
     hipLaunchKernelGGL((tileListFastKernel<true, TileKey>), grid, block, 0, stream, count, s.countDevice, scr, order, clipXY, screenEllipse,
-                       (int32_t*) nullptr, (const int32_t*) s.waveOffsets, (TileKey*) tileKeys, values, capacity);
+                       (int32_t*) nullptr, (const int32_t*) s.waveOffsets, (TileKey*) tileKeys, values, capacity, s.hitMasks);
 }
 
 } // namespace
 
 void launchScanInt32(hipStream_t stream, int n, const int32_t* in, int32_t* out, int64_t* total)
 {
-    hipLaunchKernelGGL(scanFastKernel, dim3(1), dim3(kScanThreads), 0, stream, n, (const int*) nullptr, in, out, total, (int64_t*) nullptr);
+    hipLaunchKernelGGL(scanFastKernel, dim3(1), dim3(kScanThreads), 0, stream, n, (const int*) nullptr, kWave, in, out, total, (int64_t*) nullptr);
+}
+
+void ensureTileListFastScratch(TileListScratch& s, int count)
+{
+    ensureTileListScratch(s, count);
+    const int groups = (count + kGroup - 1) / kGroup;
+    if (groups > s.capacityMaskGroups)
+    {
+        if (s.hitMasks) GS_CHECK(hipFree(s.hitMasks));
+        GS_CHECK(hipMalloc((void**) &s.hitMasks, (size_t) groups * kMaskRounds * kGroup));
+        s.capacityMaskGroups = groups;
+    }
 }
 
 void launchTileListFastCount(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
                              const float4* screenEllipse, TileListScratch& s)
 {
-    ensureTileListScratch(s, count);
-    const int waves = (count + kWave - 1) / kWave;
-    if (waves == 0)
+    ensureTileListFastScratch(s, count);
+    const int groups = (count + kGroup - 1) / kGroup;
+    if (groups == 0)
     {
         GS_CHECK(hipMemsetAsync(s.total, 0, sizeof(int64_t), stream));
     }
     else
     {
-        const dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
-        hipLaunchKernelGGL((tileListFastKernel<false, uint16_t>), grid, block, 0, stream, count, s.countDevice, scr, order, clipXY, screenEllipse,
-                           s.waveCounts, (const int32_t*) nullptr, (uint16_t*) nullptr, (int32_t*) nullptr, 0);
-        hipLaunchKernelGGL(scanFastKernel, dim3(1), dim3(kScanThreads), 0, stream, waves, s.countDevice, s.waveCounts, s.waveOffsets, s.total,
-                           s.totalHostMapped);
+        // per-group totals and their scan live in the first ceil(N/256) entries of the per-wave arrays
+        hipLaunchKernelGGL((tileListFastKernel<false, uint16_t>), dim3(groups), dim3(kGroup), 0, stream, count, s.countDevice, scr, order, clipXY,
+                           screenEllipse, s.waveCounts, (const int32_t*) nullptr, (uint16_t*) nullptr, (int32_t*) nullptr, 0, s.hitMasks);
+        hipLaunchKernelGGL(scanFastKernel, dim3(1), dim3(kScanThreads), 0, stream, groups, s.countDevice, kGroup, s.waveCounts, s.waveOffsets,
+                           s.total, s.totalHostMapped);
     }
-    if (waves == 0 || s.totalHostMapped == nullptr)
+    if (groups == 0 || s.totalHostMapped == nullptr)
         GS_CHECK(hipMemcpyAsync(s.totalHost, s.total, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
 }
 
@@ -360,9 +419,9 @@ void launchTileListFastEmit(hipStream_t stream, int count, const Screen& scr, co
                             const float4* screenEllipse, const TileListScratch& s, void* tileKeys, int tileKeyBytes, int32_t* values,
                             int capacity)
 {
-    const int waves = (count + kWave - 1) / kWave;
-    if (waves == 0 || capacity <= 0) return;
-    const dim3 grid((waves + kWavesPerBlock - 1) / kWavesPerBlock), block(kWave * kWavesPerBlock);
+    const int groups = (count + kGroup - 1) / kGroup;
+    if (groups == 0 || capacity <= 0) return;
+    const dim3 grid(groups), block(kGroup);
     if (tileKeyBytes == 2) launchEmit<uint16_t>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, tileKeys, values, capacity);
     else launchEmit<uint32_t>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, tileKeys, values, capacity);
 }
