@@ -359,6 +359,7 @@ struct GsRenderer
     int32_t splatCount = 0, shDegree = 0, shCount = 0;
     float *position = nullptr, *scaleAndRotation = nullptr, *color = nullptr, *sh = nullptr;
     float *clipXY = nullptr, *clipZ = nullptr, *conic = nullptr, *ellipse = nullptr;
+    float* tileRecord = nullptr; // 8 floats per splat: clip x, y, cos, sin, extent x, y, 0, 0 (one memory sector)
     uint32_t* depthKey[2] = {nullptr, nullptr};
     int32_t* order[2] = {nullptr, nullptr};
     // band cull (multi-GPU): per-splat coefficients in the [splat][shCount] layout for gathered SH evaluation,
@@ -444,7 +445,7 @@ void allocTileList(GsRenderer* r, int32_t capacity)
 }
 void freeScene(GsRenderer* r)
 {
-    float** bufs[] = {&r->position, &r->scaleAndRotation, &r->color, &r->sh, &r->clipXY, &r->clipZ, &r->conic, &r->ellipse};
+    float** bufs[] = {&r->position, &r->scaleAndRotation, &r->color, &r->sh, &r->clipXY, &r->clipZ, &r->conic, &r->ellipse, &r->tileRecord};
     for (float** b : bufs)
     {
         gs_device_free(*b);
@@ -578,6 +579,8 @@ extern "C" int gs_renderer_set_scene(GsRenderer* r, int32_t n, const float* posi
     r->ellipse = (float*) gs_device_alloc(f4);
     r->clipXY = (float*) gs_device_alloc(sizeof(float) * 2 * (size_t) n);
     r->clipZ = (float*) gs_device_alloc(sizeof(float) * (size_t) n);
+    r->tileRecord = getenv("GS_NO_TILE_RECORD") ? nullptr : (float*) gs_device_alloc(sizeof(float) * 8 * (size_t) n);
+    r->scratch.tileRecord = (const float4*) r->tileRecord;
     for (int i = 0; i != 2; ++i)
     {
         r->depthKey[i] = (uint32_t*) gs_device_alloc(sizeof(uint32_t) * (size_t) n);
@@ -788,14 +791,15 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         {
             launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation,
                                 (float2*) r->clipXY, r->clipZ, (float4*) r->ellipse, (float4*) r->conic, r->depthKey[0],
-                                (uint32_t*) r->order[0], nullptr, nullptr, nullptr, binned ? nullptr : r->tileRange, 2 * scr.totalTiles);
+                                (uint32_t*) r->order[0], nullptr, nullptr, nullptr, binned ? nullptr : r->tileRange, 2 * scr.totalTiles,
+                                (float4*) r->tileRecord);
         }
         else
         {
             // clip data for every splat + keep-mask, then an order-preserving compaction of (depth key, index)
             launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation,
                                 (float2*) r->clipXY, r->clipZ, (float4*) r->ellipse, (float4*) r->conic, nullptr, nullptr, r->bandMask,
-                                r->bandCounts, nullptr, binned ? nullptr : r->tileRange, 2 * scr.totalTiles);
+                                r->bandCounts, nullptr, binned ? nullptr : r->tileRange, 2 * scr.totalTiles, (float4*) r->tileRecord);
             launchScanInt32(g.stream, (n + kWave - 1) / kWave, r->bandCounts, r->bandOffsets, r->bandTotal);
             launchCompactBand(g.stream, n, r->bandMask, r->bandOffsets, r->clipZ, r->depthKey[0], (uint32_t*) r->order[0]);
             countDevice = (const int*) r->bandTotal; // low 32 bits of the little-endian int64 total
@@ -1022,12 +1026,12 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
     if (!cull)
         launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
                             (float2*) r->clipXY, r->clipZ, (float4*) r->ellipse, (float4*) r->conic, r->depthKey[0],
-                            (uint32_t*) r->order[0], nullptr, nullptr, r->paramsDevice, clearTable, clearEntries);
+                            (uint32_t*) r->order[0], nullptr, nullptr, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord);
     else
     {
         launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
                             (float2*) r->clipXY, r->clipZ, (float4*) r->ellipse, (float4*) r->conic, nullptr, nullptr, r->bandMask,
-                            r->bandCounts, r->paramsDevice, clearTable, clearEntries);
+                            r->bandCounts, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord);
         launchScanInt32(g.stream, (n + kWave - 1) / kWave, r->bandCounts, r->bandOffsets, r->bandTotal);
         launchCompactBand(g.stream, n, r->bandMask, r->bandOffsets, r->clipZ, r->depthKey[0], (uint32_t*) r->order[0]);
         countDevice = (const int*) r->bandTotal;

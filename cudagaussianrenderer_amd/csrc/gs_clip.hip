@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
                                                             uint32_t* __restrict__ depthKey, uint32_t* __restrict__ splatOrder,
                                                             unsigned long long* __restrict__ bandMask,
                                                             int32_t* __restrict__ bandWaveCounts, int32_t* __restrict__ rangeTable,
-                                                            int rangeEntries)
+                                                            int rangeEntries, float4* __restrict__ tileRecord)
 {
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
     // The renderer has this kernel reset the tile range table to -1 (Demo.cpp:403) on the side: it is the first kernel
@@ -163,6 +163,13 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
     clipXY[index] = make_float2(clipX, clipY);
     clipZ[index] = clipDepth;
     screenEllipse[index] = make_float4(cosA, sinA, extentX, extentY);
+    if (tileRecord != nullptr)
+    {
+        // the same six numbers once more as ONE 32-byte record: the tile-list passes fetch them through the depth order
+        // (random access), where two separate arrays cost two memory sectors per splat
+        tileRecord[2 * index] = make_float4(clipX, clipY, cosA, sinA);
+        tileRecord[2 * index + 1] = make_float4(extentX, extentY, 0.0f, 0.0f);
+    }
     conicOut[index] = make_float4(covC * invDet, -covB * invDet, covA * invDet, 0.0f);
 }
 
@@ -200,12 +207,12 @@ void launchCompactBand(hipStream_t stream, int count, const unsigned long long* 
 void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const ClipCamera& cam, const float4* position,
                          const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic,
                          uint32_t* depthKey, uint32_t* splatOrder, unsigned long long* bandMask, int32_t* bandWaveCounts,
-                         const FrameParams* paramsDevice, int32_t* rangeTableToClear, int rangeEntries)
+                         const FrameParams* paramsDevice, int32_t* rangeTableToClear, int rangeEntries, float4* tileRecord)
 {
     if (count <= 0) return;
     const dim3 grid((count + 255) / 256), block(256);
     hipLaunchKernelGGL(splatClipDataKernel, grid, block, 0, stream, count, scr, cam, paramsDevice, position, scaleAndRotation, clipXY, clipZ,
-                       screenEllipse, conic, depthKey, splatOrder, bandMask, bandWaveCounts, rangeTableToClear, rangeEntries);
+                       screenEllipse, conic, depthKey, splatOrder, bandMask, bandWaveCounts, rangeTableToClear, rangeEntries, tileRecord);
 }
 
 } // namespace gs

@@ -72,7 +72,7 @@ void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const
                          const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic,
                          uint32_t* depthKeyOrNull, uint32_t* splatOrderOrNull, unsigned long long* bandMaskOrNull = nullptr,
                          int32_t* bandWaveCountsOrNull = nullptr, const FrameParams* paramsDeviceOrNull = nullptr,
-                         int32_t* rangeTableToClearOrNull = nullptr, int rangeEntries = 0);
+                         int32_t* rangeTableToClearOrNull = nullptr, int rangeEntries = 0, float4* tileRecordOrNull = nullptr);
 // Band cull (multi-GPU): the clip kernel flags the splats whose tile AABB reaches this GPU's rows (one 64-bit mask and
 // one count per 64 splats); after an exclusive scan of the counts this writes the kept splats' depth keys and indices,
 // order preserved.
@@ -98,6 +98,9 @@ struct TileListScratch
     // 256 splats), replayed by the emit pass instead of repeating the overlap tests
     uint8_t* hitMasks = nullptr;
     int32_t capacityMaskGroups = 0;
+    // optional: (clip x, y, cos, sin | extent x, y, 0, 0) per splat as one 32-byte record (written by the clip kernel);
+    // when set, the renderer's builders read it instead of clipXY + screenEllipse
+    const float4* tileRecord = nullptr;
     const int* countDevice = nullptr; // optional device-side splat count (renderer, culled list); nullptr = host count
 };
 void ensureTileListScratch(TileListScratch& s, int count);

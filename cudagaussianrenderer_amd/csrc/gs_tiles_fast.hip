@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                                                              const float2* __restrict__ clipXY, const float4* __restrict__ screenEllipse,
                                                              int32_t* __restrict__ groupCounts, const int32_t* __restrict__ groupOffsets,
                                                              TileKey* __restrict__ tileKeys, int32_t* __restrict__ values, int capacity,
-                                                             uint8_t* __restrict__ hitMasks)
+                                                             uint8_t* __restrict__ hitMasks, const float4* __restrict__ tileRecord)
 {
     __shared__ GroupStage st;
     __shared__ int waveTotals[kWavesPerBlock];
@@ -76,8 +76,19 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
     if (sorted < count)
     {
         splat = (int) order[sorted];
-        const float2 c = clipXY[splat];
-        const float4 se = screenEllipse[splat]; // cos, sin, extent.x, extent.y
+        float2 c;
+        float4 se; // cos, sin, extent.x, extent.y
+        if (tileRecord != nullptr)
+        {
+            const float4 ra = tileRecord[2 * splat], rb = tileRecord[2 * splat + 1]; // one 32-byte sector
+            c = make_float2(ra.x, ra.y);
+            se = make_float4(ra.z, ra.w, rb.x, rb.y);
+        }
+        else
+        {
+            c = clipXY[splat];
+            se = screenEllipse[splat];
+        }
         cx = c.x;
         cy = c.y;
         // AABB in tiles, exactly as gs_tiles.hip / GaussianRender.cu:408-436,537-551 (shared with the band cull).
@@ -372,7 +383,7 @@ void launchEmit(hipStream_t stream, dim3 grid, dim3 block, int count, const Scre
                 const float4* screenEllipse, const TileListScratch& s, void* tileKeys, int32_t* values, int capacity)
 {
     hipLaunchKernelGGL((tileListFastKernel<true, TileKey>), grid, block, 0, stream, count, s.countDevice, scr, order, clipXY, screenEllipse,
-                       (int32_t*) nullptr, (const int32_t*) s.waveOffsets, (TileKey*) tileKeys, values, capacity, s.hitMasks);
+                       (int32_t*) nullptr, (const int32_t*) s.waveOffsets, (TileKey*) tileKeys, values, capacity, s.hitMasks, s.tileRecord);
 }
 
 } // namespace
@@ -407,7 +418,7 @@ void launchTileListFastCount(hipStream_t stream, int count, const Screen& scr, c
     {
         // per-group totals and their scan live in the first ceil(N/256) entries of the per-wave arrays
         hipLaunchKernelGGL((tileListFastKernel<false, uint16_t>), dim3(groups), dim3(kGroup), 0, stream, count, s.countDevice, scr, order, clipXY,
-                           screenEllipse, s.waveCounts, (const int32_t*) nullptr, (uint16_t*) nullptr, (int32_t*) nullptr, 0, s.hitMasks);
+                           screenEllipse, s.waveCounts, (const int32_t*) nullptr, (uint16_t*) nullptr, (int32_t*) nullptr, 0, s.hitMasks, s.tileRecord);
         hipLaunchKernelGGL(scanFastKernel, dim3(1), dim3(kScanThreads), 0, stream, groups, s.countDevice, kGroup, s.waveCounts, s.waveOffsets,
                            s.total, s.totalHostMapped);
     }
