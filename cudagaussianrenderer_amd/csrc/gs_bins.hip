@@ -61,6 +61,7 @@ struct BinArgs
     const uint32_t* order;
     const float2* clipXY;
     const float4* screenEllipse;
+    const float4* tileRecord; // optional: (x, y, cos, sin | extent x, y, 0, 0), one sector per splat
     uint16_t* counts;     // [rows][stride]
     uint32_t* offsets;    // [rows][stride]
     int32_t* rowFlags;    // [rows] 1 = the row has hits
@@ -140,11 +141,20 @@ __global__ __launch_bounds__(kWave) void binRowsKernel(BinArgs a)
     int splatNext2 = loadIndex(1);
     float2 cNext = make_float2(0.f, 0.f);
     float4 seNext = make_float4(1.f, 0.f, 0.f, 0.f);
-    if (splatNext >= 0)
-    {
-        cNext = a.clipXY[splatNext];
-        seNext = a.screenEllipse[splatNext];
-    }
+    auto loadSplat = [&](int splat, float2& c, float4& se) {
+        if (a.tileRecord != nullptr)
+        {
+            const float4 ra = a.tileRecord[2 * splat], rb = a.tileRecord[2 * splat + 1];
+            c = make_float2(ra.x, ra.y);
+            se = make_float4(ra.z, ra.w, rb.x, rb.y);
+        }
+        else
+        {
+            c = a.clipXY[splat];
+            se = a.screenEllipse[splat];
+        }
+    };
+    if (splatNext >= 0) loadSplat(splatNext, cNext, seNext);
 
     for (int batch = 0; batch < a.batches; ++batch)
     {
@@ -155,11 +165,7 @@ __global__ __launch_bounds__(kWave) void binRowsKernel(BinArgs a)
         const float4 se = seNext; // cos, sin, extent.x, extent.y
         splatNext = splatNext2;
         splatNext2 = loadIndex(batch + 2);
-        if (splatNext >= 0)
-        {
-            cNext = a.clipXY[splatNext];
-            seNext = a.screenEllipse[splatNext];
-        }
+        if (splatNext >= 0) loadSplat(splatNext, cNext, seNext);
 
         int area = 0, x0 = 0, y0 = 0, w = 0, splat = 0;
         float cx = 0.f, cy = 0.f, m00 = 0.f, m01 = 0.f, m10 = 0.f, m11 = 0.f, invUU = 0.f, invVV = 0.f;
@@ -473,7 +479,9 @@ void ensureBinScratch(BinScratch& s, int splats, int bandTiles, int batches)
     const int stride = (std::max(bandTiles, 1) + kColumnPad - 1) / kColumnPad * kColumnPad;
     if (rows > s.rowsCapacity || stride > s.strideCapacity)
     {
+        const float4* record = s.tileRecord; // not owned: survives the reallocation
         freeBinScratch(s);
+        s.tileRecord = record;
         s.rowsCapacity = rows;
         s.strideCapacity = stride;
         GS_CHECK(hipMalloc((void**) &s.counts, sizeof(uint16_t) * (size_t) rows * stride));
@@ -523,6 +531,7 @@ BinArgs makeArgs(int count, const int* countDevice, const Screen& scr, const uin
     a.order = order;
     a.clipXY = clipXY;
     a.screenEllipse = screenEllipse;
+    a.tileRecord = s.tileRecord;
     a.counts = s.counts;
     a.offsets = s.offsets;
     a.rowFlags = s.rowFlags;

@@ -581,6 +581,7 @@ extern "C" int gs_renderer_set_scene(GsRenderer* r, int32_t n, const float* posi
     r->clipZ = (float*) gs_device_alloc(sizeof(float) * (size_t) n);
     r->tileRecord = getenv("GS_NO_TILE_RECORD") ? nullptr : (float*) gs_device_alloc(sizeof(float) * 8 * (size_t) n);
     r->scratch.tileRecord = (const float4*) r->tileRecord;
+    r->bins.tileRecord = (const float4*) r->tileRecord;
     for (int i = 0; i != 2; ++i)
     {
         r->depthKey[i] = (uint32_t*) gs_device_alloc(sizeof(uint32_t) * (size_t) n);
@@ -630,6 +631,13 @@ extern "C" void gs_renderer_buffers(GsRenderer* r, GsRendererBuffers* out)
     out->positionClipSpaceZ = r->clipZ;
     out->conic = r->conic;
     out->screenEllipse = r->ellipse;
+    if (r->tileRecord != nullptr && r->pipeline != GS_PIPELINE_REFERENCE && r->splatCount > 0)
+    {
+        // the two-level / binned frames keep the ellipses only inside the packed tile records: unpack them for the caller
+        StreamScope scope(r);
+        launchUnpackEllipse(g.stream, r->splatCount, (const float4*) r->tileRecord, (float4*) r->ellipse);
+        GS_CHECK(hipStreamSynchronize(g.stream));
+    }
     out->tileRange = r->tileRange;
     out->keys = r->keys[r->selector];
     out->values = r->values[r->selector];
@@ -790,7 +798,7 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         if (!cull)
         {
             launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation,
-                                (float2*) r->clipXY, r->clipZ, (float4*) r->ellipse, (float4*) r->conic, r->depthKey[0],
+                                (float2*) r->clipXY, r->clipZ, r->tileRecord ? nullptr : (float4*) r->ellipse, (float4*) r->conic, r->depthKey[0],
                                 (uint32_t*) r->order[0], nullptr, nullptr, nullptr, binned ? nullptr : r->tileRange, 2 * scr.totalTiles,
                                 (float4*) r->tileRecord);
         }
@@ -798,7 +806,7 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         {
             // clip data for every splat + keep-mask, then an order-preserving compaction of (depth key, index)
             launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation,
-                                (float2*) r->clipXY, r->clipZ, (float4*) r->ellipse, (float4*) r->conic, nullptr, nullptr, r->bandMask,
+                                (float2*) r->clipXY, r->clipZ, r->tileRecord ? nullptr : (float4*) r->ellipse, (float4*) r->conic, nullptr, nullptr, r->bandMask,
                                 r->bandCounts, nullptr, binned ? nullptr : r->tileRange, 2 * scr.totalTiles, (float4*) r->tileRecord);
             launchScanInt32(g.stream, (n + kWave - 1) / kWave, r->bandCounts, r->bandOffsets, r->bandTotal);
             launchCompactBand(g.stream, n, r->bandMask, r->bandOffsets, r->clipZ, r->depthKey[0], (uint32_t*) r->order[0]);
@@ -1025,12 +1033,12 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
     const int* countDevice = nullptr;
     if (!cull)
         launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
-                            (float2*) r->clipXY, r->clipZ, (float4*) r->ellipse, (float4*) r->conic, r->depthKey[0],
+                            (float2*) r->clipXY, r->clipZ, r->tileRecord ? nullptr : (float4*) r->ellipse, (float4*) r->conic, r->depthKey[0],
                             (uint32_t*) r->order[0], nullptr, nullptr, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord);
     else
     {
         launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
-                            (float2*) r->clipXY, r->clipZ, (float4*) r->ellipse, (float4*) r->conic, nullptr, nullptr, r->bandMask,
+                            (float2*) r->clipXY, r->clipZ, r->tileRecord ? nullptr : (float4*) r->ellipse, (float4*) r->conic, nullptr, nullptr, r->bandMask,
                             r->bandCounts, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord);
         launchScanInt32(g.stream, (n + kWave - 1) / kWave, r->bandCounts, r->bandOffsets, r->bandTotal);
         launchCompactBand(g.stream, n, r->bandMask, r->bandOffsets, r->clipZ, r->depthKey[0], (uint32_t*) r->order[0]);

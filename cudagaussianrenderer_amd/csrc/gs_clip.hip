@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
     }
     clipXY[index] = make_float2(clipX, clipY);
     clipZ[index] = clipDepth;
-    screenEllipse[index] = make_float4(cosA, sinA, extentX, extentY);
+    if (screenEllipse != nullptr) screenEllipse[index] = make_float4(cosA, sinA, extentX, extentY);
     if (tileRecord != nullptr)
     {
         // the same six numbers once more as ONE 32-byte record: the tile-list passes fetch them through the depth order
@@ -194,7 +194,21 @@ __global__ __launch_bounds__(256) void compactBandKernel(int count, const unsign
     }
 }
 
+// screenEllipse of every splat from the packed tile records (for callers that ask for the renderer's buffers)
+__global__ __launch_bounds__(256) void unpackEllipseKernel(int count, const float4* __restrict__ tileRecord, float4* __restrict__ screenEllipse)
+{
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= count) return;
+    const float4 ra = tileRecord[2 * index], rb = tileRecord[2 * index + 1];
+    screenEllipse[index] = make_float4(ra.z, ra.w, rb.x, rb.y);
+}
+
 } // namespace
+
+void launchUnpackEllipse(hipStream_t stream, int count, const float4* tileRecord, float4* screenEllipse)
+{
+    if (count > 0) hipLaunchKernelGGL(unpackEllipseKernel, dim3((count + 255) / 256), dim3(256), 0, stream, count, tileRecord, screenEllipse);
+}
 
 void launchCompactBand(hipStream_t stream, int count, const unsigned long long* bandMask, const int32_t* waveOffsets, const float* clipZ,
                        uint32_t* depthKey, uint32_t* splatOrder)

@@ -73,6 +73,8 @@ void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const
                          uint32_t* depthKeyOrNull, uint32_t* splatOrderOrNull, unsigned long long* bandMaskOrNull = nullptr,
                          int32_t* bandWaveCountsOrNull = nullptr, const FrameParams* paramsDeviceOrNull = nullptr,
                          int32_t* rangeTableToClearOrNull = nullptr, int rangeEntries = 0, float4* tileRecordOrNull = nullptr);
+// screenEllipse[i] = (cos, sin, extent x, extent y) from the 32-byte tile records the clip kernel can write instead.
+void launchUnpackEllipse(hipStream_t stream, int count, const float4* tileRecord, float4* screenEllipse);
 // Band cull (multi-GPU): the clip kernel flags the splats whose tile AABB reaches this GPU's rows (one 64-bit mask and
 // one count per 64 splats); after an exclusive scan of the counts this writes the kept splats' depth keys and indices,
 // order preserved.
@@ -172,6 +174,7 @@ struct BinScratch
     int32_t* tileTotals = nullptr; // [stride]
     uint32_t* tileStart = nullptr; // [stride]
     int rowsCapacity = 0, strideCapacity = 0;
+    const float4* tileRecord = nullptr; // optional packed (centre, ellipse) records: read instead of clipXY + screenEllipse
 };
 bool binsSupported(const Screen& scr);
 int binBatchesFor(int bandTiles);
