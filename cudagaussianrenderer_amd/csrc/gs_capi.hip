@@ -344,6 +344,8 @@ struct FrameState
     bool blocking = false;
     bool listDone = false; // reference pipeline: the sorted list and ranges were produced in begin()
     int orderSel = 0, tileKeyBytes = 2;
+    bool lazyColours = false; // colours are evaluated by the raster kernel, entry by entry (no SH pass this frame)
+    float cameraPosition[3] = {0.f, 0.f, 0.f};
     bool binned = false; // binned pipeline: lists and ranges are on their way, only the pair total is awaited
     int binBatches = 0;
     const int* binCountDevice = nullptr;
@@ -359,6 +361,8 @@ struct GsRenderer
     int32_t splatCount = 0, shDegree = 0, shCount = 0;
     float *position = nullptr, *scaleAndRotation = nullptr, *color = nullptr, *sh = nullptr;
     float *clipXY = nullptr, *clipZ = nullptr, *conic = nullptr, *ellipse = nullptr;
+    bool colourStale = false;   // the last frame evaluated its colours inside the raster kernel: r->color is not current
+    float lastCameraPosition[3] = {0.f, 0.f, 0.f};
     float* tileRecord = nullptr; // 8 floats per splat: clip x, y, cos, sin, extent x, y, 0, 0 (one memory sector)
     uint32_t* depthKey[2] = {nullptr, nullptr};
     int32_t* order[2] = {nullptr, nullptr};
@@ -378,7 +382,7 @@ struct GsRenderer
     hipGraphExec_t graphExec = nullptr;
     FrameParams* paramsDevice = nullptr;
     FrameParams* paramsHost = nullptr; // pinned
-    int graphCapacity = 0, graphSplats = 0, graphRowBegin = -1, graphRowEnd = -1, graphCull = -1, graphBinned = -1, graphFootprint = -1, graphSelector = 0, graphKeyBytes = 2;
+    int graphCapacity = 0, graphSplats = 0, graphRowBegin = -1, graphRowEnd = -1, graphCull = -1, graphBinned = -1, graphFootprint = -1, graphLazy = -1, graphSelector = 0, graphKeyBytes = 2;
     bool pending = false; // begin() issued, finish() not yet
     FrameState frame;
     unsigned long long* bandMask = nullptr;
@@ -423,6 +427,27 @@ struct StreamScope
 
 namespace
 {
+// Colours on demand: the two-level / binned frames skip the SH pass and let the raster kernel evaluate the colour of every
+// list entry it stages ("Colours on demand").  Needs the [splat][shCount] coefficient copy and a degree whose
+// rows are 16-byte multiples; GS_NO_LAZY_SH=1 keeps the reference's stage order.
+bool useLazyColours(const GsRenderer* r)
+{
+    static const bool disabled = getenv("GS_NO_LAZY_SH") != nullptr;
+    return !disabled && r->shDegree != 0 && r->shPerSplat != nullptr && r->pipeline != GS_PIPELINE_REFERENCE &&
+           rasterCanEvaluateColours(r->shDegree, r->shCount);
+}
+RasterColourSource colourSource(const GsRenderer* r, const float* cameraPosition, const FrameParams* paramsDevice)
+{
+    RasterColourSource src;
+    src.degree = r->shDegree;
+    src.shCount = r->shCount;
+    src.position = (const float4*) r->position;
+    src.shPerSplat = r->shPerSplat;
+    if (cameraPosition) src.cameraPosition = make_float3(cameraPosition[0], cameraPosition[1], cameraPosition[2]);
+    src.params = paramsDevice;
+    return src;
+}
+
 void freeTileList(GsRenderer* r)
 {
     for (int i = 0; i != 2; ++i)
@@ -638,6 +663,15 @@ extern "C" void gs_renderer_buffers(GsRenderer* r, GsRendererBuffers* out)
         launchUnpackEllipse(g.stream, r->splatCount, (const float4*) r->tileRecord, (float4*) r->ellipse);
         GS_CHECK(hipStreamSynchronize(g.stream));
     }
+    if (r->colourStale && r->shDegree != 0 && r->splatCount > 0)
+    {
+        // the last frame evaluated colours inside the raster kernel: run the SH pass once for the caller
+        StreamScope scope(r);
+        launchSphericalHarmonics(g.stream, r->splatCount, r->shDegree, r->shCount, (const float4*) r->position, r->sh,
+                                 make_float3(r->lastCameraPosition[0], r->lastCameraPosition[1], r->lastCameraPosition[2]), (float4*) r->color);
+        GS_CHECK(hipStreamSynchronize(g.stream));
+        r->colourStale = false;
+    }
     out->tileRange = r->tileRange;
     out->keys = r->keys[r->selector];
     out->values = r->values[r->selector];
@@ -744,7 +778,9 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
     const bool cull = twoLevel && n > 0 && cfg.sortBackend == GS_SORT_BACKEND_NATIVE &&
                       (r->bandCull == GS_BAND_CULL_ON || (r->bandCull == GS_BAND_CULL_AUTO && strictBand));
 
-    if (r->shDegree != 0 && !cull) // Demo.cpp:432
+    f.lazyColours = useLazyColours(r);
+    for (int k = 0; k != 3; ++k) f.cameraPosition[k] = r->lastCameraPosition[k] = camera->position[k];
+    if (r->shDegree != 0 && !cull && !f.lazyColours) // Demo.cpp:432
     {
         gs_evaluate_spherical_harmonics(stageTimers[0], n);
         if (blocking) st.msSphericalHarmonics = gs_timer_elapsed_ms(stageTimers[0]);
@@ -814,7 +850,7 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         }
         gs_timer_stop(stageTimers[1]);
         if (blocking) st.msClipData = gs_timer_elapsed_ms(stageTimers[1]);
-        if (cull && r->shDegree != 0)
+        if (cull && r->shDegree != 0 && !f.lazyColours)
         {
             // SH colour of the kept splats only (list = the compacted, still index-ordered order[0])
             gs_timer_start(stageTimers[0]);
@@ -980,8 +1016,11 @@ extern "C" int gs_renderer_finish(GsRenderer* r, GsFrameStats* stats)
         GS_CHECK(hipMemsetAsync(consumed, 0, sizeof(unsigned long long), g.stream));
     }
     gs_timer_start(stageTimers[5]);
+    const RasterColourSource lazySource = colourSource(r, f.cameraPosition, nullptr);
     launchRasterize(g.stream, scr, r->tileRange, r->values[r->selector], (const float2*) r->clipXY, (const float4*) r->conic,
-                    (const float4*) r->color, (uchar4*) r->backBuffer, consumed, r->pipeline != GS_PIPELINE_REFERENCE);
+                    (const float4*) r->color, (uchar4*) r->backBuffer, consumed, r->pipeline != GS_PIPELINE_REFERENCE,
+                    f.lazyColours ? &lazySource : nullptr);
+    r->colourStale = f.lazyColours;
     gs_timer_stop(stageTimers[5]);
     if (hipGetLastError() != hipSuccess) printf("kernel error renderDepthBuffer\n");
     if (blocking) st.msRasterize = gs_timer_elapsed_ms(stageTimers[5]);
@@ -1015,8 +1054,10 @@ namespace
 // are serialised process-wide (they happen once per renderer; replays take no lock).
 std::mutex g_captureMutex;
 
-int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool binned)
+int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool binned, bool lazy)
 {
+    const RasterColourSource lazySource = colourSource(r, nullptr, r->paramsDevice);
+    const RasterColourSource* lazyColours = lazy ? &lazySource : nullptr;
     const int n = r->splatCount;
     const int tileKeyBytes = scr.totalTiles > 65536 ? 4 : 2;
     const int tBits = tileBits(scr.totalTiles);
@@ -1027,7 +1068,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
     // the range table is reset to -1 by the clip kernel (not a memset node: see gs_ranges.hip); binned frames write every range
     int32_t* clearTable = binned ? nullptr : r->tileRange;
     const int clearEntries = 2 * scr.totalTiles;
-    if (r->shDegree != 0 && !cull)
+    if (r->shDegree != 0 && !cull && !lazy)
         launchSphericalHarmonics(g.stream, n, r->shDegree, r->shCount, (const float4*) r->position, r->sh, unused, (float4*) r->color,
                                  r->paramsDevice);
     const int* countDevice = nullptr;
@@ -1043,7 +1084,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
         launchScanInt32(g.stream, (n + kWave - 1) / kWave, r->bandCounts, r->bandOffsets, r->bandTotal);
         launchCompactBand(g.stream, n, r->bandMask, r->bandOffsets, r->clipZ, r->depthKey[0], (uint32_t*) r->order[0]);
         countDevice = (const int*) r->bandTotal;
-        if (r->shDegree != 0)
+        if (r->shDegree != 0 && !lazy)
             launchSphericalHarmonicsGather(g.stream, n, countDevice, r->shDegree, r->shCount, r->order[0], (const float4*) r->position,
                                            r->shPerSplat, unused, (float4*) r->color, r->paramsDevice);
     }
@@ -1062,7 +1103,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
         r->radix.countDevice = nullptr;
         r->scratch.countDevice = nullptr;
         launchRasterize(g.stream, scr, r->tileRange, r->values[0], (const float2*) r->clipXY, (const float4*) r->conic,
-                        (const float4*) r->color, (uchar4*) r->backBuffer, nullptr, true);
+                        (const float4*) r->color, (uchar4*) r->backBuffer, nullptr, true, lazyColours);
         r->graphSelector = 0;
         r->graphKeyBytes = 0;
         return 0;
@@ -1079,7 +1120,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
     r->radix.countDevice = nullptr;
     launchTileRanges(g.stream, r->tileListCapacity, tileKeyBytes, r->keys[sel], r->tileRange, pairCount);
     launchRasterize(g.stream, scr, r->tileRange, r->values[sel], (const float2*) r->clipXY, (const float4*) r->conic,
-                    (const float4*) r->color, (uchar4*) r->backBuffer, nullptr, true);
+                    (const float4*) r->color, (uchar4*) r->backBuffer, nullptr, true, lazyColours);
     r->graphSelector = sel;
     r->graphKeyBytes = tileKeyBytes;
     return 0;
@@ -1125,9 +1166,10 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
     }
     const bool binned = r->pipeline == GS_PIPELINE_BINNED && binsSupported(scr) && radixSortSupported(4, n) &&
                         r->scratch.totalHostMapped != nullptr;
+    const bool lazy = useLazyColours(r);
     if (r->graphValid && (r->graphCapacity != r->tileListCapacity || r->graphSplats != n || r->graphRowBegin != scr.rowBegin ||
                           r->graphRowEnd != scr.rowEnd || r->graphCull != (int) cull || r->graphBinned != (int) binned ||
-                          r->graphFootprint != scr.epanechnikov))
+                          r->graphFootprint != scr.epanechnikov || r->graphLazy != (int) lazy))
         r->graphValid = false;
 
     FrameParams fp{};
@@ -1136,7 +1178,8 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
     fp.camera.fovCotY = camera->fovCotangent[1];
     fp.camera.depthScale = camera->depthScaleBias[0];
     fp.camera.depthBias = camera->depthScaleBias[1];
-    for (int k = 0; k != 3; ++k) fp.cameraPosition[k] = camera->position[k];
+    for (int k = 0; k != 3; ++k) fp.cameraPosition[k] = r->lastCameraPosition[k] = camera->position[k];
+    r->colourStale = lazy;
     *r->paramsHost = fp;
 
     if (!r->graphValid)
@@ -1152,7 +1195,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
         r->graphExec = nullptr;
         r->graph = nullptr;
         GS_CHECK(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
-        enqueueCapturableFrame(r, scr, cull, binned);
+        enqueueCapturableFrame(r, scr, cull, binned, lazy);
         GS_CHECK(hipStreamEndCapture(g.stream, &r->graph));
         GS_CHECK(hipGraphInstantiate(&r->graphExec, r->graph, nullptr, nullptr, 0));
         r->graphValid = true;
@@ -1163,6 +1206,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
         r->graphCull = (int) cull;
         r->graphBinned = (int) binned;
         r->graphFootprint = scr.epanechnikov;
+        r->graphLazy = (int) lazy;
     }
     GS_CHECK(hipGraphLaunch(r->graphExec, g.stream));
     r->selector = r->graphSelector;

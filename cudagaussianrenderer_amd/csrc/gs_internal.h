@@ -187,9 +187,21 @@ void launchBinEmit(hipStream_t stream, int count, const int* countDevice, const 
                    const float4* screenEllipse, const BinScratch& s, int batches, int32_t* values, int capacity, int32_t* tileRange,
                    int64_t* total, int64_t* totalHostMapped);
 
+// Where the raster kernel gets an entry's colour when it is NOT read from the colour buffer: the splat's coefficient row
+// ([splat][shCount] layout) and position, evaluated when the entry is staged (gs_raster.hip, template parameter SH).
+struct RasterColourSource
+{
+    int degree = 0, shCount = 0;
+    const float4* position = nullptr;
+    const float* shPerSplat = nullptr;
+    float3 cameraPosition = {0.f, 0.f, 0.f};
+    const FrameParams* params = nullptr; // captured frames: the camera position lives on the device
+};
+bool rasterCanEvaluateColours(int degree, int shCount);
 void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileRange, const int32_t* values,
                      const float2* clipXY, const float4* conic, const float4* color, uchar4* backBuffer,
-                     unsigned long long* consumedPairsOrNull, bool clearEmptyTiles = false);
+                     unsigned long long* consumedPairsOrNull, bool clearEmptyTiles = false,
+                     const RasterColourSource* lazyColoursOrNull = nullptr);
 
 int sortEndBit(int totalTiles);
 int tileBits(int totalTiles);

@@ -21,6 +21,7 @@
 // The kernel is VALU/transcendental-bound, not HBM-bound: per consumed entry it reads 44 B but does
 // ~11 VALU ops for each of 256 pixels ("Raster roofline").
 #include "gs_internal.h"
+#include "gs_sh_eval.h"
 
 namespace gs
 {
@@ -61,14 +62,19 @@ __device__ __forceinline__ uint32_t quantize8(float c)
 }
 
 // EPAN: the reference's EPANECHNIKOV_KERNEL option (GaussianRender.cu:977-981): density 1 - q/7 instead of exp(-q/2).
-template <int PPL, bool EPAN>
+// SH: 0 = colours come from the colour buffer (the reference's stage order: evaluateSphericalHarmonics ran before);
+//     1..4 = the colour of a list entry is evaluated HERE from the splat's coefficient row when the entry is staged, with the
+//     routine the SH kernels use (same bits).  A frame consumes the lists' front only -- at C3 88 K distinct splats of 1 M --
+//     so evaluating on demand replaces the 224 MB pass over all coefficients by ~4 memory sectors per staged entry.
+template <int PPL, bool EPAN, int SH>
 __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, int firstTile, int numTiles,
                                                                   const int32_t* __restrict__ tileRange,
                                                                   const int32_t* __restrict__ values,
                                                                   const float2* __restrict__ clipXY,
                                                                   const float4* __restrict__ conic,
                                                                   const float4* __restrict__ color, uchar4* __restrict__ backBuffer,
-                                                                  unsigned long long* __restrict__ consumedPairs, int clearEmptyTiles)
+                                                                  unsigned long long* __restrict__ consumedPairs, int clearEmptyTiles,
+                                                                  RasterColourSource lazy)
 {
     constexpr int THREADS = 256 / PPL;
     constexpr int GROUPS_X = kTileSize / PPL;
@@ -127,13 +133,31 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
     // Register-staged gather of one list entry per lane.
     float2 gCentre = make_float2(0.f, 0.f);
     float4 gConic = make_float4(0.f, 0.f, 0.f, 0.f), gColor = make_float4(0.f, 0.f, 0.f, 0.f);
+    static_assert(SH == 0 || (3 * (SH + 1) * (SH + 1)) % 4 == 0, "on-demand colours need 16-byte coefficient rows (degrees 1 and 3)");
+    constexpr int kRowQuads = SH ? 3 * (SH + 1) * (SH + 1) / 4 : 1;
+    float4 gRow[kRowQuads]; // SH: the splat's coefficient row, in flight while the previous batch is blended
+    float3 lazyCam = make_float3(0.f, 0.f, 0.f);
+    if constexpr (SH != 0)
+    {
+        lazyCam = lazy.params ? make_float3(lazy.params->cameraPosition[0], lazy.params->cameraPosition[1], lazy.params->cameraPosition[2])
+                              : lazy.cameraPosition;
+#pragma unroll
+        for (int m = 0; m != kRowQuads; ++m) gRow[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     auto gather = [&](int base) {
         if (t < kBatch && base + t < count)
         {
             const int src = values[first + base + t]; // GaussianRender.cu:957-960
             gCentre = clipXY[src];
             gConic = conic[src];
-            gColor = color[src];
+            if constexpr (SH == 0) gColor = color[src];
+            else
+            {
+                gColor = lazy.position[src]; // xyz + opacity; becomes the colour when the entry is staged
+                const float4* row = reinterpret_cast<const float4*>(lazy.shPerSplat + (size_t) src * lazy.shCount);
+#pragma unroll
+                for (int m = 0; m != kRowQuads; ++m) gRow[m] = row[m];
+            }
         }
     };
     gather(0);
@@ -150,6 +174,10 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
             // Entries past the end of the list are staged as all-zero records: opacity 0 makes them exact no-ops
             // (w = T*0, C += c*0, T -= T*0), so the blend loop can always run whole groups of four.
             const bool live = t < n;
+            if constexpr (SH != 0)
+            {
+                if (live) gColor = sheval::colourFromQuads<SH>(gRow, gColor, lazyCam);
+            }
             sA[t] = live ? make_float4(gCentre.x, gCentre.y, gConic.x * kHalfLog2e, gConic.y * (2.0f * kHalfLog2e))
                          : make_float4(0.f, 0.f, 0.f, 0.f);
             sB[t] = live ? make_float4(gConic.z * kHalfLog2e, gColor.x, gColor.y, gColor.z) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -253,32 +281,54 @@ int rasterPixelsPerLane() { return g_rasterPixelsPerLane; }
 
 void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileRange, const int32_t* values,
                      const float2* clipXY, const float4* conic, const float4* color, uchar4* backBuffer,
-                     unsigned long long* consumedPairsOrNull, bool clearEmptyTiles)
+                     unsigned long long* consumedPairsOrNull, bool clearEmptyTiles, const RasterColourSource* lazyColours)
 {
     const int firstTile = scr.rowBegin * scr.tilesX;
     const int numTiles = (scr.rowEnd - scr.rowBegin) * scr.tilesX;
     if (numTiles <= 0) return;
-#define GS_LAUNCH_RASTER(PPL, EPAN)                                                                                                   \
-    hipLaunchKernelGGL((rasterizeTilesKernel<PPL, EPAN>), dim3(numTiles), dim3(256 / PPL), 0, stream, scr, firstTile, numTiles, tileRange, \
-                       values, clipXY, conic, color, backBuffer, consumedPairsOrNull, clearEmptyTiles ? 1 : 0)
+    RasterColourSource lazy{};
+    if (lazyColours != nullptr) lazy = *lazyColours;
+#define GS_LAUNCH_RASTER(PPL, EPAN, SH)                                                                                                  \
+    hipLaunchKernelGGL((rasterizeTilesKernel<PPL, EPAN, SH>), dim3(numTiles), dim3(256 / PPL), 0, stream, scr, firstTile, numTiles,       \
+                       tileRange, values, clipXY, conic, color, backBuffer, consumedPairsOrNull, clearEmptyTiles ? 1 : 0, lazy)
     const bool epan = scr.epanechnikov != 0;
+    // on-demand colours: two pixels per lane only (the default shape), degrees whose coefficient rows are 16-byte multiples
+    if (lazyColours != nullptr && g_rasterPixelsPerLane == 2 && rasterCanEvaluateColours(lazy.degree, lazy.shCount))
+    {
+        if (lazy.degree == 1)
+        {
+            if (epan) GS_LAUNCH_RASTER(2, true, 1);
+            else GS_LAUNCH_RASTER(2, false, 1);
+        }
+        else
+        {
+            if (epan) GS_LAUNCH_RASTER(2, true, 3);
+            else GS_LAUNCH_RASTER(2, false, 3);
+        }
+        return;
+    }
     switch (g_rasterPixelsPerLane)
     {
     case 1:
-        if (epan) GS_LAUNCH_RASTER(1, true);
-        else GS_LAUNCH_RASTER(1, false);
+        if (epan) GS_LAUNCH_RASTER(1, true, 0);
+        else GS_LAUNCH_RASTER(1, false, 0);
         break;
     case 2:
-        if (epan) GS_LAUNCH_RASTER(2, true);
-        else GS_LAUNCH_RASTER(2, false);
+        if (epan) GS_LAUNCH_RASTER(2, true, 0);
+        else GS_LAUNCH_RASTER(2, false, 0);
         break;
     case 4:
     default:
-        if (epan) GS_LAUNCH_RASTER(4, true);
-        else GS_LAUNCH_RASTER(4, false);
+        if (epan) GS_LAUNCH_RASTER(4, true, 0);
+        else GS_LAUNCH_RASTER(4, false, 0);
         break;
     }
 #undef GS_LAUNCH_RASTER
+}
+
+bool rasterCanEvaluateColours(int degree, int shCount)
+{
+    return (degree == 1 || degree == 3) && shCount == 3 * (degree + 1) * (degree + 1) && g_rasterPixelsPerLane == 2;
 }
 
 } // namespace gs

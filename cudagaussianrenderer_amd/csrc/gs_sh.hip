@@ -13,7 +13,7 @@
 //   * sphericalHarmonicsGatherKernel -- only the splats of a device-side index list (the band-culled list of a
 //     multi-GPU rank), coefficients in the plain [splat][S] layout parsePly produces, 192 contiguous bytes per splat
 //     at degree 3, so a gathered splat costs three 64-byte lines instead of 48 scattered 4-byte accesses.
-#include "gs_internal.h"
+#include "gs_sh_eval.h"
 
 // Both kernels must produce the same bits for the same splat: no compiler-chosen contraction, only the explicit fmaf.
 #pragma clang fp contract(off)
@@ -27,142 +27,7 @@ constexpr int kGroup = GS_SH_GROUP_SIZE;  // 256 splats per coefficient block
 constexpr int kSplatsPerLane = 4;         // 256 / 64
 constexpr int kWavesPerBlock = 4;         // 256 threads
 
-template <typename V>
-struct Rgb
-{
-    V r, g, b; // V = float4: one float per owned splat; V = float: one splat
-};
-using Rgb4 = Rgb<float4>;
-
-__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
-__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c)
-{
-    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
-}
-__device__ __forceinline__ float4 splat4(float v) { return make_float4(v, v, v, v); }
-__device__ __forceinline__ float4 scale4(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
-__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
-__device__ __forceinline__ float4 affine4(float m, float4 a, float c) // m*a + c
-{
-    return make_float4(fmaf(m, a.x, c), fmaf(m, a.y, c), fmaf(m, a.z, c), fmaf(m, a.w, c));
-}
-// The same operations on ONE splat per lane (the gather kernel): component for component the arithmetic above.
-__device__ __forceinline__ float mul4(float a, float b) { return a * b; }
-__device__ __forceinline__ float fma4(float a, float b, float c) { return fmaf(a, b, c); }
-__device__ __forceinline__ float scale4(float s, float a) { return s * a; }
-__device__ __forceinline__ float add4(float a, float b) { return a + b; }
-__device__ __forceinline__ float sub4(float a, float b) { return a - b; }
-__device__ __forceinline__ float affine4(float m, float a, float c) { return fmaf(m, a, c); }
-template <typename V>
-__device__ __forceinline__ V broadcast(float v);
-template <>
-__device__ __forceinline__ float4 broadcast<float4>(float v) { return splat4(v); }
-template <>
-__device__ __forceinline__ float broadcast<float>(float v) { return v; }
-
-// Accumulate basis rows [FIRST, FIRST+COUNT) into rgb. load(j, c) returns coefficient j of channel c for the
-// lane's four splats.
-template <int FIRST, int COUNT, typename V, typename Load>
-__device__ __forceinline__ void accumulateLevel(const Load& load, const V (&basis)[COUNT], Rgb<V>& rgb)
-{
-    V cr[COUNT], cg[COUNT], cb[COUNT];
-#pragma unroll
-    for (int j = 0; j != COUNT; ++j)
-    {
-        cr[j] = load(FIRST + j, 0);
-        cg[j] = load(FIRST + j, 1);
-        cb[j] = load(FIRST + j, 2);
-    }
-#pragma unroll
-    for (int j = 0; j != COUNT; ++j)
-    {
-        rgb.r = fma4(basis[j], cr[j], rgb.r);
-        rgb.g = fma4(basis[j], cg[j], rgb.g);
-        rgb.b = fma4(basis[j], cb[j], rgb.b);
-    }
-}
-
-// Real SH basis of GaussianRender.cu:62-155 (generated by sh_gen.py; all-positive level-1 signs, level-2 m=0
-// written in xx+yy), evaluated for four splats at once and contracted with their coefficients.
-template <int L, typename V, typename Load>
-__device__ __forceinline__ Rgb<V> evaluateBasis(V x, V y, V z, const Load& load);
-
-template <int L, typename Load>
-__device__ __forceinline__ Rgb4 evaluateFour(const float4 (&p)[4], float3 cam, const Load& load)
-{
-    // rayDir = normalize(camera - splat)  (GaussianRender.cu:171), component-wise over the four splats.
-    const float4 dx = make_float4(cam.x - p[0].x, cam.x - p[1].x, cam.x - p[2].x, cam.x - p[3].x);
-    const float4 dy = make_float4(cam.y - p[0].y, cam.y - p[1].y, cam.y - p[2].y, cam.y - p[3].y);
-    const float4 dz = make_float4(cam.z - p[0].z, cam.z - p[1].z, cam.z - p[2].z, cam.z - p[3].z);
-    const float4 len2 = fma4(dz, dz, fma4(dy, dy, mul4(dx, dx)));
-    const float4 inv = make_float4(1.0f / sqrtf(len2.x), 1.0f / sqrtf(len2.y), 1.0f / sqrtf(len2.z), 1.0f / sqrtf(len2.w));
-    return evaluateBasis<L, float4>(mul4(dx, inv), mul4(dy, inv), mul4(dz, inv), load);
-}
-
-template <int L, typename Load>
-__device__ __forceinline__ Rgb<float> evaluateOne(float4 p, float3 cam, const Load& load)
-{
-    const float dx = cam.x - p.x, dy = cam.y - p.y, dz = cam.z - p.z;
-    const float len2 = fma4(dz, dz, fma4(dy, dy, mul4(dx, dx)));
-    const float inv = 1.0f / sqrtf(len2);
-    return evaluateBasis<L, float>(mul4(dx, inv), mul4(dy, inv), mul4(dz, inv), load);
-}
-
-template <int L, typename V, typename Load>
-__device__ __forceinline__ Rgb<V> evaluateBasis(V x, V y, V z, const Load& load)
-{
-    Rgb<V> rgb{broadcast<V>(0.0f), broadcast<V>(0.0f), broadcast<V>(0.0f)};
-    {
-        const V b0[1] = {broadcast<V>(0.282094792f)};
-        accumulateLevel<0, 1>(load, b0, rgb);
-    }
-    if constexpr (L > 0)
-    {
-        const V b1[3] = {scale4(0.488602512f, y), scale4(0.488602512f, z), scale4(0.488602512f, x)};
-        accumulateLevel<1, 3>(load, b1, rgb);
-    }
-    if constexpr (L > 1)
-    {
-        const V xx = mul4(x, x), yy = mul4(y, y);
-        const V s = add4(xx, yy), d = sub4(xx, yy);
-        const V xy = mul4(x, y), yz = mul4(y, z), xz = mul4(x, z);
-        {
-            const V b2[5] = {scale4(1.09254843f, xy), scale4(1.09254843f, yz), affine4(-0.946174696f, s, 0.630783131f),
-                                  scale4(1.09254843f, xz), scale4(0.546274215f, d)};
-            accumulateLevel<4, 5>(load, b2, rgb);
-        }
-        if constexpr (L > 2)
-        {
-            const V t3 = sub4(scale4(3.0f, xx), yy); // 3xx - yy
-            const V u3 = sub4(xx, scale4(3.0f, yy)); // xx - 3yy
-            {
-                const V b3[7] = {scale4(0.59004359f, mul4(y, t3)),
-                                      scale4(2.89061144f, mul4(xy, z)),
-                                      mul4(scale4(3.6563664f, y), affine4(-0.625f, s, 0.5f)),
-                                      mul4(scale4(0.373176333f, z), affine4(-5.0f, s, 2.0f)),
-                                      mul4(scale4(0.457045799f, x), affine4(-5.0f, s, 4.0f)),
-                                      scale4(1.44530572f, mul4(z, d)),
-                                      scale4(0.59004359f, mul4(x, u3))};
-                accumulateLevel<9, 7>(load, b3, rgb);
-            }
-            if constexpr (L > 3)
-            {
-                const V b4[9] = {scale4(2.50334294f, mul4(xy, d)),
-                                      scale4(1.77013077f, mul4(yz, t3)),
-                                      mul4(scale4(1.26156626f, xy), affine4(-5.25f, s, 4.5f)),
-                                      mul4(scale4(1.78412412f, yz), affine4(-2.625f, s, 1.5f)),
-                                      fma4(s, affine4(3.70249414f, s, -4.23142188f), broadcast<V>(0.846284375f)),
-                                      mul4(scale4(0.669046544f, xz), affine4(-7.0f, s, 4.0f)),
-                                      mul4(scale4(-0.473087348f, d), affine4(7.0f, s, -6.0f)),
-                                      scale4(1.77013077f, mul4(xz, u3)),
-                                      scale4(0.625835735f, fma4(d, d, scale4(-4.0f, mul4(xx, yy))))};
-                accumulateLevel<16, 9>(load, b4, rgb);
-            }
-        }
-    }
-    return rgb;
-}
+using namespace sheval;
 
 __device__ __forceinline__ float4 finalColour(const Rgb4& rgb, int i, float alpha)
 {
@@ -210,34 +75,13 @@ __global__ __launch_bounds__(256) void sphericalHarmonicsGatherKernel(int countH
                                                                        const float* __restrict__ shPerSplat, float3 camArg,
                                                                        float4* __restrict__ color, const FrameParams* __restrict__ params)
 {
-    constexpr int kCoefficients = 3 * (L + 1) * (L + 1);
     const float3 cam = params ? make_float3(params->cameraPosition[0], params->cameraPosition[1], params->cameraPosition[2]) : camArg;
     const int count = countDevice ? min(*countDevice, countHost) : countHost;
     const int entry = blockIdx.x * blockDim.x + threadIdx.x;
     if (entry >= count) return;
     const int idx = indices[entry];
     const float* row = shPerSplat + (size_t) idx * shCount;
-    const float4 p = position[idx];
-    Rgb<float> rgb;
-    if (kCoefficients % 4 == 0 && shCount % 4 == 0) // 16-byte aligned rows (uniform branch)
-    {
-        float4 q[(kCoefficients + 3) / 4];
-#pragma unroll
-        for (int m = 0; m != kCoefficients / 4; ++m) q[m] = reinterpret_cast<const float4*>(row)[m];
-        const auto load = [&q](int j, int c) {
-            const int k = 3 * j + c;
-            const float4 v = q[k >> 2];
-            return (k & 3) == 0 ? v.x : (k & 3) == 1 ? v.y : (k & 3) == 2 ? v.z : v.w;
-        };
-        rgb = evaluateOne<L>(p, cam, load);
-    }
-    else
-    {
-        const auto load = [row](int j, int c) { return row[3 * j + c]; };
-        rgb = evaluateOne<L>(p, cam, load);
-    }
-    // clamp(result + 0.5, 0, 1) (GaussianRender.cu:154); alpha = position.w (:168,180)
-    color[idx] = make_float4(__saturatef(rgb.r + 0.5f), __saturatef(rgb.g + 0.5f), __saturatef(rgb.b + 0.5f), p.w);
+    color[idx] = colourFromRow<L>(row, shCount, position[idx], cam);
 }
 
 } // namespace

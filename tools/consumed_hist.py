@@ -26,3 +26,12 @@ print("pairs", st.tileListSize, "consumed", st.consumedPairs, "sum", int(c.sum()
 print("percentiles of consumed entries per tile:", {p: int(np.percentile(buf, p)) for p in (50, 90, 99, 99.9, 100)})
 print("tiles by consumed:", {k: int((buf == k).sum()) for k in (0, 32, 64, 96, 128)}, "more", int((buf > 128).sum()))
 print("row sums (consumed) per tile row:", c.sum(1).tolist())
+# distinct splats among the consumed entries (how many SH evaluations the frame really needs)
+xy, zz, ell, con = gsref.evaluate_splat_clip_data(ply["position"], ply["scaleAndRotation"], cams[0], W, H)
+k, v, total = gsref.build_tile_list(xy, zz, ell, W, H)
+k, v = gsref.sort_tile_list(k, v, gsref.sort_end_bit(W, H))
+rng = gsref.evaluate_tile_ranges(k, tx * ty).reshape(-1, 2)
+used = np.zeros(n, bool)
+for t in np.nonzero(buf)[0]:
+    used[v[rng[t, 0]: rng[t, 0] + buf[t]]] = True
+print("splats in some list:", int(np.unique(v).size), "consumed entries:", int(buf.sum()), "distinct consumed splats:", int(used.sum()))
