@@ -29,16 +29,20 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def algorithmic_bytes(n, p, pc, tiles, nonempty_tiles, w, h, sh_degree, sort_passes):
-    """bytes each stage must move per frame, independent of implementation."""
-    sh = n * (16 + 12 * (sh_degree + 1) ** 2 + 16) if sh_degree else 0
+def algorithmic_bytes(n, p, pc, tiles, nonempty_tiles, w, h, sh_degree, sort_passes, colours_on_demand=False):
+    """bytes each stage must move per frame, independent of implementation.
+    With colours on demand there is no SH pass; a consumed list entry then costs the raster its position (16 B) and
+    coefficient row (12 (L+1)^2 B) instead of the 16-byte colour: 44 - 16 + 16 + 12 (L+1)^2 bytes per consumed pair."""
+    sh_row = 12 * (sh_degree + 1) ** 2
+    sh = n * (16 + sh_row + 16) if sh_degree and not colours_on_demand else 0
+    per_pair = 44 + (sh_row if colours_on_demand else 0)
     return {
         "sh": sh,
         "clip": 76 * n,
         "tile_list": 28 * n + 12 * p,
         "sort": p * (8 + 24 * sort_passes),
         "ranges": 8 * p + 8 * nonempty_tiles,
-        "raster": 44 * pc + 8 * tiles + 4 * w * h,
+        "raster": per_pair * pc + 8 * tiles + 4 * w * h,
     }
 
 
@@ -252,7 +256,10 @@ def main():
         end_bit = gs.sort_end_bit(W, H)
         sort_passes = (end_bit + 7) // 8
         band_h = pixel_rows(band)[1] - pixel_rows(band)[0]
-        ab = algorithmic_bytes(N, p_mean, pc_mean, band_tiles, band_tiles, W, band_h, args.sh_degree, sort_passes)
+        on_demand = renderer.colours_on_demand()
+        if on_demand:
+            stage_ms["sh"] = 0.0  # no SH pass: the colours are evaluated inside the raster kernel (the timer pair is empty)
+        ab = algorithmic_bytes(N, p_mean, pc_mean, band_tiles, band_tiles, W, band_h, args.sh_degree, sort_passes, on_demand)
         stages = {k: {"ms": round(stage_ms[k], 4), "algorithmic_MB": round(ab[k] / 1e6, 2),
                       "GBps": round(ab[k] / 1e9 / (stage_ms[k] / 1e3), 1) if stage_ms[k] > 0 else None} for k in stage_ms}
         dominant = max(stage_ms, key=lambda k: stage_ms[k])
@@ -277,14 +284,14 @@ def main():
                             f"{views}-view orbit, tile-row bands over {world} GPU(s)",
                 "splats": N, "width": W, "height": H, "sh_degree": args.sh_degree, "views": views,
                 "pairs_per_frame": round(p_mean), "consumed_pairs_per_frame": round(pc_mean),
-                "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": name, "frames_in_flight": depth, "captured_frames": not args.no_graph, "footprint": "epanechnikov" if args.epanechnikov else "gaussian", "pipeline": {1: "two_level", 2: "binned"}.get(args.pipeline, str(args.pipeline)), "tile_row_bands": [list(b) for b in bands],
+                "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": name, "frames_in_flight": depth, "captured_frames": not args.no_graph, "colours": "on demand in the raster kernel (no SH pass)" if renderer.colours_on_demand() else "SH pass over all splats", "footprint": "epanechnikov" if args.epanechnikov else "gaussian", "pipeline": {1: "two_level", 2: "binned"}.get(args.pipeline, str(args.pipeline)), "tile_row_bands": [list(b) for b in bands],
                 "opacity_mean_raw": args.opacity_mean, "ingest_s": round(t_ingest, 2),
                 "gathered_frame_equals_single_gpu_frame": gathered_ok,
             },
             "roofline": {
                 "kernel": "rasterizeTilesKernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), **pmc_traffic(world, N, W, H, args),
-                "note": "VALU/exp-bound kernel (44 B vs ~2800 VALU lane-ops per consumed pair); see DESIGN.md",
+                "note": "VALU/exp-bound kernel (44 B, or 236 B with on-demand SH colours, vs ~2800 VALU lane-ops per consumed pair); see DESIGN.md",
                 "dominant_stage": dominant,
                 "dominant_stage_GBps": stages[dominant]["GBps"],
                 "dominant_stage_frac": round((stages[dominant]["GBps"] or 0.0) / HBM_PEAK_GBS, 4),

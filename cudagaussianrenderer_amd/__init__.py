@@ -290,6 +290,10 @@ class Renderer:
             raise RuntimeError(f"gs_renderer_render failed ({rc})")
         return st
 
+    def colours_on_demand(self):
+        """True when this renderer's frames evaluate SH colours inside the raster kernel (no SH pass)."""
+        return bool(lib().gs_renderer_colours_on_demand(self.handle))
+
     def set_graph(self, enabled=True):
         """Replay plain frames (render(camera) without timers/stats) as one captured hipGraph launch."""
         lib().gs_renderer_set_graph(self.handle, 1 if enabled else 0)

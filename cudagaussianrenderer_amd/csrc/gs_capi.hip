@@ -580,6 +580,8 @@ extern "C" void gs_renderer_set_pipeline(GsRenderer* r, int pipeline)
     r->graphValid = false;
 }
 
+extern "C" int gs_renderer_colours_on_demand(const GsRenderer* r) { return useLazyColours(r) ? 1 : 0; }
+
 extern "C" void gs_renderer_set_band_cull(GsRenderer* r, int mode)
 {
     r->bandCull = (mode == GS_BAND_CULL_ON || mode == GS_BAND_CULL_OFF) ? mode : GS_BAND_CULL_AUTO;

@@ -230,6 +230,12 @@ void gs_renderer_set_band_cull(GsRenderer* r, int mode);
  * (GsRendererBuffers.keys is meaningless, keyBytes 0).  Bands of more than 8192 tiles fall back to TWO_LEVEL. */
 #define GS_PIPELINE_BINNED 2
 void gs_renderer_set_pipeline(GsRenderer* r, int pipeline);
+/* 1 when the renderer's frames evaluate SH colours on demand inside the raster kernel instead of running the SH pass over all
+ * splats (two-level / binned pipelines, SH degree 1 or 3, two pixels per lane; GS_NO_LAZY_SH=1 in the environment turns it
+ * off).  Same colours bit for bit (one shared routine); a frame consumes only the front of its lists -- 88 K distinct splats
+ * of 1 M at BASELINE.json configs[2] -- so most of the reference's evaluateSphericalHarmonics work is never needed.
+ * GsRendererBuffers.color is brought up to date (one SH pass) when gs_renderer_buffers is called. */
+int gs_renderer_colours_on_demand(const GsRenderer* r);
 /* Upload a scene from host arrays (Demo.cpp:314-331). sh is [N][shCount] un-aligned (as parsePly
  * returns it) and is realigned here (Demo.cpp:291-296); may be NULL at degree 0. */
 int gs_renderer_set_scene(GsRenderer* r, int32_t splatCount, const float* position4, const float* scaleAndRotation4,

@@ -584,3 +584,34 @@ def test_renderer_empty_scene_and_scene_swap(gs, graph):
         r.render(cam)
         assert not r.read_image().any()
         r.close()
+
+
+@pytest.mark.parametrize("degree", [1, 2, 3])
+def test_colours_on_demand_equal_the_sh_pass(gs, tmp_path, degree):
+    """Two-level / binned frames of a degree-1 or degree-3 scene evaluate colours inside the raster kernel instead of running
+    the SH pass; the reference-shaped pipeline always runs it.  Same bytes in the image, and the colour buffer handed out by
+    gs_renderer_buffers equals the SH pass's.  (Degree 2: rows of 27 floats -- the SH pass stays, everything still agrees.)"""
+    w, h = 800, 448
+    ply = _ply_scene(gs, tmp_path, 40000, degree, log_scale_mean=-3.1)
+    n = ply["vertexCount"]
+    scene = (ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+    from cudagaussianrenderer_amd import scenes
+
+    cams = [gs.camera_from_pose(p, q, w, h) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 3)]
+    results = {}
+    for pipeline in (gs.PIPELINE_REFERENCE, gs.PIPELINE_TWO_LEVEL, gs.PIPELINE_BINNED):
+        r = gs.Renderer(w, h, pipeline=pipeline)
+        r.set_scene(*scene)
+        assert r.colours_on_demand() == (pipeline != gs.PIPELINE_REFERENCE and degree in (1, 3))
+        frames = []
+        for cam in cams:
+            r.render(cam)
+            image = r.read_image()
+            colour = r.download(r.buffers().color, 4 * n, np.float32)
+            frames.append((image, colour))
+        r.close()
+        results[pipeline] = frames
+    for pipeline in (gs.PIPELINE_TWO_LEVEL, gs.PIPELINE_BINNED):
+        for (img_ref, col_ref), (img, col) in zip(results[gs.PIPELINE_REFERENCE], results[pipeline]):
+            assert np.array_equal(img, img_ref)
+            assert np.array_equal(col, col_ref)
