@@ -25,5 +25,11 @@ json.dump({"kernel": "rasterizeTilesKernel<2>",
            "correction": "MI355X_MICROARCH.md: FETCH_SIZE reports 1/2 of the bytes of WIDE coalesced streaming reads; the raster's reads are 4-B list entries plus 8/16-B gathers (uncalibrated width), so the raw value is reported as the lower bound and 2x as the upper bound",
            "traffic_bytes_per_launch_low": (f + w) * 1024, "traffic_bytes_per_launch_high": (2 * f + w) * 1024},
           open(f"profiles/{tag}_pmc_raster.json", "w"), indent=1)
+# the bench line of this very run read the PREVIOUS counter file: attach the counters collected with it
+bench = json.load(open(f"profiles/{tag}_bench_c3.json"))
+bench["roofline"]["traffic"] = round((f + w) * 1024)
+bench["roofline"]["traffic_source"] = (f"profiles/{tag}_pmc_raster.json (FETCH_SIZE raw + WRITE_SIZE; gather widths are uncalibrated, "
+                                       f"upper bound {round((2 * f + w) * 1024)} with the wide-read 2x correction)")
+json.dump(bench, open(f"profiles/{tag}_bench_c3.json", "w"))
 PY
 ls profiles
