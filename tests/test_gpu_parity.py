@@ -509,11 +509,12 @@ def test_captured_frames_overflow_then_recover(gs):
     r.close()
 
 
-def test_epanechnikov_footprint(gs, gsref, tmp_path):
+@pytest.mark.parametrize("degree", [2, 3])
+def test_epanechnikov_footprint(gs, gsref, tmp_path, degree):
     """The reference's EPANECHNIKOV_KERNEL option as a run-time switch: clip extents, pair lists and image against the
     oracle run with the same switch; the renderer's pipelines agree with each other; captured frames re-capture."""
     w, h = 640, 360
-    ply = _ply_scene(gs, tmp_path, 30000, 2, log_scale_mean=-3.0)
+    ply = _ply_scene(gs, tmp_path, 30000, degree, log_scale_mean=-3.0)  # degree 3: colours evaluated inside the raster kernel
     n = ply["vertexCount"]
     cam = gs.camera_from_bounds(ply["boundsMin"], ply["boundsMax"], w, h)
     scene = (ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
