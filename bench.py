@@ -6,8 +6,9 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A "step" is one frame: clears -> SH colour -> clip data -> tile list -> radix sort -> tile ranges -> raster
-(src/Demo.cpp:394-479), inputs resident in HBM, plus -- for N > 1 -- the framebuffer gather.  With N GPUs
+A "step" is one frame of the renderer: clip data -> depth sort of the splats -> tile list -> tile sort -> tile ranges ->
+raster with the SH colours evaluated on demand (the work of src/Demo.cpp:394-479; same image bytes as the reference's stage
+order, tests/test_gpu_parity.py), inputs resident in HBM, plus -- for N > 1 -- the framebuffer gather.  With N GPUs
 the screen is split into N bands of tile rows (splat buffers replicated); every rank renders its band and
 rank 0 receives the bands over RCCL directly into its framebuffer.  Total work is fixed -> "strong" scaling.
 
@@ -133,8 +134,7 @@ def main():
         bands = scenes.balanced_tile_row_bands(row_cost, world)
     band = bands[rank]
     # D frames in flight: D renderers, each with its own stream, intermediates and framebuffer (the scene is uploaded
-    # to each; 0.43 GB apiece). One host thread drives them: begin(frame i+D-1) is issued before finish(frame i), so
-    # the latency-bound stages of one frame overlap the others' and the pair-count readback never idles the GPU.
+    # to each; 0.6 GB apiece), so the latency-bound stages of one frame overlap the others' kernels.
     depth = max(1, args.inflight)
     streams = [torch.cuda.Stream(device) for _ in range(depth)]
     renderers, framebuffers = [], []

@@ -326,13 +326,17 @@ extern "C" void gs_rasterize_tile(GsTimer* timer)
 
 // ---- one-call renderer (Demo.cpp:314-331 buffers, :352-479 frame) ---------------------------------
 //
-// Two pipelines produce the same frame:
+// Three pipelines produce the same frame:
 //   GS_PIPELINE_REFERENCE  the reference's stage order through the eight staged calls above: pairs keyed by
 //                          (tile << 32 | depth), one 64-bit radix sort over all pairs (44-47 key bits);
 //   GS_PIPELINE_TWO_LEVEL  (default) sort the SPLATS by the 32-bit depth key first (N elements), emit the
 //                          pairs in that order keyed by the tile index only, then one stable sort on the
 //                          13-15 tile bits.  The resulting value list is identical (same total order, ties by
-//                          splat index) while the radix-sort traffic drops from ~152 B to ~30 B per pair.
+//                          splat index) while the radix-sort traffic drops from ~152 B to ~30 B per pair;
+//   GS_PIPELINE_BINNED     the same depth sort, then every hit is written straight to its slot of the per-tile
+//                          lists through LDS cursors (gs_bins.hip): no pair sort, no range search.
+// The last two leave the SH pass out when the raster kernel can evaluate colours on demand (useLazyColours below),
+// keep centre + ellipse in one 32-byte record per splat, and reset the range table from inside the clip kernel.
 namespace
 {
 constexpr int kStageTimers = 7; // sh, clip, tile list, pair sort, ranges, raster, depth sort (added to the sort total)
