@@ -12,6 +12,7 @@ ap.add_argument("--bits", type=int, default=13)
 ap.add_argument("--key-bytes", type=int, default=2)
 ap.add_argument("--reps", type=int, default=50)
 ap.add_argument("--random", type=int, default=0)
+ap.add_argument("--backend", type=int, default=1, help="1 native, 2 onesweep, 3 native with fused column scan")
 args = ap.parse_args()
 rng = np.random.default_rng(1)
 n = args.n
@@ -30,10 +31,11 @@ values = np.arange(n, dtype=np.int32)
 kb = [gs.DeviceBuffer(keys), gs.DeviceBuffer(nbytes=keys.nbytes, dtype=dt)]
 vb = [gs.DeviceBuffer(values), gs.DeviceBuffer(nbytes=values.nbytes, dtype=np.int32)]
 lib = gs.lib()
+lib.gs_set_sort_backend(args.backend)
 for i in range(args.reps + 5):
     if i == 5:
         lib.gs_synchronize()
         t = time.perf_counter()
     lib.gs_radix_sort_pairs(args.key_bytes, kb[0].ptr, kb[1].ptr, vb[0].ptr, vb[1].ptr, n, 0, args.bits)
 lib.gs_synchronize()
-print(f"n={n} bits={args.bits}: {1e6 * (time.perf_counter() - t) / args.reps:.1f} us per sort (debug={os.environ.get('GS_RADIX_DEBUG', '0')})")
+print(f"n={n} bits={args.bits}: {1e6 * (time.perf_counter() - t) / args.reps:.1f} us per sort (backend {args.backend})")
