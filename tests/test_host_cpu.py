@@ -155,3 +155,26 @@ def test_tile_row_bands():
     assert [b - a for a, b in scenes.tile_row_bands(68, 8)] == [9, 9, 9, 9, 8, 8, 8, 8]
     assert scenes.tile_row_bands(135, 8)[-1][1] == 135
     assert scenes.tile_row_bands(16, 1) == [(0, 16)]
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/gsplat_hip.h is the drop-in boundary: it must compile as C99 (no C++ types in the signatures), and a C
+    program must link against the library and call a host-side entry point."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "cabi.c"
+    src.write_text('#include <stdio.h>\n#include "gsplat_hip.h"\n'
+                   'int main(void) { GsGlobalArgs a; GsTileListArgs t; (void) a; (void) t;\n'
+                   '  printf("%d %d\\n", gs_sort_end_bit(1920, 1080), gs_sort_end_bit(1024, 1024)); return 0; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)],
+                   check=True)
+    exe = tmp_path / "cabi"
+    libdir = os.path.join(root, "cudagaussianrenderer_amd")
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe), "-L", libdir, "-lgsplat_hip",
+                    "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out == ["45", "44"]  # 32 + ceil(log2(tiles)): 8160 tiles -> 13 bits, 4096 tiles -> 12 bits
