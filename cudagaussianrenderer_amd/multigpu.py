@@ -41,18 +41,27 @@ def gather_bands(framebuffer, bands, rank, world, root=0):
             if b > a:
                 dist.send(framebuffer[a:b].cpu(), root)
         return
-    ops = []
-    if rank == root:
-        for src in range(world):
-            if src == root:
-                continue
-            a, b = pixel_rows(bands[src], height)
+    # The per-frame set of transfers never changes for a given framebuffer: build the P2POp list once and reuse it (the
+    # descriptors only name the op, the tensor view and the peer), so a frame costs one batch_isend_irecv call.
+    key = (framebuffer.data_ptr(), tuple(tuple(b) for b in bands), rank, world, root)
+    ops = _OPS_CACHE.get(key)
+    if ops is None:
+        ops = []
+        if rank == root:
+            for src in range(world):
+                if src == root:
+                    continue
+                a, b = pixel_rows(bands[src], height)
+                if b > a:
+                    ops.append(dist.P2POp(dist.irecv, framebuffer[a:b], src))
+        else:
+            a, b = pixel_rows(bands[rank], height)
             if b > a:
-                ops.append(dist.P2POp(dist.irecv, framebuffer[a:b], src))
-    else:
-        a, b = pixel_rows(bands[rank], height)
-        if b > a:
-            ops.append(dist.P2POp(dist.isend, framebuffer[a:b], root))
+                ops.append(dist.P2POp(dist.isend, framebuffer[a:b], root))
+        _OPS_CACHE[key] = ops
     if ops:
         for work in dist.batch_isend_irecv(ops):
             work.wait()
+
+
+_OPS_CACHE = {}
