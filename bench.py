@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--band-cull", type=int, default=0, help="0 auto (compact the visible splats on strict bands only), 1 always, 2 never")
     ap.add_argument("--epanechnikov", action="store_true", help="the reference's EPANECHNIKOV_KERNEL option (footprint sqrt(7) sigma, density 1 - q/7)")
     ap.add_argument("--rehearse", action="store_true", help="multi-rank control flow on ONE GPU: every rank on cuda:0, gloo instead of RCCL (not a measurement)")
-    ap.add_argument("--inflight", type=int, default=3, help="frames in flight per GPU (renderers on separate HIP streams)")
+    ap.add_argument("--inflight", type=int, default=0, help="frames in flight per GPU (renderers on separate HIP streams); 0 = 3 on one GPU, 4 per rank when the screen is split (measured optima)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -135,7 +135,7 @@ def main():
     band = bands[rank]
     # D frames in flight: D renderers, each with its own stream, intermediates and framebuffer (the scene is uploaded
     # to each; 0.6 GB apiece), so the latency-bound stages of one frame overlap the others' kernels.
-    depth = max(1, args.inflight)
+    depth = args.inflight if args.inflight > 0 else (3 if world == 1 else 4)
     streams = [torch.cuda.Stream(device) for _ in range(depth)]
     renderers, framebuffers = [], []
     for d in range(depth):
