@@ -216,7 +216,8 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
                     V density;
 #pragma unroll
                     for (int p = 0; p != PPL; ++p)
-                        PV::set(density, p, EPAN ? __saturatef(1.0f + PV::get(power, p)) : __saturatef(__builtin_amdgcn_exp2f(PV::get(power, p))));
+                        // saturate = one v_med3_f32 (a NaN density becomes 0, like __saturatef)
+                        PV::set(density, p, __builtin_amdgcn_fmed3f(EPAN ? 1.0f + PV::get(power, p) : __builtin_amdgcn_exp2f(PV::get(power, p)), 0.0f, 1.0f));
                     alpha[e] = V(opacity[e]) * density;
                 }
 #pragma unroll
