@@ -298,6 +298,10 @@ class Renderer:
         """Replay plain frames (render(camera) without timers/stats) as one captured hipGraph launch."""
         lib().gs_renderer_set_graph(self.handle, 1 if enabled else 0)
 
+    def captured_retries(self):
+        """Captured frames rendered a second time because their pair demand exceeded the list capacity (never handed out truncated)."""
+        return int(lib().gs_renderer_captured_retries(self.handle))
+
     def set_stream(self, hip_stream):
         """Give this renderer its own stream (e.g. torch.cuda.Stream().cuda_stream) so frames can overlap."""
         lib().gs_renderer_set_stream(self.handle, hip_stream)

@@ -140,6 +140,7 @@ SIGNATURES = {
     "gs_get_footprint": (C.c_int, []),
     "gs_get_sort_backend": (C.c_int, []),
     "gs_radix_sort_pairs": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int, C.c_int]),
+    "gs_debug_set_raster_trace": (None, [C.c_void_p]),
     "gs_set_raster_pixels_per_lane": (None, [C.c_int]),
     "gs_get_raster_pixels_per_lane": (C.c_int, []),
     "gs_set_device": (None, [C.c_int]),
@@ -173,6 +174,7 @@ SIGNATURES = {
                                         C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int]),
     "gs_renderer_render": (C.c_int, [C.c_void_p, C.POINTER(CameraData), C.c_int, C.POINTER(FrameStats)]),
     "gs_renderer_set_graph": (None, [C.c_void_p, C.c_int]),
+    "gs_renderer_captured_retries": (C.c_int, [C.c_void_p]),
     "gs_renderer_set_stream": (None, [C.c_void_p, C.c_void_p]),
     "gs_renderer_begin": (C.c_int, [C.c_void_p, C.POINTER(CameraData), C.c_int]),
     "gs_renderer_finish": (C.c_int, [C.c_void_p, C.POINTER(FrameStats)]),

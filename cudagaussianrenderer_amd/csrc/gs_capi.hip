@@ -12,6 +12,7 @@ namespace gs
 
 void setRasterPixelsPerLane(int ppl);
 int rasterPixelsPerLane();
+void setRasterTrace(unsigned long long* deviceBufferOrNull);
 
 namespace
 {
@@ -310,6 +311,7 @@ extern "C" int gs_radix_sort_pairs(int keyBytes, void* keys0, void* keys1, int32
     return launchRadixSortPairs(g.stream, g.radix, keyBytes, keys0, keys1, values0, values1, count, beginBit, endBit);
 }
 
+extern "C" void gs_debug_set_raster_trace(uint64_t* deviceBufferOrNull) { setRasterTrace((unsigned long long*) deviceBufferOrNull); }
 extern "C" void gs_set_raster_pixels_per_lane(int ppl) { setRasterPixelsPerLane(ppl); }
 extern "C" int gs_get_raster_pixels_per_lane(void) { return rasterPixelsPerLane(); }
 
@@ -388,6 +390,7 @@ struct GsRenderer
     FrameParams* paramsHost = nullptr; // pinned
     int graphCapacity = 0, graphSplats = 0, graphRowBegin = -1, graphRowEnd = -1, graphCull = -1, graphBinned = -1, graphFootprint = -1, graphLazy = -1, graphSelector = 0, graphKeyBytes = 2;
     bool pending = false; // begin() issued, finish() not yet
+    int capturedRetries = 0; // captured frames rendered again because their pair demand exceeded the list capacity
     FrameState frame;
     unsigned long long* bandMask = nullptr;
     int32_t *bandCounts = nullptr, *bandOffsets = nullptr;
@@ -1052,8 +1055,8 @@ extern "C" int gs_renderer_finish(GsRenderer* r, GsFrameStats* stats)
 // The two-level frame with every list size left on the device (the pair count feeds the tile sort and the range kernel
 // through pointers, grids are sized for the list capacity), so the frame has no host round trip and can be captured once
 // and replayed as ONE graph launch per frame.  The camera travels in a small device struct that a memcpy node refreshes.
-// Overflow follows the reference (Demo.cpp:357-366,447): a frame whose demand exceeds the capacity is truncated, the
-// next frame runs with a doubled list.
+// The pair total reaches the host through a host-mapped word in the middle of the frame; a frame whose demand exceeds the
+// list capacity is rendered again with a larger list before the call returns (never handed out truncated).
 namespace
 {
 // Allocation / legacy-stream work of one host thread must not overlap another thread's stream capture: set-up and capture
@@ -1132,6 +1135,31 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
     return 0;
 }
 
+// The pair total of a captured frame lands in a host-mapped word (written by the scan kernel, or by the binned emit pass).
+// The host arms the word with -1 before the launch and waits for the frame's own value: a few microseconds of polling in
+// the middle of the frame, long before its raster kernel ends.
+int64_t awaitPairTotal(GsRenderer* r)
+{
+    volatile int64_t* word = r->scratch.totalHost;
+    for (unsigned spins = 0;; ++spins)
+    {
+        const int64_t v = *word;
+        if (v >= 0) return v;
+        if ((spins & 63u) == 63u && hipStreamQuery(g.stream) == hipSuccess)
+        {
+            // the whole frame is done: every write of it is visible by now
+            const int64_t w = *word;
+            if (w >= 0) return w;
+            int64_t fromDevice = 0; // (no host-mapped address: the total was left in device memory)
+            GS_CHECK(hipMemcpy(&fromDevice, r->scratch.total, sizeof(int64_t), hipMemcpyDeviceToHost));
+            return fromDevice;
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+}
+
 int renderCaptured(GsRenderer* r, const GsCameraData* camera)
 {
     if (!r->hasStream && g.stream == nullptr)
@@ -1148,8 +1176,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
     const bool strictBand = scr.rowBegin > 0 || scr.rowEnd < scr.tilesY;
     const bool cull = n > 0 && (r->bandCull == GS_BAND_CULL_ON || (r->bandCull == GS_BAND_CULL_AUTO && strictBand));
 
-    // The previous frame of this renderer is complete before its parameter block is overwritten; its pair count is on
-    // the host by then, so an overflow is noticed here and the list doubled for this frame.
+    // The previous frame of this renderer is complete before its parameter block is overwritten.
     GS_CHECK(hipStreamSynchronize(g.stream));
     if (r->paramsDevice == nullptr)
     {
@@ -1157,26 +1184,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
         GS_CHECK(hipMalloc((void**) &r->paramsDevice, sizeof(FrameParams)));
         GS_CHECK(hipHostMalloc((void**) &r->paramsHost, sizeof(FrameParams), hipHostMallocDefault));
     }
-    if (r->graphValid && r->scratch.totalHost != nullptr)
-    {
-        const int64_t demand = *r->scratch.totalHost;
-        g.lastDemand = demand;
-        r->tileListSize = (int32_t) std::min<int64_t>(demand, r->tileListCapacity);
-        bool grew = false;
-        if (demand > r->tileListCapacity)
-        {
-            std::lock_guard<std::mutex> lock(g_captureMutex);
-            grew = growTileListIfNeeded(r, demand);
-        }
-        if (grew) r->graphValid = false;
-    }
-    const bool binned = r->pipeline == GS_PIPELINE_BINNED && binsSupported(scr) && radixSortSupported(4, n) &&
-                        r->scratch.totalHostMapped != nullptr;
     const bool lazy = useLazyColours(r);
-    if (r->graphValid && (r->graphCapacity != r->tileListCapacity || r->graphSplats != n || r->graphRowBegin != scr.rowBegin ||
-                          r->graphRowEnd != scr.rowEnd || r->graphCull != (int) cull || r->graphBinned != (int) binned ||
-                          r->graphFootprint != scr.epanechnikov || r->graphLazy != (int) lazy))
-        r->graphValid = false;
 
     FrameParams fp{};
     std::memcpy(fp.camera.view, camera->view, sizeof(fp.camera.view));
@@ -1188,36 +1196,61 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
     r->colourStale = lazy;
     *r->paramsHost = fp;
 
-    if (!r->graphValid)
+    // A frame whose pair demand exceeds the list capacity is NOT handed out (the reference would show it truncated and double
+    // the list for the next one, Demo.cpp:357-366,447): the list is grown, the frame re-captured and the SAME camera rendered
+    // again, so every frame that leaves this function is complete.
+    for (;;)
     {
-        std::lock_guard<std::mutex> lock(g_captureMutex);
-        // allocate everything the frame needs BEFORE capturing (no allocation may happen inside a capture)
-        ensureTileListFastScratch(r->scratch, n);
-        ensureRadixScratch(r->radix, n);
-        ensureRadixScratch(r->radix, r->tileListCapacity);
-        if (binned) ensureBinScratch(r->bins, n, (scr.rowEnd - scr.rowBegin) * scr.tilesX, binBatchesFor((scr.rowEnd - scr.rowBegin) * scr.tilesX));
-        if (r->graphExec) (void) hipGraphExecDestroy(r->graphExec);
-        if (r->graph) (void) hipGraphDestroy(r->graph);
-        r->graphExec = nullptr;
-        r->graph = nullptr;
-        GS_CHECK(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
-        enqueueCapturableFrame(r, scr, cull, binned, lazy);
-        GS_CHECK(hipStreamEndCapture(g.stream, &r->graph));
-        GS_CHECK(hipGraphInstantiate(&r->graphExec, r->graph, nullptr, nullptr, 0));
-        r->graphValid = true;
-        r->graphCapacity = r->tileListCapacity;
-        r->graphSplats = n;
-        r->graphRowBegin = scr.rowBegin;
-        r->graphRowEnd = scr.rowEnd;
-        r->graphCull = (int) cull;
-        r->graphBinned = (int) binned;
-        r->graphFootprint = scr.epanechnikov;
-        r->graphLazy = (int) lazy;
+        const bool binned = r->pipeline == GS_PIPELINE_BINNED && binsSupported(scr) && radixSortSupported(4, n) &&
+                            r->scratch.totalHostMapped != nullptr;
+        if (r->graphValid && (r->graphCapacity != r->tileListCapacity || r->graphSplats != n || r->graphRowBegin != scr.rowBegin ||
+                              r->graphRowEnd != scr.rowEnd || r->graphCull != (int) cull || r->graphBinned != (int) binned ||
+                              r->graphFootprint != scr.epanechnikov || r->graphLazy != (int) lazy))
+            r->graphValid = false;
+        if (!r->graphValid)
+        {
+            std::lock_guard<std::mutex> lock(g_captureMutex);
+            // allocate everything the frame needs BEFORE capturing (no allocation may happen inside a capture)
+            ensureTileListFastScratch(r->scratch, n);
+            ensureRadixScratch(r->radix, n);
+            ensureRadixScratch(r->radix, r->tileListCapacity);
+            if (binned) ensureBinScratch(r->bins, n, (scr.rowEnd - scr.rowBegin) * scr.tilesX, binBatchesFor((scr.rowEnd - scr.rowBegin) * scr.tilesX));
+            if (r->graphExec) (void) hipGraphExecDestroy(r->graphExec);
+            if (r->graph) (void) hipGraphDestroy(r->graph);
+            r->graphExec = nullptr;
+            r->graph = nullptr;
+            GS_CHECK(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+            enqueueCapturableFrame(r, scr, cull, binned, lazy);
+            GS_CHECK(hipStreamEndCapture(g.stream, &r->graph));
+            GS_CHECK(hipGraphInstantiate(&r->graphExec, r->graph, nullptr, nullptr, 0));
+            r->graphValid = true;
+            r->graphCapacity = r->tileListCapacity;
+            r->graphSplats = n;
+            r->graphRowBegin = scr.rowBegin;
+            r->graphRowEnd = scr.rowEnd;
+            r->graphCull = (int) cull;
+            r->graphBinned = (int) binned;
+            r->graphFootprint = scr.epanechnikov;
+            r->graphLazy = (int) lazy;
+        }
+        *r->scratch.totalHost = -1; // armed; the previous frame is complete, nothing else writes the word
+        GS_CHECK(hipGraphLaunch(r->graphExec, g.stream));
+        r->selector = r->graphSelector;
+        r->keyBytes = r->graphKeyBytes;
+
+        const int64_t demand = awaitPairTotal(r);
+        g.lastDemand = demand;
+        r->tileListSize = (int32_t) std::min<int64_t>(demand, r->tileListCapacity);
+        if (demand <= r->tileListCapacity) return 0;
+        if (demand > 0x7FFFFFFF) return -2;
+        GS_CHECK(hipStreamSynchronize(g.stream)); // the truncated frame drains before its buffers are replaced
+        {
+            std::lock_guard<std::mutex> lock(g_captureMutex);
+            growTileListIfNeeded(r, demand);
+        }
+        r->graphValid = false;
+        r->capturedRetries += 1;
     }
-    GS_CHECK(hipGraphLaunch(r->graphExec, g.stream));
-    r->selector = r->graphSelector;
-    r->keyBytes = r->graphKeyBytes;
-    return 0;
 }
 } // namespace
 
@@ -1226,6 +1259,8 @@ extern "C" void gs_renderer_set_graph(GsRenderer* r, int enabled)
     r->useGraph = enabled != 0;
     r->graphValid = false;
 }
+
+extern "C" int gs_renderer_captured_retries(const GsRenderer* r) { return r->capturedRetries; }
 
 extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsFrameStats* stats)
 {

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
                                                                   const float4* __restrict__ conic,
                                                                   const float4* __restrict__ color, uchar4* __restrict__ backBuffer,
                                                                   unsigned long long* __restrict__ consumedPairs, int clearEmptyTiles,
-                                                                  RasterColourSource lazy)
+                                                                  RasterColourSource lazy, unsigned long long* __restrict__ trace)
 {
     constexpr int THREADS = 256 / PPL;
     constexpr int GROUPS_X = kTileSize / PPL;
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
         if (group + 64 <= numTiles) wg = remapped; // the ragged last group keeps the identity map
     }
     const int tile = firstTile + wg;
+    const unsigned long long traceStart = trace ? wall_clock64() : 0ull; // diagnostics only (gs_debug_set_raster_trace)
 
     // GaussianRender.cu:917-931 (wave-uniform: scalar loads)
     int first = tileRange[tile * 2];
@@ -248,6 +249,14 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
     }
 
     if (consumedPairs != nullptr && t == 0) atomicAdd(consumedPairs, (unsigned long long) consumed);
+    if (trace != nullptr && t == 0)
+    {
+        // per tile: start and end on the 100 MHz wall clock, list length, consumed entries
+        trace[4 * (size_t) tile + 0] = traceStart;
+        trace[4 * (size_t) tile + 1] = wall_clock64();
+        trace[4 * (size_t) tile + 2] = (unsigned long long) count;
+        trace[4 * (size_t) tile + 3] = ((unsigned long long) blockIdx.x << 32) | (unsigned long long) consumed;
+    }
 
     // GaussianRender.cu:1007-1015: row 0 of the buffer is clip y = -1.
     if (py < scr.height)
@@ -274,9 +283,11 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
 }
 
 int g_rasterPixelsPerLane = 2;
+unsigned long long* g_rasterTrace = nullptr;
 
 } // namespace
 
+void setRasterTrace(unsigned long long* deviceBufferOrNull) { g_rasterTrace = deviceBufferOrNull; }
 void setRasterPixelsPerLane(int ppl) { g_rasterPixelsPerLane = (ppl == 1 || ppl == 2 || ppl == 4) ? ppl : 2; }
 int rasterPixelsPerLane() { return g_rasterPixelsPerLane; }
 
@@ -291,7 +302,7 @@ void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileR
     if (lazyColours != nullptr) lazy = *lazyColours;
 #define GS_LAUNCH_RASTER(PPL, EPAN, SH)                                                                                                  \
     hipLaunchKernelGGL((rasterizeTilesKernel<PPL, EPAN, SH>), dim3(numTiles), dim3(256 / PPL), 0, stream, scr, firstTile, numTiles,       \
-                       tileRange, values, clipXY, conic, color, backBuffer, consumedPairsOrNull, clearEmptyTiles ? 1 : 0, lazy)
+                       tileRange, values, clipXY, conic, color, backBuffer, consumedPairsOrNull, clearEmptyTiles ? 1 : 0, lazy, g_rasterTrace)
     const bool epan = scr.epanechnikov != 0;
     // on-demand colours: two pixels per lane only (the default shape), degrees whose coefficient rows are 16-byte multiples
     if (lazyColours != nullptr && g_rasterPixelsPerLane == 2 && rasterCanEvaluateColours(lazy.degree, lazy.shCount))

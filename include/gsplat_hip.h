@@ -150,6 +150,10 @@ int gs_radix_sort_pairs(int keyBytes, void* keys0, void* keys1, int32_t* values0
  * 4 (one wave per tile). */
 void gs_set_raster_pixels_per_lane(int pixelsPerLane);
 int gs_get_raster_pixels_per_lane(void);
+/* Diagnostics (tools/raster_trace.py): when set, every raster workgroup writes four uint64 to deviceBuffer[4 * tile]:
+ * start and end on the 100 MHz wall clock, the tile's list length, and (dispatch index << 32 | consumed entries).
+ * Process-wide; NULL (default) switches it off.  Not for captured frames (the pointer is a frozen kernel argument there). */
+void gs_debug_set_raster_trace(uint64_t* deviceBufferOrNull);
 
 /* ---- stream / device (additions) ------------------------------------------------------------- */
 void gs_set_device(int device);
@@ -246,10 +250,14 @@ int gs_renderer_set_scene(GsRenderer* r, int32_t splatCount, const float* positi
  *   timed == 2: one non-blocking event pair per stage on the stream; read the sums later with
  *               gs_renderer_collect_stage_times (the frames are not slowed by host waits). */
 int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsFrameStats* statsOrNull);
-/* Captured frames: gs_renderer_render (timed == 0, stats == NULL, TWO_LEVEL pipeline, native sort) replays the whole frame
- * as ONE hipGraph launch; list sizes stay on the device, the camera is refreshed by a memcpy node. Overflow then follows
- * the reference (a frame whose demand exceeds the list capacity is truncated and the list is doubled for the next one). */
+/* Captured frames: gs_renderer_render (timed == 0, stats == NULL, TWO_LEVEL or BINNED pipeline, native sort) replays the whole
+ * frame as ONE hipGraph launch; list sizes stay on the device, the camera is refreshed by a memcpy node.  The call returns once
+ * the frame's pair total has reached the host (mid-frame, through a host-mapped word).  A frame whose demand exceeds the list
+ * capacity is NOT handed out truncated (the reference shows it and doubles the list for the next frame, Demo.cpp:357-366,447):
+ * the list is grown, the frame re-captured and the same camera rendered again before the call returns. */
 void gs_renderer_set_graph(GsRenderer* r, int enabled);
+/* Number of captured frames that had to be rendered again because the list was too small (diagnostics). */
+int gs_renderer_captured_retries(const GsRenderer* r);
 /* The same frame in two halves, so that one host thread can keep several renderers (each with its own stream and
  * buffers, gs_renderer_set_stream) busy: begin() enqueues everything up to the pair emission and returns; finish()
  * picks up the pair count -- by then on the host -- and enqueues tile sort, ranges and raster. render() = begin + finish. */

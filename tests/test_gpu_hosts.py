@@ -1,0 +1,111 @@
+"""The two host programs above the C ABI, run the way a user runs them (-m gpu):
+
+  * bench.py as a command line: `--gpus 2` WITHOUT a launcher must start its own two ranks (rehearsal mode: both on cuda:0, gloo)
+    and report n_gpus 2; the N = 1 line must carry `roofline`, `cpu_baseline` and a passing `parity` block;
+  * the C++ host tools/gsplat_demo.cpp (the reference's frame loop src/Demo.cpp:394-479 over include/GaussianRender.hpp):
+    built with `make demo`, its PPM (rows flipped, Demo.cpp:146-147 convention) must equal the Python Renderer's
+    reference-pipeline frame byte for byte.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_bench(*flags, timeout=600):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                          timeout=timeout, env=env, cwd=ROOT)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert proc.returncode == 0 and len(lines) == 1, (proc.returncode, proc.stdout[-2000:], proc.stderr[-4000:])
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_without_launcher_runs_two_ranks():
+    """plain `python bench.py --gpus 2` spawns two ranks (here both on the one GPU, gloo) and says so."""
+    out = _run_bench("--gpus", "2", "--rehearse", "--steps", "6", "--warmup", "2", "--splats", "60000", "--width", "640", "--height", "368",
+                     "--views", "3", "--cpu-frames", "0")
+    assert out["n_gpus"] == 2 and out["config"]["dist_world_size"] == 2 and out["config"]["dist_backend"] == "gloo"
+    assert out["config"]["rehearsal_on_one_gpu"] is True
+    assert out["config"]["gathered_frame_equals_single_gpu_frame"] is True
+    assert len(out["config"]["tile_row_bands"]) == 2 and out["scaling"] == "strong"
+
+
+def test_bench_single_gpu_line_has_roofline_cpu_baseline_and_parity():
+    """A reduced workload (200 k splats at 1280x720) so the CPU leg stays short; same code path as the default run."""
+    out = _run_bench("--steps", "16", "--warmup", "4", "--splats", "200000", "--width", "1280", "--height", "720", "--cpu-frames", "2",
+                     "--no-extra")
+    assert out["n_gpus"] == 1 and out["unit"] == "frames/s" and out["value"] > 0 and out["dtype"] == "f32"
+    rf = out["roofline"]
+    pc, tiles = out["config"]["consumed_pairs_per_frame"], 80 * 45
+    assert abs(rf["algorithmic_bytes"] - (44 * pc + 8 * tiles + 4 * 1280 * 720)) <= 44 * 8  # 44 P_c + 8 T + 4 W H
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["bound"] == "hbm" and rf["traffic"] is None  # not the profiled workload
+    assert abs(rf["achieved"] - rf["algorithmic_bytes"] / 1e9 / (rf["kernel_ms"] / 1e3)) <= 0.01 * rf["achieved"] + 0.1
+    cpu, par = out["cpu_baseline"], out["parity"]
+    assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0
+    assert par["ok"] is True and par["views"] == 2 and par["max_lsb"] <= 3 and par["frac_gt1"] <= 1e-3
+    assert all(abs(a - b) <= par["tolerance"]["pairs_abs"] for a, b in zip(par["pairs_gpu"], par["pairs_oracle"]))
+
+
+def _read_ppm(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"P6"
+        w, h = [int(v) for v in f.readline().split()]
+        assert f.readline().strip() == b"255"
+        data = np.frombuffer(f.read(), np.uint8)
+    return data.reshape(h, w, 3)
+
+
+@pytest.fixture(scope="module")
+def demo_binary():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "cudagaussianrenderer_amd", "csrc"), "demo"], stdout=subprocess.DEVNULL)
+    path = os.path.join(ROOT, "tools", "gsplat_demo")
+    assert os.path.exists(path)
+    return path
+
+
+def test_cpp_host_procedural_frame_equals_python_reference_pipeline(gs, demo_binary, tmp_path):
+    """BASELINE.json configs[0] (10 k procedural splats, 256x256) through the C++ frame loop: eight staged calls, caller-owned
+    DeviceBuffer<T>s, blocking timers, PPM writer."""
+    out = str(tmp_path / "c1.ppm")
+    log = subprocess.run([demo_binary, "--procedural", "10000", "256", "256", "3", out], stdout=subprocess.PIPE, text=True, check=True).stdout
+    assert "Rasterize" in log and "Sort Tile List" in log
+    pos, sr, col = gs.generate_random_gaussians(10000, seed=1234, min_scale=0.01, max_scale=0.5)
+    cam = gs.camera_from_bounds([-4] * 3, [4] * 3, 256, 256)
+    r = gs.Renderer(256, 256, pipeline=gs.PIPELINE_REFERENCE)
+    r.set_scene(pos, sr, col)
+    r.render(cam)
+    want = r.read_image()
+    r.close()
+    got = _read_ppm(out)[::-1]  # the writer puts buffer row H-1 (clip y = +1) first
+    assert got.shape == (256, 256, 3) and np.array_equal(got, want[..., :3]) and got.max() > 0
+
+
+def test_cpp_host_ply_frame_equals_python_reference_pipeline(gs, demo_binary, tmp_path):
+    """A degree-3 .ply through gs::parsePly, realignSphericalHarmonics and the SH stage of the C++ loop, 333x177 (partial tiles);
+    the tile list grows past its initial 8 N capacity on the way (Demo.cpp:357-366)."""
+    from cudagaussianrenderer_amd import scenes
+
+    ply_path = str(tmp_path / "scene.ply")
+    scenes.write_synthetic_ply(ply_path, 20000, sh_degree=3, seed=3, log_scale_mean=-1.0)  # ~14 pairs per splat
+    out = str(tmp_path / "ply.ppm")
+    subprocess.run([demo_binary, ply_path, "333", "177", "4", out], stdout=subprocess.DEVNULL, check=True)
+    ply = gs.parse_ply(ply_path)
+    cam = gs.camera_from_bounds(ply["boundsMin"], ply["boundsMax"], 333, 177)
+    r = gs.Renderer(333, 177, pipeline=gs.PIPELINE_REFERENCE)
+    r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+    st = r.render(cam, stats=True)
+    want = r.read_image()
+    r.close()
+    assert st.tileListSize > 8 * 20000  # the C++ loop had to double its buffers to get the complete frame
+    assert np.array_equal(_read_ppm(out)[::-1], want[..., :3])

@@ -331,16 +331,32 @@ def test_band_renders_stitch_to_full_frame(gs):
     assert np.array_equal(stitched, want)
 
 
-@pytest.mark.parametrize("n,w,h", [(1_000_000, 1920, 1080), (5_000_000, 3840, 2160)])
-def test_full_size_properties(gs, tmp_path, n, w, h):
-    """BASELINE.json configs[2] (1 M splats, SH degree 3, 1920x1080) and configs[4] (5 M splats, SH degree 3, 3840x2160)
-    are too slow for the serial oracle inside a test; check size-independent properties instead: sortedness,
-    range/key consistency, determinism, and that a tile-row band rendered alone equals the same rows of the full frame."""
+_FULL_SCENES = {}
+
+
+def _full_scene(gs, tmp_path_factory, n):
+    """The bench scene (synthetic lilly_boquet-class .ply, SH degree 3, seed 1234) at n splats, ingested once per session."""
     from cudagaussianrenderer_amd import scenes
 
-    path = str(tmp_path / "scene.ply")
-    scenes.write_synthetic_ply(path, n, sh_degree=3, seed=1234)
-    ply = gs.parse_ply(path)
+    if n not in _FULL_SCENES:
+        path = str(tmp_path_factory.mktemp("full") / f"scene_{n}.ply")
+        scenes.write_synthetic_ply(path, n, sh_degree=3, seed=1234)
+        _FULL_SCENES[n] = gs.parse_ply(path)
+        import os
+
+        os.remove(path)
+    return _FULL_SCENES[n]
+
+
+@pytest.mark.parametrize("n,w,h", [(1_000_000, 1920, 1080), (5_000_000, 3840, 2160)])
+def test_full_size_properties(gs, tmp_path_factory, n, w, h):
+    """BASELINE.json configs[2] (1 M splats, SH degree 3, 1920x1080) and configs[4] (5 M splats, SH degree 3, 3840x2160):
+    size-independent properties of the lists -- sortedness, range/key consistency, determinism, and that a tile-row band
+    rendered alone equals the same rows of the full frame.  (The images of these frames are compared with the oracle in
+    test_full_size_parity_with_oracle.)"""
+    from cudagaussianrenderer_amd import scenes
+
+    ply = _full_scene(gs, tmp_path_factory, n)
     assert ply["vertexCount"] == n and ply["shDegree"] == 3 and ply["shCount"] == 48
     cam = gs.camera_from_bounds(ply["boundsMin"], ply["boundsMax"], w, h)
     tx, ty = gs.tile_counts(w, h)
@@ -487,9 +503,10 @@ def test_captured_frames_equal_regular_frames(gs, tmp_path):
         captured.close()
 
 
-def test_captured_frames_overflow_then_recover(gs):
-    """A captured frame whose demand exceeds the list capacity is truncated (the reference's behaviour, Demo.cpp:447);
-    the list is doubled for the next frame, which is complete again."""
+def test_captured_frames_never_hand_out_a_truncated_frame(gs):
+    """A captured frame whose pair demand exceeds the list capacity is rendered again with a grown list before render()
+    returns (no incomplete frames; the reference would show the truncated frame, Demo.cpp:447): the FIRST
+    frame already equals the regular path's, for the two-level and the binned pipeline, and later frames need no retry."""
     w = h = 512
     pos, sr, col = _procedural(gs, 3000, seed=9, min_scale=0.3, max_scale=1.5)  # ~40 pairs per splat >> the 8 provisioned
     cam = gs.camera_from_bounds([-4] * 3, [4] * 3, w, h)
@@ -497,16 +514,24 @@ def test_captured_frames_overflow_then_recover(gs):
     ref.set_scene(pos, sr, col)
     st = ref.render(cam, stats=True)
     want = ref.read_image()
-    assert st.tileListSize > 8 * 3000
+    want_values = ref.download(ref.buffers().values, st.tileListSize, np.int32)
+    assert st.tileListSize > 8 * 3000 and st.grewTileList == 1
     ref.close()
-    r = gs.Renderer(w, h)
-    r.set_graph(True)
-    r.set_scene(pos, sr, col)
-    for _ in range(6):  # capacity 24k -> doubles until the demand fits
-        r.render(cam)
-    assert r.buffers().tileListSize == st.tileListSize
-    assert np.array_equal(r.read_image(), want)
-    r.close()
+    for pipeline in (gs.PIPELINE_TWO_LEVEL, gs.PIPELINE_BINNED):
+        r = gs.Renderer(w, h, pipeline=pipeline)
+        r.set_graph(True)
+        r.set_scene(pos, sr, col)
+        r.render(cam)  # capacity 24 k -> grown until the demand fits, inside this one call
+        assert r.captured_retries() >= 1
+        b = r.buffers()
+        assert b.tileListSize == st.tileListSize
+        assert np.array_equal(r.download(b.values, b.tileListSize, np.int32), want_values)
+        assert np.array_equal(r.read_image(), want)
+        retries = r.captured_retries()
+        for _ in range(3):
+            r.render(cam)
+        assert r.captured_retries() == retries and np.array_equal(r.read_image(), want)
+        r.close()
 
 
 @pytest.mark.parametrize("degree", [2, 3])
@@ -616,3 +641,207 @@ def test_colours_on_demand_equal_the_sh_pass(gs, tmp_path, degree):
         for (img_ref, col_ref), (img, col) in zip(results[gs.PIPELINE_REFERENCE], results[pipeline]):
             assert np.array_equal(img, img_ref)
             assert np.array_equal(col, col_ref)
+
+
+# ---- full-size parity against the oracle (BASELINE.json configs[1], [2], [4]) ---------------------------------------------
+@pytest.mark.parametrize("config", ["C2", "C3", "C5"])
+def test_full_size_parity_with_oracle(gs, gsref, tmp_path_factory, config):
+    """One view of each full-size configuration through the renderer's default path (two-level sort, colours on demand) AND
+    as a captured frame, against the serial oracle's frame: image within the tolerance at the top of this file, the same number
+    of pairs (borderline tiles aside), the same consumed-entry count to a vote's rounding.
+      C2 = configs[1]: 100 k procedural splats, SH degree 0, 1024x1024 (the reference's native case, Demo.cpp:258-269);
+      C3 = configs[2]: 1 M splats, SH degree 3, 1920x1080 (the bench workload);
+      C5 = configs[4]: 5 M splats, SH degree 3, 3840x2160 (full frame on one GPU)."""
+    if config == "C2":
+        w = h = 1024
+        pos, sr, col = _procedural(gs, 100_000, seed=1234, min_scale=0.005, max_scale=0.05)
+        scene = {"position": pos, "scaleAndRotation": sr, "color": col, "sh": None, "shDegree": 0, "shCount": 0}
+        cam = gs.camera_from_bounds([-4] * 3, [4] * 3, w, h)
+    else:
+        n, w, h = (1_000_000, 1920, 1080) if config == "C3" else (5_000_000, 3840, 2160)
+        scene = _full_scene(gs, tmp_path_factory, n)
+        cam = gs.camera_from_bounds(scene["boundsMin"], scene["boundsMax"], w, h)
+    n = scene["position"].shape[0]
+    sh_al = gs.realign_spherical_harmonics(scene["sh"], scene["shCount"], n) if scene["shDegree"] else None
+    want, rst, _ = gsref.render(scene["position"], scene["scaleAndRotation"], scene["color"], sh_al, scene["shDegree"], scene["shCount"],
+                                cam, w, h)
+    del sh_al
+    gs.lib().gs_set_collect_raster_stats(1)
+    try:
+        r = gs.Renderer(w, h)
+        r.set_scene(scene["position"], scene["scaleAndRotation"], scene["color"], scene["sh"], scene["shDegree"], scene["shCount"])
+        st = r.render(cam, stats=True)
+        got = r.read_image()
+    finally:
+        gs.lib().gs_set_collect_raster_stats(0)
+    stats = _assert_image_close(got, want, config)
+    assert abs(st.tileListSize - rst.tileListSize) <= max(4, 2e-5 * rst.tileListSize), (st.tileListSize, rst.tileListSize)
+    assert abs(st.consumedPairs - rst.consumedPairs) <= 0.002 * rst.consumedPairs + 64, (st.consumedPairs, rst.consumedPairs)
+    assert np.array_equal(got[..., 3], want[..., 3])  # alpha: 255 exactly where the oracle's tiles had work
+    # the captured frame (what bench.py times) hands out the same bytes
+    r.set_graph(True)
+    r.render(cam)
+    r.render(cam)
+    assert np.array_equal(r.read_image(), got)
+    r.close()
+    print(f"{config}: P={st.tileListSize} (oracle {rst.tileListSize}), P_c={st.consumedPairs} ({rst.consumedPairs}), {stats}")
+
+
+# ---- reference edge cases pushed through the HIP path ---------------------------------------------------------------------
+def _bits_to_float(bits):
+    return np.array([bits], np.uint32).view(np.float32)[0]
+
+
+def _staged_lists(gs, gsref, pos, sr, col, cam, w, h):
+    """Clip data on the GPU, then pair list / sorted list / ranges through the staged calls against the oracle fed with the
+    GPU's clip data (bit-exact, NaNs included)."""
+    f = StagedFrame(pos, sr, col, cam, w, h, capacity=max(64, 64 * len(pos)))
+    f.begin()
+    xy, z, ell, con = f.run_clip()
+    rk, rv, total = gsref.build_tile_list(xy, z, ell, w, h)
+    keys, values, size = f.run_build()
+    assert size == total and np.array_equal(keys, rk) and np.array_equal(values, rv)
+    sk, sv = f.run_sort()
+    rsk, rsv = gsref.sort_tile_list(rk, rv, gs.sort_end_bit(w, h))
+    assert np.array_equal(sk, rsk) and np.array_equal(sv, rsv)
+    assert np.array_equal(f.run_ranges(), gsref.evaluate_tile_ranges(rsk, f.total_tiles))
+    f.free_sort_temp()
+    return (xy, z, ell, con), (sk, sv)
+
+
+def _renderer_lists(gs, scene, cam, w, h):
+    """Sorted value list + image of every renderer pipeline, and of a captured frame."""
+    out = {}
+    for name, pipeline, graph in (("reference", gs.PIPELINE_REFERENCE, False), ("two_level", gs.PIPELINE_TWO_LEVEL, False),
+                                  ("binned", gs.PIPELINE_BINNED, False), ("captured", gs.PIPELINE_TWO_LEVEL, True)):
+        r = gs.Renderer(w, h, pipeline=pipeline)
+        r.set_graph(graph)
+        r.set_scene(scene["position"], scene["scaleAndRotation"], scene["color"])
+        r.render(cam)
+        if graph:
+            r.render(cam)
+        b = r.buffers()
+        out[name] = (r.download(b.values, b.tileListSize, np.int32), r.read_image())
+        r.close()
+    return out
+
+
+def _oracle_image_from_clip(gsref, clip, col, w, h):
+    """The oracle's list + raster stages on given clip data (xy, z, ellipse, conic): image and sorted values."""
+    xy, z, ell, con = clip
+    k, v, _ = gsref.build_tile_list(xy, z, ell, w, h)
+    k, v = gsref.sort_tile_list(k, v, gsref.sort_end_bit(w, h))
+    rng = gsref.evaluate_tile_ranges(k, ((w + 15) // 16) * ((h + 15) // 16))
+    img, _ = gsref.rasterize_tiles(w, h, rng, v, xy, con, col)
+    return img, v
+
+
+def test_edge_nan_ellipse_axis_aligned_covariance(gs, gsref):
+    """GaussianRender.cu:290: normalize(vec2(b, lambda0 - a)) is 0/0 when the clip covariance is exactly diagonal with a > c and
+    mid + radius rounds to a; the NaN axis makes every bound of the splat's tile rectangle NaN and the splat emits no pairs
+    (:537-551) although it is visible and has non-zero extents.  Constructed with on-axis splats, an axis-aligned camera and
+    the exactly representable quaternion bytes (255,255,255,0) = (1,1,1,-1), whose un-normalised rotation matrix has
+    r01 = r12 = r20 = 0: scale (sx, 0, sz) then gives b == 0 exactly, a ~ sx^2, c ~ sz^2.  Roughly 70 % of such splats hit the
+    0/0 (which ones depends on the last bit of sqrt(mid^2 - det), so the oracle is fed the GPU's clip data downstream)."""
+    w, h = 640, 360
+    cam = gs.camera_from_pose([0, 0, 5], [0, 0, 0, 1], w, h)
+    q = _bits_to_float(0xFFFFFF00)
+    rng = np.random.default_rng(1)
+    n_axis = 192
+    pos, sr, col = _procedural(gs, n_axis + 300, seed=29, min_scale=0.05, max_scale=0.3)
+    pos[:n_axis, :3] = 0.0
+    sr[:n_axis, 0] = rng.uniform(0.5, 3.0, n_axis).astype(np.float32)  # a > c
+    sr[:n_axis, 1] = 0.0
+    sr[:n_axis, 2] = 0.3
+    sr[:n_axis, 3] = q
+    sr[n_axis - 8:n_axis, 0] = 0.01  # b == 0 too, but a < c: lambda0 - a = c - a, a valid axis -- these must be drawn
+    col[:n_axis, 3] = 0.02
+    rxy, rz, rell, rcon = gsref.evaluate_splat_clip_data(pos, sr, cam, w, h)
+    assert np.isnan(rell[:n_axis - 8, 0]).sum() > 20 and not np.isnan(rell[n_axis - 8:, :2]).any()  # the oracle hits the case
+    clip, (sk, sv) = _staged_lists(gs, gsref, pos, sr, col, cam, w, h)  # bit-exact lists from the GPU's clip data, NaNs included
+    xy, z, ell, con = clip
+    nan = np.isnan(ell[:, 0])
+    assert nan[:n_axis - 8].sum() > 20 and not nan[n_axis - 8:].any()  # ... and so does the HIP clip kernel
+    assert np.all(np.isnan(ell[nan, 1])) and np.all(xy[nan] == 0.0) and np.all(ell[nan, 2:] > 0.0)  # visible, non-zero extents
+    assert (nan[:n_axis - 8] == np.isnan(rell[:n_axis - 8, 0])).mean() > 0.5
+    present = np.zeros(len(pos), bool)
+    present[sv] = True
+    assert not present[nan].any() and present[:n_axis][~nan[:n_axis]].all()
+    want, want_values = _oracle_image_from_clip(gsref, clip, col, w, h)
+    assert np.array_equal(want_values, sv)
+    scene = {"position": pos, "scaleAndRotation": sr, "color": col}
+    for name, (values, image) in _renderer_lists(gs, scene, cam, w, h).items():
+        assert np.array_equal(values, sv), name
+        _assert_image_close(image, want, name)
+
+
+def test_edge_depth_equals_far_key_saturation(gs, gsref):
+    """GaussianRender.cu:452: (uint32)(1.0f * (float)0xFFFFFFFF) overflows at clip depth == 1 (a visible depth, :316-318);
+    the key's depth word saturates to 0xFFFFFFFF here and in the oracle.  depthScaleBias = (-1/64, -9/16) maps view z = -100 to
+    exactly 1.0 in any evaluation order (with the reference's near/far constants no float lands on 1.0 under fma)."""
+    w, h = 320, 192
+    cam = gs.camera_from_pose([0, 0, 5], [0, 0, 0, 1], w, h)
+    cam.depthScaleBias[0], cam.depthScaleBias[1] = -0.015625, -0.5625
+    q = _bits_to_float(gs.encode_vec4([0.1, 0.2, 0.3, 0.9]))
+    zs = [-95.0, -94.99999, -95.0, -60.0, -95.00001, -95.0]  # 0, 2, 5: depth exactly 1; 1, 3: nearer; 4: beyond far (culled)
+    pos = np.array([[0.0, 0.0, z, 1.0] for z in zs], np.float32)
+    sr = np.array([[6, 6, 6, q]] * len(zs), np.float32)
+    col = np.array([[1, 0, 0, 0.6], [0, 1, 0, 0.5], [0, 0, 1, 0.6], [1, 1, 1, 0.3], [1, 0, 1, 1], [0, 1, 1, 0.6]], np.float32)
+    (xy, z, ell, con), (sk, sv) = _staged_lists(gs, gsref, pos, sr, col, cam, w, h)
+    assert z[0] == z[2] == z[5] == 1.0 and z[4] == -128.0 and -1.0 < z[3] < z[1] < 1.0
+    low = (sk & np.uint64(0xFFFFFFFF)).astype(np.uint64)
+    far = np.isin(sv, [0, 2, 5])
+    assert far.any() and np.all(low[far] == 0xFFFFFFFF) and np.all(low[~far] < 0xFFFFFFFF)
+    assert int(sk[far][0]) == gsref.get_key(int(sk[far][0] >> np.uint64(32)), 1.0)
+    # inside a tile: nearer splats first, the three far-plane splats last in index order (equal keys)
+    centre_tile = (h // 2 // 16) * ((w + 15) // 16) + w // 2 // 16
+    assert sv[(sk >> np.uint64(32)) == np.uint64(centre_tile)].tolist() == [3, 1, 0, 2, 5]
+    scene = {"position": pos, "scaleAndRotation": sr, "color": col}
+    want, rst, _ = gsref.render(pos, sr, col, None, 0, 0, cam, w, h)
+    for name, (values, image) in _renderer_lists(gs, scene, cam, w, h).items():
+        assert np.array_equal(values, sv), name
+        _assert_image_close(image, want, name)
+
+
+def test_edge_unnormalised_quaternion(gs, gsref):
+    """GaussianRender.cu:220-221: the packed quaternion is decoded and used WITHOUT renormalisation, so arbitrary bytes give a
+    non-orthogonal 'rotation' (|q| from 0 to 2).  Random bytes, including the extremes, through clip data, lists and image."""
+    w, h = 640, 360
+    rng = np.random.default_rng(5)
+    n = 4096
+    pos, sr, col = _procedural(gs, n, seed=17, min_scale=0.02, max_scale=0.3)
+    bits = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    bits[:6] = [0x00000000, 0xFFFFFFFF, 0x7F7F7F7F, 0x808080FF, 0xFF000000, 0x000000FF]  # |q| = 2, 2, ~0.008, ~1, 2, 2
+    exp = (bits >> np.uint32(23)) & np.uint32(0xFF)
+    bits[exp == 0xFF] ^= np.uint32(0x00800000)  # keep the carrier float finite: a NaN payload may not survive host copies
+    sr[:, 3] = bits.view(np.float32)
+    cam = gs.camera_from_bounds([-4] * 3, [4] * 3, w, h)
+    _check_clip(gs, gsref, pos, sr, cam, w, h)
+    _staged_lists(gs, gsref, pos, sr, col, cam, w, h)
+    got, want, st, rst = _end_to_end(gs, gsref, {"position": pos, "scaleAndRotation": sr, "color": col}, cam, w, h)
+    _assert_image_close(got, want)
+    assert abs(st.tileListSize - rst.tileListSize) <= 2
+
+
+def test_edge_whole_chunks_out_of_frustum(gs, gsref):
+    """Changelog.md:33: whole chunks of consecutive splats outside the frustum (the reference's builder consumes splats in
+    chunks of 32 per warp; here a wave takes 64 and a workgroup 256).  Runs of 64, 256 and 1000 culled splats between visible
+    ones, a culled head and a culled tail."""
+    w, h = 512, 288
+    pos, sr, col = _procedural(gs, 3000, seed=23, min_scale=0.02, max_scale=0.25)
+    culled = np.zeros(3000, bool)
+    for a, b in ((0, 64), (128, 192), (256, 512), (1000, 2000), (2936, 3000)):
+        culled[a:b] = True
+    pos[culled, :3] = [0.0, 60.0, 60.0]  # behind the default camera
+    cam = gs.camera_from_bounds([-4] * 3, [4] * 3, w, h)
+    (xy, z, ell, con), (sk, sv) = _staged_lists(gs, gsref, pos, sr, col, cam, w, h)
+    assert np.all(xy[culled, 0] == -128.0) and np.all(ell[culled, 2:] == 0.0)
+    assert not np.isin(sv, np.nonzero(culled)[0]).any() and len(sv) > 0
+    scene = {"position": pos, "scaleAndRotation": sr, "color": col}
+    want, rst, _ = gsref.render(pos, sr, col, None, 0, 0, cam, w, h)
+    lists = _renderer_lists(gs, scene, cam, w, h)
+    for name, (values, image) in lists.items():
+        assert not np.isin(values, np.nonzero(culled)[0]).any(), name
+        assert abs(len(values) - len(sv)) <= 2, name
+        _assert_image_close(image, want, name)
+    assert np.array_equal(lists["two_level"][0], lists["binned"][0]) and np.array_equal(lists["two_level"][0], lists["captured"][0])
