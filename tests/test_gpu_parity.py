@@ -695,7 +695,7 @@ def _bits_to_float(bits):
 def _staged_lists(gs, gsref, pos, sr, col, cam, w, h):
     """Clip data on the GPU, then pair list / sorted list / ranges through the staged calls against the oracle fed with the
     GPU's clip data (bit-exact, NaNs included)."""
-    f = StagedFrame(pos, sr, col, cam, w, h, capacity=max(64, 64 * len(pos)))
+    f = StagedFrame(pos, sr, col, cam, w, h, capacity=max(64, len(pos) * ((w + 15) // 16) * ((h + 15) // 16)))  # every splat on every tile
     f.begin()
     xy, z, ell, con = f.run_clip()
     rk, rv, total = gsref.build_tile_list(xy, z, ell, w, h)
