@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsplat_hip.so")
+# GSPLAT_HIP_LIBRARY: another build of the same library (A/B measurements of kernel variants, tools/ab_bench.sh)
+LIB_PATH = os.environ.get("GSPLAT_HIP_LIBRARY") or os.path.join(_HERE, "libgsplat_hip.so")
 
 
 class GsplatLibraryMissing(RuntimeError):

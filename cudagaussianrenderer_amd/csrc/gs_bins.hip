@@ -504,7 +504,6 @@ void freeBinScratch(BinScratch& s)
 
 int binBatchesFor(int bandTiles)
 {
-    if (const char* e = getenv("GS_BIN_BATCHES")) return std::max(1, std::min(16, atoi(e)));
     // Rows as long as the LDS cursor table is worth: the tables cost 6 bytes per (row, tile).
     return bandTiles > 4096 ? 8 : bandTiles > 1024 ? 4 : 2;
 }

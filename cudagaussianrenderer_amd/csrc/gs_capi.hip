@@ -613,7 +613,7 @@ extern "C" int gs_renderer_set_scene(GsRenderer* r, int32_t n, const float* posi
     r->ellipse = (float*) gs_device_alloc(f4);
     r->clipXY = (float*) gs_device_alloc(sizeof(float) * 2 * (size_t) n);
     r->clipZ = (float*) gs_device_alloc(sizeof(float) * (size_t) n);
-    r->tileRecord = getenv("GS_NO_TILE_RECORD") ? nullptr : (float*) gs_device_alloc(sizeof(float) * 8 * (size_t) n);
+    r->tileRecord = (float*) gs_device_alloc(sizeof(float) * 8 * (size_t) n);
     r->scratch.tileRecord = (const float4*) r->tileRecord;
     r->bins.tileRecord = (const float4*) r->tileRecord;
     for (int i = 0; i != 2; ++i)
@@ -836,7 +836,7 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
     else
     {
         // ---- two-level sort ------------------------------------------------------------------------
-        f.tileKeyBytes = (getenv("GS_TILEKEY4") || scr.totalTiles > 65536) ? 4 : 2;
+        f.tileKeyBytes = scr.totalTiles > 65536 ? 4 : 2;
 
         gs_timer_start(stageTimers[1]);
         const int* countDevice = nullptr;
