@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 SIMDS = 256 * 4         # 256 CUs x 4 SIMDs
 IMAGE_MAX_LSB = 3       # DESIGN.md section 6 / tests/test_gpu_parity.py
 IMAGE_FRAC_GT1 = 1e-3
-DEPTH_SORT_PASSES = 4   # gs_radix.hip: the splats' 32-bit depth keys are sorted in four 8-bit passes
+DEPTH_SORT_PASSES = 3   # gs_radix.hip: the splats' 27-bit depth codes are sorted in three 9-bit passes
 
 
 # ---- byte counts ----------------------------------------------------------------------------------------------------
@@ -348,6 +348,7 @@ def main():
     ap.add_argument("--band-cull", type=int, default=0, help="0 auto (compact the visible splats on strict bands only), 1 always, 2 never")
     ap.add_argument("--epanechnikov", action="store_true", help="the reference's EPANECHNIKOV_KERNEL option (footprint sqrt(7) sigma, density 1 - q/7)")
     ap.add_argument("--rehearse", action="store_true", help="multi-rank control flow on ONE GPU: every rank on cuda:0, gloo instead of RCCL (not a measurement)")
+    ap.add_argument("--ablate", type=int, default=0, help="diagnostics: leave stages out of the timed frames (bit 0 clip, 1 depth sort, 2 count, 3 emit, 4 tile sort, 5 ranges, 6 raster); prints frames/s only")
     ap.add_argument("--inflight", type=int, default=0, help="frames in flight per GPU (renderers on separate HIP streams); 0 = 3 on one GPU, 4 per rank when the screen is split (measured optima)")
     args = ap.parse_args()
 
@@ -409,6 +410,16 @@ def main():
     depth = args.inflight if args.inflight > 0 else (3 if world == 1 else 4)
 
     rig = Rig(ctx, ply, cameras, bands, depth, args)
+    if args.ablate >= 0 and args.ablate != 0 or "--ablate" in sys.argv:
+        # marginal cost of stages in the pipelined loop: the renderers are primed with complete frames, then re-capture without
+        # the masked stages (list sizes and buffers stay valid, the images are garbage)
+        lib.gs_debug_set_ablation(args.ablate)
+        elapsed = rig.timed_run(args.steps, args.warmup)
+        lib.gs_debug_set_ablation(0)
+        if rank == 0:
+            print(json.dumps({"ablate": args.ablate, "value": round(args.steps / elapsed, 2), "ms_per_step": round(1e3 * elapsed / args.steps, 4)}))
+        rig.close()
+        return
     elapsed = rig.timed_run(args.steps, args.warmup)
 
     # ---- N > 1: one more frame through the same path, compared on rank 0 with a full-frame render of its own --------

@@ -176,6 +176,7 @@ SIGNATURES = {
     "gs_renderer_render": (C.c_int, [C.c_void_p, C.POINTER(CameraData), C.c_int, C.POINTER(FrameStats)]),
     "gs_renderer_set_graph": (None, [C.c_void_p, C.c_int]),
     "gs_renderer_captured_retries": (C.c_int, [C.c_void_p]),
+    "gs_debug_set_ablation": (None, [C.c_int]),
     "gs_renderer_set_stream": (None, [C.c_void_p, C.c_void_p]),
     "gs_renderer_begin": (C.c_int, [C.c_void_p, C.POINTER(CameraData), C.c_int]),
     "gs_renderer_finish": (C.c_int, [C.c_void_p, C.POINTER(FrameStats)]),

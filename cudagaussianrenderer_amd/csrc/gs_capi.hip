@@ -17,6 +17,7 @@ void setRasterTrace(unsigned long long* deviceBufferOrNull);
 namespace
 {
 int g_footprint = GS_FOOTPRINT_GAUSSIAN; // process-wide, like the reference's #define
+int g_ablation = 0;                      // diagnostics: stages left out of captured frames (gs_debug_set_ablation)
 }
 
 Screen makeScreen(int width, int height, int rowBegin, int rowEnd)
@@ -388,7 +389,7 @@ struct GsRenderer
     hipGraphExec_t graphExec = nullptr;
     FrameParams* paramsDevice = nullptr;
     FrameParams* paramsHost = nullptr; // pinned
-    int graphCapacity = 0, graphSplats = 0, graphRowBegin = -1, graphRowEnd = -1, graphCull = -1, graphBinned = -1, graphFootprint = -1, graphLazy = -1, graphSelector = 0, graphKeyBytes = 2;
+    int graphCapacity = 0, graphSplats = 0, graphRowBegin = -1, graphRowEnd = -1, graphCull = -1, graphBinned = -1, graphFootprint = -1, graphLazy = -1, graphAblation = 0, graphSelector = 0, graphKeyBytes = 2;
     bool pending = false; // begin() issued, finish() not yet
     int capturedRetries = 0; // captured frames rendered again because their pair demand exceeded the list capacity
     FrameState frame;
@@ -880,12 +881,12 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         if (n > 0)
         {
             if (native && radixSortSupported(4, n))
-                orderSel = launchRadixSortPairs(g.stream, r->radix, 4, r->depthKey[0], r->depthKey[1], r->order[0], r->order[1], n, 0, 32);
+                orderSel = launchRadixSortPairs(g.stream, r->radix, 4, r->depthKey[0], r->depthKey[1], r->order[0], r->order[1], n, 0, kDepthKeyBits);
             else
             {
-                ensureSortTemp(r, sortTempBytes(4, n, 0, 32));
+                ensureSortTemp(r, sortTempBytes(4, n, 0, kDepthKeyBits));
                 orderSel = launchSortPairs(g.stream, r->sortTemp, r->sortTempBytes, 4, r->depthKey[0], r->depthKey[1], r->order[0],
-                                           r->order[1], 0, n, 0, 32);
+                                           r->order[1], 0, n, 0, kDepthKeyBits);
             }
         }
         gs_timer_stop(stageTimers[6]);
@@ -1082,9 +1083,12 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
                                  r->paramsDevice);
     const int* countDevice = nullptr;
     if (!cull)
-        launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
-                            (float2*) r->clipXY, r->clipZ, r->tileRecord ? nullptr : (float4*) r->ellipse, (float4*) r->conic, r->depthKey[0],
-                            (uint32_t*) r->order[0], nullptr, nullptr, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord);
+    {
+        if (!(g_ablation & 1))
+            launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
+                                (float2*) r->clipXY, r->clipZ, r->tileRecord ? nullptr : (float4*) r->ellipse, (float4*) r->conic, r->depthKey[0],
+                                (uint32_t*) r->order[0], nullptr, nullptr, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord);
+    }
     else
     {
         launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
@@ -1100,7 +1104,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
     r->radix.onesweep = false; // its ticket base / epoch are host-side launch arguments: not replayable
     r->radix.countDevice = countDevice;
     r->scratch.countDevice = countDevice;
-    const int orderSel = launchRadixSortPairs(g.stream, r->radix, 4, r->depthKey[0], r->depthKey[1], r->order[0], r->order[1], n, 0, 32);
+    const int orderSel = (g_ablation & 2) ? 0 : launchRadixSortPairs(g.stream, r->radix, 4, r->depthKey[0], r->depthKey[1], r->order[0], r->order[1], n, 0, kDepthKeyBits);
     const uint32_t* order = (const uint32_t*) r->order[orderSel];
     if (binned)
     {
@@ -1117,19 +1121,22 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
         r->graphKeyBytes = 0;
         return 0;
     }
-    launchTileListFastCount(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch);
-    launchTileListFastEmit(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],
-                           tileKeyBytes, r->values[0], r->tileListCapacity);
+    if (!(g_ablation & 4)) launchTileListFastCount(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch);
+    if (!(g_ablation & 8))
+        launchTileListFastEmit(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],
+                               tileKeyBytes, r->values[0], r->tileListCapacity);
     // tile sort + ranges on the device-side pair count (low word of the int64 total), grids sized for the capacity
     const int* pairCount = (const int*) r->scratch.total;
     r->radix.countDevice = pairCount;
     r->scratch.countDevice = nullptr;
-    const int sel = launchRadixSortPairs(g.stream, r->radix, tileKeyBytes, r->keys[0], r->keys[1], r->values[0], r->values[1],
-                                         r->tileListCapacity, 0, tBits);
+    const int sel = (g_ablation & 16) ? 0
+                                      : launchRadixSortPairs(g.stream, r->radix, tileKeyBytes, r->keys[0], r->keys[1], r->values[0], r->values[1],
+                                                             r->tileListCapacity, 0, tBits);
     r->radix.countDevice = nullptr;
-    launchTileRanges(g.stream, r->tileListCapacity, tileKeyBytes, r->keys[sel], r->tileRange, pairCount);
-    launchRasterize(g.stream, scr, r->tileRange, r->values[sel], (const float2*) r->clipXY, (const float4*) r->conic,
-                    (const float4*) r->color, (uchar4*) r->backBuffer, nullptr, true, lazyColours);
+    if (!(g_ablation & 32)) launchTileRanges(g.stream, r->tileListCapacity, tileKeyBytes, r->keys[sel], r->tileRange, pairCount);
+    if (!(g_ablation & 64))
+        launchRasterize(g.stream, scr, r->tileRange, r->values[sel], (const float2*) r->clipXY, (const float4*) r->conic,
+                        (const float4*) r->color, (uchar4*) r->backBuffer, nullptr, true, lazyColours);
     r->graphSelector = sel;
     r->graphKeyBytes = tileKeyBytes;
     return 0;
@@ -1205,7 +1212,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
                             r->scratch.totalHostMapped != nullptr;
         if (r->graphValid && (r->graphCapacity != r->tileListCapacity || r->graphSplats != n || r->graphRowBegin != scr.rowBegin ||
                               r->graphRowEnd != scr.rowEnd || r->graphCull != (int) cull || r->graphBinned != (int) binned ||
-                              r->graphFootprint != scr.epanechnikov || r->graphLazy != (int) lazy))
+                              r->graphFootprint != scr.epanechnikov || r->graphLazy != (int) lazy || r->graphAblation != g_ablation))
             r->graphValid = false;
         if (!r->graphValid)
         {
@@ -1232,6 +1239,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
             r->graphBinned = (int) binned;
             r->graphFootprint = scr.epanechnikov;
             r->graphLazy = (int) lazy;
+            r->graphAblation = g_ablation;
         }
         *r->scratch.totalHost = -1; // armed; the previous frame is complete, nothing else writes the word
         GS_CHECK(hipGraphLaunch(r->graphExec, g.stream));
@@ -1261,6 +1269,7 @@ extern "C" void gs_renderer_set_graph(GsRenderer* r, int enabled)
 }
 
 extern "C" int gs_renderer_captured_retries(const GsRenderer* r) { return r->capturedRetries; }
+extern "C" void gs_debug_set_ablation(int mask) { g_ablation = mask; }
 
 extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsFrameStats* stats)
 {

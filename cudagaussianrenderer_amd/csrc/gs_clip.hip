@@ -21,6 +21,21 @@ struct Sym3
     float xx, xy, xz, yy, yz, zz;
 };
 
+// Quantised depth of getKey() (GaussianRender.cu:446-454; (uint32) of 2^32 saturated) re-coded on kDepthKeyBits = 27 bits.
+// q = floor(n * 2^32) with n a float in [0, 1] has at most 24 significant bits: for q >= 2^23 the bits below (top bit - 23)
+// are zero, so (class = top bit position - 22, the 23 bits after the top bit) is a lossless, order-preserving code; q < 2^23
+// is its own code (class 0); the saturated 0xFFFFFFFF of n == 1 (the only value with 32 significant bits) gets class 10.
+__device__ __forceinline__ uint32_t compactDepthKey(float clipDepth)
+{
+    const float n01 = fminf(fmaxf((clipDepth + 1.0f) * 0.5f, 0.0f), 1.0f);
+    const float scaled = n01 * 4294967296.0f;
+    if (scaled >= 4294967296.0f) return 10u << 23;
+    const uint32_t q = (uint32_t) scaled;
+    if (q < (1u << 23)) return q;
+    const int top = 31 - __clz((int) q);
+    return ((uint32_t) (top - 22) << 23) | ((q >> (top - 23)) & 0x7FFFFFu);
+}
+
 __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr, ClipCamera camArg, const FrameParams* __restrict__ params,
                                                             const float4* __restrict__ position,
                                                             const float4* __restrict__ scaleAndRotation,
@@ -153,11 +168,9 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
     }
     if (depthKey != nullptr)
     {
-        // Quantised depth of getKey() (GaussianRender.cu:446-454) as a 32-bit sort key of its own, plus the
-        // identity permutation: the one-call renderer sorts SPLATS by depth before expanding them to tiles.
-        const float n01 = fminf(fmaxf((clipDepth + 1.0f) * 0.5f, 0.0f), 1.0f);
-        const float scaled = n01 * 4294967296.0f;
-        depthKey[index] = (scaled >= 4294967296.0f) ? 0xFFFFFFFFu : (uint32_t) scaled;
+        // Quantised depth of getKey() (GaussianRender.cu:446-454) as a sort key of its own (27-bit code, see above), plus
+        // the identity permutation: the one-call renderer sorts SPLATS by depth before expanding them to tiles.
+        depthKey[index] = compactDepthKey(clipDepth);
         splatOrder[index] = (uint32_t) index;
     }
     clipXY[index] = make_float2(clipX, clipY);
@@ -187,9 +200,7 @@ __global__ __launch_bounds__(256) void compactBandKernel(int count, const unsign
     {
         const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
         const int pos = waveOffsets[index >> 6] + __popcll(mask & lower);
-        const float n01 = fminf(fmaxf((clipZ[index] + 1.0f) * 0.5f, 0.0f), 1.0f);
-        const float scaled = n01 * 4294967296.0f;
-        depthKey[pos] = (scaled >= 4294967296.0f) ? 0xFFFFFFFFu : (uint32_t) scaled;
+        depthKey[pos] = compactDepthKey(clipZ[index]);
         splatOrder[pos] = (uint32_t) index;
     }
 }

@@ -203,6 +203,10 @@ void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileR
                      unsigned long long* consumedPairsOrNull, bool clearEmptyTiles = false,
                      const RasterColourSource* lazyColoursOrNull = nullptr);
 
+// The renderer sorts its splats on a 27-bit re-coding of getKey()'s 32-bit quantised depth (GaussianRender.cu:446-454): the
+// quantised value comes from a float, so it has at most 24 significant bits -- (position of the top bit, next 23 bits) says
+// everything: same order, same ties, three 9-bit radix passes instead of four 8-bit ones (gs_clip.hip: compactDepthKey).
+constexpr int kDepthKeyBits = 27;
 int sortEndBit(int totalTiles);
 int tileBits(int totalTiles);
 

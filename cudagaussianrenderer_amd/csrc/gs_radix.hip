@@ -6,7 +6,8 @@
 // passes (merge-sort fallback at 1 M elements, two memsets + look-back state per onesweep pass), so the
 // renderer uses this plain three-kernel pass instead; every kernel is barrier-free across workgroups (no
 // look-back, no spinning), so there is nothing that can hang:
-//   1. histogram   -- one workgroup per 1024/2048-element tile counts its 8-bit digits in LDS -> table[tile][digit];
+//   1. histogram   -- one workgroup per 1024/2048-element tile counts its digits (up to 9 bits: 512 bins, two per lane) in LDS
+//                     -> table[digit][tile];
 //   2. column scan -- one workgroup per digit: exclusive scan of that digit's column over the tiles + its total;
 //   3. scatter     -- the tile is re-read (keys and values in registers), ranked stably (ballot match + per-wave
 //                     running counters in LDS), reordered by digit in LDS, and written out as runs of consecutive
@@ -27,6 +28,7 @@ constexpr int kItemsLarge = 8;
 constexpr int kItemsSmall = 4;
 constexpr int kSmallLimit = 2 * 1024 * 1024;
 constexpr int kDigits = 256;
+constexpr int kMaxDigitBits = 9; // 512 bins: two per lane in the histogram and scatter kernels
 
 // Lanes of the wave whose (valid) digit equals this lane's digit.  Written on the two 32-bit halves of the mask with
 // xnor/and against the ballot of each digit bit: seven VALU instructions per bit and no scalar temporaries beyond the
@@ -58,7 +60,8 @@ __global__ __launch_bounds__(kThreads) void radixHistogramKernel(const K* __rest
                                                                   int skewed, int32_t* __restrict__ table, int stride)
 {
     constexpr int kTile = kThreads * ITEMS;
-    __shared__ int hist[kHistTiles][kDigits];
+    constexpr int DIGITS = BITS > 8 ? 2 * kDigits : kDigits; // 9-bit digits: every lane owns two bins
+    __shared__ int hist[kHistTiles][DIGITS];
     const int t = threadIdx.x;
     // The element count may live on the device (the renderer's band-culled splat list): nHost is then only the
     // upper bound the grid was sized for; tiles past the real count do nothing.
@@ -66,7 +69,9 @@ __global__ __launch_bounds__(kThreads) void radixHistogramKernel(const K* __rest
     const int firstTile = blockIdx.x * kHistTiles;
     if (firstTile * kTile >= n) return;
 #pragma unroll
-    for (int j = 0; j != kHistTiles; ++j) hist[j][t] = 0;
+    for (int j = 0; j != kHistTiles; ++j)
+#pragma unroll
+        for (int d = t; d < DIGITS; d += kThreads) hist[j][d] = 0;
     __syncthreads();
     for (int j = 0; j != kHistTiles; ++j)
     {
@@ -141,7 +146,9 @@ __global__ __launch_bounds__(kThreads) void radixHistogramKernel(const K* __rest
     }
     __syncthreads();
     // [digit][tile]: every digit's row is contiguous for the scan; stride is a multiple of 4, so the quad is aligned
-    *reinterpret_cast<int4*>(table + (size_t) t * stride + firstTile) = make_int4(hist[0][t], hist[1][t], hist[2][t], hist[3][t]);
+#pragma unroll
+    for (int d = t; d < DIGITS; d += kThreads)
+        *reinterpret_cast<int4*>(table + (size_t) d * stride + firstTile) = make_int4(hist[0][d], hist[1][d], hist[2][d], hist[3][d]);
 }
 
 // One workgroup (1024 lanes) per digit: exclusive scan of that digit's row of table[digit][tile] over the tiles
@@ -201,9 +208,11 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
 {
     constexpr int kTile = kThreads * ITEMS;
     constexpr int kDigitMask = (1 << BITS) - 1;
-    __shared__ int cnt[kWaves][kDigits]; // per-wave running digit counters, then per-wave exclusive prefixes
-    __shared__ int localBase[kDigits];   // first slot of each digit inside the tile
-    __shared__ int globalBase[kDigits];  // first output index of each digit for this tile
+    constexpr int DIGITS = BITS > 8 ? 2 * kDigits : kDigits; // 9-bit digits: 512 bins, lane t owns bins OWN*t .. OWN*t + OWN-1
+    constexpr int OWN = DIGITS / kThreads;
+    __shared__ int cnt[kWaves][DIGITS]; // per-wave running digit counters, then per-wave exclusive prefixes
+    __shared__ int localBase[DIGITS];   // first slot of each digit inside the tile
+    __shared__ int globalBase[DIGITS];  // first output index of each digit for this tile
     __shared__ int waveSums[2][kWaves];
     __shared__ K sKeys[kTile];
     __shared__ int32_t sVals[kTile];
@@ -232,10 +241,17 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
         key[r] = valid ? keysIn[i] : K(0);
         val[r] = valid ? valuesIn[i] : 0;
     }
-    const int digitTotal = totals[t];
-    const int tileEntry = scanned[t * stride + tile];
+    int digitTotal[OWN], tileEntry[OWN];
 #pragma unroll
-    for (int w = 0; w != kWaves; ++w) cnt[w][t] = 0;
+    for (int o = 0; o != OWN; ++o)
+    {
+        digitTotal[o] = totals[OWN * t + o];
+        tileEntry[o] = scanned[(size_t) (OWN * t + o) * stride + tile];
+    }
+#pragma unroll
+    for (int w = 0; w != kWaves; ++w)
+#pragma unroll
+        for (int o = 0; o != OWN; ++o) cnt[w][OWN * t + o] = 0;
     __syncthreads();
 
     // ---- stable rank inside the wave: ballot match, then running per-digit counters ----------------------
@@ -264,17 +280,26 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
     }
     __syncthreads();
 
-    // ---- per digit (lane t owns digit t): prefixes over waves, tile-local base, global base ----------
+    // ---- per digit (lane t owns OWN consecutive digits): prefixes over waves, tile-local base, global base ----------
     {
-        int sum = 0;
+        int sum[OWN], sumAll = 0, totalAll = 0;
 #pragma unroll
-        for (int w = 0; w != kWaves; ++w)
+        for (int o = 0; o != OWN; ++o)
         {
-            const int c = cnt[w][t];
-            cnt[w][t] = sum;
-            sum += c;
+            const int d = OWN * t + o;
+            int acc = 0;
+#pragma unroll
+            for (int w = 0; w != kWaves; ++w)
+            {
+                const int c = cnt[w][d];
+                cnt[w][d] = acc;
+                acc += c;
+            }
+            sum[o] = acc;
+            sumAll += acc;
+            totalAll += digitTotal[o];
         }
-        int inclLocal = sum, inclGlobal = digitTotal;
+        int inclLocal = sumAll, inclGlobal = totalAll;
 #pragma unroll
         for (int delta = 1; delta < kWave; delta <<= 1)
         {
@@ -299,8 +324,15 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
             beforeLocal += (w < wave) ? waveSums[0][w] : 0;
             beforeGlobal += (w < wave) ? waveSums[1][w] : 0;
         }
-        localBase[t] = beforeLocal + inclLocal - sum;
-        globalBase[t] = beforeGlobal + inclGlobal - digitTotal + tileEntry;
+        int local = beforeLocal + inclLocal - sumAll, global = beforeGlobal + inclGlobal - totalAll;
+#pragma unroll
+        for (int o = 0; o != OWN; ++o)
+        {
+            localBase[OWN * t + o] = local;
+            globalBase[OWN * t + o] = global + tileEntry[o];
+            local += sum[o];
+            global += digitTotal[o];
+        }
     }
     __syncthreads();
 
@@ -625,7 +657,7 @@ void runPassItems(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, 
     const int numTiles = (n + kTile - 1) / kTile;
     const int stride = (numTiles + 3) & ~3; // tiles per digit row of the tables
     hipLaunchKernelGGL((radixHistogramKernel<K, BITS, ITEMS>), dim3((numTiles + kHistTiles - 1) / kHistTiles), dim3(kThreads), 0, stream, keysIn, n, s.countDevice, shift, skewed ? 1 : 0, s.table, stride);
-    hipLaunchKernelGGL(radixColumnScanKernel, dim3(kDigits), dim3(kScanThreads), 0, stream, n, s.countDevice, kTile, stride, s.table, s.scanned, s.chunkTotals);
+    hipLaunchKernelGGL(radixColumnScanKernel, dim3(BITS > 8 ? 2 * kDigits : kDigits), dim3(kScanThreads), 0, stream, n, s.countDevice, kTile, stride, s.table, s.scanned, s.chunkTotals);
     hipLaunchKernelGGL((radixScatterKernel<K, BITS, ITEMS>), dim3(8 * ((numTiles + 7) / 8)), dim3(kThreads), 0, stream, keysIn, valuesIn, keysOut,
                        valuesOut, n, s.countDevice, shift, s.scanned, s.chunkTotals, stride);
 }
@@ -651,17 +683,19 @@ void runPassBits(hipStream_t stream, int bits, const K* keysIn, const int32_t* v
     case 5: runPass<K, 5>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
     case 6: runPass<K, 6>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
     case 7: runPass<K, 7>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
-    default: runPass<K, 8>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
+    case 8: runPass<K, 8>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
+    default: runPass<K, 9>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
     }
 }
 
 template <typename K>
 int sortT(hipStream_t stream, K* keys0, K* keys1, int32_t* values0, int32_t* values1, int n, int beginBit, int endBit, RadixScratch& s)
 {
-    // As few passes as 8-bit digits allow, the bits spread evenly over them (13 tile bits -> 7 + 6, not 8 + 5): fewer
-    // digits per pass means longer runs of consecutive output addresses per workgroup in BOTH passes.
+    // As few passes as 9-bit digits allow (512 bins, two per lane: the 27-bit compact depth keys sort in three passes), the bits
+    // spread evenly over them (13 tile bits -> 7 + 6, not 8 + 5): fewer digits per pass means longer runs of consecutive
+    // output addresses per workgroup in BOTH passes.  9 bits are only used where they save a pass (32 bits stay 4 x 8).
     const int totalBits = endBit - beginBit;
-    const int passes = (totalBits + 7) / 8;
+    const int passes = (totalBits + kMaxDigitBits - 1) / kMaxDigitBits;
     int sel = 0, shift = beginBit;
     for (int pass = 0; pass != passes; ++pass)
     {
@@ -688,7 +722,7 @@ void ensureRadixScratch(RadixScratch& s, int n)
 {
     const int tile = kThreads * itemsPerLane(n);
     const int numTiles = (n + tile - 1) / tile;
-    const int entries = kDigits * ((std::max(numTiles, 1) + 3) & ~3);
+    const int entries = 2 * kDigits * ((std::max(numTiles, 1) + 3) & ~3); // up to 512 digit rows
     if (entries > s.capacityEntries)
     {
         if (s.table) GS_CHECK(hipFree(s.table));
@@ -697,7 +731,7 @@ void ensureRadixScratch(RadixScratch& s, int n)
         GS_CHECK(hipMalloc((void**) &s.scanned, sizeof(int32_t) * (size_t) entries));
         s.capacityEntries = entries;
     }
-    if (s.chunkTotals == nullptr) GS_CHECK(hipMalloc((void**) &s.chunkTotals, sizeof(int32_t) * kDigits));
+    if (s.chunkTotals == nullptr) GS_CHECK(hipMalloc((void**) &s.chunkTotals, sizeof(int32_t) * 2 * kDigits));
     if (s.digitCounts == nullptr)
     {
         GS_CHECK(hipMalloc((void**) &s.digitCounts, sizeof(unsigned) * 4 * kDigits));

@@ -256,6 +256,9 @@ int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsF
  * capacity is NOT handed out truncated (the reference shows it and doubles the list for the next frame, Demo.cpp:357-366,447):
  * the list is grown, the frame re-captured and the same camera rendered again before the call returns. */
 void gs_renderer_set_graph(GsRenderer* r, int enabled);
+/* Diagnostics (bench.py --ablate): leave stages out of the captured frames -- bit 0 clip, 1 depth sort, 2 pair count, 3 pair emit,
+ * 4 tile sort, 5 ranges, 6 raster -- to measure what each stage costs the pipelined frame rate.  The images are garbage. */
+void gs_debug_set_ablation(int mask);
 /* Number of captured frames that had to be rendered again because the list was too small (diagnostics). */
 int gs_renderer_captured_retries(const GsRenderer* r);
 /* The same frame in two halves, so that one host thread can keep several renderers (each with its own stream and

@@ -404,7 +404,10 @@ def test_full_size_properties(gs, tmp_path_factory, n, w, h):
 
 
 @pytest.mark.parametrize("key_bytes,n,begin,end,skew", [(4, 1_000_003, 0, 32, False), (4, 4096, 0, 32, True), (4, 1, 0, 32, False),
-                                                      (2, 5_000_017, 0, 13, False), (2, 70_001, 0, 15, True), (4, 300_000, 8, 21, False)])
+                                                      (2, 5_000_017, 0, 13, False), (2, 70_001, 0, 15, True), (4, 300_000, 8, 21, False),
+                                                      # 9-bit digits (512 bins, two per lane): 27 bits = 3 x 9 (the depth codes), 18 = 2 x 9, 9 = 1 x 9
+                                                      (4, 1_000_003, 0, 27, False), (4, 200_000, 5, 23, False), (4, 300_000, 0, 9, True),
+                                                      (4, 2_500_000, 0, 26, False), (2, 9_001, 3, 12, False)])
 @pytest.mark.parametrize("backend", [1, 2])
 def test_native_radix_sort_bit_exact(gs, key_bytes, n, begin, end, skew, backend):
     """The renderer's own LSD radix sort (three-kernel passes, and the single-kernel look-back variant): stable,

@@ -1,0 +1,75 @@
+// frame_pump.cpp -- the pipelined frame loop of bench.py driven by NATIVE host threads (one per frame in flight) straight over
+// the C ABI, to separate what the GPU can do from what the Python harness adds (GIL, futures, ctypes marshalling).
+//   frame_pump scene.ply cams.bin W H rowBegin rowEnd inflight frames [graph=1]
+// cams.bin: consecutive GsCameraData structs (224 bytes each), written by tools/frame_pump.py.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+
+#include "gsplat_hip.h"
+
+int main(int argc, char** argv)
+{
+    if (argc < 9)
+    {
+        std::fprintf(stderr, "usage: %s scene.ply cams.bin W H rowBegin rowEnd inflight frames [graph]\n", argv[0]);
+        return 2;
+    }
+    const char* plyPath = argv[1];
+    const int W = std::atoi(argv[3]), H = std::atoi(argv[4]), rowBegin = std::atoi(argv[5]), rowEnd = std::atoi(argv[6]);
+    const int D = std::atoi(argv[7]), frames = std::atoi(argv[8]);
+    const int graph = argc > 9 ? std::atoi(argv[9]) : 1;
+    std::vector<GsCameraData> cams;
+    {
+        std::FILE* f = std::fopen(argv[2], "rb");
+        if (!f) return 1;
+        GsCameraData c;
+        while (std::fread(&c, sizeof(c), 1, f) == 1) cams.push_back(c);
+        std::fclose(f);
+    }
+    GsPly ply;
+    char err[256];
+    if (gs_parse_ply(plyPath, &ply, err, sizeof(err)) < 0)
+    {
+        std::fprintf(stderr, "%s\n", err);
+        return 1;
+    }
+    gs_set_device(0);
+    std::vector<GsRenderer*> rs(D);
+    std::vector<hipStream_t> streams(D);
+    for (int d = 0; d != D; ++d)
+    {
+        rs[d] = gs_renderer_create(W, H);
+        if (rowEnd > rowBegin) gs_renderer_set_tile_rows(rs[d], rowBegin, rowEnd);
+        gs_renderer_set_scene(rs[d], ply.vertexCount, ply.position, ply.scaleAndRotation, ply.color, ply.sphericalHarmonics,
+                              ply.sphericalHarmonicsDegree, ply.sphericalHarmonicsCount);
+        (void) hipStreamCreateWithFlags(&streams[d], hipStreamNonBlocking);
+        gs_renderer_set_stream(rs[d], streams[d]);
+        gs_renderer_set_graph(rs[d], graph);
+    }
+    auto run = [&](int count) {
+        std::vector<std::thread> threads;
+        for (int d = 0; d != D; ++d)
+            threads.emplace_back([&, d] {
+                gs_set_device(0);
+                for (int i = d; i < count; i += D) gs_renderer_render(rs[d], &cams[i % cams.size()], 0, nullptr);
+                (void) hipStreamSynchronize(streams[d]);
+            });
+        for (auto& t : threads) t.join();
+    };
+    run(8 * D);
+    const auto t0 = std::chrono::steady_clock::now();
+    run(frames);
+    const auto t1 = std::chrono::steady_clock::now();
+    const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count() / frames;
+    std::printf("{\"inflight\": %d, \"rows\": [%d, %d], \"graph\": %d, \"ms_per_frame\": %.4f, \"frames_per_s\": %.1f}\n", D, rowBegin, rowEnd, graph, ms,
+                1e3 / ms);
+    for (int d = 0; d != D; ++d) gs_renderer_destroy(rs[d]);
+    gs_free_ply(&ply);
+    return 0;
+}
