@@ -168,7 +168,7 @@ class Rig:
         import torch
 
         with torch.cuda.stream(self.streams[d]):
-            self.ctx["multigpu"].gather_bands(self.framebuffers[d], self.bands, self.ctx["rank"], self.ctx["world"])
+            self.ctx["multigpu"].gather_bands(self.framebuffers[d], self.bands, self.ctx["rank"], self.ctx["world"], comm=self.ctx["comm"])
 
     def run_frames(self, count, first=0):
         """Frame j's bands -> rank 0 (one grouped RCCL send/recv set, receives land directly in the framebuffer rows),
@@ -223,7 +223,7 @@ class Rig:
         with torch.cuda.stream(self.streams[0]):
             for i in range(steps):
                 r.render(self.cameras[i % len(self.cameras)], timed=2)
-                self.ctx["multigpu"].gather_bands(self.framebuffers[0], self.bands, self.ctx["rank"], self.ctx["world"])
+                self.ctx["multigpu"].gather_bands(self.framebuffers[0], self.bands, self.ctx["rank"], self.ctx["world"], comm=self.ctx["comm"])
             frames, sums = r.collect_stage_times()
         return {"sh": sums.msSphericalHarmonics / frames, "clip": sums.msClipData / frames, "tile_list": sums.msBuildTileList / frames,
                 "sort": sums.msSortTileList / frames, "ranges": sums.msTileRanges / frames, "raster": sums.msRasterize / frames}
@@ -347,6 +347,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=1, help="1 two-level sort (default, fastest at C3), 2 binned tile lists (no pair sort)")
     ap.add_argument("--band-cull", type=int, default=0, help="0 auto (compact the visible splats on strict bands only), 1 always, 2 never")
     ap.add_argument("--epanechnikov", action="store_true", help="the reference's EPANECHNIKOV_KERNEL option (footprint sqrt(7) sigma, density 1 - q/7)")
+    ap.add_argument("--gather", choices=["library", "torch"], default="library", help="multi-GPU framebuffer gather: the library's grouped ncclSend/ncclRecv (gs_gather_bands) or torch.distributed point-to-point operations")
     ap.add_argument("--rehearse", action="store_true", help="multi-rank control flow on ONE GPU: every rank on cuda:0, gloo instead of RCCL (not a measurement)")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostics: leave stages out of the timed frames (bit 0 clip, 1 depth sort, 2 count, 3 emit, 4 tile sort, 5 ranges, 6 raster); prints frames/s only")
     ap.add_argument("--inflight", type=int, default=0, help="frames in flight per GPU (renderers on separate HIP streams); 0 = 3 on one GPU, 4 per rank when the screen is split (measured optima)")
@@ -355,6 +356,11 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))  # nothing GPU-related has been imported yet
 
+    if args.gpus > 1:
+        # Four frames in flight per rank need four HIP streams that really run side by side: with the runtime's default of 4
+        # hardware queues four streams share two of them (tools/micro/graph_streams.hip: 4 chains take the time of 2), with 8
+        # they get one each.  Must be in the environment before the HIP runtime starts.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = 0 if args.rehearse else int(os.environ.get("LOCAL_RANK", "0"))
@@ -384,8 +390,10 @@ def main():
         lib.gs_set_raster_pixels_per_lane(args.ppl)
     if args.epanechnikov:
         gs.set_footprint(gs.FOOTPRINT_EPANECHNIKOV)
+    # the band gather's own communicator (RCCL through the C ABI); torch.distributed stays the bootstrap, barrier and timing reduce
+    comm = multigpu.BandComm(rank, world, device) if (world > 1 and not args.rehearse and args.gather == "library") else None
     ctx = {"gs": gs, "lib": lib, "multigpu": multigpu, "scenes": scenes, "rank": rank, "world": world, "local_rank": local_rank,
-           "device": device, "rehearse": args.rehearse}
+           "device": device, "rehearse": args.rehearse, "comm": comm}
 
     W, H, N = args.width, args.height, args.splats
     ply, t_ingest = make_scene(ctx, args, args.opacity_mean)
@@ -476,6 +484,9 @@ def main():
                 "pipeline": {1: "two_level", 2: "binned"}.get(args.pipeline, str(args.pipeline)),
                 "tile_row_bands": [list(b) for b in bands], "ingest_s": round(t_ingest, 2),
                 "dist_backend": backend, "dist_world_size": world, "rehearsal_on_one_gpu": bool(args.rehearse),
+                "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
+                "gather": None if world == 1 else ("gs_gather_bands: grouped ncclSend/ncclRecv through the C ABI" if comm is not None
+                                                   else "torch.distributed point-to-point"),
                 "gathered_frame_equals_single_gpu_frame": gathered_ok,
             },
             "roofline": {
@@ -524,6 +535,8 @@ def main():
 
     if world > 1:
         dist.barrier()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))

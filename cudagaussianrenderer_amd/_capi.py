@@ -185,6 +185,13 @@ SIGNATURES = {
     "gs_renderer_set_back_buffer": (None, [C.c_void_p, C.c_void_p]),
     "gs_renderer_read_back_buffer": (None, [C.c_void_p, C.c_void_p]),
     "gs_renderer_buffers": (None, [C.c_void_p, C.POINTER(RendererBuffers)]),
+    "gs_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "gs_comm_create": (C.c_void_p, [C.c_int, C.c_int, C.c_char_p]),
+    "gs_comm_destroy": (None, [C.c_void_p]),
+    "gs_comm_rank": (C.c_int, [C.c_void_p]),
+    "gs_comm_world": (C.c_int, [C.c_void_p]),
+    "gs_band_pixel_rows": (None, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gs_gather_bands": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
     "gs_version": (C.c_char_p, []),
 }
 

@@ -1075,9 +1075,14 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
     ClipCamera unusedCamera{};
 
     GS_CHECK(hipMemcpyAsync(r->paramsDevice, r->paramsHost, sizeof(FrameParams), hipMemcpyHostToDevice, g.stream));
-    // the range table is reset to -1 by the clip kernel (not a memset node: see gs_ranges.hip); binned frames write every range
+    // the range table is reset to -1 by the clip kernel (one node less than a memset; see gs_ranges.hip); binned frames write every range
     int32_t* clearTable = binned ? nullptr : r->tileRange;
     const int clearEntries = 2 * scr.totalTiles;
+#ifdef GS_DEBUG_MEMSET_NODE
+    // audit build (tools/micro/graph_memset.hip): the table is cleared by a memset NODE instead
+    if (clearTable != nullptr) GS_CHECK(hipMemsetAsync(clearTable, 0xFF, sizeof(int32_t) * (size_t) clearEntries, g.stream));
+    clearTable = nullptr;
+#endif
     if (r->shDegree != 0 && !cull && !lazy)
         launchSphericalHarmonics(g.stream, n, r->shDegree, r->shCount, (const float4*) r->position, r->sh, unused, (float4*) r->color,
                                  r->paramsDevice);

@@ -159,12 +159,17 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
         // Band cull for the multi-GPU split: does this splat's tile AABB reach the tile rows this GPU owns?  Same AABB
         // routine as the tile-list builder, so nothing that would emit a pair is dropped. One 64-bit mask per wave.
         const TileAabb box = splatTileAabb(clipX, clipY, cosA, sinA, extentX, extentY, scr);
-        const unsigned long long mask = __ballot(box.x1 > box.x0 && box.y1 > box.y0);
+        const bool kept = box.x1 > box.x0 && box.y1 > box.y0;
+        const unsigned long long mask = __ballot(kept);
         if ((threadIdx.x & (kWave - 1)) == 0)
         {
             bandMask[index >> 6] = mask;
             bandWaveCounts[index >> 6] = __popcll(mask);
         }
+        // Nothing downstream ever looks at a splat that does not reach the band (the compacted list holds the kept ones only):
+        // its 60 bytes of per-splat outputs are not written.  With 8 bands ~80 % of the splats stop here, which takes this
+        // replicated, HBM-bound pass from ~100 to ~45 bytes per splat.
+        if (!kept) return;
     }
     if (depthKey != nullptr)
     {

@@ -289,6 +289,26 @@ typedef struct GsRendererBuffers
 } GsRendererBuffers;
 void gs_renderer_buffers(GsRenderer* r, GsRendererBuffers* out);
 
+/* ---- multi-GPU: framebuffer gather (no counterpart in the single-GPU reference) --------------------
+ * One process per GPU.  Rank r renders tile rows [bands[2r], bands[2r+1]) of the frame (gs_renderer_set_tile_rows) into its own
+ * full-size back buffer; gs_gather_bands then moves every band's pixel rows to `root` with ONE grouped ncclSend/ncclRecv set,
+ * enqueued on `hipStream` (use the stream the frame was rendered on: the transfer then waits for the raster kernel, and the next
+ * frame of that renderer waits for the transfer).  The root's receives land directly in the destination rows of its back buffer.
+ * RCCL (librccl.so.1) is loaded on first use; a world of 1 needs no RCCL and every call is a no-op.
+ * Bootstrap: rank 0 calls gs_comm_unique_id and hands the 128 bytes to the other ranks by any means (MPI, a file, a socket,
+ * torch.distributed); every rank then calls gs_comm_create with its device current (gs_set_device). */
+#define GS_COMM_UNIQUE_ID_BYTES 128
+typedef struct GsComm GsComm;
+int gs_comm_unique_id(char out[GS_COMM_UNIQUE_ID_BYTES]);                       /* 0, or -1 when RCCL is unavailable        */
+GsComm* gs_comm_create(int rank, int world, const char uniqueId[GS_COMM_UNIQUE_ID_BYTES]); /* NULL on failure; id ignored at world 1 */
+void gs_comm_destroy(GsComm* comm);
+int gs_comm_rank(const GsComm* comm);
+int gs_comm_world(const GsComm* comm);
+/* Pixel rows [rowBegin, rowEnd) of a tile-row band; the last band may end on a partial tile row. */
+void gs_band_pixel_rows(int tileRowBegin, int tileRowEnd, int height, int* rowBegin, int* rowEnd);
+/* tileRowBands: 2 * world int32 (begin, end per rank).  Returns 0, -1 on bad arguments, -2 on an RCCL error. */
+int gs_gather_bands(GsComm* comm, uint8_t* deviceBackBuffer, int width, int height, const int32_t* tileRowBands, int root, void* hipStream);
+
 const char* gs_version(void);
 
 #ifdef __cplusplus

@@ -178,3 +178,22 @@ def test_public_header_is_plain_c(tmp_path):
                     "-Wl,-rpath," + libdir], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert out == ["45", "44"]  # 32 + ceil(log2(tiles)): 8160 tiles -> 13 bits, 4096 tiles -> 12 bits
+
+
+def test_band_gather_entry_points_without_a_gpu(gs):
+    """include/gsplat_hip.h multi-GPU section: pixel rows of a band, and a world of one (no RCCL, every call a no-op)."""
+    import ctypes as C
+
+    lib = gs.lib()
+    a, b = C.c_int(), C.c_int()
+    lib.gs_band_pixel_rows(60, 68, 1080, C.byref(a), C.byref(b))
+    assert (a.value, b.value) == (960, 1080)  # the last tile row of 1080p is half a tile
+    lib.gs_band_pixel_rows(9, 18, 1080, C.byref(a), C.byref(b))
+    assert (a.value, b.value) == (144, 288)
+    comm = lib.gs_comm_create(0, 1, None)
+    assert comm and lib.gs_comm_rank(comm) == 0 and lib.gs_comm_world(comm) == 1
+    bands = (C.c_int32 * 2)(0, 68)
+    assert lib.gs_gather_bands(comm, C.c_void_p(16), 1920, 1080, bands, 0, None) == 0  # nothing is touched at world 1
+    assert lib.gs_gather_bands(comm, C.c_void_p(16), 1920, 1080, bands, 3, None) == -1  # root outside the world
+    lib.gs_comm_destroy(comm)
+    assert not lib.gs_comm_create(2, 2, None)  # rank outside the world

@@ -3,12 +3,18 @@
 //
 //   gsplat_demo scene.ply [width height frames out.ppm]     render a 3DGS .ply from its default camera pose
 //   gsplat_demo --procedural N [width height frames out.ppm] N random splats (Demo.cpp:119-143, seeded)
+//   ... --world N --rank R --id-file PATH                    one process per GPU (device R): rank R builds, sorts and rasterises
+//                                                            its band of tile rows only, and the bands are gathered on rank 0
+//                                                            with the library's RCCL exchange (gs_gather_bands) every frame; the
+//                                                            128-byte RCCL id travels through PATH.  Rank 0 writes the image.
 //
 // Build: make -C cudagaussianrenderer_amd/csrc demo
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "GaussianRender.hpp"
@@ -19,6 +25,47 @@ int main(int argc, char** argv)
     {
         std::fprintf(stderr, "usage: %s scene.ply|--procedural N [width height frames out.ppm]\n", argv[0]);
         return 2;
+    }
+    // multi-GPU options (anywhere on the command line)
+    int world = 1, rank = 0;
+    const char* idFile = nullptr;
+    std::vector<char*> positional;
+    for (int i = 0; i < argc; ++i)
+    {
+        if (std::strcmp(argv[i], "--world") == 0 && i + 1 < argc) world = std::atoi(argv[++i]);
+        else if (std::strcmp(argv[i], "--rank") == 0 && i + 1 < argc) rank = std::atoi(argv[++i]);
+        else if (std::strcmp(argv[i], "--id-file") == 0 && i + 1 < argc) idFile = argv[++i];
+        else positional.push_back(argv[i]);
+    }
+    argc = (int) positional.size();
+    argv = positional.data();
+    if (world > 1) gs_set_device(rank);
+    GsComm* comm = nullptr;
+    {
+        char id[GS_COMM_UNIQUE_ID_BYTES] = {0};
+        if (world > 1)
+        {
+            if (idFile == nullptr) return 2;
+            const std::string tmp = std::string(idFile) + ".tmp";
+            if (rank == 0)
+            {
+                if (gs_comm_unique_id(id) != 0) return 1;
+                std::FILE* f = std::fopen(tmp.c_str(), "wb");
+                std::fwrite(id, 1, sizeof(id), f);
+                std::fclose(f);
+                std::rename(tmp.c_str(), idFile);
+            }
+            else
+            {
+                std::FILE* f = nullptr;
+                for (int tries = 0; tries != 600 && (f = std::fopen(idFile, "rb")) == nullptr; ++tries)
+                    std::this_thread::sleep_for(std::chrono::milliseconds(100));
+                if (f == nullptr || std::fread(id, 1, sizeof(id), f) != sizeof(id)) return 1;
+                std::fclose(f);
+            }
+        }
+        comm = gs_comm_create(rank, world, id);
+        if (comm == nullptr) return 1;
     }
     int arg = 1;
     std::vector<gs::float4_t> position, scaleAndRotation, color;
@@ -53,6 +100,14 @@ int main(int argc, char** argv)
 
     int tilesX = 0, tilesY = 0;
     gs_tile_counts(width, height, &tilesX, &tilesY);
+    // contiguous bands of tile rows, sizes differing by at most one (1080p, 8 ranks: 9,9,9,9,8,8,8,8)
+    std::vector<int32_t> bands(2 * (size_t) world);
+    for (int r = 0, begin = 0; r != world; ++r)
+    {
+        const int rows = tilesY / world + (r < tilesY % world ? 1 : 0);
+        bands[2 * r] = begin;
+        bands[2 * r + 1] = begin += rows;
+    }
 
     // Device buffers, owned by the caller as in the reference.
     gs::DeviceBuffer<gs::float4_t> positionBuffer(position), scaleAndRotationBuffer(scaleAndRotation), colorBuffer(color);
@@ -104,6 +159,8 @@ int main(int argc, char** argv)
         args.tileRange = tileRangeBuffer.getPtr();
         args.width = width;
         args.height = height;
+        args.tileRowBegin = world > 1 ? bands[2 * rank] : 0;
+        args.tileRowEnd = world > 1 ? bands[2 * rank + 1] : 0;
         gs::setGlobalArgs(&args);
 
         gs::TileListArgs list{keysA.getPtr(), valuesA.getPtr(), 0, capacity};
@@ -137,6 +194,8 @@ int main(int argc, char** argv)
         }
         gs::rasterizeTile(timer);
         msRaster += timer.getElapseTimedMs();
+        // the one exchange of the frame: every band's pixel rows -> rank 0's back buffer (no-op in a world of one)
+        if (gs_gather_bands(comm, &backBuffer.getPtr()->x, width, height, bands.data(), 0, gs_get_stream()) != 0) return 1;
         gs_synchronize();
     }
     gs_device_free(sortTemp);
@@ -148,7 +207,8 @@ int main(int argc, char** argv)
                 msSh / f, msClip / f, msBuild / f, msSort / f, msRanges / f, msRaster / f,
                 (msSh + msClip + msBuild + msSort + msRanges + msRaster) / f);
 
-    if (outPath != nullptr)
+    gs_comm_destroy(comm);
+    if (outPath != nullptr && rank == 0)
     {
         std::vector<gs::uchar4_t> image;
         backBuffer.copyTo(image, (size_t) width * height);
