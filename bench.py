@@ -350,17 +350,17 @@ def main():
     ap.add_argument("--gather", choices=["library", "torch"], default="library", help="multi-GPU framebuffer gather: the library's grouped ncclSend/ncclRecv (gs_gather_bands) or torch.distributed point-to-point operations")
     ap.add_argument("--rehearse", action="store_true", help="multi-rank control flow on ONE GPU: every rank on cuda:0, gloo instead of RCCL (not a measurement)")
     ap.add_argument("--ablate", type=int, default=0, help="diagnostics: leave stages out of the timed frames (bit 0 clip, 1 depth sort, 2 count, 3 emit, 4 tile sort, 5 ranges, 6 raster); prints frames/s only")
-    ap.add_argument("--inflight", type=int, default=0, help="frames in flight per GPU (renderers on separate HIP streams); 0 = 3 on one GPU, 4 per rank when the screen is split (measured optima)")
+    ap.add_argument("--inflight", type=int, default=0, help="frames in flight per GPU (renderers on separate HIP streams); 0 = 4 (the measured optimum with 8 hardware queues)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))  # nothing GPU-related has been imported yet
 
-    if args.gpus > 1:
-        # Four frames in flight per rank need four HIP streams that really run side by side: with the runtime's default of 4
-        # hardware queues four streams share two of them (tools/micro/graph_streams.hip: 4 chains take the time of 2), with 8
-        # they get one each.  Must be in the environment before the HIP runtime starts.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # Four frames in flight need four HIP streams that really run side by side: with the runtime's default of 4 hardware queues
+    # four streams share two of them (tools/micro/graph_streams.hip: 4 chains take the time of 2), with 8 they get one each
+    # (profiles/r02_frame_pump.txt: 4 879 -> 5 030 frames/s on one GPU, 0.088 -> 0.070 ms per frame of an 8-way band).  Must be
+    # in the environment before the HIP runtime starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = 0 if args.rehearse else int(os.environ.get("LOCAL_RANK", "0"))
@@ -415,7 +415,7 @@ def main():
             row_cost += counts.sum(1) + 6.0 * np.minimum(counts, 256.0).sum(1)
         cal.close()
         bands = scenes.balanced_tile_row_bands(row_cost, world)
-    depth = args.inflight if args.inflight > 0 else (3 if world == 1 else 4)
+    depth = args.inflight if args.inflight > 0 else 4
 
     rig = Rig(ctx, ply, cameras, bands, depth, args)
     if args.ablate >= 0 and args.ablate != 0 or "--ablate" in sys.argv:

@@ -162,8 +162,6 @@ int launchRadixSortPairs(hipStream_t stream, RadixScratch& s, int keyBytes, void
 void launchTileRanges(hipStream_t stream, int size, int keyBytes, const void* keys, int32_t* tileRange,
                       const int* sizeDevice = nullptr);
 
-void launchFillInt32(hipStream_t stream, int32_t* p, int32_t value, int n);
-
 // Binned tile lists (gs_bins.hip): depth-sorted splats -> final per-tile lists + ranges, no pair sort.
 constexpr int kBinMaxTiles = 8192; // LDS cursor table: 4 bytes per band tile and wave
 struct BinScratch

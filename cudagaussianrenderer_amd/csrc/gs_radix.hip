@@ -151,9 +151,11 @@ __global__ __launch_bounds__(kThreads) void radixHistogramKernel(const K* __rest
         *reinterpret_cast<int4*>(table + (size_t) d * stride + firstTile) = make_int4(hist[0][d], hist[1][d], hist[2][d], hist[3][d]);
 }
 
-// One workgroup (1024 lanes) per digit: exclusive scan of that digit's row of table[digit][tile] over the tiles
-// (contiguous: 16 bytes per lane and round), row total to totals[digit].
-constexpr int kScanThreads = 1024;
+// One workgroup per digit: exclusive scan of that digit's row of table[digit][tile] over the tiles (contiguous: 16 bytes per
+// lane and round), row total to totals[digit].  256 lanes for rows of up to 4096 tiles (one to four rounds), 1024 lanes beyond:
+// the kernel is pure latency, and with 1024 lanes per digit its 256-512 workgroups took every wave slot of the chip, so that in
+// the pipelined frame loop nothing of the other frames could run beside it (17 us per launch there against 5 us alone).
+template <int kScanThreads>
 __global__ __launch_bounds__(kScanThreads) void radixColumnScanKernel(int nHost, const int* __restrict__ nDevice, int tileElements, int stride,
                                                                       const int32_t* __restrict__ table, int32_t* __restrict__ scanned,
                                                                       int32_t* __restrict__ totals)
@@ -657,7 +659,13 @@ void runPassItems(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, 
     const int numTiles = (n + kTile - 1) / kTile;
     const int stride = (numTiles + 3) & ~3; // tiles per digit row of the tables
     hipLaunchKernelGGL((radixHistogramKernel<K, BITS, ITEMS>), dim3((numTiles + kHistTiles - 1) / kHistTiles), dim3(kThreads), 0, stream, keysIn, n, s.countDevice, shift, skewed ? 1 : 0, s.table, stride);
-    hipLaunchKernelGGL(radixColumnScanKernel, dim3(BITS > 8 ? 2 * kDigits : kDigits), dim3(kScanThreads), 0, stream, n, s.countDevice, kTile, stride, s.table, s.scanned, s.chunkTotals);
+#ifndef GS_SCAN_ROW_LIMIT
+#define GS_SCAN_ROW_LIMIT 4096 // A/B builds: 0 = always 1024 lanes
+#endif
+    if (numTiles <= GS_SCAN_ROW_LIMIT)
+        hipLaunchKernelGGL(radixColumnScanKernel<256>, dim3(BITS > 8 ? 2 * kDigits : kDigits), dim3(256), 0, stream, n, s.countDevice, kTile, stride, s.table, s.scanned, s.chunkTotals);
+    else
+        hipLaunchKernelGGL(radixColumnScanKernel<1024>, dim3(BITS > 8 ? 2 * kDigits : kDigits), dim3(1024), 0, stream, n, s.countDevice, kTile, stride, s.table, s.scanned, s.chunkTotals);
     hipLaunchKernelGGL((radixScatterKernel<K, BITS, ITEMS>), dim3(8 * ((numTiles + 7) / 8)), dim3(kThreads), 0, stream, keysIn, valuesIn, keysOut,
                        valuesOut, n, s.countDevice, shift, s.scanned, s.chunkTotals, stride);
 }

@@ -71,25 +71,14 @@ void launchT(hipStream_t stream, int size, const void* keys, int32_t* tileRange,
     hipLaunchKernelGGL(tileRangesKernel<Key>, dim3((lanes + 255) / 256), dim3(256), 0, stream, size, sizeDevice, (const Key*) keys, tileRange);
 }
 
-// Plain fill kernel for the range table (renderer paths whose clip kernel does not reset the table on the side).
-// History: in round 1 a hipMemsetAsync NODE of a captured band frame was seen to leave bytes that were not 0xFF, and the clear was
-// moved into the clip kernel.  Round 2 looked for the cause: a standalone 28-node graph with a memcpy node, a memset node and
-// by-value 96-byte kernel arguments (tools/micro/graph_memset.hip, 400 replays, both node orders) never shows it, and neither
-// does the library itself built with the memset node back in place (-DGS_DEBUG_MEMSET_NODE: all captured / band / cull tests
-// pass).  So it was not a ROCm defect; whatever wrote into the table then is gone.  The clear stays in the clip kernel because
-// it is one graph node less, not as a workaround.
-__global__ __launch_bounds__(256) void fillInt32Kernel(int32_t* __restrict__ p, int32_t value, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = value;
-}
+// History of the range-table clear: in round 1 a hipMemsetAsync NODE of a captured band frame was seen to leave bytes that were not
+// 0xFF, and the clear was moved into the clip kernel.  Round 2 looked for the cause: a standalone 28-node graph with a memcpy node,
+// a memset node and by-value 96-byte kernel arguments (tools/micro/graph_memset.hip, 400 replays, both node orders) never shows it,
+// and neither does the library itself built with the memset node back in place (-DGS_DEBUG_MEMSET_NODE: all captured / band / cull
+// tests pass).  So it was not a ROCm defect; whatever wrote into the table then is gone.  The clear stays in the clip kernel
+// because it is one graph node less, not as a workaround.
 
 } // namespace
-
-void launchFillInt32(hipStream_t stream, int32_t* p, int32_t value, int n)
-{
-    if (n > 0) hipLaunchKernelGGL(fillInt32Kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, value, n);
-}
 
 void launchTileRanges(hipStream_t stream, int size, int keyBytes, const void* keys, int32_t* tileRange, const int* sizeDevice)
 {

@@ -1,35 +1,55 @@
 #!/bin/bash
-# usage: tools/collect_profiles.sh r01   -- copies the summaries tools/profile_round.sh left in gpurun_out/ into profiles/
-TAG=${1:-r01}
+# usage: tools/collect_profiles.sh r02   -- copies the summaries tools/profile_round.sh left in gpurun_out/ into profiles/
+TAG=${1:-r02}
 G=gpurun_out
 tail -1 $G/${TAG}_bench_c3.json > profiles/${TAG}_bench_c3.json
 tail -1 $G/${TAG}_bench_under_rocprof.json > profiles/${TAG}_bench_under_rocprof_pipelined.json
 tail -1 $G/${TAG}_bench_under_rocprof_serial.json > profiles/${TAG}_bench_under_rocprof_serial.json
 cp $G/${TAG}_stats/stats_kernel_stats.csv profiles/${TAG}_kernel_stats_pipelined.csv
 cp $G/${TAG}_stats_serial/stats_kernel_stats.csv profiles/${TAG}_kernel_stats_serial.csv
-cp $G/${TAG}_pmc_FETCH_SIZE/pmc_counter_collection_summary.txt profiles/${TAG}_pmc_fetch_size_kb.txt
-cp $G/${TAG}_pmc_WRITE_SIZE/pmc_counter_collection_summary.txt profiles/${TAG}_pmc_write_size_kb.txt
+cp $G/${TAG}_pmc_FETCH_SIZE.txt profiles/${TAG}_pmc_fetch_size_kb.txt
+cp $G/${TAG}_pmc_WRITE_SIZE.txt profiles/${TAG}_pmc_write_size_kb.txt
+cat $G/${TAG}_pmc_SQ_BUSY_CYCLES.txt $G/${TAG}_pmc_SQ_ACTIVE_INST_LDS.txt $G/${TAG}_pmc_SQ_WAIT_ANY.txt > profiles/${TAG}_pmc_sq_counters.txt
+for f in band_sim ablation frame_pump raster_trace raster_trace_low_opacity micro_valu_lds_rate micro_graph_streams micro_atomic_rate micro_graph_memset; do
+  [ -f $G/${TAG}_$f.txt ] && cp $G/${TAG}_$f.txt profiles/${TAG}_$f.txt
+done
 python3 - "$TAG" <<'PY'
-import json, re, sys
+import json, sys
+sys.path.insert(0, ".")
+import bench
 tag = sys.argv[1]
-def raster(path, key):
+def raster(path):
     for line in open(path):
         if line.startswith("void rasterizeTilesKernel"):
-            d = eval(line[line.index("{"):line.index("}") + 1])
-            return d[key], int(line.rsplit(" ", 1)[1])
-f, n = raster(f"profiles/{tag}_pmc_fetch_size_kb.txt", "FETCH_SIZE")
-w, _ = raster(f"profiles/{tag}_pmc_write_size_kb.txt", "WRITE_SIZE")
-json.dump({"kernel": "rasterizeTilesKernel<2>",
-           "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), bench.py --steps 16 --warmup 4 --inflight 1 --no-graph, mean per dispatch over {n} dispatches; profiles/{tag}_pmc_fetch_size_kb.txt, {tag}_pmc_write_size_kb.txt",
-           "fetch_size_kb_raw": f, "write_size_kb": w,
-           "correction": "MI355X_MICROARCH.md: FETCH_SIZE reports 1/2 of the bytes of WIDE coalesced streaming reads; the raster's reads are 4-B list entries plus 8/16-B gathers (uncalibrated width), so the raw value is reported as the lower bound and 2x as the upper bound",
-           "traffic_bytes_per_launch_low": (f + w) * 1024, "traffic_bytes_per_launch_high": (2 * f + w) * 1024},
-          open(f"profiles/{tag}_pmc_raster.json", "w"), indent=1)
-# the bench line of this very run read the PREVIOUS counter file: attach the counters collected with it
-bench = json.load(open(f"profiles/{tag}_bench_c3.json"))
-bench["roofline"]["traffic"] = round((f + w) * 1024)
-bench["roofline"]["traffic_source"] = (f"profiles/{tag}_pmc_raster.json (FETCH_SIZE raw + WRITE_SIZE; gather widths are uncalibrated, "
-                                       f"upper bound {round((2 * f + w) * 1024)} with the wide-read 2x correction)")
-json.dump(bench, open(f"profiles/{tag}_bench_c3.json", "w"))
+            return eval(line[line.index("{"):line.index("}") + 1]), int(line.rsplit(" ", 1)[1])
+    raise SystemExit("no raster line in " + path)
+f, n = raster(f"profiles/{tag}_pmc_fetch_size_kb.txt")
+w, _ = raster(f"profiles/{tag}_pmc_write_size_kb.txt")
+sq = {}
+for line in open(f"profiles/{tag}_pmc_sq_counters.txt"):
+    if line.startswith("void rasterizeTilesKernel"):
+        sq.update(eval(line[line.index("{"):line.index("}") + 1]))
+simds, ses = 256 * 4, 32
+busy = sq["SQ_BUSY_CYCLES"] / ses          # SQ_BUSY_CYCLES counts per shader engine (8 XCDs x 4): cycles the kernel kept an SE busy
+out = {
+    "kernel": "rasterizeTilesKernel<2, gaussian, SH 3>", "source_hash": bench.source_hash(),
+    "workload": "bench.py default scene (1 M splats, SH 3, 1920x1080, seed 1234), --steps 16 --warmup 4 --inflight 1 --no-graph",
+    "fetch_size_kb_raw": f["FETCH_SIZE"], "write_size_kb": w["WRITE_SIZE"], "dispatches": n,
+    "traffic_bytes_per_launch": (f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024,
+    "traffic_bytes_per_launch_high": (2 * f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024,
+    "traffic_source": f"profiles/{tag}_pmc_fetch_size_kb.txt + {tag}_pmc_write_size_kb.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
+                      "kernel trace only, mean per dispatch; FETCH_SIZE raw (the kernel's reads are 4-byte list entries and 8/16-byte gathers: "
+                      "MI355X_MICROARCH.md calibrates the 2x under-count only for wide coalesced streams, so raw is the lower bound and "
+                      "traffic_bytes_per_launch_high the upper)",
+    "sq": sq,
+    "sq_source": f"profiles/{tag}_pmc_sq_counters.txt; SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md:488), SQ_BUSY_CYCLES per shader engine",
+    "busy_cycles_per_se": busy,
+    "waves_per_simd": round(4 * sq["SQ_WAVE_CYCLES"] / (simds * busy), 3),
+    "valu_issue_frac": round(4 * sq["SQ_ACTIVE_INST_VALU"] / (simds * busy), 3),
+    "cycles_per_valu_instruction": round(4 * sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_INSTS_VALU"], 2),
+    "waves_per_simd_if_counters_were_cycles": round(sq["SQ_WAVE_CYCLES"] / (simds * busy), 3),
+}
+json.dump(out, open(f"profiles/{tag}_pmc_raster.json", "w"), indent=1)
+print(json.dumps({k: out[k] for k in ("traffic_bytes_per_launch", "waves_per_simd", "valu_issue_frac", "cycles_per_valu_instruction", "source_hash")}))
 PY
-ls profiles
+ls profiles | grep $TAG

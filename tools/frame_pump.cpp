@@ -1,6 +1,9 @@
 // frame_pump.cpp -- the pipelined frame loop of bench.py driven by NATIVE host threads (one per frame in flight) straight over
 // the C ABI, to separate what the GPU can do from what the Python harness adds (GIL, futures, ctypes marshalling).
-//   frame_pump scene.ply cams.bin W H rowBegin rowEnd inflight frames [graph=1]
+//   frame_pump scene.ply cams.bin W H rowBegin rowEnd inflight frames [graph=1] [mask=0]
+// mask: 0 = plain streams; 1 = every stream restricted to its own share of the compute units, bits dealt round-robin
+// (bit i -> stream i % inflight: with the driver's XCC-interleaved mask layout a share of whole XCDs when inflight divides 8);
+// 2 = contiguous shares of the mask (bit i -> stream i / (256 / inflight)).
 // cams.bin: consecutive GsCameraData structs (224 bytes each), written by tools/frame_pump.py.
 #include <chrono>
 #include <cstdio>
@@ -24,6 +27,7 @@ int main(int argc, char** argv)
     const int W = std::atoi(argv[3]), H = std::atoi(argv[4]), rowBegin = std::atoi(argv[5]), rowEnd = std::atoi(argv[6]);
     const int D = std::atoi(argv[7]), frames = std::atoi(argv[8]);
     const int graph = argc > 9 ? std::atoi(argv[9]) : 1;
+    const int maskMode = argc > 10 ? std::atoi(argv[10]) : 0;
     std::vector<GsCameraData> cams;
     {
         std::FILE* f = std::fopen(argv[2], "rb");
@@ -48,7 +52,17 @@ int main(int argc, char** argv)
         if (rowEnd > rowBegin) gs_renderer_set_tile_rows(rs[d], rowBegin, rowEnd);
         gs_renderer_set_scene(rs[d], ply.vertexCount, ply.position, ply.scaleAndRotation, ply.color, ply.sphericalHarmonics,
                               ply.sphericalHarmonicsDegree, ply.sphericalHarmonicsCount);
-        (void) hipStreamCreateWithFlags(&streams[d], hipStreamNonBlocking);
+        if (maskMode == 0) (void) hipStreamCreateWithFlags(&streams[d], hipStreamNonBlocking);
+        else
+        {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // 256 compute units
+            for (int cu = 0; cu != 256; ++cu)
+            {
+                const int owner = maskMode == 1 ? cu % D : cu / ((256 + D - 1) / D);
+                if (owner == d) mask[cu >> 5] |= 1u << (cu & 31);
+            }
+            if (hipExtStreamCreateWithCUMask(&streams[d], 8, mask) != hipSuccess) return 3;
+        }
         gs_renderer_set_stream(rs[d], streams[d]);
         gs_renderer_set_graph(rs[d], graph);
     }
@@ -67,8 +81,8 @@ int main(int argc, char** argv)
     run(frames);
     const auto t1 = std::chrono::steady_clock::now();
     const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count() / frames;
-    std::printf("{\"inflight\": %d, \"rows\": [%d, %d], \"graph\": %d, \"ms_per_frame\": %.4f, \"frames_per_s\": %.1f}\n", D, rowBegin, rowEnd, graph, ms,
-                1e3 / ms);
+    std::printf("{\"inflight\": %d, \"rows\": [%d, %d], \"graph\": %d, \"cu_mask\": %d, \"ms_per_frame\": %.4f, \"frames_per_s\": %.1f}\n", D, rowBegin,
+                rowEnd, graph, maskMode, ms, 1e3 / ms);
     for (int d = 0; d != D; ++d) gs_renderer_destroy(rs[d]);
     gs_free_ply(&ply);
     return 0;

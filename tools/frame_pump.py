@@ -23,8 +23,11 @@ env = dict(os.environ)
 for extra in sys.argv[1:]:
     k, v = extra.split("=")
     env[k] = v
+masks = [int(v) for v in os.environ.get("PUMP_MASKS", "0").split(",")]
+depths = [int(v) for v in os.environ.get("PUMP_DEPTHS", "1,2,3,4,6").split(",")]
 for rows in [(0, 0), (29, 34), (0, 17)]:
-    for d in (1, 2, 3, 4, 6):
-        print(subprocess.run([exe, ply_path, os.path.join(out, "cams.bin"), str(W), str(H), str(rows[0]), str(rows[1]), str(d), "512"], env=env,
-                             stdout=subprocess.PIPE, text=True).stdout.strip(), flush=True)
+    for mask in masks:
+        for d in depths:
+            print(subprocess.run([exe, ply_path, os.path.join(out, "cams.bin"), str(W), str(H), str(rows[0]), str(rows[1]), str(d), "512", "1", str(mask)],
+                                 env=env, stdout=subprocess.PIPE, text=True).stdout.strip(), flush=True)
 os.remove(ply_path)

@@ -1,24 +1,33 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): tools/profile_round.sh r01
-# Writes under gpurun_out/<tag>_*: the default bench line, rocprofv3 kernel stats of the same command, and HBM traffic
-# counters (separate --pmc passes, kernel trace only, as MI355X_MICROARCH.md prescribes).
-set -e
-TAG=${1:-r01}
+# usage (on the GPU box, from the repo root): tools/profile_round.sh r02
+# Writes under gpurun_out/<tag>_*: the default bench line, rocprofv3 kernel stats of the same command (pipelined) and of the
+# frames one at a time (serial), HBM traffic and SQ counters of the kernels (separate --pmc passes, kernel trace only, as
+# MI355X_MICROARCH.md prescribes), and the diagnostic tables DESIGN.md cites.  tools/collect_profiles.sh copies the summaries
+# into profiles/.
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
+cd $ROOT
+python3 bench.py > $OUT/${TAG}_bench_c3.json 2> $OUT/${TAG}_bench_c3.err; echo "bench rc=$?"
 cd /tmp && export TMPDIR=/tmp
-python3 $ROOT/bench.py > $OUT/${TAG}_bench_c3.json 2> $OUT/${TAG}_bench_c3.err
-echo "bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o stats -- python3 $ROOT/bench.py --steps 256 --warmup 32 --cpu-frames 0 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_stats.err
-echo "stats done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o stats -- python3 $ROOT/bench.py --steps 256 --warmup 32 --cpu-frames 0 --no-extra > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_stats.err; echo "stats rc=$?"
 # the same frames one at a time (one frame in flight, plain launches): per-kernel averages without overlap from other frames,
 # comparable with the per-stage HIP-event times bench.py reports in "stages" / "roofline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_serial -o stats -- python3 $ROOT/bench.py --steps 256 --warmup 32 --cpu-frames 0 --inflight 1 --no-graph > $OUT/${TAG}_bench_under_rocprof_serial.json 2> $OUT/${TAG}_stats_serial.err
-echo "serial stats done"
-for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$c -o pmc -- python3 $ROOT/bench.py --steps 16 --warmup 4 --cpu-frames 0 --inflight 1 --no-graph > $OUT/${TAG}_pmc_$c.json 2> $OUT/${TAG}_pmc_$c.err
-  echo "$c done"
-done
-find $OUT -name "*counter_collection.csv" | while read f; do python3 $ROOT/tools/pmc_summary.py $f > ${f%.csv}_summary.txt; done
-ls $OUT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_serial -o stats -- python3 $ROOT/bench.py --steps 256 --warmup 32 --cpu-frames 0 --no-extra --inflight 1 --no-graph > $OUT/${TAG}_bench_under_rocprof_serial.json 2> $OUT/${TAG}_stats_serial.err; echo "serial stats rc=$?"
+cd $ROOT
+tools/pmc_pass.sh $TAG "FETCH_SIZE"
+tools/pmc_pass.sh $TAG "WRITE_SIZE"
+tools/pmc_pass.sh $TAG "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
+tools/pmc_pass.sh $TAG "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY"
+tools/pmc_pass.sh $TAG "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES SQ_INST_CYCLES_VMEM"
+echo "pmc done"
+GPU_MAX_HW_QUEUES=8 python3 tools/band_sim.py --worlds 1,2,4,8 --frames 256 --inflight 4 2>/dev/null | grep -E "world|bands" > $OUT/${TAG}_band_sim.txt; echo "band_sim rc=$?"
+tools/ablation.sh 2>/dev/null | grep ablate > $OUT/${TAG}_ablation.txt
+PUMP_MASKS=0 PUMP_DEPTHS=1,2,3,4 python3 tools/frame_pump.py 2>/dev/null | grep inflight > $OUT/${TAG}_frame_pump.txt
+echo "--- GPU_MAX_HW_QUEUES=8" >> $OUT/${TAG}_frame_pump.txt
+PUMP_MASKS=0 PUMP_DEPTHS=1,2,3,4,6 python3 tools/frame_pump.py GPU_MAX_HW_QUEUES=8 2>/dev/null | grep inflight >> $OUT/${TAG}_frame_pump.txt
+for m in valu_lds_rate graph_streams atomic_rate graph_memset; do [ -x tools/micro/$m ] && timeout -k 5 200 tools/micro/$m > $OUT/${TAG}_micro_$m.txt 2>/dev/null; done
+python3 tools/raster_trace.py --frames 3 2>/dev/null > $OUT/${TAG}_raster_trace.txt
+python3 tools/raster_trace.py --frames 3 --opacity-mean -3 2>/dev/null > $OUT/${TAG}_raster_trace_low_opacity.txt
+ls $OUT | grep $TAG
