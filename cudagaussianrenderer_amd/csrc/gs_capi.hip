@@ -916,9 +916,9 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         else
         {
             launchTileListFastCount(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch);
-            GS_CHECK(hipEventRecord(r->countReady, g.stream));
             launchTileListFastEmit(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],
                                    f.tileKeyBytes, r->values[0], r->tileListCapacity);
+            GS_CHECK(hipEventRecord(r->countReady, g.stream)); // the emit pass leaves the pair total
         }
         gs_timer_stop(stageTimers[2]);
     }

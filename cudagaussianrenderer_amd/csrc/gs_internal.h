@@ -118,6 +118,8 @@ void launchTileListEmit(hipStream_t stream, int count, const Screen& scr, const 
 // inside a capture).
 void ensureTileListFastScratch(TileListScratch& s, int count);
 // Renderer-only builder (gs_tiles_fast.hip): splats visited in `order` (depth-sorted), key = tile index (2 or 4 bytes).
+// Count leaves one pair total per group of 256 splats; Emit sums the totals in front of each group itself and leaves the pair
+// total of the frame in *s.total (+ the host-mapped word): the demand is known to the host only after Emit.
 void launchTileListFastCount(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
                              const float4* screenEllipse, TileListScratch& s);
 void launchTileListFastEmit(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,

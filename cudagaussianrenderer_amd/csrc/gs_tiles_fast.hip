@@ -59,15 +59,23 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                                                              const float2* __restrict__ clipXY, const float4* __restrict__ screenEllipse,
                                                              int32_t* __restrict__ groupCounts, const int32_t* __restrict__ groupOffsets,
                                                              TileKey* __restrict__ tileKeys, int32_t* __restrict__ values, int capacity,
-                                                             uint8_t* __restrict__ hitMasks, const float4* __restrict__ tileRecord)
+                                                             uint8_t* __restrict__ hitMasks, const float4* __restrict__ tileRecord,
+                                                             int64_t* __restrict__ total, int64_t* __restrict__ totalHostMapped)
 {
     __shared__ GroupStage st;
     __shared__ int waveTotals[kWavesPerBlock];
+    __shared__ long long scanTotals[kWavesPerBlock];
     __shared__ int roundHits[2][kWavesPerBlock];
     const int t = threadIdx.x;
     const int wave = t >> 6, lane = t & (kWave - 1);
     const int group = blockIdx.x;
     const int count = countDevice ? min(*countDevice, countHost) : countHost; // device-side count: culled splat list
+    if (EMIT && count <= 0 && group == 0 && t == 0)
+    {
+        // nothing reached the band: no workgroup gets as far as the pair total below
+        *total = 0;
+        if (totalHostMapped != nullptr) *totalHostMapped = 0;
+    }
     if (group * kGroup >= count) return; // whole workgroup
     const int sorted = group * kGroup + t;
 
@@ -131,10 +139,35 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
         unitsBefore += (wv < wave) ? v : 0;
         totalUnits += v;
     }
-    if (totalUnits == 0) // nothing on screen (e.g. the culled splats, which sort first): uniform exit
+    const int lastGroup = (count + kGroup - 1) / kGroup - 1;
+    if (totalUnits == 0 && !(EMIT && group == lastGroup)) // nothing on screen (e.g. the culled splats, which sort first): uniform exit
     {
         if (!EMIT && t == 0) groupCounts[group] = 0;
         return;
+    }
+    // EMIT: where this workgroup's pairs start = the pairs of all groups before it.  Every workgroup sums the count pass's group
+    // totals in front of it itself (at most a few thousand L2-resident words, 16 per lane) instead of reading the result of a
+    // one-workgroup scan kernel: one kernel and one dependent launch less per frame.  The last group also leaves the pair total.
+    int outBase = 0;
+    if (EMIT)
+    {
+        long long mine = 0;
+        for (int j = t; j < group; j += kGroup) mine += groupCounts[j];
+#pragma unroll
+        for (int delta = kWave / 2; delta != 0; delta >>= 1) mine += __shfl_xor(mine, delta);
+        __syncthreads(); // waveTotals: everybody is past the prologue's reads
+        if (lane == 0) scanTotals[wave] = mine;
+        __syncthreads();
+        const long long before = scanTotals[0] + scanTotals[1] + scanTotals[2] + scanTotals[3];
+        outBase = (int) min(before, (long long) 0x7FFFFFFF);
+        if (group == lastGroup && t == 0)
+        {
+            const long long all = before + groupCounts[group];
+            *total = all;
+            // pinned, device-mapped host word: the host reads it while the rest of the frame runs (no copy kernel)
+            if (totalHostMapped != nullptr) *totalHostMapped = all;
+        }
+        if (totalUnits == 0) return;
     }
 
     st.excl[t] = unitsBefore + incl - units;
@@ -148,8 +181,6 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
     __syncthreads();
 
     int running = 0; // COUNT: hits of this wave so far; EMIT: hits of the whole workgroup in the rounds before this one
-    int outBase = 0;
-    if (EMIT) outBase = groupOffsets[group];
     const unsigned long long lowerLanes = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
     const float sx = scr.tileClipSizeX, sy = scr.tileClipSizeY;
 
@@ -383,7 +414,8 @@ void launchEmit(hipStream_t stream, dim3 grid, dim3 block, int count, const Scre
                 const float4* screenEllipse, const TileListScratch& s, void* tileKeys, int32_t* values, int capacity)
 {
     hipLaunchKernelGGL((tileListFastKernel<true, TileKey>), grid, block, 0, stream, count, s.countDevice, scr, order, clipXY, screenEllipse,
-                       (int32_t*) nullptr, (const int32_t*) s.waveOffsets, (TileKey*) tileKeys, values, capacity, s.hitMasks, s.tileRecord);
+                       s.waveCounts, (const int32_t*) nullptr, (TileKey*) tileKeys, values, capacity, s.hitMasks, s.tileRecord, s.total,
+                       s.totalHostMapped);
 }
 
 } // namespace
@@ -417,13 +449,13 @@ void launchTileListFastCount(hipStream_t stream, int count, const Screen& scr, c
     else
     {
         // per-group totals and their scan live in the first ceil(N/256) entries of the per-wave arrays
+        // per-group totals live in the first ceil(N/256) entries of the per-wave array; the emit pass sums them itself and
+        // leaves the pair total (no scan kernel in between)
         hipLaunchKernelGGL((tileListFastKernel<false, uint16_t>), dim3(groups), dim3(kGroup), 0, stream, count, s.countDevice, scr, order, clipXY,
-                           screenEllipse, s.waveCounts, (const int32_t*) nullptr, (uint16_t*) nullptr, (int32_t*) nullptr, 0, s.hitMasks, s.tileRecord);
-        hipLaunchKernelGGL(scanFastKernel, dim3(1), dim3(kScanThreads), 0, stream, groups, s.countDevice, kGroup, s.waveCounts, s.waveOffsets,
-                           s.total, s.totalHostMapped);
+                           screenEllipse, s.waveCounts, (const int32_t*) nullptr, (uint16_t*) nullptr, (int32_t*) nullptr, 0, s.hitMasks, s.tileRecord,
+                           (int64_t*) nullptr, (int64_t*) nullptr);
     }
-    if (groups == 0 || s.totalHostMapped == nullptr)
-        GS_CHECK(hipMemcpyAsync(s.totalHost, s.total, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    if (groups == 0) GS_CHECK(hipMemcpyAsync(s.totalHost, s.total, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
 }
 
 void launchTileListFastEmit(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
@@ -431,10 +463,12 @@ void launchTileListFastEmit(hipStream_t stream, int count, const Screen& scr, co
                             int capacity)
 {
     const int groups = (count + kGroup - 1) / kGroup;
-    if (groups == 0 || capacity <= 0) return;
+    if (groups == 0) return;
+    // (capacity 0 still runs: the pass is also what produces the pair total; nothing is written past `capacity`)
     const dim3 grid(groups), block(kGroup);
     if (tileKeyBytes == 2) launchEmit<uint16_t>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, tileKeys, values, capacity);
     else launchEmit<uint32_t>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, tileKeys, values, capacity);
+    if (s.totalHostMapped == nullptr) GS_CHECK(hipMemcpyAsync(s.totalHost, s.total, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
 }
 
 } // namespace gs

@@ -39,14 +39,17 @@ for cam in cams:
     counts = (rng[..., 1] - rng[..., 0]).astype(np.float64)
     row_cost += counts.sum(1) + 6.0 * np.minimum(counts, 256.0).sum(1)
 cal.close()
+# the same D streams for every band: which hardware queue a new stream lands on depends on how many streams the process has
+# created before, and a band must not look slow because its streams happened to share a queue
+D = args.inflight
+shared_streams = [torch.cuda.Stream() for _ in range(D)]
 for world in [int(x) for x in args.worlds.split(",")]:
     times = []
 
-    D = args.inflight
     bands = scenes.balanced_tile_row_bands(row_cost, world) if args.balanced else scenes.tile_row_bands(ty, world)
     print('bands', bands)
     for band in bands:
-        streams = [torch.cuda.Stream() for _ in range(D)]
+        streams = shared_streams
         rs = []
         for d in range(D):
             r = gs.Renderer(W, H, tile_rows=band if world > 1 else None, band_cull=args.cull, pipeline=args.pipeline)
