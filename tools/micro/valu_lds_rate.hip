@@ -149,7 +149,9 @@ int main()
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
     printf("%s, %d CUs; %d iterations\n", prop.gcnArchName, cus, kIters);
-    printf("%-28s %6s %12s %16s %18s\n", "kernel", "w/SIMD", "time us", "wave-0 cycles", "cycles/instr/SIMD");
+    printf("(waves of one SIMD are served oldest first, so wave 0's own cycle count barely changes with the occupancy: the issue cost of an\n"
+           " instruction is read from the TIME added per extra resident wave)\n");
+    printf("%-28s %6s %12s %16s\n", "kernel", "w/SIMD", "time us", "wave-0 cycles");
     struct Test
     {
         const char* name;
@@ -159,6 +161,8 @@ int main()
     const Test tests[] = {{"v_fma_f32", 8, 0}, {"v_pk_fma_f32", 8, 1}, {"v_exp_f32", 8, 2}, {"2 exp + 6 pk_fma", 8, 3},
                           {"ds_read_b128 broadcast", 8, 4}, {"ds_read_b128 per lane", 8, 5}, {"s_load 32 B (L2 table)", 8, 6}};
     for (const Test& t : tests)
+    {
+        double timeAt[5] = {0, 0, 0, 0, 0};
         for (int wavesPerSimd : {1, 2, 4})
         {
             const int blocks = cus * wavesPerSimd; // 256 threads = 4 waves = one per SIMD
@@ -182,9 +186,11 @@ int main()
             }
             unsigned long long cycles = 0;
             CHECK(hipMemcpy(&cycles, clk, 8, hipMemcpyDeviceToHost));
-            // wave 0 shares its SIMD with wavesPerSimd - 1 others: SIMD cycles per instruction = its cycles / (instructions of all)
-            const double perInstr = (double) cycles / ((double) kIters * t.instrPerIter * wavesPerSimd);
-            printf("%-28s %6d %12.1f %16llu %18.2f\n", t.name, wavesPerSimd, ms * 1e3, cycles, perInstr);
+            timeAt[wavesPerSimd] = ms * 1e3;
+            printf("%-28s %6d %12.1f %16llu\n", t.name, wavesPerSimd, ms * 1e3, cycles);
         }
+        printf("%-28s -> %.2f ns of SIMD time per wave64 instruction (loop body of %d)\n", t.name,
+               1e3 * (timeAt[4] - timeAt[1]) / 3.0 / ((double) kIters * t.instrPerIter), t.instrPerIter);
+    }
     return 0;
 }
