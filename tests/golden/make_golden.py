@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Generate the committed golden fixtures from the REFERENCE itself (authoring container only).
 
-Sources of truth used here, none of which travels with the repository:
+Sources of truth used here, none of which is part of the repository's history (no reference source is copied):
   * oracle/_ref/libgsupstream.so -- the reference's own src/PlyParser.cpp and src/CameraControls.cpp
-    compiled from /root/reference by oracle/Makefile (driver: oracle/upstream_driver.cpp);
+    compiled from /root/reference by oracle/Makefile (driver: oracle/upstream_driver.cpp).  The built .so is
+    git-ignored; like every in-tree .so it is in the snapshot gpurun sends to a GPU box, where nothing loads it
+    (the fixtures below are what the tests use);
   * /root/reference/sh_gen.py    -- the reference's SH code generator, imported and run; the closed forms
     it prints ("l=.., m=.. -> expr") are evaluated numerically with sympy.
 
