@@ -349,7 +349,7 @@ def main():
     ap.add_argument("--epanechnikov", action="store_true", help="the reference's EPANECHNIKOV_KERNEL option (footprint sqrt(7) sigma, density 1 - q/7)")
     ap.add_argument("--gather", choices=["library", "torch"], default="library", help="multi-GPU framebuffer gather: the library's grouped ncclSend/ncclRecv (gs_gather_bands) or torch.distributed point-to-point operations")
     ap.add_argument("--rehearse", action="store_true", help="multi-rank control flow on ONE GPU: every rank on cuda:0, gloo instead of RCCL (not a measurement)")
-    ap.add_argument("--ablate", type=int, default=0, help="diagnostics: leave stages out of the timed frames (bit 0 clip, 1 depth sort, 2 count, 3 emit, 4 tile sort, 5 ranges, 6 raster); prints frames/s only")
+    ap.add_argument("--ablate", type=int, default=-1, help="diagnostics: leave stages out of the timed frames (bit 0 clip, 1 depth sort, 2 count, 3 emit, 4 tile sort, 5 ranges, 6 raster; 0 = none, the reference point); prints frames/s only")
     ap.add_argument("--inflight", type=int, default=0, help="frames in flight per GPU (renderers on separate HIP streams); 0 = 4 (the measured optimum with 8 hardware queues)")
     args = ap.parse_args()
 
@@ -418,7 +418,7 @@ def main():
     depth = args.inflight if args.inflight > 0 else 4
 
     rig = Rig(ctx, ply, cameras, bands, depth, args)
-    if args.ablate >= 0 and args.ablate != 0 or "--ablate" in sys.argv:
+    if args.ablate >= 0:
         # marginal cost of stages in the pipelined loop: the renderers are primed with complete frames, then re-capture without
         # the masked stages (list sizes and buffers stay valid, the images are garbage)
         lib.gs_debug_set_ablation(args.ablate)
