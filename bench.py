@@ -391,7 +391,19 @@ def main():
     if args.epanechnikov:
         gs.set_footprint(gs.FOOTPRINT_EPANECHNIKOV)
     # the band gather's own communicator (RCCL through the C ABI); torch.distributed stays the bootstrap, barrier and timing reduce
-    comm = multigpu.BandComm(rank, world, device) if (world > 1 and not args.rehearse and args.gather == "library") else None
+    comm, gather_note = None, None
+    if world > 1 and not args.rehearse and args.gather == "library":
+        try:
+            comm = multigpu.BandComm(rank, world, device)
+        except Exception as exc:  # e.g. librccl.so not loadable: every rank must then take the same path
+            gather_note = f"gs_comm_create failed on rank {rank}: {exc}"
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if comm is not None:
+                comm.close()
+            comm = None
+            gather_note = gather_note or "gs_comm_create failed on another rank"
     ctx = {"gs": gs, "lib": lib, "multigpu": multigpu, "scenes": scenes, "rank": rank, "world": world, "local_rank": local_rank,
            "device": device, "rehearse": args.rehearse, "comm": comm}
 
@@ -486,7 +498,7 @@ def main():
                 "dist_backend": backend, "dist_world_size": world, "rehearsal_on_one_gpu": bool(args.rehearse),
                 "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
                 "gather": None if world == 1 else ("gs_gather_bands: grouped ncclSend/ncclRecv through the C ABI" if comm is not None
-                                                   else "torch.distributed point-to-point"),
+                                                   else "torch.distributed point-to-point" + (f" (fallback: {gather_note})" if gather_note else "")),
                 "gathered_frame_equals_single_gpu_frame": gathered_ok,
             },
             "roofline": {
