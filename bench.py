@@ -64,15 +64,15 @@ def moved_bytes(n, p, pc, tiles, w, h, sh_degree, tile_key_bytes, colours_on_dem
     return {
         # SH pass only when colours are not evaluated on demand
         "sh": 0 if (colours_on_demand or not sh_degree) else n * (16 + sh_row + 16),
-        # clip: position + scale/rotation in; centre, depth, conic, depth key, order, 32-byte tile record out
-        "clip": n * (32 + 8 + 4 + 16 + 4 + 4 + 32),
+        # clip: position + scale/rotation in; depth code, order, 32-byte tile record and 32-byte raster record out
+        "clip": n * (32 + 4 + 4 + 32 + 32),
         # count + emit: order entry and tile record per splat and pass, 16 hit-mask bytes written then read, pairs out
         "tile_list": n * (2 * (4 + 32) + 2 * 16) + p * (kb + 4),
         # LSD passes: histogram reads keys, scatter reads and writes (key, value)
         "sort": depth_passes * n * (4 + 2 * 8) + tile_passes * p * (kb + 2 * (kb + 4)),
         "ranges": kb * p + 8 * tiles,
-        # per consumed entry: value, centre+conic(+opacity), colour -- or position + coefficient row with colours on demand
-        "raster": pc * (4 + 8 + 16 + (16 + sh_row if colours_on_demand else 16)) + 8 * tiles + 4 * w * h,
+        # per consumed entry: value, 32-byte raster record (centre, conic), colour -- or position + coefficient row with colours on demand
+        "raster": pc * (4 + 32 + (16 + sh_row if colours_on_demand else 16)) + 8 * tiles + 4 * w * h,
     }
 
 

@@ -371,6 +371,7 @@ struct GsRenderer
     bool colourStale = false;   // the last frame evaluated its colours inside the raster kernel: r->color is not current
     float lastCameraPosition[3] = {0.f, 0.f, 0.f};
     float* tileRecord = nullptr; // 8 floats per splat: clip x, y, cos, sin, extent x, y, 0, 0 (one memory sector)
+    float* rasterRecord = nullptr; // 8 floats per splat: clip x, y, conic x, y, z, 0, 0, 0 (what the raster gathers per list entry)
     uint32_t* depthKey[2] = {nullptr, nullptr};
     int32_t* order[2] = {nullptr, nullptr};
     // band cull (multi-GPU): per-splat coefficients in the [splat][shCount] layout for gathered SH evaluation,
@@ -478,7 +479,8 @@ void allocTileList(GsRenderer* r, int32_t capacity)
 }
 void freeScene(GsRenderer* r)
 {
-    float** bufs[] = {&r->position, &r->scaleAndRotation, &r->color, &r->sh, &r->clipXY, &r->clipZ, &r->conic, &r->ellipse, &r->tileRecord};
+    float** bufs[] = {&r->position, &r->scaleAndRotation, &r->color,   &r->sh,         &r->clipXY,
+                      &r->clipZ,    &r->conic,            &r->ellipse, &r->tileRecord, &r->rasterRecord};
     for (float** b : bufs)
     {
         gs_device_free(*b);
@@ -615,6 +617,7 @@ extern "C" int gs_renderer_set_scene(GsRenderer* r, int32_t n, const float* posi
     r->clipXY = (float*) gs_device_alloc(sizeof(float) * 2 * (size_t) n);
     r->clipZ = (float*) gs_device_alloc(sizeof(float) * (size_t) n);
     r->tileRecord = (float*) gs_device_alloc(sizeof(float) * 8 * (size_t) n);
+    r->rasterRecord = (float*) gs_device_alloc(sizeof(float) * 8 * (size_t) n);
     r->scratch.tileRecord = (const float4*) r->tileRecord;
     r->bins.tileRecord = (const float4*) r->tileRecord;
     for (int i = 0; i != 2; ++i)
@@ -668,9 +671,10 @@ extern "C" void gs_renderer_buffers(GsRenderer* r, GsRendererBuffers* out)
     out->screenEllipse = r->ellipse;
     if (r->tileRecord != nullptr && r->pipeline != GS_PIPELINE_REFERENCE && r->splatCount > 0)
     {
-        // the two-level / binned frames keep the ellipses only inside the packed tile records: unpack them for the caller
+        // the two-level / binned frames keep ellipses, centres and conics only inside the packed records: unpack them for the caller
         StreamScope scope(r);
         launchUnpackEllipse(g.stream, r->splatCount, (const float4*) r->tileRecord, (float4*) r->ellipse);
+        launchUnpackRasterRecord(g.stream, r->splatCount, (const float4*) r->rasterRecord, (float2*) r->clipXY, r->clipZ, (float4*) r->conic);
         GS_CHECK(hipStreamSynchronize(g.stream));
     }
     if (r->colourStale && r->shDegree != 0 && r->splatCount > 0)
@@ -844,16 +848,17 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         if (!cull)
         {
             launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation,
-                                (float2*) r->clipXY, r->clipZ, r->tileRecord ? nullptr : (float4*) r->ellipse, (float4*) r->conic, r->depthKey[0],
+                                binned ? (float2*) r->clipXY : nullptr, nullptr, nullptr, nullptr, r->depthKey[0],
                                 (uint32_t*) r->order[0], nullptr, nullptr, nullptr, binned ? nullptr : r->tileRange, 2 * scr.totalTiles,
-                                (float4*) r->tileRecord);
+                                (float4*) r->tileRecord, (float4*) r->rasterRecord);
         }
         else
         {
             // clip data for every splat + keep-mask, then an order-preserving compaction of (depth key, index)
             launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation,
-                                (float2*) r->clipXY, r->clipZ, r->tileRecord ? nullptr : (float4*) r->ellipse, (float4*) r->conic, nullptr, nullptr, r->bandMask,
-                                r->bandCounts, nullptr, binned ? nullptr : r->tileRange, 2 * scr.totalTiles, (float4*) r->tileRecord);
+                                binned ? (float2*) r->clipXY : nullptr, r->clipZ, nullptr, nullptr, nullptr, nullptr, r->bandMask,
+                                r->bandCounts, nullptr, binned ? nullptr : r->tileRange, 2 * scr.totalTiles, (float4*) r->tileRecord,
+                                (float4*) r->rasterRecord);
             launchScanInt32(g.stream, (n + kWave - 1) / kWave, r->bandCounts, r->bandOffsets, r->bandTotal);
             launchCompactBand(g.stream, n, r->bandMask, r->bandOffsets, r->clipZ, r->depthKey[0], (uint32_t*) r->order[0]);
             countDevice = (const int*) r->bandTotal; // low 32 bits of the little-endian int64 total
@@ -1029,7 +1034,7 @@ extern "C" int gs_renderer_finish(GsRenderer* r, GsFrameStats* stats)
     const RasterColourSource lazySource = colourSource(r, f.cameraPosition, nullptr);
     launchRasterize(g.stream, scr, r->tileRange, r->values[r->selector], (const float2*) r->clipXY, (const float4*) r->conic,
                     (const float4*) r->color, (uchar4*) r->backBuffer, consumed, r->pipeline != GS_PIPELINE_REFERENCE,
-                    f.lazyColours ? &lazySource : nullptr);
+                    f.lazyColours ? &lazySource : nullptr, r->pipeline != GS_PIPELINE_REFERENCE ? (const float4*) r->rasterRecord : nullptr);
     r->colourStale = f.lazyColours;
     gs_timer_stop(stageTimers[5]);
     if (hipGetLastError() != hipSuccess) printf("kernel error renderDepthBuffer\n");
@@ -1091,14 +1096,15 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
     {
         if (!(g_ablation & 1))
             launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
-                                (float2*) r->clipXY, r->clipZ, r->tileRecord ? nullptr : (float4*) r->ellipse, (float4*) r->conic, r->depthKey[0],
-                                (uint32_t*) r->order[0], nullptr, nullptr, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord);
+                                binned ? (float2*) r->clipXY : nullptr, nullptr, nullptr, nullptr, r->depthKey[0],
+                                (uint32_t*) r->order[0], nullptr, nullptr, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord,
+                                (float4*) r->rasterRecord);
     }
     else
     {
         launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
-                            (float2*) r->clipXY, r->clipZ, r->tileRecord ? nullptr : (float4*) r->ellipse, (float4*) r->conic, nullptr, nullptr, r->bandMask,
-                            r->bandCounts, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord);
+                            binned ? (float2*) r->clipXY : nullptr, r->clipZ, nullptr, nullptr, nullptr, nullptr, r->bandMask,
+                            r->bandCounts, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord, (float4*) r->rasterRecord);
         launchScanInt32(g.stream, (n + kWave - 1) / kWave, r->bandCounts, r->bandOffsets, r->bandTotal);
         launchCompactBand(g.stream, n, r->bandMask, r->bandOffsets, r->clipZ, r->depthKey[0], (uint32_t*) r->order[0]);
         countDevice = (const int*) r->bandTotal;
@@ -1121,7 +1127,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
         r->radix.countDevice = nullptr;
         r->scratch.countDevice = nullptr;
         launchRasterize(g.stream, scr, r->tileRange, r->values[0], (const float2*) r->clipXY, (const float4*) r->conic,
-                        (const float4*) r->color, (uchar4*) r->backBuffer, nullptr, true, lazyColours);
+                        (const float4*) r->color, (uchar4*) r->backBuffer, nullptr, true, lazyColours, (const float4*) r->rasterRecord);
         r->graphSelector = 0;
         r->graphKeyBytes = 0;
         return 0;
@@ -1141,7 +1147,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
     if (!(g_ablation & 32)) launchTileRanges(g.stream, r->tileListCapacity, tileKeyBytes, r->keys[sel], r->tileRange, pairCount);
     if (!(g_ablation & 64))
         launchRasterize(g.stream, scr, r->tileRange, r->values[sel], (const float2*) r->clipXY, (const float4*) r->conic,
-                        (const float4*) r->color, (uchar4*) r->backBuffer, nullptr, true, lazyColours);
+                        (const float4*) r->color, (uchar4*) r->backBuffer, nullptr, true, lazyColours, (const float4*) r->rasterRecord);
     r->graphSelector = sel;
     r->graphKeyBytes = tileKeyBytes;
     return 0;

@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
                                                             uint32_t* __restrict__ depthKey, uint32_t* __restrict__ splatOrder,
                                                             unsigned long long* __restrict__ bandMask,
                                                             int32_t* __restrict__ bandWaveCounts, int32_t* __restrict__ rangeTable,
-                                                            int rangeEntries, float4* __restrict__ tileRecord)
+                                                            int rangeEntries, float4* __restrict__ tileRecord,
+                                                            float4* __restrict__ rasterRecord)
 {
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
     // The renderer has this kernel reset the tile range table to -1 (Demo.cpp:403) on the side: it is the first kernel
@@ -178,8 +179,8 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
         depthKey[index] = compactDepthKey(clipDepth);
         splatOrder[index] = (uint32_t) index;
     }
-    clipXY[index] = make_float2(clipX, clipY);
-    clipZ[index] = clipDepth;
+    if (clipXY != nullptr) clipXY[index] = make_float2(clipX, clipY);
+    if (clipZ != nullptr) clipZ[index] = clipDepth;
     if (screenEllipse != nullptr) screenEllipse[index] = make_float4(cosA, sinA, extentX, extentY);
     if (tileRecord != nullptr)
     {
@@ -188,7 +189,14 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
         tileRecord[2 * index] = make_float4(clipX, clipY, cosA, sinA);
         tileRecord[2 * index + 1] = make_float4(extentX, extentY, 0.0f, 0.0f);
     }
-    conicOut[index] = make_float4(covC * invDet, -covB * invDet, covA * invDet, 0.0f);
+    if (conicOut != nullptr) conicOut[index] = make_float4(covC * invDet, -covB * invDet, covA * invDet, 0.0f);
+    if (rasterRecord != nullptr)
+    {
+        // what the raster kernel gathers per list entry besides the colour, as ONE 32-byte record (one memory sector instead of one
+        // for the centre and one for the conic)
+        rasterRecord[2 * index] = make_float4(clipX, clipY, covC * invDet, -covB * invDet);
+        rasterRecord[2 * index + 1] = make_float4(covA * invDet, clipDepth, 0.0f, 0.0f); // (the depth rides along for gs_renderer_buffers)
+    }
 }
 
 // Order-preserving compaction of the splats flagged by the band cull: depth key + splat index of every kept splat at
@@ -210,6 +218,18 @@ __global__ __launch_bounds__(256) void compactBandKernel(int count, const unsign
     }
 }
 
+// centre and conic of every splat from the packed raster records (for callers that ask for the renderer's buffers)
+__global__ __launch_bounds__(256) void unpackRasterRecordKernel(int count, const float4* __restrict__ rasterRecord, float2* __restrict__ clipXY,
+                                                                 float* __restrict__ clipZ, float4* __restrict__ conic)
+{
+    const int index = blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= count) return;
+    const float4 ra = rasterRecord[2 * index], rb = rasterRecord[2 * index + 1];
+    clipXY[index] = make_float2(ra.x, ra.y);
+    clipZ[index] = rb.y;
+    conic[index] = make_float4(ra.z, ra.w, rb.x, 0.0f);
+}
+
 // screenEllipse of every splat from the packed tile records (for callers that ask for the renderer's buffers)
 __global__ __launch_bounds__(256) void unpackEllipseKernel(int count, const float4* __restrict__ tileRecord, float4* __restrict__ screenEllipse)
 {
@@ -220,6 +240,12 @@ __global__ __launch_bounds__(256) void unpackEllipseKernel(int count, const floa
 }
 
 } // namespace
+
+void launchUnpackRasterRecord(hipStream_t stream, int count, const float4* rasterRecord, float2* clipXY, float* clipZ, float4* conic)
+{
+    if (count > 0)
+        hipLaunchKernelGGL(unpackRasterRecordKernel, dim3((count + 255) / 256), dim3(256), 0, stream, count, rasterRecord, clipXY, clipZ, conic);
+}
 
 void launchUnpackEllipse(hipStream_t stream, int count, const float4* tileRecord, float4* screenEllipse)
 {
@@ -237,12 +263,14 @@ void launchCompactBand(hipStream_t stream, int count, const unsigned long long* 
 void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const ClipCamera& cam, const float4* position,
                          const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic,
                          uint32_t* depthKey, uint32_t* splatOrder, unsigned long long* bandMask, int32_t* bandWaveCounts,
-                         const FrameParams* paramsDevice, int32_t* rangeTableToClear, int rangeEntries, float4* tileRecord)
+                         const FrameParams* paramsDevice, int32_t* rangeTableToClear, int rangeEntries, float4* tileRecord,
+                         float4* rasterRecord)
 {
     if (count <= 0) return;
     const dim3 grid((count + 255) / 256), block(256);
     hipLaunchKernelGGL(splatClipDataKernel, grid, block, 0, stream, count, scr, cam, paramsDevice, position, scaleAndRotation, clipXY, clipZ,
-                       screenEllipse, conic, depthKey, splatOrder, bandMask, bandWaveCounts, rangeTableToClear, rangeEntries, tileRecord);
+                       screenEllipse, conic, depthKey, splatOrder, bandMask, bandWaveCounts, rangeTableToClear, rangeEntries, tileRecord,
+                       rasterRecord);
 }
 
 } // namespace gs

@@ -72,9 +72,13 @@ void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const
                          const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic,
                          uint32_t* depthKeyOrNull, uint32_t* splatOrderOrNull, unsigned long long* bandMaskOrNull = nullptr,
                          int32_t* bandWaveCountsOrNull = nullptr, const FrameParams* paramsDeviceOrNull = nullptr,
-                         int32_t* rangeTableToClearOrNull = nullptr, int rangeEntries = 0, float4* tileRecordOrNull = nullptr);
+                         int32_t* rangeTableToClearOrNull = nullptr, int rangeEntries = 0, float4* tileRecordOrNull = nullptr,
+                         float4* rasterRecordOrNull = nullptr);
 // screenEllipse[i] = (cos, sin, extent x, extent y) from the 32-byte tile records the clip kernel can write instead.
 void launchUnpackEllipse(hipStream_t stream, int count, const float4* tileRecord, float4* screenEllipse);
+// positionClipSpaceXY / Z / conic from the 32-byte raster records (cx, cy, conic.x, conic.y | conic.z, depth, 0, 0) the clip kernel can
+// write instead of the three arrays (what the raster gathers per list entry is then ONE memory sector instead of two).
+void launchUnpackRasterRecord(hipStream_t stream, int count, const float4* rasterRecord, float2* clipXY, float* clipZ, float4* conic);
 // Band cull (multi-GPU): the clip kernel flags the splats whose tile AABB reaches this GPU's rows (one 64-bit mask and
 // one count per 64 splats); after an exclusive scan of the counts this writes the kept splats' depth keys and indices,
 // order preserved.
@@ -201,7 +205,7 @@ bool rasterCanEvaluateColours(int degree, int shCount);
 void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileRange, const int32_t* values,
                      const float2* clipXY, const float4* conic, const float4* color, uchar4* backBuffer,
                      unsigned long long* consumedPairsOrNull, bool clearEmptyTiles = false,
-                     const RasterColourSource* lazyColoursOrNull = nullptr);
+                     const RasterColourSource* lazyColoursOrNull = nullptr, const float4* rasterRecordOrNull = nullptr);
 
 // The renderer sorts its splats on a 27-bit re-coding of getKey()'s 32-bit quantised depth (GaussianRender.cu:446-454): the
 // quantised value comes from a float, so it has at most 24 significant bits -- (position of the top bit, next 23 bits) says

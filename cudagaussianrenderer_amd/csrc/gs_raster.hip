@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
                                                                   const float4* __restrict__ conic,
                                                                   const float4* __restrict__ color, uchar4* __restrict__ backBuffer,
                                                                   unsigned long long* __restrict__ consumedPairs, int clearEmptyTiles,
-                                                                  RasterColourSource lazy, unsigned long long* __restrict__ trace)
+                                                                  RasterColourSource lazy, unsigned long long* __restrict__ trace,
+                                                                  const float4* __restrict__ rasterRecord)
 {
     constexpr int THREADS = 256 / PPL;
     constexpr int GROUPS_X = kTileSize / PPL;
@@ -179,8 +180,18 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
         if (t < kBatch && base + t < count)
         {
             const int src = values[first + base + t]; // GaussianRender.cu:957-960
-            gCentre = clipXY[src];
-            gConic = conic[src];
+            if (rasterRecord != nullptr)
+            {
+                // the renderer: centre and conic from ONE 32-byte record (one memory sector); wave-uniform branch
+                const float4 ra = rasterRecord[2 * (size_t) src], rb = rasterRecord[2 * (size_t) src + 1];
+                gCentre = make_float2(ra.x, ra.y);
+                gConic = make_float4(ra.z, ra.w, rb.x, 0.0f);
+            }
+            else
+            {
+                gCentre = clipXY[src];
+                gConic = conic[src];
+            }
             if constexpr (SH == 0) gColor = color[src];
             else
             {
@@ -323,7 +334,8 @@ int rasterPixelsPerLane() { return g_rasterPixelsPerLane; }
 
 void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileRange, const int32_t* values,
                      const float2* clipXY, const float4* conic, const float4* color, uchar4* backBuffer,
-                     unsigned long long* consumedPairsOrNull, bool clearEmptyTiles, const RasterColourSource* lazyColours)
+                     unsigned long long* consumedPairsOrNull, bool clearEmptyTiles, const RasterColourSource* lazyColours,
+                     const float4* rasterRecord)
 {
     const int firstTile = scr.rowBegin * scr.tilesX;
     const int numTiles = (scr.rowEnd - scr.rowBegin) * scr.tilesX;
@@ -339,7 +351,7 @@ void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileR
     if (lazyColours != nullptr) lazy = *lazyColours;
 #define GS_LAUNCH_RASTER(PPL, EPAN, SH)                                                                                                  \
     hipLaunchKernelGGL((rasterizeTilesKernel<PPL, EPAN, SH>), dim3(gridTiles), dim3(256 / PPL), 0, stream, scr, firstTile, numTiles,      \
-                       tileRange, values, clipXY, conic, color, backBuffer, consumedPairsOrNull, clearEmptyTiles ? 1 : 0, lazy, g_rasterTrace)
+                       tileRange, values, clipXY, conic, color, backBuffer, consumedPairsOrNull, clearEmptyTiles ? 1 : 0, lazy, g_rasterTrace, rasterRecord)
     const bool epan = scr.epanechnikov != 0;
     // on-demand colours: two pixels per lane only (the default shape), degrees whose coefficient rows are 16-byte multiples
     if (lazyColours != nullptr && g_rasterPixelsPerLane == 2 && rasterCanEvaluateColours(lazy.degree, lazy.shCount))
