@@ -276,7 +276,9 @@ uint8_t* gs_renderer_back_buffer(GsRenderer* r);
 void gs_renderer_set_back_buffer(GsRenderer* r, uint8_t* deviceBackBufferOrNull);
 /* Copy the back buffer to host (blocking). */
 void gs_renderer_read_back_buffer(GsRenderer* r, uint8_t* hostRgba);
-/* Device pointers of the per-splat intermediates, for tests/inspection. */
+/* Device pointers of the per-splat intermediates, for tests/inspection.  The two-level / binned frames keep centre, depth, conic and
+ * ellipse inside two packed 32-byte records per splat; this call unpacks them into the reference's arrays (and brings the colour buffer
+ * up to date when the colours were evaluated on demand). */
 typedef struct GsRendererBuffers
 {
     float *position, *scaleAndRotation, *color, *sphericalHarmonics;
