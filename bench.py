@@ -136,7 +136,10 @@ class Rig:
         self.renderers, self.framebuffers = [], []
         for d in range(depth):
             r = gs.Renderer(self.W, self.H, tile_rows=self.band if world > 1 else None, band_cull=args.band_cull, pipeline=args.pipeline)
-            r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+            if d == 0 or args.own_scene_copies:
+                r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+            else:
+                r.share_scene(self.renderers[0])  # one copy of the read-only scene for all frames in flight
             fb = torch.zeros((self.H, self.W, 4), dtype=torch.uint8, device=device)
             r.set_back_buffer(fb.data_ptr())
             r.set_stream(self.streams[d].cuda_stream)
@@ -349,6 +352,7 @@ def main():
     ap.add_argument("--epanechnikov", action="store_true", help="the reference's EPANECHNIKOV_KERNEL option (footprint sqrt(7) sigma, density 1 - q/7)")
     ap.add_argument("--gather", choices=["library", "torch"], default="library", help="multi-GPU framebuffer gather: the library's grouped ncclSend/ncclRecv (gs_gather_bands) or torch.distributed point-to-point operations")
     ap.add_argument("--rehearse", action="store_true", help="multi-rank control flow on ONE GPU: every rank on cuda:0, gloo instead of RCCL (not a measurement)")
+    ap.add_argument("--own-scene-copies", action="store_true", help="every renderer uploads its own copy of the scene instead of sharing renderer 0's read-only buffers")
     ap.add_argument("--ablate", type=int, default=-1, help="diagnostics: leave stages out of the timed frames (bit 0 clip, 1 depth sort, 2 count, 3 emit, 4 tile sort, 5 ranges, 6 raster; 0 = none, the reference point); prints frames/s only")
     ap.add_argument("--inflight", type=int, default=0, help="frames in flight per GPU (renderers on separate HIP streams); 0 = 4 (the measured optimum with 8 hardware queues)")
     args = ap.parse_args()

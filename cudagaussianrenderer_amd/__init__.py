@@ -278,6 +278,13 @@ class Renderer:
             raise ValueError("gs_renderer_set_scene failed")
         self.splat_count = n
 
+    def share_scene(self, owner):
+        """Use `owner`'s read-only scene buffers (several renderers of one scene = frames in flight); `owner` must outlive self."""
+        if lib().gs_renderer_share_scene(self.handle, owner.handle) != 0:
+            raise ValueError("gs_renderer_share_scene failed")
+        self.splat_count = owner.splat_count
+        self._scene_owner = owner  # keep it alive
+
     def set_back_buffer(self, device_ptr):
         lib().gs_renderer_set_back_buffer(self.handle, device_ptr)
 

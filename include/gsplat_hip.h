@@ -244,6 +244,10 @@ int gs_renderer_colours_on_demand(const GsRenderer* r);
  * returns it) and is realigned here (Demo.cpp:291-296); may be NULL at degree 0. */
 int gs_renderer_set_scene(GsRenderer* r, int32_t splatCount, const float* position4, const float* scaleAndRotation4,
                           const float* color4, const float* sh, int shDegree, int shCount);
+/* Several renderers of ONE scene (frames in flight on separate streams): `r` uses `owner`'s read-only inputs (position, scale/rotation,
+ * SH coefficients) instead of a copy of its own and allocates only its intermediates and lists.  `owner` must have its scene set, must
+ * not be a sharer itself, and must outlive `r` (or `r` must get another scene first).  Returns 0, -1 on bad arguments. */
+int gs_renderer_share_scene(GsRenderer* r, const GsRenderer* owner);
 /* Render one frame into the renderer's device back buffer.
  *   timed == 0: no stage timers (throughput mode);
  *   timed == 1: per-stage timings in *stats, blocking after every stage like the reference's CudaTimer;

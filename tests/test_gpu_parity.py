@@ -848,3 +848,34 @@ def test_edge_whole_chunks_out_of_frustum(gs, gsref):
         assert abs(len(values) - len(sv)) <= 2, name
         _assert_image_close(image, want, name)
     assert np.array_equal(lists["two_level"][0], lists["binned"][0]) and np.array_equal(lists["two_level"][0], lists["captured"][0])
+
+
+def test_renderers_sharing_one_scene(gs, tmp_path):
+    """gs_renderer_share_scene: a second renderer on the owner's read-only scene buffers renders the same bytes (plain and
+    captured frames, colours on demand and the colour buffer), survives the owner getting closed first at teardown, and can be
+    given a scene of its own afterwards."""
+    w, h = 800, 448
+    ply = _ply_scene(gs, tmp_path, 30000, 3, log_scale_mean=-3.0)
+    scene = (ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+    cam = gs.camera_from_bounds(ply["boundsMin"], ply["boundsMax"], w, h)
+    owner = gs.Renderer(w, h)
+    owner.set_scene(*scene)
+    owner.render(cam)
+    want = owner.read_image()
+    want_colour = owner.download(owner.buffers().color, 4 * 30000, np.float32)
+    for graph in (False, True):
+        sharer = gs.Renderer(w, h)
+        sharer.set_graph(graph)
+        sharer.share_scene(owner)
+        sharer.render(cam)
+        sharer.render(cam)
+        assert np.array_equal(sharer.read_image(), want)
+        assert np.array_equal(sharer.download(sharer.buffers().color, 4 * 30000, np.float32), want_colour)
+        pos, sr, col = _procedural(gs, 5000, seed=3)
+        sharer.set_scene(pos, sr, col)  # leaves the shared buffers alone
+        sharer.render(gs.camera_from_bounds([-4] * 3, [4] * 3, w, h))
+        assert sharer.read_image()[..., :3].max() > 0
+        sharer.close()
+    owner.render(cam)
+    assert np.array_equal(owner.read_image(), want)
+    owner.close()
