@@ -77,12 +77,12 @@ def moved_bytes(n, p, pc, tiles, w, h, sh_degree, tile_key_bytes, colours_on_dem
 
 
 def source_hash():
-    """Hash of the kernel sources: counter files under profiles/ name the hash they were collected with, and are only
-    attached to a run whose sources are the same."""
+    """Hash of the device code (csrc/*.hip and the headers they include): counter files under profiles/ name the hash they were
+    collected with, and are only attached to a run whose kernels are the same.  Host-only sources (*.cpp) are not part of it."""
     h = hashlib.sha256()
     src = os.path.join(ROOT, "cudagaussianrenderer_amd", "csrc")
     for name in sorted(os.listdir(src)):
-        if name.endswith((".hip", ".h", ".cpp")):
+        if name.endswith((".hip", ".h")):
             with open(os.path.join(src, name), "rb") as f:
                 h.update(name.encode())
                 h.update(f.read())

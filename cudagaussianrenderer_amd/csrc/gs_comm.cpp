@@ -116,6 +116,25 @@ extern "C" void gs_comm_destroy(GsComm* c)
     delete c;
 }
 
+// Diagnostics: the same RCCL entry points gs_gather_bands uses (communicator of one rank, grouped send + receive to itself) on
+// ONE GPU, so that the run-time binding, the call signatures and the stream handling are exercised where only one GPU exists.
+extern "C" int gs_debug_rccl_self_exchange(void* dst, const void* src, size_t bytes, void* hipStream)
+{
+    const Rccl& r = rccl();
+    if (!r.ok) return -1;
+    ncclUniqueId id;
+    if (!check(r.getUniqueId(&id), "ncclGetUniqueId")) return -2;
+    ncclComm_t comm = nullptr;
+    if (!check(r.commInitRank(&comm, 1, id, 0), "ncclCommInitRank")) return -2;
+    bool ok = check(r.groupStart(), "ncclGroupStart");
+    ok = ok && check(r.send(src, bytes, ncclUint8, 0, comm, (hipStream_t) hipStream), "ncclSend");
+    ok = ok && check(r.recv(dst, bytes, ncclUint8, 0, comm, (hipStream_t) hipStream), "ncclRecv");
+    ok = check(r.groupEnd(), "ncclGroupEnd") && ok;
+    if (hipStreamSynchronize((hipStream_t) hipStream) != hipSuccess) ok = false;
+    (void) r.commDestroy(comm);
+    return ok ? 0 : -2;
+}
+
 extern "C" int gs_comm_rank(const GsComm* c) { return c ? c->rank : -1; }
 extern "C" int gs_comm_world(const GsComm* c) { return c ? c->world : 0; }
 

@@ -54,6 +54,22 @@ def test_rccl_is_loadable_and_world_one_gather_is_a_noop():
     comm.close()
 
 
+def test_rccl_send_recv_path_on_one_gpu():
+    """The grouped ncclSend/ncclRecv calls of gs_gather_bands, through the run-time-bound RCCL, on a one-rank communicator that sends
+    a band-sized block to itself: proves binding, signatures and stream handling on the hardware the test box has."""
+    import numpy as np
+
+    import cudagaussianrenderer_amd as gs
+
+    lib = gs.lib()
+    lib.gs_set_device(0)
+    rows = np.random.default_rng(3).integers(0, 256, (144, 1920, 4), dtype=np.uint8)  # 9 tile rows of a 1080p frame
+    src = gs.DeviceBuffer(rows)
+    dst = gs.DeviceBuffer(np.zeros_like(rows))
+    assert lib.gs_debug_rccl_self_exchange(dst.ptr, src.ptr, rows.nbytes, None) == 0
+    assert np.array_equal(dst.copy_to(dtype=np.uint8).reshape(rows.shape), rows)
+
+
 def _two_gpu_worker(rank, world, port, out_path):
     import numpy as np
     import torch
