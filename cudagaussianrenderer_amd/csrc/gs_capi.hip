@@ -1,6 +1,8 @@
 // gs_capi.hip -- the C ABI of include/gsplat_hip.h: library state, timers, device buffers, the eight
 // staged host functions (GaussianRender.cuh:118-143) and the one-call renderer (Demo.cpp:352-479).
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -387,10 +389,13 @@ struct GsRenderer
     unsigned long long* consumed = nullptr;
     // captured frame (hipGraph): the whole two-level frame as one graph launch, list sizes kept on the device
     bool useGraph = false, graphValid = false, ownsStream = false;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graphExec = nullptr;
+    // TWO instances of the captured frame, each reading the camera from its own pinned slot: a frame can be launched while the
+    // previous one of this renderer is still running (its slot is not touched), so the stream never runs dry between frames
+    hipGraph_t graph[2] = {nullptr, nullptr};
+    hipGraphExec_t graphExec[2] = {nullptr, nullptr};
+    int graphSlot = 0; // instance of the NEXT launch
     FrameParams* paramsDevice = nullptr;
-    FrameParams* paramsHost = nullptr; // pinned
+    FrameParams* paramsHost = nullptr; // pinned, two slots
     int graphCapacity = 0, graphSplats = 0, graphRowBegin = -1, graphRowEnd = -1, graphCull = -1, graphBinned = -1, graphFootprint = -1, graphLazy = -1, graphAblation = 0, graphSelector = 0, graphKeyBytes = 2;
     bool pending = false; // begin() issued, finish() not yet
     int capturedRetries = 0; // captured frames rendered again because their pair demand exceeded the list capacity
@@ -563,8 +568,11 @@ extern "C" void gs_renderer_destroy(GsRenderer* r)
     freeTileListScratch(r->scratch);
     freeRadixScratch(r->radix);
     freeBinScratch(r->bins);
-    if (r->graphExec) (void) hipGraphExecDestroy(r->graphExec);
-    if (r->graph) (void) hipGraphDestroy(r->graph);
+    for (int k = 0; k != 2; ++k)
+    {
+        if (r->graphExec[k]) (void) hipGraphExecDestroy(r->graphExec[k]);
+        if (r->graph[k]) (void) hipGraphDestroy(r->graph[k]);
+    }
     if (r->ownsStream) (void) hipStreamDestroy(r->stream);
     if (r->paramsDevice) (void) hipFree(r->paramsDevice);
     if (r->paramsHost) (void) hipHostFree(r->paramsHost);
@@ -630,7 +638,10 @@ void allocateSceneIntermediates(GsRenderer* r, int32_t n)
     r->bandOffsets = (int32_t*) gs_device_alloc(sizeof(int32_t) * waves);
     r->bandTotal = (int64_t*) gs_device_alloc(sizeof(int64_t));
     // Demo.cpp:325: 8 pairs per splat to start with; grown on demand.
-    if (r->tileListCapacity < std::max(n, 1) * 8) allocTileList(r, std::max(n, 1) * 8);
+#ifndef GS_INITIAL_LIST_FACTOR
+#define GS_INITIAL_LIST_FACTOR 8
+#endif
+    if (r->tileListCapacity < std::max(n, 1) * GS_INITIAL_LIST_FACTOR) allocTileList(r, std::max(n, 1) * GS_INITIAL_LIST_FACTOR);
 }
 } // namespace
 
@@ -1109,8 +1120,10 @@ namespace
 // Allocation / legacy-stream work of one host thread must not overlap another thread's stream capture: set-up and capture
 // are serialised process-wide (they happen once per renderer; replays take no lock).
 std::mutex g_captureMutex;
+// host-side cost of captured frames (diagnostic, gs_debug_host_times): time inside hipGraphLaunch, time waiting for the pair total
+std::atomic<long long> g_hostLaunchNs{0}, g_hostAwaitNs{0}, g_hostFrames{0};
 
-int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool binned, bool lazy)
+int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool binned, bool lazy, int slot)
 {
     const RasterColourSource lazySource = colourSource(r, nullptr, r->paramsDevice);
     const RasterColourSource* lazyColours = lazy ? &lazySource : nullptr;
@@ -1120,7 +1133,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
     const float3 unused = make_float3(0.f, 0.f, 0.f);
     ClipCamera unusedCamera{};
 
-    GS_CHECK(hipMemcpyAsync(r->paramsDevice, r->paramsHost, sizeof(FrameParams), hipMemcpyHostToDevice, g.stream));
+    GS_CHECK(hipMemcpyAsync(r->paramsDevice, r->paramsHost + slot, sizeof(FrameParams), hipMemcpyHostToDevice, g.stream));
     // the range table is reset to -1 by the clip kernel (one node less than a memset; see gs_ranges.hip); binned frames write every range
     int32_t* clearTable = binned ? nullptr : r->tileRange;
     const int clearEntries = 2 * scr.totalTiles;
@@ -1235,13 +1248,14 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
     const bool strictBand = scr.rowBegin > 0 || scr.rowEnd < scr.tilesY;
     const bool cull = n > 0 && (r->bandCull == GS_BAND_CULL_ON || (r->bandCull == GS_BAND_CULL_AUTO && strictBand));
 
-    // The previous frame of this renderer is complete before its parameter block is overwritten.
-    GS_CHECK(hipStreamSynchronize(g.stream));
+    // No wait for the previous frame of this renderer: it may still be sorting or rasterising (render() returned when its pair
+    // total was known).  What this call overwrites is the OTHER parameter slot, last read by the frame before the previous one,
+    // which is complete -- the previous frame's emit pass ran behind it on the same stream and its total has been seen.
     if (r->paramsDevice == nullptr)
     {
         std::lock_guard<std::mutex> lock(g_captureMutex);
         GS_CHECK(hipMalloc((void**) &r->paramsDevice, sizeof(FrameParams)));
-        GS_CHECK(hipHostMalloc((void**) &r->paramsHost, sizeof(FrameParams), hipHostMallocDefault));
+        GS_CHECK(hipHostMalloc((void**) &r->paramsHost, 2 * sizeof(FrameParams), hipHostMallocDefault));
     }
     const bool lazy = useLazyColours(r);
 
@@ -1253,7 +1267,6 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
     fp.camera.depthBias = camera->depthScaleBias[1];
     for (int k = 0; k != 3; ++k) fp.cameraPosition[k] = r->lastCameraPosition[k] = camera->position[k];
     r->colourStale = lazy;
-    *r->paramsHost = fp;
 
     // A frame whose pair demand exceeds the list capacity is NOT handed out (the reference would show it truncated and double
     // the list for the next one, Demo.cpp:357-366,447): the list is grown, the frame re-captured and the SAME camera rendered
@@ -1268,20 +1281,24 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
             r->graphValid = false;
         if (!r->graphValid)
         {
+            GS_CHECK(hipStreamSynchronize(g.stream)); // frames of the old instances drain before these are destroyed
             std::lock_guard<std::mutex> lock(g_captureMutex);
             // allocate everything the frame needs BEFORE capturing (no allocation may happen inside a capture)
             ensureTileListFastScratch(r->scratch, n);
             ensureRadixScratch(r->radix, n);
             ensureRadixScratch(r->radix, r->tileListCapacity);
             if (binned) ensureBinScratch(r->bins, n, (scr.rowEnd - scr.rowBegin) * scr.tilesX, binBatchesFor((scr.rowEnd - scr.rowBegin) * scr.tilesX));
-            if (r->graphExec) (void) hipGraphExecDestroy(r->graphExec);
-            if (r->graph) (void) hipGraphDestroy(r->graph);
-            r->graphExec = nullptr;
-            r->graph = nullptr;
-            GS_CHECK(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
-            enqueueCapturableFrame(r, scr, cull, binned, lazy);
-            GS_CHECK(hipStreamEndCapture(g.stream, &r->graph));
-            GS_CHECK(hipGraphInstantiate(&r->graphExec, r->graph, nullptr, nullptr, 0));
+            for (int slot = 0; slot != 2; ++slot)
+            {
+                if (r->graphExec[slot]) (void) hipGraphExecDestroy(r->graphExec[slot]);
+                if (r->graph[slot]) (void) hipGraphDestroy(r->graph[slot]);
+                r->graphExec[slot] = nullptr;
+                r->graph[slot] = nullptr;
+                GS_CHECK(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+                enqueueCapturableFrame(r, scr, cull, binned, lazy, slot);
+                GS_CHECK(hipStreamEndCapture(g.stream, &r->graph[slot]));
+                GS_CHECK(hipGraphInstantiate(&r->graphExec[slot], r->graph[slot], nullptr, nullptr, 0));
+            }
             r->graphValid = true;
             r->graphCapacity = r->tileListCapacity;
             r->graphSplats = n;
@@ -1293,12 +1310,21 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
             r->graphLazy = (int) lazy;
             r->graphAblation = g_ablation;
         }
-        *r->scratch.totalHost = -1; // armed; the previous frame is complete, nothing else writes the word
-        GS_CHECK(hipGraphLaunch(r->graphExec, g.stream));
+        const int slot = r->graphSlot;
+        r->graphSlot ^= 1;
+        r->paramsHost[slot] = fp;
+        *r->scratch.totalHost = -1; // armed; the previous frame has left its total (seen by the host), nothing else writes the word
+        const auto hostT0 = std::chrono::steady_clock::now();
+        GS_CHECK(hipGraphLaunch(r->graphExec[slot], g.stream));
+        const auto hostT1 = std::chrono::steady_clock::now();
         r->selector = r->graphSelector;
         r->keyBytes = r->graphKeyBytes;
 
         const int64_t demand = awaitPairTotal(r);
+        const auto hostT2 = std::chrono::steady_clock::now();
+        g_hostLaunchNs.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(hostT1 - hostT0).count(), std::memory_order_relaxed);
+        g_hostAwaitNs.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(hostT2 - hostT1).count(), std::memory_order_relaxed);
+        g_hostFrames.fetch_add(1, std::memory_order_relaxed);
         g.lastDemand = demand;
         r->tileListSize = (int32_t) std::min<int64_t>(demand, r->tileListCapacity);
         if (demand <= r->tileListCapacity) return 0;
@@ -1322,6 +1348,14 @@ extern "C" void gs_renderer_set_graph(GsRenderer* r, int enabled)
 
 extern "C" int gs_renderer_captured_retries(const GsRenderer* r) { return r->capturedRetries; }
 extern "C" void gs_debug_set_ablation(int mask) { g_ablation = mask; }
+extern "C" long long gs_debug_host_times(double* launchMicroseconds, double* awaitMicroseconds, int reset)
+{
+    const long long frames = g_hostFrames.load();
+    if (launchMicroseconds) *launchMicroseconds = frames ? 1e-3 * (double) g_hostLaunchNs.load() / (double) frames : 0.0;
+    if (awaitMicroseconds) *awaitMicroseconds = frames ? 1e-3 * (double) g_hostAwaitNs.load() / (double) frames : 0.0;
+    if (reset) g_hostLaunchNs = 0, g_hostAwaitNs = 0, g_hostFrames = 0;
+    return frames;
+}
 
 extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsFrameStats* stats)
 {

@@ -256,13 +256,17 @@ int gs_renderer_share_scene(GsRenderer* r, const GsRenderer* owner);
 int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsFrameStats* statsOrNull);
 /* Captured frames: gs_renderer_render (timed == 0, stats == NULL, TWO_LEVEL or BINNED pipeline, native sort) replays the whole
  * frame as ONE hipGraph launch; list sizes stay on the device, the camera is refreshed by a memcpy node.  The call returns once
- * the frame's pair total has reached the host (mid-frame, through a host-mapped word).  A frame whose demand exceeds the list
+ * the frame's pair total has reached the host (mid-frame, through a host-mapped word); the next call may follow at once (two
+ * instances of the graph with a camera slot each, so the stream always holds the next frame).  A frame whose demand exceeds the list
  * capacity is NOT handed out truncated (the reference shows it and doubles the list for the next frame, Demo.cpp:357-366,447):
  * the list is grown, the frame re-captured and the same camera rendered again before the call returns. */
 void gs_renderer_set_graph(GsRenderer* r, int enabled);
 /* Diagnostics (bench.py --ablate): leave stages out of the captured frames -- bit 0 clip, 1 depth sort, 2 pair count, 3 pair emit,
  * 4 tile sort, 5 ranges, 6 raster -- to measure what each stage costs the pipelined frame rate.  The images are garbage. */
 void gs_debug_set_ablation(int mask);
+/* Diagnostics (tools/frame_pump): host-side cost of the captured frames of this process since the last reset -- average microseconds
+ * per frame inside hipGraphLaunch and waiting for the frame's pair total; returns the number of frames averaged over. */
+long long gs_debug_host_times(double* launchMicroseconds, double* awaitMicroseconds, int reset);
 /* Number of captured frames that had to be rendered again because the list was too small (diagnostics). */
 int gs_renderer_captured_retries(const GsRenderer* r);
 /* The same frame in two halves, so that one host thread can keep several renderers (each with its own stream and

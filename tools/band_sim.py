@@ -19,6 +19,7 @@ ap.add_argument("--graph", type=int, default=1)
 ap.add_argument("--sort-backend", type=int, default=1, help="0 rocPRIM, 1 native, 2 onesweep")
 ap.add_argument("--ppl", type=int, default=2, help="raster pixels per lane")
 ap.add_argument("--pipeline", type=int, default=1)
+ap.add_argument("--ablate", type=int, default=0, help="gs_debug_set_ablation mask for the timed frames (diagnostic: stages left out)")
 args = ap.parse_args()
 W, H = 1920, 1080
 gs.lib().gs_set_sort_backend(args.sort_backend)
@@ -42,6 +43,7 @@ cal.close()
 # the same D streams for every band: which hardware queue a new stream lands on depends on how many streams the process has
 # created before, and a band must not look slow because its streams happened to share a queue
 D = args.inflight
+gs.lib().gs_debug_set_ablation(args.ablate)
 shared_streams = [torch.cuda.Stream() for _ in range(D)]
 for world in [int(x) for x in args.worlds.split(",")]:
     times = []

@@ -77,12 +77,16 @@ int main(int argc, char** argv)
         for (auto& t : threads) t.join();
     };
     run(8 * D);
+    (void) gs_debug_host_times(nullptr, nullptr, 1);
     const auto t0 = std::chrono::steady_clock::now();
     run(frames);
     const auto t1 = std::chrono::steady_clock::now();
     const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count() / frames;
-    std::printf("{\"inflight\": %d, \"rows\": [%d, %d], \"graph\": %d, \"cu_mask\": %d, \"ms_per_frame\": %.4f, \"frames_per_s\": %.1f}\n", D, rowBegin,
-                rowEnd, graph, maskMode, ms, 1e3 / ms);
+    double launchUs = 0.0, awaitUs = 0.0;
+    (void) gs_debug_host_times(&launchUs, &awaitUs, 0);
+    std::printf("{\"inflight\": %d, \"rows\": [%d, %d], \"graph\": %d, \"cu_mask\": %d, \"ms_per_frame\": %.4f, \"frames_per_s\": %.1f, "
+                "\"host_us_in_graph_launch\": %.1f, \"host_us_awaiting_total\": %.1f}\n",
+                D, rowBegin, rowEnd, graph, maskMode, ms, 1e3 / ms, launchUs, awaitUs);
     for (int d = 0; d != D; ++d) gs_renderer_destroy(rs[d]);
     gs_free_ply(&ply);
     return 0;

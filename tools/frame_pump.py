@@ -8,7 +8,7 @@ import numpy as np
 import cudagaussianrenderer_amd as gs
 from cudagaussianrenderer_amd import scenes
 W, H, N = 1920, 1080, 1_000_000
-out = os.path.join(ROOT, "gpurun_out", "pump")
+out = os.environ.get("PUMP_DIR", "/tmp/gs_pump")  # (not under gpurun_out/: the scene is 250 MB)
 os.makedirs(out, exist_ok=True)
 ply_path = os.path.join(out, "scene.ply")
 scenes.write_synthetic_ply(ply_path, N, sh_degree=3, seed=1234)
@@ -28,6 +28,11 @@ depths = [int(v) for v in os.environ.get("PUMP_DEPTHS", "1,2,3,4,6").split(",")]
 for rows in [(0, 0), (29, 34), (0, 17)]:
     for mask in masks:
         for d in depths:
-            print(subprocess.run([exe, ply_path, os.path.join(out, "cams.bin"), str(W), str(H), str(rows[0]), str(rows[1]), str(d), "512", "1", str(mask)],
-                                 env=env, stdout=subprocess.PIPE, text=True).stdout.strip(), flush=True)
-os.remove(ply_path)
+            try:
+                print(subprocess.run([exe, ply_path, os.path.join(out, "cams.bin"), str(W), str(H), str(rows[0]), str(rows[1]), str(d), "512", "1", str(mask)],
+                                     env=env, stdout=subprocess.PIPE, text=True, timeout=60).stdout.strip(), flush=True)
+            except subprocess.TimeoutExpired:
+                print("timeout", rows, mask, d, flush=True)
+                sys.exit(1)  # no further GPU work after a hang
+if not os.environ.get("PUMP_KEEP"):
+    os.remove(ply_path)
