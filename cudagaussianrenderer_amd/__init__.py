@@ -258,9 +258,12 @@ def parse_ply(path):
 class Renderer:
     """The frame loop body of src/Demo.cpp:352-479 behind one call."""
 
-    def __init__(self, width, height, tile_rows=None, pipeline=None, band_cull=None):
+    def __init__(self, width, height, tile_rows=None, pipeline=None, band_cull=None, views=1):
         self.width, self.height = width, height
         self.handle = lib().gs_renderer_create(width, height)
+        self.views = int(views)
+        if self.views != 1 and lib().gs_renderer_set_views(self.handle, self.views) != 0:
+            raise ValueError(f"views must be 1..4 (got {views})")
         if tile_rows is not None:
             lib().gs_renderer_set_tile_rows(self.handle, tile_rows[0], tile_rows[1])
         if pipeline is not None:
@@ -296,6 +299,15 @@ class Renderer:
         if rc != 0:
             raise RuntimeError(f"gs_renderer_render failed ({rc})")
         return st
+
+    def render_views(self, cameras):
+        """`views` frames of the scene by ONE replay of the captured chain (set_graph(True) first); image v: read_image(view=v)."""
+        if len(cameras) != self.views:
+            raise ValueError(f"{self.views} cameras expected, got {len(cameras)}")
+        arr = (_capi.CameraData * self.views)(*cameras)
+        rc = lib().gs_renderer_render_views(self.handle, arr)
+        if rc != 0:
+            raise RuntimeError(f"gs_renderer_render_views failed ({rc})")
 
     def colours_on_demand(self):
         """True when this renderer's frames evaluate SH colours inside the raster kernel (no SH pass)."""
@@ -333,13 +345,14 @@ class Renderer:
         frames = lib().gs_renderer_collect_stage_times(self.handle, C.byref(st))
         return frames, st
 
-    def read_image(self):
+    def read_image(self, view=0):
         img = np.empty((self.height, self.width, 4), np.uint8)
-        lib().gs_renderer_read_back_buffer(self.handle, img.ctypes.data_as(C.c_void_p))
+        if lib().gs_renderer_read_back_buffer_view(self.handle, int(view), img.ctypes.data_as(C.c_void_p)) != 0:
+            raise ValueError(f"no view {view}")
         return img
 
-    def back_buffer_ptr(self):
-        return lib().gs_renderer_back_buffer(self.handle)
+    def back_buffer_ptr(self, view=0):
+        return lib().gs_renderer_back_buffer_view(self.handle, int(view))
 
     def buffers(self):
         b = _capi.RendererBuffers()

@@ -176,6 +176,11 @@ SIGNATURES = {
     "gs_renderer_share_scene": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gs_renderer_render": (C.c_int, [C.c_void_p, C.POINTER(CameraData), C.c_int, C.POINTER(FrameStats)]),
     "gs_renderer_set_graph": (None, [C.c_void_p, C.c_int]),
+    "gs_renderer_set_views": (C.c_int, [C.c_void_p, C.c_int]),
+    "gs_renderer_views": (C.c_int, [C.c_void_p]),
+    "gs_renderer_render_views": (C.c_int, [C.c_void_p, C.POINTER(CameraData)]),
+    "gs_renderer_back_buffer_view": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "gs_renderer_read_back_buffer_view": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "gs_renderer_captured_retries": (C.c_int, [C.c_void_p]),
     "gs_debug_set_ablation": (None, [C.c_int]),
     "gs_debug_host_times": (C.c_longlong, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),

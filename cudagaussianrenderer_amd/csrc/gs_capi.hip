@@ -394,6 +394,7 @@ struct GsRenderer
     hipGraph_t graph[2] = {nullptr, nullptr};
     hipGraphExec_t graphExec[2] = {nullptr, nullptr};
     int graphSlot = 0; // instance of the NEXT launch
+    int views = 1;     // cameras per captured chain (gs_renderer_set_views)
     FrameParams* paramsDevice = nullptr;
     FrameParams* paramsHost = nullptr; // pinned, two slots
     int graphCapacity = 0, graphSplats = 0, graphRowBegin = -1, graphRowEnd = -1, graphCull = -1, graphBinned = -1, graphFootprint = -1, graphLazy = -1, graphAblation = 0, graphSelector = 0, graphKeyBytes = 2;
@@ -622,17 +623,19 @@ void allocateSceneIntermediates(GsRenderer* r, int32_t n)
     r->conic = (float*) gs_device_alloc(f4);
     r->ellipse = (float*) gs_device_alloc(f4);
     r->clipXY = (float*) gs_device_alloc(sizeof(float) * 2 * (size_t) n);
-    r->clipZ = (float*) gs_device_alloc(sizeof(float) * (size_t) n);
-    r->tileRecord = (float*) gs_device_alloc(sizeof(float) * 8 * (size_t) n);
-    r->rasterRecord = (float*) gs_device_alloc(sizeof(float) * 8 * (size_t) n);
+    // per-view results (clip data of the "virtual splats" view * n + i, their depth keys and order, the band-cull masks): x views
+    const size_t nv = (size_t) n * (size_t) r->views;
+    r->clipZ = (float*) gs_device_alloc(sizeof(float) * nv);
+    r->tileRecord = (float*) gs_device_alloc(sizeof(float) * 8 * nv);
+    r->rasterRecord = (float*) gs_device_alloc(sizeof(float) * 8 * nv);
     r->scratch.tileRecord = (const float4*) r->tileRecord;
     r->bins.tileRecord = (const float4*) r->tileRecord;
     for (int i = 0; i != 2; ++i)
     {
-        r->depthKey[i] = (uint32_t*) gs_device_alloc(sizeof(uint32_t) * (size_t) n);
-        r->order[i] = (int32_t*) gs_device_alloc(sizeof(int32_t) * (size_t) n);
+        r->depthKey[i] = (uint32_t*) gs_device_alloc(sizeof(uint32_t) * nv);
+        r->order[i] = (int32_t*) gs_device_alloc(sizeof(int32_t) * nv);
     }
-    const size_t waves = ((size_t) n + kWave - 1) / kWave;
+    const size_t waves = (((size_t) n + kWave - 1) / kWave) * (size_t) r->views;
     r->bandMask = (unsigned long long*) gs_device_alloc(sizeof(unsigned long long) * waves);
     r->bandCounts = (int32_t*) gs_device_alloc(sizeof(int32_t) * waves);
     r->bandOffsets = (int32_t*) gs_device_alloc(sizeof(int32_t) * waves);
@@ -641,7 +644,8 @@ void allocateSceneIntermediates(GsRenderer* r, int32_t n)
 #ifndef GS_INITIAL_LIST_FACTOR
 #define GS_INITIAL_LIST_FACTOR 8
 #endif
-    if (r->tileListCapacity < std::max(n, 1) * GS_INITIAL_LIST_FACTOR) allocTileList(r, std::max(n, 1) * GS_INITIAL_LIST_FACTOR);
+    const int64_t initial = std::min<int64_t>((int64_t) std::max(n, 1) * GS_INITIAL_LIST_FACTOR * r->views, 0x7FFFFFFF);
+    if (r->tileListCapacity < initial) allocTileList(r, (int32_t) initial);
 }
 } // namespace
 
@@ -703,12 +707,47 @@ extern "C" int gs_renderer_share_scene(GsRenderer* r, const GsRenderer* owner)
 }
 
 extern "C" uint8_t* gs_renderer_back_buffer(GsRenderer* r) { return r->backBuffer; }
+extern "C" uint8_t* gs_renderer_back_buffer_view(GsRenderer* r, int view)
+{
+    if (view < 0 || view >= r->views) return nullptr;
+    return r->backBuffer + (size_t) view * r->width * r->height * 4;
+}
+extern "C" int gs_renderer_views(const GsRenderer* r) { return r->views; }
+
+// Several cameras per chain of kernels (header: gs_renderer_set_views).  Before the scene is set: the per-view intermediates are
+// sized there.
+extern "C" int gs_renderer_set_views(GsRenderer* r, int views)
+{
+    if (views < 1 || views > kMaxViews || r->position != nullptr) return -1;
+    if (views == r->views) return 0;
+    StreamScope scope(r);
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    const Screen scr = makeScreen(r->width, r->height, 0, 0);
+    const bool external = r->backBuffer != r->backBufferOwned;
+    gs_device_free(r->tileRange);
+    gs_device_free(r->backBufferOwned);
+    r->views = views;
+    r->tileRange = (int32_t*) gs_device_alloc(sizeof(int32_t) * 2 * (size_t) scr.totalTiles * views);
+    GS_CHECK(hipMemset(r->tileRange, 0xFF, sizeof(int32_t) * 2 * (size_t) scr.totalTiles * views));
+    r->backBufferOwned = (uint8_t*) gs_device_alloc((size_t) scr.width * scr.height * 4 * views);
+    GS_CHECK(hipMemset(r->backBufferOwned, 0, (size_t) scr.width * scr.height * 4 * views)); // rows outside a band stay zero
+    if (!external) r->backBuffer = r->backBufferOwned;
+    r->graphValid = false;
+    return 0;
+}
 extern "C" void gs_renderer_set_back_buffer(GsRenderer* r, uint8_t* p) { r->backBuffer = p ? p : r->backBufferOwned; }
 
 extern "C" void gs_renderer_read_back_buffer(GsRenderer* r, uint8_t* hostRgba)
 {
     StreamScope scope(r);
     gs_device_download(hostRgba, r->backBuffer, (size_t) r->width * r->height * 4);
+}
+extern "C" int gs_renderer_read_back_buffer_view(GsRenderer* r, int view, uint8_t* hostRgba)
+{
+    if (view < 0 || view >= r->views) return -1;
+    StreamScope scope(r);
+    gs_device_download(hostRgba, r->backBuffer + (size_t) view * r->width * r->height * 4, (size_t) r->width * r->height * 4);
+    return 0;
 }
 
 extern "C" void gs_renderer_buffers(GsRenderer* r, GsRendererBuffers* out)
@@ -911,8 +950,8 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
                                 binned ? (float2*) r->clipXY : nullptr, r->clipZ, nullptr, nullptr, nullptr, nullptr, r->bandMask,
                                 r->bandCounts, nullptr, binned ? nullptr : r->tileRange, 2 * scr.totalTiles, (float4*) r->tileRecord,
                                 (float4*) r->rasterRecord);
-            launchScanInt32(g.stream, (n + kWave - 1) / kWave, r->bandCounts, r->bandOffsets, r->bandTotal);
-            launchCompactBand(g.stream, n, r->bandMask, r->bandOffsets, r->clipZ, r->depthKey[0], (uint32_t*) r->order[0]);
+            launchBandCompaction(g.stream, n, 1, r->bandMask, r->bandCounts, r->bandOffsets, r->bandTotal, r->clipZ, r->depthKey[0],
+                                 (uint32_t*) r->order[0]);
             countDevice = (const int*) r->bandTotal; // low 32 bits of the little-endian int64 total
         }
         gs_timer_stop(stageTimers[1]);
@@ -1128,15 +1167,20 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
     const RasterColourSource lazySource = colourSource(r, nullptr, r->paramsDevice);
     const RasterColourSource* lazyColours = lazy ? &lazySource : nullptr;
     const int n = r->splatCount;
-    const int tileKeyBytes = scr.totalTiles > 65536 ? 4 : 2;
-    const int tBits = tileBits(scr.totalTiles);
+    // Several views per chain: V grid rows in the clip, compaction and raster kernels; everything in between works on the
+    // n * V virtual splats and V * totalTiles virtual tiles as if they were one frame's (gs_internal.h: kMaxViews).
+    const int views = r->views;
+    const int nv = n * views;
+    const int virtualTiles = scr.totalTiles * views;
+    const int tileKeyBytes = virtualTiles > 65536 ? 4 : 2;
+    const int tBits = tileBits(virtualTiles);
     const float3 unused = make_float3(0.f, 0.f, 0.f);
     ClipCamera unusedCamera{};
 
-    GS_CHECK(hipMemcpyAsync(r->paramsDevice, r->paramsHost + slot, sizeof(FrameParams), hipMemcpyHostToDevice, g.stream));
+    GS_CHECK(hipMemcpyAsync(r->paramsDevice, r->paramsHost + slot * kMaxViews, sizeof(FrameParams) * views, hipMemcpyHostToDevice, g.stream));
     // the range table is reset to -1 by the clip kernel (one node less than a memset; see gs_ranges.hip); binned frames write every range
     int32_t* clearTable = binned ? nullptr : r->tileRange;
-    const int clearEntries = 2 * scr.totalTiles;
+    const int clearEntries = 2 * virtualTiles;
 #ifdef GS_DEBUG_MEMSET_NODE
     // audit build (tools/micro/graph_memset.hip): the table is cleared by a memset NODE instead
     if (clearTable != nullptr) GS_CHECK(hipMemsetAsync(clearTable, 0xFF, sizeof(int32_t) * (size_t) clearEntries, g.stream));
@@ -1152,15 +1196,16 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
             launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
                                 binned ? (float2*) r->clipXY : nullptr, nullptr, nullptr, nullptr, r->depthKey[0],
                                 (uint32_t*) r->order[0], nullptr, nullptr, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord,
-                                (float4*) r->rasterRecord);
+                                (float4*) r->rasterRecord, views);
     }
     else
     {
         launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
                             binned ? (float2*) r->clipXY : nullptr, r->clipZ, nullptr, nullptr, nullptr, nullptr, r->bandMask,
-                            r->bandCounts, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord, (float4*) r->rasterRecord);
-        launchScanInt32(g.stream, (n + kWave - 1) / kWave, r->bandCounts, r->bandOffsets, r->bandTotal);
-        launchCompactBand(g.stream, n, r->bandMask, r->bandOffsets, r->clipZ, r->depthKey[0], (uint32_t*) r->order[0]);
+                            r->bandCounts, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord, (float4*) r->rasterRecord,
+                            views);
+        launchBandCompaction(g.stream, n, views, r->bandMask, r->bandCounts, r->bandOffsets, r->bandTotal, r->clipZ, r->depthKey[0],
+                             (uint32_t*) r->order[0]);
         countDevice = (const int*) r->bandTotal;
         if (r->shDegree != 0 && !lazy)
             launchSphericalHarmonicsGather(g.stream, n, countDevice, r->shDegree, r->shCount, r->order[0], (const float4*) r->position,
@@ -1169,7 +1214,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
     r->radix.onesweep = false; // its ticket base / epoch are host-side launch arguments: not replayable
     r->radix.countDevice = countDevice;
     r->scratch.countDevice = countDevice;
-    const int orderSel = (g_ablation & 2) ? 0 : launchRadixSortPairs(g.stream, r->radix, 4, r->depthKey[0], r->depthKey[1], r->order[0], r->order[1], n, 0, kDepthKeyBits);
+    const int orderSel = (g_ablation & 2) ? 0 : launchRadixSortPairs(g.stream, r->radix, 4, r->depthKey[0], r->depthKey[1], r->order[0], r->order[1], nv, 0, kDepthKeyBits);
     const uint32_t* order = (const uint32_t*) r->order[orderSel];
     if (binned)
     {
@@ -1186,10 +1231,10 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
         r->graphKeyBytes = 0;
         return 0;
     }
-    if (!(g_ablation & 4)) launchTileListFastCount(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch);
+    if (!(g_ablation & 4)) launchTileListFastCount(g.stream, nv, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch);
     if (!(g_ablation & 8))
-        launchTileListFastEmit(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],
-                               tileKeyBytes, r->values[0], r->tileListCapacity);
+        launchTileListFastEmit(g.stream, nv, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],
+                               tileKeyBytes, r->values[0], r->tileListCapacity, views > 1 ? n : 0);
     // tile sort + ranges on the device-side pair count (low word of the int64 total), grids sized for the capacity
     const int* pairCount = (const int*) r->scratch.total;
     r->radix.countDevice = pairCount;
@@ -1201,7 +1246,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
     if (!(g_ablation & 32)) launchTileRanges(g.stream, r->tileListCapacity, tileKeyBytes, r->keys[sel], r->tileRange, pairCount);
     if (!(g_ablation & 64))
         launchRasterize(g.stream, scr, r->tileRange, r->values[sel], (const float2*) r->clipXY, (const float4*) r->conic,
-                        (const float4*) r->color, (uchar4*) r->backBuffer, nullptr, true, lazyColours, (const float4*) r->rasterRecord);
+                        (const float4*) r->color, (uchar4*) r->backBuffer, nullptr, true, lazyColours, (const float4*) r->rasterRecord, views, n);
     r->graphSelector = sel;
     r->graphKeyBytes = tileKeyBytes;
     return 0;
@@ -1232,7 +1277,8 @@ int64_t awaitPairTotal(GsRenderer* r)
     }
 }
 
-int renderCaptured(GsRenderer* r, const GsCameraData* camera)
+// `cameras`: r->views of them (one frame per view, rendered by one chain).
+int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
 {
     if (!r->hasStream && g.stream == nullptr)
     {
@@ -1254,18 +1300,22 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
     if (r->paramsDevice == nullptr)
     {
         std::lock_guard<std::mutex> lock(g_captureMutex);
-        GS_CHECK(hipMalloc((void**) &r->paramsDevice, sizeof(FrameParams)));
-        GS_CHECK(hipHostMalloc((void**) &r->paramsHost, 2 * sizeof(FrameParams), hipHostMallocDefault));
+        GS_CHECK(hipMalloc((void**) &r->paramsDevice, sizeof(FrameParams) * kMaxViews));
+        GS_CHECK(hipHostMalloc((void**) &r->paramsHost, 2 * kMaxViews * sizeof(FrameParams), hipHostMallocDefault));
     }
     const bool lazy = useLazyColours(r);
 
-    FrameParams fp{};
-    std::memcpy(fp.camera.view, camera->view, sizeof(fp.camera.view));
-    fp.camera.fovCotX = camera->fovCotangent[0];
-    fp.camera.fovCotY = camera->fovCotangent[1];
-    fp.camera.depthScale = camera->depthScaleBias[0];
-    fp.camera.depthBias = camera->depthScaleBias[1];
-    for (int k = 0; k != 3; ++k) fp.cameraPosition[k] = r->lastCameraPosition[k] = camera->position[k];
+    FrameParams fp[kMaxViews] = {};
+    for (int v = 0; v != r->views; ++v)
+    {
+        const GsCameraData* camera = cameras + v;
+        std::memcpy(fp[v].camera.view, camera->view, sizeof(fp[v].camera.view));
+        fp[v].camera.fovCotX = camera->fovCotangent[0];
+        fp[v].camera.fovCotY = camera->fovCotangent[1];
+        fp[v].camera.depthScale = camera->depthScaleBias[0];
+        fp[v].camera.depthBias = camera->depthScaleBias[1];
+        for (int k = 0; k != 3; ++k) fp[v].cameraPosition[k] = r->lastCameraPosition[k] = camera->position[k];
+    }
     r->colourStale = lazy;
 
     // A frame whose pair demand exceeds the list capacity is NOT handed out (the reference would show it truncated and double
@@ -1274,7 +1324,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
     for (;;)
     {
         const bool binned = r->pipeline == GS_PIPELINE_BINNED && binsSupported(scr) && radixSortSupported(4, n) &&
-                            r->scratch.totalHostMapped != nullptr;
+                            r->scratch.totalHostMapped != nullptr && r->views == 1;
         if (r->graphValid && (r->graphCapacity != r->tileListCapacity || r->graphSplats != n || r->graphRowBegin != scr.rowBegin ||
                               r->graphRowEnd != scr.rowEnd || r->graphCull != (int) cull || r->graphBinned != (int) binned ||
                               r->graphFootprint != scr.epanechnikov || r->graphLazy != (int) lazy || r->graphAblation != g_ablation))
@@ -1284,8 +1334,8 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
             GS_CHECK(hipStreamSynchronize(g.stream)); // frames of the old instances drain before these are destroyed
             std::lock_guard<std::mutex> lock(g_captureMutex);
             // allocate everything the frame needs BEFORE capturing (no allocation may happen inside a capture)
-            ensureTileListFastScratch(r->scratch, n);
-            ensureRadixScratch(r->radix, n);
+            ensureTileListFastScratch(r->scratch, n * r->views);
+            ensureRadixScratch(r->radix, n * r->views);
             ensureRadixScratch(r->radix, r->tileListCapacity);
             if (binned) ensureBinScratch(r->bins, n, (scr.rowEnd - scr.rowBegin) * scr.tilesX, binBatchesFor((scr.rowEnd - scr.rowBegin) * scr.tilesX));
             for (int slot = 0; slot != 2; ++slot)
@@ -1312,7 +1362,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* camera)
         }
         const int slot = r->graphSlot;
         r->graphSlot ^= 1;
-        r->paramsHost[slot] = fp;
+        for (int v = 0; v != r->views; ++v) r->paramsHost[slot * kMaxViews + v] = fp[v];
         *r->scratch.totalHost = -1; // armed; the previous frame has left its total (seen by the host), nothing else writes the word
         const auto hostT0 = std::chrono::steady_clock::now();
         GS_CHECK(hipGraphLaunch(r->graphExec[slot], g.stream));
@@ -1361,12 +1411,24 @@ extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int
 {
     // Captured path: plain frames (no stage timers, no stats) of the two-level pipeline on the native sort.
     if (r->useGraph && timed == 0 && stats == nullptr && r->pipeline != GS_PIPELINE_REFERENCE &&
-        cfg.sortBackend == GS_SORT_BACKEND_NATIVE && !cfg.collectRasterStats && r->splatCount > 0)
+        cfg.sortBackend == GS_SORT_BACKEND_NATIVE && !cfg.collectRasterStats && r->splatCount > 0 && r->views == 1)
         return renderCaptured(r, camera);
     r->graphValid = false; // the regular path re-sizes scratch as it likes
     const int rc = gs_renderer_begin(r, camera, timed);
     if (rc != 0) return rc;
     return gs_renderer_finish(r, stats);
+}
+
+// r->views frames by ONE chain of kernels (header: gs_renderer_set_views); captured frames of the two-level pipeline only.
+extern "C" int gs_renderer_render_views(GsRenderer* r, const GsCameraData* cameras)
+{
+    if (r == nullptr || cameras == nullptr) return -1;
+    if (r->views == 1) return gs_renderer_render(r, cameras, 0, nullptr);
+    const bool coloursPerView = r->shDegree != 0 && !useLazyColours(r); // an SH pass would need one colour buffer per view
+    if (!r->useGraph || r->pipeline != GS_PIPELINE_TWO_LEVEL || cfg.sortBackend != GS_SORT_BACKEND_NATIVE || cfg.collectRasterStats ||
+        r->splatCount <= 0 || coloursPerView || !radixSortSupported(4, r->splatCount * r->views))
+        return -3;
+    return renderCaptured(r, cameras);
 }
 
 extern "C" int gs_renderer_collect_stage_times(GsRenderer* r, GsFrameStats* sums)

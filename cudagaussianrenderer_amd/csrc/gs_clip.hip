@@ -36,28 +36,60 @@ __device__ __forceinline__ uint32_t compactDepthKey(float clipDepth)
     return ((uint32_t) (top - 22) << 23) | ((q >> (top - 23)) & 0x7FFFFFu);
 }
 
-__global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr, ClipCamera camArg, const FrameParams* __restrict__ params,
-                                                            const float4* __restrict__ position,
-                                                            const float4* __restrict__ scaleAndRotation,
-                                                            float2* __restrict__ clipXY, float* __restrict__ clipZ,
-                                                            float4* __restrict__ screenEllipse, float4* __restrict__ conicOut,
-                                                            uint32_t* __restrict__ depthKey, uint32_t* __restrict__ splatOrder,
-                                                            unsigned long long* __restrict__ bandMask,
-                                                            int32_t* __restrict__ bandWaveCounts, int32_t* __restrict__ rangeTable,
-                                                            int rangeEntries, float4* __restrict__ tileRecord,
-                                                            float4* __restrict__ rasterRecord)
+// View-space centre and the para-perspective terms every later step needs (GaussianRender.cu:227-259,265).  ONE routine for the
+// band cull's early test and for the projection proper, so that both see the same clip position bit for bit.
+struct ViewTerms
 {
-    const int index = blockIdx.x * blockDim.x + threadIdx.x;
-    // The renderer has this kernel reset the tile range table to -1 (Demo.cpp:403) on the side: it is the first kernel
-    // of the frame and nothing reads the table before the range search, so the frame needs no separate clear.
-    if (rangeTable != nullptr)
-        for (int i = index; i < rangeEntries; i += (int) (gridDim.x * blockDim.x)) rangeTable[i] = -1;
-    if (index >= count) return;
-    const ClipCamera cam = params ? params->camera : camArg; // device-resident when the frame is a captured graph
+    float vx, vy, vz, zRcp, zRcpSqr, scaleX, scaleY, cotTrsX, cotTrsY, shearX, shearY;
+    float clipX, clipY, clipDepth;
+    bool inside; // centre-in-frustum test of GaussianRender.cu:316-321 (without its lambda1 term, which never fails: lambda1 >= 0)
+};
+__device__ __forceinline__ ViewTerms viewTerms(const float4 pd, const ClipCamera& cam)
+{
+    ViewTerms t;
+    // View-space centre (GaussianRender.cu:227); v[col*4+row].
+    const float* v = cam.view;
+    t.vx = (v[0] * pd.x + v[4] * pd.y) + (v[8] * pd.z + v[12]);
+    t.vy = (v[1] * pd.x + v[5] * pd.y) + (v[9] * pd.z + v[13]);
+    t.vz = (v[2] * pd.x + v[6] * pd.y) + (v[10] * pd.z + v[14]);
+    // Para-perspective Jacobian (GaussianRender.cu:236-259).
+    t.zRcp = 1.0f / t.vz;
+    t.zRcpSqr = t.zRcp * t.zRcp;
+    t.scaleX = -cam.fovCotX * t.zRcp;
+    t.scaleY = -cam.fovCotY * t.zRcp;
+    t.cotTrsX = cam.fovCotX * t.vx;
+    t.cotTrsY = cam.fovCotY * t.vy;
+    t.shearX = t.cotTrsX * t.zRcpSqr;
+    t.shearY = t.cotTrsY * t.zRcpSqr;
+    // Clip position = J * (view pos, 1) (GaussianRender.cu:265): x = scaleX*vx + shearX*vz + translationX.
+    t.clipX = (t.scaleX * t.vx + 0.0f * t.vy) + (t.shearX * t.vz + (-t.cotTrsX * t.zRcp));
+    t.clipY = (0.0f * t.vx + t.scaleY * t.vy) + (t.shearY * t.vz + (-t.cotTrsY * t.zRcp));
+    t.clipDepth = (0.0f * t.vx + 0.0f * t.vy) + (cam.depthScale * t.vz + cam.depthBias);
+    // Centre-in-frustum cull (GaussianRender.cu:316-321). step(edge,x) = x < edge ? 0 : 1, so NaN passes, as in glm.
+    t.inside = !(t.clipX < -1.0f) && !(1.0f < t.clipX) && !(t.clipY < -1.0f) && !(1.0f < t.clipY) && !(t.clipDepth < -1.0f) &&
+               !(1.0f < t.clipDepth);
+    return t;
+}
 
-    const float4 pd = position[index];
-    const float4 sr = scaleAndRotation[index];
+// What the kernel writes per (virtual) splat; null pointers are outputs nobody asked for.
+struct ClipOutputs
+{
+    float2* clipXY;
+    float* clipZ;
+    float4* screenEllipse;
+    float4* conic;
+    uint32_t* depthKey;
+    uint32_t* splatOrder;
+    float4* tileRecord;
+    float4* rasterRecord;
+};
 
+// The projection proper for one splat: covariance, eigen decomposition, conic, frustum cull, (band test,) stores under `out`.
+// Returns whether the splat reaches the band (always true without a band test).
+template <bool BAND>
+__device__ __forceinline__ bool projectSplat(const float4 pd, const float4 sr, const ClipCamera& cam, const Screen& scr, int out,
+                                             const ClipOutputs& o)
+{
     // decodeVec4 (GaussianRender.cu:55-58,220-221): four truncated bytes -> [-1,1], x in the top byte;
     // the quaternion is NOT renormalised.
     const uint32_t bits = __float_as_uint(sr.w);
@@ -86,21 +118,9 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
     S.yz = m01 * m02 + m11 * m12 + m21 * m22;
     S.zz = m02 * m02 + m12 * m12 + m22 * m22;
 
-    // View-space centre (GaussianRender.cu:227); v[col*4+row].
     const float* v = cam.view;
-    const float vx = (v[0] * pd.x + v[4] * pd.y) + (v[8] * pd.z + v[12]);
-    const float vy = (v[1] * pd.x + v[5] * pd.y) + (v[9] * pd.z + v[13]);
-    const float vz = (v[2] * pd.x + v[6] * pd.y) + (v[10] * pd.z + v[14]);
-
-    // Para-perspective Jacobian (GaussianRender.cu:236-259).
-    const float zRcp = 1.0f / vz;
-    const float zRcpSqr = zRcp * zRcp;
-    const float scaleX = -cam.fovCotX * zRcp;
-    const float scaleY = -cam.fovCotY * zRcp;
-    const float cotTrsX = cam.fovCotX * vx;
-    const float cotTrsY = cam.fovCotY * vy;
-    const float shearX = cotTrsX * zRcpSqr;
-    const float shearY = cotTrsY * zRcpSqr;
+    const ViewTerms t = viewTerms(pd, cam);
+    const float scaleX = t.scaleX, scaleY = t.scaleY, shearX = t.shearX, shearY = t.shearY;
 
     // Rows 0 and 1 of VP = mat3(J) * mat3(view) (GaussianRender.cu:262); row 2 never reaches the 2x2 block we need.
     //   J row0 = (scaleX, 0, shearX), row1 = (0, scaleY, shearY)
@@ -118,10 +138,7 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
     const float covB = b0 * sa0 + b1 * sa1 + b2 * sa2; // [1][0]
     float covC = b0 * sb0 + b1 * sb1 + b2 * sb2; // [1][1]
 
-    // Clip position = J * (view pos, 1) (GaussianRender.cu:265): x = scaleX*vx + shearX*vz + translationX.
-    float clipX = (scaleX * vx + 0.0f * vy) + (shearX * vz + (-cotTrsX * zRcp));
-    float clipY = (0.0f * vx + scaleY * vy) + (shearY * vz + (-cotTrsY * zRcp));
-    float clipDepth = (0.0f * vx + 0.0f * vy) + (cam.depthScale * vz + cam.depthBias);
+    float clipX = t.clipX, clipY = t.clipY, clipDepth = t.clipDepth;
 
     // Trace bump (GaussianRender.cu:271-276).
     covA += scr.traceBump;
@@ -144,9 +161,8 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
     // Conic (GaussianRender.cu:305-307).
     const float invDet = 1.0f / fmaxf(epsilon, det);
 
-    // Centre-in-frustum cull (GaussianRender.cu:316-321). step(edge,x) = x < edge ? 0 : 1, so NaN passes, as in glm.
-    const bool inside = !(clipX < -1.0f) && !(1.0f < clipX) && !(clipY < -1.0f) && !(1.0f < clipY) && !(clipDepth < -1.0f) &&
-                        !(1.0f < clipDepth) && !(lambda1 < 0.0f);
+    // Centre-in-frustum cull (GaussianRender.cu:316-321), see viewTerms; lambda1 >= 0 by construction.
+    const bool inside = t.inside && !(lambda1 < 0.0f);
     const float isVisible = inside ? 1.0f : 0.0f;
     // mix(-128, clip, v) = -128*(1-v) + clip*v ; extent *= v  (kept as arithmetic so inf/NaN propagate as in the reference)
     clipX = -128.0f * (1.0f - isVisible) + clipX * isVisible;
@@ -155,66 +171,182 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
     extentX *= isVisible;
     extentY *= isVisible;
 
-    if (bandMask != nullptr)
+    if (BAND)
     {
         // Band cull for the multi-GPU split: does this splat's tile AABB reach the tile rows this GPU owns?  Same AABB
-        // routine as the tile-list builder, so nothing that would emit a pair is dropped. One 64-bit mask per wave.
+        // routine as the tile-list builder, so nothing that would emit a pair is dropped.
         const TileAabb box = splatTileAabb(clipX, clipY, cosA, sinA, extentX, extentY, scr);
-        const bool kept = box.x1 > box.x0 && box.y1 > box.y0;
-        const unsigned long long mask = __ballot(kept);
-        if ((threadIdx.x & (kWave - 1)) == 0)
-        {
-            bandMask[index >> 6] = mask;
-            bandWaveCounts[index >> 6] = __popcll(mask);
-        }
         // Nothing downstream ever looks at a splat that does not reach the band (the compacted list holds the kept ones only):
-        // its 60 bytes of per-splat outputs are not written.  With 8 bands ~80 % of the splats stop here, which takes this
-        // replicated, HBM-bound pass from ~100 to ~45 bytes per splat.
-        if (!kept) return;
+        // its per-splat outputs are not written.
+        if (!(box.x1 > box.x0 && box.y1 > box.y0)) return false;
     }
-    if (depthKey != nullptr)
+    if (o.depthKey != nullptr)
     {
         // Quantised depth of getKey() (GaussianRender.cu:446-454) as a sort key of its own (27-bit code, see above), plus
         // the identity permutation: the one-call renderer sorts SPLATS by depth before expanding them to tiles.
-        depthKey[index] = compactDepthKey(clipDepth);
-        splatOrder[index] = (uint32_t) index;
+        o.depthKey[out] = compactDepthKey(clipDepth);
+        o.splatOrder[out] = (uint32_t) out;
     }
-    if (clipXY != nullptr) clipXY[index] = make_float2(clipX, clipY);
-    if (clipZ != nullptr) clipZ[index] = clipDepth;
-    if (screenEllipse != nullptr) screenEllipse[index] = make_float4(cosA, sinA, extentX, extentY);
-    if (tileRecord != nullptr)
+    if (o.clipXY != nullptr) o.clipXY[out] = make_float2(clipX, clipY);
+    if (o.clipZ != nullptr) o.clipZ[out] = clipDepth;
+    if (o.screenEllipse != nullptr) o.screenEllipse[out] = make_float4(cosA, sinA, extentX, extentY);
+    if (o.tileRecord != nullptr)
     {
         // the same six numbers once more as ONE 32-byte record: the tile-list passes fetch them through the depth order
         // (random access), where two separate arrays cost two memory sectors per splat
-        tileRecord[2 * index] = make_float4(clipX, clipY, cosA, sinA);
-        tileRecord[2 * index + 1] = make_float4(extentX, extentY, 0.0f, 0.0f);
+        o.tileRecord[2 * (size_t) out] = make_float4(clipX, clipY, cosA, sinA);
+        o.tileRecord[2 * (size_t) out + 1] = make_float4(extentX, extentY, 0.0f, 0.0f);
     }
-    if (conicOut != nullptr) conicOut[index] = make_float4(covC * invDet, -covB * invDet, covA * invDet, 0.0f);
-    if (rasterRecord != nullptr)
+    if (o.conic != nullptr) o.conic[out] = make_float4(covC * invDet, -covB * invDet, covA * invDet, 0.0f);
+    if (o.rasterRecord != nullptr)
     {
         // what the raster kernel gathers per list entry besides the colour, as ONE 32-byte record (one memory sector instead of one
         // for the centre and one for the conic)
-        rasterRecord[2 * index] = make_float4(clipX, clipY, covC * invDet, -covB * invDet);
-        rasterRecord[2 * index + 1] = make_float4(covA * invDet, clipDepth, 0.0f, 0.0f); // (the depth rides along for gs_renderer_buffers)
+        o.rasterRecord[2 * (size_t) out] = make_float4(clipX, clipY, covC * invDet, -covB * invDet);
+        o.rasterRecord[2 * (size_t) out + 1] = make_float4(covA * invDet, clipDepth, 0.0f, 0.0f); // (the depth rides along for gs_renderer_buffers)
+    }
+    return true;
+}
+
+// Band cull, early test: can this splat be ruled out WITHOUT the projection proper?  Exact part: a centre outside the frustum
+// gets clip = -128 and extents * 0, whose tile AABB is empty whatever the ellipse (gs_aabb.h) -- never kept.  Conservative part:
+// the AABB's half-height in clip units is |sin| eX + |cos| eY <= sqrt(eX^2 + eY^2) = f sqrt(lambda0 + lambda1) <= f sqrt(A + C),
+// A + C = |M^T a|^2 + |M^T b|^2 + 2 bump <= |M|_F^2 (|a|^2 + |b|^2) + 2 bump with M = R S, a, b the rows of J W; the bound is
+// evaluated in plain floats with 2 % on the radicand and 0.02 tile rows of slack for the rounding of either side, and anything
+// not finite compares false, i.e. stays a candidate.  Candidates go through projectSplat<true>, which decides exactly.
+__device__ __forceinline__ bool bandCandidate(const float4 pd, const float4 sr, const ClipCamera& cam, const Screen& scr)
+{
+    const ViewTerms t = viewTerms(pd, cam);
+    if (!t.inside) return false;
+    const uint32_t bits = __float_as_uint(sr.w);
+    const float k = 2.0f / 255.0f;
+    const float qx = (float) ((bits >> 24) & 0xFFu) * k - 1.0f, qy = (float) ((bits >> 16) & 0xFFu) * k - 1.0f;
+    const float qz = (float) ((bits >> 8) & 0xFFu) * k - 1.0f, qw = (float) (bits & 0xFFu) * k - 1.0f;
+    const float qxx = qx * qx, qyy = qy * qy, qzz = qz * qz;
+    const float qxz = qx * qz, qxy = qx * qy, qyz = qy * qz;
+    const float qwx = qw * qx, qwy = qw * qy, qwz = qw * qz;
+    const float r00 = 1.0f - 2.0f * (qyy + qzz), r01 = 2.0f * (qxy + qwz), r02 = 2.0f * (qxz - qwy);
+    const float r10 = 2.0f * (qxy - qwz), r11 = 1.0f - 2.0f * (qxx + qzz), r12 = 2.0f * (qyz + qwx);
+    const float r20 = 2.0f * (qxz + qwy), r21 = 2.0f * (qyz - qwx), r22 = 1.0f - 2.0f * (qxx + qyy);
+    const float frobenius = sr.x * sr.x * (r00 * r00 + r01 * r01 + r02 * r02) + sr.y * sr.y * (r10 * r10 + r11 * r11 + r12 * r12) +
+                            sr.z * sr.z * (r20 * r20 + r21 * r21 + r22 * r22); // |R S|_F^2 = trace(Sigma)
+    const float* v = cam.view;
+    const float a0 = t.scaleX * v[0] + t.shearX * v[2], a1 = t.scaleX * v[4] + t.shearX * v[6], a2 = t.scaleX * v[8] + t.shearX * v[10];
+    const float b0 = t.scaleY * v[1] + t.shearY * v[2], b1 = t.scaleY * v[5] + t.shearY * v[6], b2 = t.scaleY * v[9] + t.shearY * v[10];
+    const float rows = (a0 * a0 + a1 * a1 + a2 * a2) + (b0 * b0 + b1 * b1 + b2 * b2);
+    const float traceBound = frobenius * rows + 2.0f * scr.traceBump;          // >= covA + covC >= lambda0 + lambda1
+    const float reach = scr.extentFactor * sqrtf(traceBound * 1.02f + 1e-12f); // >= the AABB's half-height, clip units
+    const float centreRow = (t.clipY + 1.0f) * 0.5f * scr.tilesPerScreenY;     // tile-row coordinate of the centre (gs_aabb.h)
+    const float reachRows = reach * 0.5f * scr.tilesPerScreenY;
+    const bool below = centreRow + reachRows < (float) scr.rowBegin - 0.02f; // the AABB ends before the band's first row
+    const bool above = centreRow - reachRows > (float) scr.rowEnd + 0.02f;   // ... or starts behind its last
+    return !(below || above);
+}
+
+#ifndef GS_CLIP_EARLY_BAND_TEST
+#define GS_CLIP_EARLY_BAND_TEST 1 // A/B and audit builds: 0 = every splat goes through the projection proper
+#endif
+
+// BAND = false: one splat per lane, every splat projected and stored (the single-GPU frame, the staged API).
+// BAND = true (multi-GPU band cull): the workgroup first rules out what it can with the early test, compacts the candidates of its
+// 256 splats in LDS and runs the projection proper on those only -- with 8 bands ~85 % of the splats stop after ~100 instructions
+// instead of ~700, and the candidates fill one wave instead of four.  Per wave of splats: the 64-bit mask of the kept ones; per
+// workgroup: their number (the compaction's scan runs over workgroups).
+template <bool BAND>
+__global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr, ClipCamera camArg, const FrameParams* __restrict__ params,
+                                                            const float4* __restrict__ position,
+                                                            const float4* __restrict__ scaleAndRotation, ClipOutputs o,
+                                                            unsigned long long* __restrict__ bandMask,
+                                                            int32_t* __restrict__ bandBlockCounts, int32_t* __restrict__ rangeTable,
+                                                            int rangeEntries)
+{
+    const int index = blockIdx.x * blockDim.x + threadIdx.x; // splat of the scene
+    const int view = blockIdx.y;                              // gs_renderer_set_views: one grid row per camera
+    // The renderer has this kernel reset the tile range table to -1 (Demo.cpp:403) on the side: it is the first kernel
+    // of the frame and nothing reads the table before the range search, so the frame needs no separate clear.
+    if (rangeTable != nullptr)
+        for (int i = view * (int) (gridDim.x * blockDim.x) + index; i < rangeEntries; i += (int) (gridDim.x * gridDim.y * blockDim.x))
+            rangeTable[i] = -1;
+    const ClipCamera cam = params ? params[view].camera : camArg; // device-resident when the frame is a captured graph
+    if constexpr (!BAND)
+    {
+        if (index >= count) return;
+        // results are stored under the "virtual splat" view * count + index
+        (void) projectSplat<false>(position[index], scaleAndRotation[index], cam, scr, view * count + index, o);
+    }
+    else
+    {
+        __shared__ int candidates[256];
+        __shared__ int waveCandidates[4];
+        __shared__ unsigned long long keptMask[4];
+        const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
+        const int blockBase = blockIdx.x * blockDim.x;
+        if (blockBase >= count) return; // whole workgroup
+        bool candidate = false;
+        if (index < count)
+        {
+#if GS_CLIP_EARLY_BAND_TEST
+            candidate = bandCandidate(position[index], scaleAndRotation[index], cam, scr);
+#else
+            candidate = true;
+#endif
+        }
+        const unsigned long long votes = __ballot(candidate);
+        if (lane == 0)
+        {
+            waveCandidates[wave] = __popcll(votes);
+            keptMask[wave] = 0ull;
+        }
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w != 4; ++w)
+        {
+            const int c = waveCandidates[w];
+            before += (w < wave) ? c : 0;
+            total += c;
+        }
+        const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
+        if (candidate) candidates[before + __popcll(votes & lower)] = t;
+        __syncthreads();
+        if (t < total) // whole waves drop out here: `total` is typically below 64
+        {
+            const int local = candidates[t];
+            const int splat = blockBase + local;
+            if (projectSplat<true>(position[splat], scaleAndRotation[splat], cam, scr, view * count + splat, o))
+                atomicOr(&keptMask[local >> 6], 1ull << (local & (kWave - 1)));
+        }
+        __syncthreads();
+        const int wavesPerView = (count + kWave - 1) / kWave, blocksPerView = (count + 255) / 256;
+        if (t < 4 && blockBase + t * kWave < count) bandMask[view * wavesPerView + (blockBase >> 6) + t] = keptMask[t];
+        if (t == 0)
+            bandBlockCounts[view * blocksPerView + blockIdx.x] =
+                __popcll(keptMask[0]) + __popcll(keptMask[1]) + __popcll(keptMask[2]) + __popcll(keptMask[3]);
     }
 }
 
-// Order-preserving compaction of the splats flagged by the band cull: depth key + splat index of every kept splat at
-// waveOffsets[wave] + (kept lanes below it).
+// Order-preserving compaction of the splats flagged by the band cull: depth key + (virtual) splat index of every kept splat at
+// blockOffsets[workgroup of 256 splats] + (kept splats of the workgroup's earlier waves) + (kept lanes below it).
 __global__ __launch_bounds__(256) void compactBandKernel(int count, const unsigned long long* __restrict__ bandMask,
-                                                          const int32_t* __restrict__ waveOffsets, const float* __restrict__ clipZ,
+                                                          const int32_t* __restrict__ blockOffsets, const float* __restrict__ clipZ,
                                                           uint32_t* __restrict__ depthKey, uint32_t* __restrict__ splatOrder)
 {
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= count) return;
+    const int view = blockIdx.y;
+    const int out = view * count + index; // virtual splat (see the clip kernel)
+    const int wavesPerView = (count + kWave - 1) / kWave, blocksPerView = (count + 255) / 256;
+    const int firstWave = view * wavesPerView + (int) blockIdx.x * 4, wave = (int) threadIdx.x >> 6;
     const int lane = index & (kWave - 1);
-    const unsigned long long mask = bandMask[index >> 6];
+    const unsigned long long mask = bandMask[firstWave + wave];
     if ((mask >> lane) & 1ull)
     {
+        int pos = blockOffsets[view * blocksPerView + blockIdx.x];
+        for (int w = 0; w < wave; ++w) pos += __popcll(bandMask[firstWave + w]); // wave-uniform: scalar loads
         const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
-        const int pos = waveOffsets[index >> 6] + __popcll(mask & lower);
-        depthKey[pos] = compactDepthKey(clipZ[index]);
-        splatOrder[pos] = (uint32_t) index;
+        pos += __popcll(mask & lower);
+        depthKey[pos] = compactDepthKey(clipZ[out]);
+        splatOrder[pos] = (uint32_t) out;
     }
 }
 
@@ -252,25 +384,31 @@ void launchUnpackEllipse(hipStream_t stream, int count, const float4* tileRecord
     if (count > 0) hipLaunchKernelGGL(unpackEllipseKernel, dim3((count + 255) / 256), dim3(256), 0, stream, count, tileRecord, screenEllipse);
 }
 
-void launchCompactBand(hipStream_t stream, int count, const unsigned long long* bandMask, const int32_t* waveOffsets, const float* clipZ,
-                       uint32_t* depthKey, uint32_t* splatOrder)
+void launchBandCompaction(hipStream_t stream, int count, int views, const unsigned long long* bandMask, const int32_t* bandBlockCounts,
+                          int32_t* bandBlockOffsets, int64_t* bandTotal, const float* clipZ, uint32_t* depthKey, uint32_t* splatOrder)
 {
     if (count <= 0) return;
-    hipLaunchKernelGGL(compactBandKernel, dim3((count + 255) / 256), dim3(256), 0, stream, count, bandMask, waveOffsets, clipZ, depthKey,
+    const int blocks = (count + 255) / 256;
+    launchScanInt32(stream, blocks * views, bandBlockCounts, bandBlockOffsets, bandTotal);
+    hipLaunchKernelGGL(compactBandKernel, dim3(blocks, views), dim3(256), 0, stream, count, bandMask, bandBlockOffsets, clipZ, depthKey,
                        splatOrder);
 }
 
 void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const ClipCamera& cam, const float4* position,
                          const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic,
-                         uint32_t* depthKey, uint32_t* splatOrder, unsigned long long* bandMask, int32_t* bandWaveCounts,
+                         uint32_t* depthKey, uint32_t* splatOrder, unsigned long long* bandMask, int32_t* bandBlockCounts,
                          const FrameParams* paramsDevice, int32_t* rangeTableToClear, int rangeEntries, float4* tileRecord,
-                         float4* rasterRecord)
+                         float4* rasterRecord, int views)
 {
     if (count <= 0) return;
-    const dim3 grid((count + 255) / 256), block(256);
-    hipLaunchKernelGGL(splatClipDataKernel, grid, block, 0, stream, count, scr, cam, paramsDevice, position, scaleAndRotation, clipXY, clipZ,
-                       screenEllipse, conic, depthKey, splatOrder, bandMask, bandWaveCounts, rangeTableToClear, rangeEntries, tileRecord,
-                       rasterRecord);
+    const dim3 grid((count + 255) / 256, views), block(256); // views > 1: cameras from paramsDevice[view], results under view * count + splat
+    const ClipOutputs o{clipXY, clipZ, screenEllipse, conic, depthKey, splatOrder, tileRecord, rasterRecord};
+    if (bandMask != nullptr)
+        hipLaunchKernelGGL(splatClipDataKernel<true>, grid, block, 0, stream, count, scr, cam, paramsDevice, position, scaleAndRotation, o,
+                           bandMask, bandBlockCounts, rangeTableToClear, rangeEntries);
+    else
+        hipLaunchKernelGGL(splatClipDataKernel<false>, grid, block, 0, stream, count, scr, cam, paramsDevice, position, scaleAndRotation, o,
+                           (unsigned long long*) nullptr, (int32_t*) nullptr, rangeTableToClear, rangeEntries);
 }
 
 } // namespace gs

@@ -29,6 +29,10 @@ namespace gs
 constexpr int kTileSize = GS_TILE_SIZE;
 constexpr int kWave = 64;        // CDNA wavefront
 constexpr int kRasterChunk = 32; // GaussianRender.cu:439,950,995: termination is voted every 32 list entries
+// Views per frame chain (gs_renderer_set_views): V cameras of ONE scene rendered by one chain of kernels.  View v's splat i is the
+// "virtual splat" v*N + i (own clip data, shared inputs) and its tile t the "virtual tile" v*totalTiles + t, so ONE depth sort and
+// ONE tile sort order the pairs of all views and every kernel of the chain runs once per V frames.
+constexpr int kMaxViews = 4;
 
 // Everything the reference derives from the compile-time k_ScreenSize (Consts.h:4-8), per frame here.
 // Passed to kernels by value (kernarg segment -> SGPRs) instead of a __constant__ symbol.
@@ -71,19 +75,19 @@ void launchSphericalHarmonics(hipStream_t stream, int count, int degree, int shC
 void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const ClipCamera& cam, const float4* position,
                          const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic,
                          uint32_t* depthKeyOrNull, uint32_t* splatOrderOrNull, unsigned long long* bandMaskOrNull = nullptr,
-                         int32_t* bandWaveCountsOrNull = nullptr, const FrameParams* paramsDeviceOrNull = nullptr,
+                         int32_t* bandBlockCountsOrNull = nullptr, const FrameParams* paramsDeviceOrNull = nullptr,
                          int32_t* rangeTableToClearOrNull = nullptr, int rangeEntries = 0, float4* tileRecordOrNull = nullptr,
-                         float4* rasterRecordOrNull = nullptr);
+                         float4* rasterRecordOrNull = nullptr, int views = 1);
 // screenEllipse[i] = (cos, sin, extent x, extent y) from the 32-byte tile records the clip kernel can write instead.
 void launchUnpackEllipse(hipStream_t stream, int count, const float4* tileRecord, float4* screenEllipse);
 // positionClipSpaceXY / Z / conic from the 32-byte raster records (cx, cy, conic.x, conic.y | conic.z, depth, 0, 0) the clip kernel can
 // write instead of the three arrays (what the raster gathers per list entry is then ONE memory sector instead of two).
 void launchUnpackRasterRecord(hipStream_t stream, int count, const float4* rasterRecord, float2* clipXY, float* clipZ, float4* conic);
-// Band cull (multi-GPU): the clip kernel flags the splats whose tile AABB reaches this GPU's rows (one 64-bit mask and
-// one count per 64 splats); after an exclusive scan of the counts this writes the kept splats' depth keys and indices,
-// order preserved.
-void launchCompactBand(hipStream_t stream, int count, const unsigned long long* bandMask, const int32_t* waveOffsets, const float* clipZ,
-                       uint32_t* depthKey, uint32_t* splatOrder);
+// Band cull (multi-GPU): the clip kernel flags the splats whose tile AABB reaches this GPU's rows (one 64-bit mask per 64 splats,
+// one count per workgroup of 256); this scans the counts and writes the kept splats' depth keys and (virtual) indices, order
+// preserved, and their number to *bandTotal.
+void launchBandCompaction(hipStream_t stream, int count, int views, const unsigned long long* bandMask, const int32_t* bandBlockCounts,
+                          int32_t* bandBlockOffsets, int64_t* bandTotal, const float* clipZ, uint32_t* depthKey, uint32_t* splatOrder);
 // Exclusive scan of n int32 on the device (one workgroup), total as int64.
 void launchScanInt32(hipStream_t stream, int n, const int32_t* in, int32_t* out, int64_t* total);
 // SH colour for the splats of a device-side index list only; coefficients in the [splat][shCount] layout.
@@ -128,7 +132,7 @@ void launchTileListFastCount(hipStream_t stream, int count, const Screen& scr, c
                              const float4* screenEllipse, TileListScratch& s);
 void launchTileListFastEmit(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
                             const float4* screenEllipse, const TileListScratch& s, void* tileKeys, int tileKeyBytes, int32_t* values,
-                            int capacity);
+                            int capacity, int viewSplats = 0);
 
 // rocPRIM radix sort of (key, int32 value) pairs on key bits [beginBit, endBit); keyBytes in {2, 4, 8}.
 size_t sortTempBytes(int keyBytes, int size, int beginBit, int endBit);
@@ -205,7 +209,8 @@ bool rasterCanEvaluateColours(int degree, int shCount);
 void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileRange, const int32_t* values,
                      const float2* clipXY, const float4* conic, const float4* color, uchar4* backBuffer,
                      unsigned long long* consumedPairsOrNull, bool clearEmptyTiles = false,
-                     const RasterColourSource* lazyColoursOrNull = nullptr, const float4* rasterRecordOrNull = nullptr);
+                     const RasterColourSource* lazyColoursOrNull = nullptr, const float4* rasterRecordOrNull = nullptr, int views = 1,
+                     int viewSplats = 0);
 
 // The renderer sorts its splats on a 27-bit re-coding of getKey()'s 32-bit quantised depth (GaussianRender.cu:446-454): the
 // quantised value comes from a float, so it has at most 24 significant bits -- (position of the top bit, next 23 bits) says

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
                                                                   const float4* __restrict__ color, uchar4* __restrict__ backBuffer,
                                                                   unsigned long long* __restrict__ consumedPairs, int clearEmptyTiles,
                                                                   RasterColourSource lazy, unsigned long long* __restrict__ trace,
-                                                                  const float4* __restrict__ rasterRecord)
+                                                                  const float4* __restrict__ rasterRecord, int viewSplats)
 {
     constexpr int THREADS = 256 / PPL;
     constexpr int GROUPS_X = kTileSize / PPL;
@@ -125,6 +125,14 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
     const int tile = firstTile + wg;
 #endif
     const unsigned long long traceStart = trace ? wall_clock64() : 0ull; // diagnostics only (gs_debug_set_raster_trace)
+
+    // Several views per chain (gs_renderer_set_views): grid row v renders view v -- its ranges are the virtual tiles
+    // v*totalTiles + t, its image the v-th of the back buffer, its list entries virtual splats v*N + i (clip data stored per
+    // view under that index; position and coefficient row are splat i's).
+    const int view = blockIdx.y;
+    const int viewFirstSplat = view * viewSplats;
+    tileRange += (size_t) view * 2 * scr.totalTiles;
+    backBuffer += (size_t) view * scr.width * scr.height;
 
     // GaussianRender.cu:917-931 (wave-uniform: scalar loads)
     int first = tileRange[tile * 2];
@@ -171,7 +179,8 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
     float3 lazyCam = make_float3(0.f, 0.f, 0.f);
     if constexpr (SH != 0)
     {
-        lazyCam = lazy.params ? make_float3(lazy.params->cameraPosition[0], lazy.params->cameraPosition[1], lazy.params->cameraPosition[2])
+        lazyCam = lazy.params ? make_float3(lazy.params[view].cameraPosition[0], lazy.params[view].cameraPosition[1],
+                                            lazy.params[view].cameraPosition[2])
                               : lazy.cameraPosition;
 #pragma unroll
         for (int m = 0; m != kRowQuads; ++m) gRow[m] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -192,11 +201,12 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
                 gCentre = clipXY[src];
                 gConic = conic[src];
             }
-            if constexpr (SH == 0) gColor = color[src];
+            const int splat = src - viewFirstSplat; // the scene's splat behind the (virtual) list entry
+            if constexpr (SH == 0) gColor = color[splat];
             else
             {
-                gColor = lazy.position[src]; // xyz + opacity; becomes the colour when the entry is staged
-                const float4* row = reinterpret_cast<const float4*>(lazy.shPerSplat + (size_t) src * lazy.shCount);
+                gColor = lazy.position[splat]; // xyz + opacity; becomes the colour when the entry is staged
+                const float4* row = reinterpret_cast<const float4*>(lazy.shPerSplat + (size_t) splat * lazy.shCount);
 #pragma unroll
                 for (int m = 0; m != kRowQuads; ++m) gRow[m] = row[m];
             }
@@ -335,7 +345,7 @@ int rasterPixelsPerLane() { return g_rasterPixelsPerLane; }
 void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileRange, const int32_t* values,
                      const float2* clipXY, const float4* conic, const float4* color, uchar4* backBuffer,
                      unsigned long long* consumedPairsOrNull, bool clearEmptyTiles, const RasterColourSource* lazyColours,
-                     const float4* rasterRecord)
+                     const float4* rasterRecord, int views, int viewSplats)
 {
     const int firstTile = scr.rowBegin * scr.tilesX;
     const int numTiles = (scr.rowEnd - scr.rowBegin) * scr.tilesX;
@@ -350,8 +360,9 @@ void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileR
     RasterColourSource lazy{};
     if (lazyColours != nullptr) lazy = *lazyColours;
 #define GS_LAUNCH_RASTER(PPL, EPAN, SH)                                                                                                  \
-    hipLaunchKernelGGL((rasterizeTilesKernel<PPL, EPAN, SH>), dim3(gridTiles), dim3(256 / PPL), 0, stream, scr, firstTile, numTiles,      \
-                       tileRange, values, clipXY, conic, color, backBuffer, consumedPairsOrNull, clearEmptyTiles ? 1 : 0, lazy, g_rasterTrace, rasterRecord)
+    hipLaunchKernelGGL((rasterizeTilesKernel<PPL, EPAN, SH>), dim3(gridTiles, views), dim3(256 / PPL), 0, stream, scr, firstTile, numTiles, \
+                       tileRange, values, clipXY, conic, color, backBuffer, consumedPairsOrNull, clearEmptyTiles ? 1 : 0, lazy, g_rasterTrace, rasterRecord, \
+                       views > 1 ? viewSplats : 0)
     const bool epan = scr.epanechnikov != 0;
     // on-demand colours: two pixels per lane only (the default shape), degrees whose coefficient rows are 16-byte multiples
     if (lazyColours != nullptr && g_rasterPixelsPerLane == 2 && rasterCanEvaluateColours(lazy.degree, lazy.shCount))

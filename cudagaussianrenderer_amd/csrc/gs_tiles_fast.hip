@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                                                              int32_t* __restrict__ groupCounts, const int32_t* __restrict__ groupOffsets,
                                                              TileKey* __restrict__ tileKeys, int32_t* __restrict__ values, int capacity,
                                                              uint8_t* __restrict__ hitMasks, const float4* __restrict__ tileRecord,
-                                                             int64_t* __restrict__ total, int64_t* __restrict__ totalHostMapped)
+                                                             int64_t* __restrict__ total, int64_t* __restrict__ totalHostMapped, int viewSplats)
 {
     __shared__ GroupStage st;
     __shared__ int waveTotals[kWavesPerBlock];
@@ -282,6 +282,12 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
             // re-walk the unit's tiles to write the hits, unit-major
             int wx = lx0, wy = ly0;
             const int splatK = st.splat[k];
+            // several views per chain (gs_renderer_set_views): virtual splat v*N + i belongs to view v, whose tiles are the virtual
+            // tiles v*totalTiles + t -- the tile sort then separates the views like it separates tiles
+            int viewTileBase = 0;
+            if (viewSplats > 0)
+#pragma unroll
+                for (int v = 1; v != kMaxViews; ++v) viewTileBase += (splatK >= v * viewSplats) ? scr.totalTiles : 0;
 #pragma unroll
             for (int e = 0; e != kTilesPerUnit; ++e)
             {
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                     if (pos < capacity)
                     {
                         const int gx = (origin & 0xFFFF) + wx, gy = (origin >> 16) + wy;
-                        tileKeys[pos] = (TileKey) (gy * scr.tilesX + gx);
+                        tileKeys[pos] = (TileKey) (gy * scr.tilesX + gx + viewTileBase);
                         values[pos] = splatK;
                     }
                     ++pos;
@@ -411,11 +417,11 @@ __global__ __launch_bounds__(kScanThreads) void scanFastKernel(int nHost, const 
 
 template <typename TileKey>
 void launchEmit(hipStream_t stream, dim3 grid, dim3 block, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
-                const float4* screenEllipse, const TileListScratch& s, void* tileKeys, int32_t* values, int capacity)
+                const float4* screenEllipse, const TileListScratch& s, void* tileKeys, int32_t* values, int capacity, int viewSplats)
 {
     hipLaunchKernelGGL((tileListFastKernel<true, TileKey>), grid, block, 0, stream, count, s.countDevice, scr, order, clipXY, screenEllipse,
                        s.waveCounts, (const int32_t*) nullptr, (TileKey*) tileKeys, values, capacity, s.hitMasks, s.tileRecord, s.total,
-                       s.totalHostMapped);
+                       s.totalHostMapped, viewSplats);
 }
 
 } // namespace
@@ -453,21 +459,21 @@ void launchTileListFastCount(hipStream_t stream, int count, const Screen& scr, c
         // leaves the pair total (no scan kernel in between)
         hipLaunchKernelGGL((tileListFastKernel<false, uint16_t>), dim3(groups), dim3(kGroup), 0, stream, count, s.countDevice, scr, order, clipXY,
                            screenEllipse, s.waveCounts, (const int32_t*) nullptr, (uint16_t*) nullptr, (int32_t*) nullptr, 0, s.hitMasks, s.tileRecord,
-                           (int64_t*) nullptr, (int64_t*) nullptr);
+                           (int64_t*) nullptr, (int64_t*) nullptr, 0);
     }
     if (groups == 0) GS_CHECK(hipMemcpyAsync(s.totalHost, s.total, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
 }
 
 void launchTileListFastEmit(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
                             const float4* screenEllipse, const TileListScratch& s, void* tileKeys, int tileKeyBytes, int32_t* values,
-                            int capacity)
+                            int capacity, int viewSplats)
 {
     const int groups = (count + kGroup - 1) / kGroup;
     if (groups == 0) return;
     // (capacity 0 still runs: the pass is also what produces the pair total; nothing is written past `capacity`)
     const dim3 grid(groups), block(kGroup);
-    if (tileKeyBytes == 2) launchEmit<uint16_t>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, tileKeys, values, capacity);
-    else launchEmit<uint32_t>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, tileKeys, values, capacity);
+    if (tileKeyBytes == 2) launchEmit<uint16_t>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, tileKeys, values, capacity, viewSplats);
+    else launchEmit<uint32_t>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, tileKeys, values, capacity, viewSplats);
     if (s.totalHostMapped == nullptr) GS_CHECK(hipMemcpyAsync(s.totalHost, s.total, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
 }
 

@@ -261,6 +261,20 @@ int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsF
  * capacity is NOT handed out truncated (the reference shows it and doubles the list for the next frame, Demo.cpp:357-366,447):
  * the list is grown, the frame re-captured and the same camera rendered again before the call returns. */
 void gs_renderer_set_graph(GsRenderer* r, int enabled);
+/* Addition: several cameras per chain of kernels.  A renderer set to V views (1..4, BEFORE its scene is set or shared) renders V
+ * frames of its scene with ONE replay of the captured chain: view v's splat i is treated as the splat v*N + i (own clip data,
+ * shared inputs) and its tile t as the tile v*T + t, so one depth sort and one tile sort order the pairs of all V frames and every
+ * kernel runs once per V frames -- what a frame of a tile-row band (multi-GPU) needs, whose kernels are too small to fill the
+ * time their launches take.  Every image is byte-identical to the one gs_renderer_render gives for that camera.  The back buffer
+ * holds the V images one after another (an external one must be that large); gs_renderer_back_buffer_view(r, v) is view v's.
+ * gs_renderer_render_views takes V cameras; it needs captured frames (gs_renderer_set_graph), the two-level pipeline and colours
+ * that do not need a per-view SH pass (SH degree 0, 1 or 3) and returns -3 otherwise; overflow of the pair list is handled as for
+ * single frames (all V frames are rendered again).  Returns 0 on success. */
+int gs_renderer_set_views(GsRenderer* r, int views);
+int gs_renderer_views(const GsRenderer* r);
+int gs_renderer_render_views(GsRenderer* r, const GsCameraData* cameras);
+uint8_t* gs_renderer_back_buffer_view(GsRenderer* r, int view);
+int gs_renderer_read_back_buffer_view(GsRenderer* r, int view, uint8_t* hostRgba); /* waits for the renderer's stream; -1: no such view */
 /* Diagnostics (bench.py --ablate): leave stages out of the captured frames -- bit 0 clip, 1 depth sort, 2 pair count, 3 pair emit,
  * 4 tile sort, 5 ranges, 6 raster -- to measure what each stage costs the pipelined frame rate.  The images are garbage. */
 void gs_debug_set_ablation(int mask);

@@ -54,20 +54,32 @@ def test_rccl_is_loadable_and_world_one_gather_is_a_noop():
     comm.close()
 
 
-def test_rccl_send_recv_path_on_one_gpu():
+_SELF_EXCHANGE = """
+import sys
+import numpy as np
+if sys.argv[1] == "torch-first":
+    import torch  # bench.py's order: torch's bundled HIP runtime and RCCL are in the process before the library binds them
+import cudagaussianrenderer_amd as gs
+lib = gs.lib()
+lib.gs_set_device(0)
+rows = np.random.default_rng(3).integers(0, 256, (144, 1920, 4), dtype=np.uint8)  # 9 tile rows of a 1080p frame
+src = gs.DeviceBuffer(rows)
+dst = gs.DeviceBuffer(np.zeros_like(rows))
+rc = lib.gs_debug_rccl_self_exchange(dst.ptr, src.ptr, rows.nbytes, None)
+assert rc == 0, rc
+assert np.array_equal(dst.copy_to(dtype=np.uint8).reshape(rows.shape), rows)
+print("exchanged", rows.nbytes)
+"""
+
+
+@pytest.mark.parametrize("order", ["library-only", "torch-first"])
+def test_rccl_send_recv_path_on_one_gpu(order):
     """The grouped ncclSend/ncclRecv calls of gs_gather_bands, through the run-time-bound RCCL, on a one-rank communicator that sends
-    a band-sized block to itself: proves binding, signatures and stream handling on the hardware the test box has."""
-    import numpy as np
-
-    import cudagaussianrenderer_amd as gs
-
-    lib = gs.lib()
-    lib.gs_set_device(0)
-    rows = np.random.default_rng(3).integers(0, 256, (144, 1920, 4), dtype=np.uint8)  # 9 tile rows of a 1080p frame
-    src = gs.DeviceBuffer(rows)
-    dst = gs.DeviceBuffer(np.zeros_like(rows))
-    assert lib.gs_debug_rccl_self_exchange(dst.ptr, src.ptr, rows.nbytes, None) == 0
-    assert np.array_equal(dst.copy_to(dtype=np.uint8).reshape(rows.shape), rows)
+    a band-sized block to itself: proves binding, signatures and stream handling on the hardware the test box has -- in a process
+    of its own (one HIP runtime per process: a test process that loaded the library before torch has two), without torch (a C++
+    host) and with torch imported first (bench.py: the library and its RCCL then bind torch's bundled runtime)."""
+    out = subprocess.run([sys.executable, "-c", _SELF_EXCHANGE, order], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "exchanged" in out.stdout, (out.stdout[-1000:], out.stderr[-2000:])
 
 
 def _two_gpu_worker(rank, world, port, out_path):

@@ -481,6 +481,35 @@ def test_band_cull_is_invisible(gs, tmp_path, degree):
         assert not img[:a].any() and not img[b_:].any()
 
 
+@pytest.mark.parametrize("log_scale_mean", [-4.0, -3.0, -1.5])
+def test_band_cull_early_test_drops_nothing(gs, tmp_path, log_scale_mean):
+    """The band cull rules most splats out with a cheap conservative bound before the projection proper (gs_clip.hip:
+    bandCandidate).  Whatever it drops must be something the exact test drops too: for narrow and wide bands, small to
+    screen-filling splats and several cameras, the band's pair list with the cull equals the list without it, entry for entry."""
+    from cudagaussianrenderer_amd import scenes
+
+    w, h = 960, 544
+    ply = _ply_scene(gs, tmp_path, 40000, 0, log_scale_mean=log_scale_mean)
+    scene = (ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+    cams = [gs.camera_from_pose(p, q, w, h) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 3)]
+    tx, ty = gs.tile_counts(w, h)
+    for band in [(0, 1), (16, 18), (9, 26), (ty - 1, ty)]:
+        lists = []
+        for mode in (2, 1):  # cull off, on
+            r = gs.Renderer(w, h, tile_rows=band, band_cull=mode)
+            r.set_scene(*scene)
+            per_cam = []
+            for cam in cams:
+                r.render(cam)
+                b = r.buffers()
+                per_cam.append((b.tileListSize, r.download(b.values, b.tileListSize, np.int32), r.read_image()))
+            lists.append(per_cam)
+            r.close()
+        for off, on in zip(*lists):
+            assert off[0] == on[0] and np.array_equal(off[1], on[1]) and np.array_equal(off[2], on[2])
+        assert any(entry[0] > 0 for entry in lists[0])
+
+
 def test_captured_frames_equal_regular_frames(gs, tmp_path):
     """hipGraph replay (device-side list sizes, camera through a memcpy node) vs the regular path: same list, same image,
     for every camera of an orbit, full frame and band-culled sub-band."""
@@ -535,6 +564,74 @@ def test_captured_frames_never_hand_out_a_truncated_frame(gs):
             r.render(cam)
         assert r.captured_retries() == retries and np.array_equal(r.read_image(), want)
         r.close()
+
+
+@pytest.mark.parametrize("views", [2, 3, 4])
+def test_views_per_chain_give_byte_identical_frames(gs, tmp_path, views):
+    """gs_renderer_set_views: V cameras rendered by ONE replay of the captured chain (virtual splats v*N + i, virtual tiles
+    v*T + t) give, view by view, the bytes of single-view frames -- full frame and band-culled sub-band, colours on demand
+    (SH 3) and static colours (SH 0), twice in a row (the two graph instances), odd splat counts (ragged waves per view)."""
+    from cudagaussianrenderer_amd import scenes
+
+    w, h = 1280, 720
+    for degree, count in ((3, 60001), (0, 20011)):
+        ply = _ply_scene(gs, tmp_path, count, degree, log_scale_mean=-3.3)
+        scene = (ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+        cams = [gs.camera_from_pose(p, q, w, h) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 8)]
+        for rows in [None, (14, 31)]:
+            single = gs.Renderer(w, h, tile_rows=rows)
+            single.set_graph(True)
+            single.set_scene(*scene)
+            want = []
+            for cam in cams:
+                single.render(cam)
+                want.append(single.read_image())
+            single.close()
+            assert any(img.any() for img in want)
+            batch = gs.Renderer(w, h, tile_rows=rows, views=views)
+            batch.set_graph(True)
+            batch.set_scene(*scene)
+            for first in (0, 3, 1):  # three chains: both graph instances, different cameras each time
+                group = [cams[(first + v) % 8] for v in range(views)]
+                batch.render_views(group)
+                for v in range(views):
+                    assert np.array_equal(batch.read_image(view=v), want[(first + v) % 8]), (degree, rows, first, v)
+            batch.close()
+
+
+def test_views_overflow_and_refusals(gs, tmp_path):
+    """A chain of views whose pair demand exceeds the list is rendered again (all views) before the call returns; what the chain
+    cannot do is refused: no captured frames, an SH degree that needs a per-view colour pass, views after the scene is set."""
+    w = h = 512
+    pos, sr, col = _procedural(gs, 3000, seed=9, min_scale=0.3, max_scale=1.5)  # ~40 pairs per splat >> the 8 provisioned
+    cams = [gs.camera_from_bounds([-4] * 3, [4] * 3, w, h), gs.camera_from_bounds([-5] * 3, [5] * 3, w, h)]
+    want = []
+    ref = gs.Renderer(w, h)
+    ref.set_scene(pos, sr, col)
+    for cam in cams:
+        ref.render(cam)
+        want.append(ref.read_image())
+    assert gs.lib().gs_renderer_set_views(ref.handle, 2) == -1  # the scene is set
+    ref.close()
+    r = gs.Renderer(w, h, views=2)
+    r.set_scene(pos, sr, col)
+    with pytest.raises(RuntimeError):
+        r.render_views(cams)  # not captured
+    r.set_graph(True)
+    r.render_views(cams)
+    assert r.captured_retries() >= 1
+    for v in range(2):
+        assert np.array_equal(r.read_image(view=v), want[v])
+    r.close()
+    with pytest.raises(ValueError):
+        gs.Renderer(w, h, views=5)
+    ply = _ply_scene(gs, tmp_path, 2000, 2)  # SH degree 2: colours need the SH pass, one buffer per view
+    r = gs.Renderer(w, h, views=2)
+    r.set_graph(True)
+    r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+    with pytest.raises(RuntimeError):
+        r.render_views(cams)
+    r.close()
 
 
 @pytest.mark.parametrize("degree", [2, 3])

@@ -19,6 +19,7 @@ ap.add_argument("--graph", type=int, default=1)
 ap.add_argument("--sort-backend", type=int, default=1, help="0 rocPRIM, 1 native, 2 onesweep")
 ap.add_argument("--ppl", type=int, default=2, help="raster pixels per lane")
 ap.add_argument("--pipeline", type=int, default=1)
+ap.add_argument("--views", type=int, default=1, help="cameras per chain of kernels (gs_renderer_set_views)")
 ap.add_argument("--ablate", type=int, default=0, help="gs_debug_set_ablation mask for the timed frames (diagnostic: stages left out)")
 args = ap.parse_args()
 W, H = 1920, 1080
@@ -54,7 +55,7 @@ for world in [int(x) for x in args.worlds.split(",")]:
         streams = shared_streams
         rs = []
         for d in range(D):
-            r = gs.Renderer(W, H, tile_rows=band if world > 1 else None, band_cull=args.cull, pipeline=args.pipeline)
+            r = gs.Renderer(W, H, tile_rows=band if world > 1 else None, band_cull=args.cull, pipeline=args.pipeline, views=args.views)
             r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
             r.set_stream(streams[d].cuda_stream)
             r.set_graph(bool(args.graph))
@@ -62,12 +63,16 @@ for world in [int(x) for x in args.worlds.split(",")]:
         from concurrent.futures import ThreadPoolExecutor
         from collections import deque
         pools = [ThreadPoolExecutor(1) for _ in range(D)]
+        V = args.views
         def run(count, first=0):
             q = deque()
-            for i in range(first, first + count):
+            for c in range(first // V, (first + count) // V):  # chain c renders frames c*V .. c*V + V-1
                 if len(q) == D:
                     q.popleft().result()
-                q.append(pools[i % D].submit(rs[i % D].render, cams[i % 8]))
+                if V == 1:
+                    q.append(pools[c % D].submit(rs[c % D].render, cams[c % 8]))
+                else:
+                    q.append(pools[c % D].submit(rs[c % D].render_views, [cams[(c * V + v) % 8] for v in range(V)]))
             while q:
                 q.popleft().result()
         run(16)

@@ -1,6 +1,6 @@
 // frame_pump.cpp -- the pipelined frame loop of bench.py driven by NATIVE host threads (one per frame in flight) straight over
 // the C ABI, to separate what the GPU can do from what the Python harness adds (GIL, futures, ctypes marshalling).
-//   frame_pump scene.ply cams.bin W H rowBegin rowEnd inflight frames [graph=1] [mask=0]
+//   frame_pump scene.ply cams.bin W H rowBegin rowEnd inflight frames [graph=1] [mask=0] [views=1]
 // mask: 0 = plain streams; 1 = every stream restricted to its own share of the compute units, bits dealt round-robin
 // (bit i -> stream i % inflight: with the driver's XCC-interleaved mask layout a share of whole XCDs when inflight divides 8);
 // 2 = contiguous shares of the mask (bit i -> stream i / (256 / inflight)).
@@ -28,6 +28,7 @@ int main(int argc, char** argv)
     const int D = std::atoi(argv[7]), frames = std::atoi(argv[8]);
     const int graph = argc > 9 ? std::atoi(argv[9]) : 1;
     const int maskMode = argc > 10 ? std::atoi(argv[10]) : 0;
+    const int views = argc > 11 ? std::atoi(argv[11]) : 1; // cameras per chain of kernels (gs_renderer_set_views)
     std::vector<GsCameraData> cams;
     {
         std::FILE* f = std::fopen(argv[2], "rb");
@@ -49,6 +50,7 @@ int main(int argc, char** argv)
     for (int d = 0; d != D; ++d)
     {
         rs[d] = gs_renderer_create(W, H);
+        if (views > 1 && gs_renderer_set_views(rs[d], views) != 0) return 4;
         if (rowEnd > rowBegin) gs_renderer_set_tile_rows(rs[d], rowBegin, rowEnd);
         gs_renderer_set_scene(rs[d], ply.vertexCount, ply.position, ply.scaleAndRotation, ply.color, ply.sphericalHarmonics,
                               ply.sphericalHarmonicsDegree, ply.sphericalHarmonicsCount);
@@ -71,7 +73,12 @@ int main(int argc, char** argv)
         for (int d = 0; d != D; ++d)
             threads.emplace_back([&, d] {
                 gs_set_device(0);
-                for (int i = d; i < count; i += D) gs_renderer_render(rs[d], &cams[i % cams.size()], 0, nullptr);
+                std::vector<GsCameraData> group(views);
+                for (int c = d; c < count / views; c += D) // chain c renders frames c*views .. c*views + views-1
+                {
+                    for (int v = 0; v != views; ++v) group[v] = cams[(c * views + v) % cams.size()];
+                    if (gs_renderer_render_views(rs[d], group.data()) != 0) std::abort();
+                }
                 (void) hipStreamSynchronize(streams[d]);
             });
         for (auto& t : threads) t.join();
@@ -84,9 +91,9 @@ int main(int argc, char** argv)
     const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count() / frames;
     double launchUs = 0.0, awaitUs = 0.0;
     (void) gs_debug_host_times(&launchUs, &awaitUs, 0);
-    std::printf("{\"inflight\": %d, \"rows\": [%d, %d], \"graph\": %d, \"cu_mask\": %d, \"ms_per_frame\": %.4f, \"frames_per_s\": %.1f, "
+    std::printf("{\"inflight\": %d, \"views\": %d, \"rows\": [%d, %d], \"graph\": %d, \"cu_mask\": %d, \"ms_per_frame\": %.4f, \"frames_per_s\": %.1f, "
                 "\"host_us_in_graph_launch\": %.1f, \"host_us_awaiting_total\": %.1f}\n",
-                D, rowBegin, rowEnd, graph, maskMode, ms, 1e3 / ms, launchUs, awaitUs);
+                D, views, rowBegin, rowEnd, graph, maskMode, ms, 1e3 / ms, launchUs, awaitUs);
     for (int d = 0; d != D; ++d) gs_renderer_destroy(rs[d]);
     gs_free_ply(&ply);
     return 0;
