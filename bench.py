@@ -132,15 +132,21 @@ class Rig:
         self.W, self.H = args.width, args.height
         world, rank, device = ctx["world"], ctx["rank"], ctx["device"]
         self.band = bands[rank]
+        # frames per chain of kernels (gs_renderer_set_views): a band's kernels are too small to fill the time their launches take,
+        # so a rank of a multi-GPU run renders V consecutive frames with one replay of the captured chain
+        self.V = args.views_per_chain if args.views_per_chain > 0 else (4 if world > 1 else 1)
+        if args.no_graph:
+            self.V = 1  # several views per chain exist for captured frames only
         self.streams = [torch.cuda.Stream(device) for _ in range(depth)]
         self.renderers, self.framebuffers = [], []
         for d in range(depth):
-            r = gs.Renderer(self.W, self.H, tile_rows=self.band if world > 1 else None, band_cull=args.band_cull, pipeline=args.pipeline)
+            r = gs.Renderer(self.W, self.H, tile_rows=self.band if world > 1 else None, band_cull=args.band_cull, pipeline=args.pipeline,
+                            views=self.V)
             if d == 0 or args.own_scene_copies:
                 r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
             else:
                 r.share_scene(self.renderers[0])  # one copy of the read-only scene for all frames in flight
-            fb = torch.zeros((self.H, self.W, 4), dtype=torch.uint8, device=device)
+            fb = torch.zeros((self.V, self.H, self.W, 4), dtype=torch.uint8, device=device)  # the V images of a chain, one after another
             r.set_back_buffer(fb.data_ptr())
             r.set_stream(self.streams[d].cuda_stream)
             r.set_graph(not args.no_graph)
@@ -157,39 +163,51 @@ class Rig:
         # frames are issued in parallel; the main thread collects the frames in order and enqueues the band gather (RCCL
         # calls stay on one thread, in the same order on every rank).
         self.pools = [ThreadPoolExecutor(1, initializer=init_worker) for _ in range(depth)]
-        # set-up outside the measured steps: one frame per renderer, one at a time (frame capture, scratch sizing, RCCL
-        # channel set-up for the gather), so the pipelined loop starts from a steady state
+        # set-up outside the measured steps: one chain per renderer, one at a time (frame capture -- both instances --, scratch
+        # sizing, RCCL channel set-up for the gather), so the pipelined loop starts from a steady state
+        self.next_chain = 0
         for d in range(depth):
-            self.pools[d].submit(self._render, d, d, 0).result()
-            self._gather(d)
+            for _ in range(2):
+                self.pools[d].submit(self._render, d, d).result()
+                self._gather(d)
             torch.cuda.synchronize(device)
 
-    def _render(self, d, i, timed):
-        self.renderers[d].render(self.cameras[i % len(self.cameras)], timed=timed)
+    def _render(self, d, chain):
+        """Chain `chain` = frames chain * V .. chain * V + V - 1 of the orbit, on renderer d."""
+        cams = [self.cameras[(chain * self.V + v) % len(self.cameras)] for v in range(self.V)]
+        if self.V == 1:
+            self.renderers[d].render(cams[0])
+        else:
+            self.renderers[d].render_views(cams)
 
     def _gather(self, d):
         import torch
 
         with torch.cuda.stream(self.streams[d]):
-            self.ctx["multigpu"].gather_bands(self.framebuffers[d], self.bands, self.ctx["rank"], self.ctx["world"], comm=self.ctx["comm"])
+            for v in range(self.V):  # one grouped send/receive set per frame
+                self.ctx["multigpu"].gather_bands(self.framebuffers[d][v], self.bands, self.ctx["rank"], self.ctx["world"], comm=self.ctx["comm"])
 
-    def run_frames(self, count, first=0):
-        """Frame j's bands -> rank 0 (one grouped RCCL send/recv set, receives land directly in the framebuffer rows),
-        ordered on the frame's own stream so the next use of that renderer waits for it."""
+    def run_frames(self, count):
+        """At least `count` more frames (whole chains of V): frame j's bands -> rank 0 (one grouped RCCL send/recv set, receives
+        land directly in the framebuffer rows), ordered on the chain's own stream so the next use of that renderer waits for it.
+        Returns the number of frames rendered."""
         from collections import deque
 
         inflight = deque()
 
-        def collect(j, future):
+        def collect(chain, future):
             future.result()
-            self._gather(j % self.depth)
+            self._gather(chain % self.depth)
 
-        for i in range(first, first + count):
+        chains = (count + self.V - 1) // self.V
+        for chain in range(self.next_chain, self.next_chain + chains):
             if len(inflight) == self.depth:
                 collect(*inflight.popleft())
-            inflight.append((i, self.pools[i % self.depth].submit(self._render, i % self.depth, i, 0)))
+            inflight.append((chain, self.pools[chain % self.depth].submit(self._render, chain % self.depth, chain)))
         while inflight:
             collect(*inflight.popleft())
+        self.next_chain += chains
+        return chains * self.V
 
     def sync_all(self):
         import torch
@@ -201,14 +219,16 @@ class Rig:
         torch.cuda.synchronize(self.ctx["device"])
 
     def timed_run(self, steps, warmup):
-        """W untimed warm-up frames, then EXACTLY `steps` frames between barrier + synchronize pairs; max over ranks."""
+        """W untimed warm-up frames, then `steps` frames between barrier + synchronize pairs; max over ranks.  With V frames per
+        chain both counts are rounded UP to whole chains: the timed region then holds ceil(steps / V) * V >= steps frames of work
+        (self.frames_timed) while the caller still divides `steps` by the time -- never in the measurement's favour."""
         import torch
         import torch.distributed as dist
 
         self.run_frames(warmup)
         self.sync_all()
         t0 = time.perf_counter()
-        self.run_frames(steps, first=warmup)
+        self.frames_timed = self.run_frames(steps)
         self.sync_all()
         elapsed = time.perf_counter() - t0
         if self.ctx["world"] > 1:
@@ -226,7 +246,7 @@ class Rig:
         with torch.cuda.stream(self.streams[0]):
             for i in range(steps):
                 r.render(self.cameras[i % len(self.cameras)], timed=2)
-                self.ctx["multigpu"].gather_bands(self.framebuffers[0], self.bands, self.ctx["rank"], self.ctx["world"], comm=self.ctx["comm"])
+                self.ctx["multigpu"].gather_bands(self.framebuffers[0][0], self.bands, self.ctx["rank"], self.ctx["world"], comm=self.ctx["comm"])
             frames, sums = r.collect_stage_times()
         return {"sh": sums.msSphericalHarmonics / frames, "clip": sums.msClipData / frames, "tile_list": sums.msBuildTileList / frames,
                 "sort": sums.msSortTileList / frames, "ranges": sums.msTileRanges / frames, "raster": sums.msRasterize / frames}
@@ -257,10 +277,14 @@ class Rig:
         import torch
 
         with torch.cuda.stream(self.streams[0]):
-            self.renderers[0].render(self.cameras[view])
+            cams = [self.cameras[(view + v) % len(self.cameras)] for v in range(self.V)]
+            if self.V == 1:
+                self.renderers[0].render(cams[0])
+            else:
+                self.renderers[0].render_views(cams)
             self._gather(0)
         torch.cuda.synchronize(self.ctx["device"])
-        return self.framebuffers[0].cpu().numpy()
+        return self.framebuffers[0][0].cpu().numpy()
 
     def close(self):
         for pool in self.pools:
@@ -354,6 +378,7 @@ def main():
     ap.add_argument("--rehearse", action="store_true", help="multi-rank control flow on ONE GPU: every rank on cuda:0, gloo instead of RCCL (not a measurement)")
     ap.add_argument("--own-scene-copies", action="store_true", help="every renderer uploads its own copy of the scene instead of sharing renderer 0's read-only buffers")
     ap.add_argument("--ablate", type=int, default=-1, help="diagnostics: leave stages out of the timed frames (bit 0 clip, 1 depth sort, 2 count, 3 emit, 4 tile sort, 5 ranges, 6 raster; 0 = none, the reference point); prints frames/s only")
+    ap.add_argument("--views-per-chain", type=int, default=0, help="frames rendered by one replay of the captured chain (gs_renderer_set_views, 1..4); 0 = 1 on one GPU, 4 on a rank of a multi-GPU run")
     ap.add_argument("--inflight", type=int, default=0, help="frames in flight per GPU (renderers on separate HIP streams); 0 = 4 (the measured optimum with 8 hardware queues)")
     args = ap.parse_args()
 
@@ -493,7 +518,8 @@ def main():
                 "splats": N, "width": W, "height": H, "sh_degree": args.sh_degree, "views": len(cameras),
                 "pairs_per_frame": round(p_mean), "consumed_pairs_per_frame": round(pc_mean), "nonempty_tiles": round(nonempty),
                 "log_scale_mean": args.log_scale_mean, "opacity_mean_raw": args.opacity_mean, "seed": args.seed,
-                "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": device_name(lib), "frames_in_flight": depth,
+                "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": device_name(lib), "frames_in_flight": depth, "frames_per_chain": rig.V,
+                "frames_in_timed_region": rig.frames_timed,
                 "captured_frames": not args.no_graph,
                 "colours": "on demand in the raster kernel (no SH pass)" if on_demand else "SH pass over all splats",
                 "footprint": "epanechnikov" if args.epanechnikov else "gaussian",

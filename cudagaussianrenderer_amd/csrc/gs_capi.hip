@@ -402,7 +402,7 @@ struct GsRenderer
     int capturedRetries = 0; // captured frames rendered again because their pair demand exceeded the list capacity
     FrameState frame;
     unsigned long long* bandMask = nullptr;
-    int32_t *bandCounts = nullptr, *bandOffsets = nullptr;
+    int32_t *bandCounts = nullptr, *bandOffsets = nullptr, *bandSlotPrefix = nullptr;
     int64_t* bandTotal = nullptr;
     int bandCull = GS_BAND_CULL_AUTO;
     int32_t* tileRange = nullptr;
@@ -509,11 +509,12 @@ void freeScene(GsRenderer* r)
     gs_device_free(r->shPerSplat);
     gs_device_free(r->bandMask);
     gs_device_free(r->bandCounts);
+    gs_device_free(r->bandSlotPrefix);
     gs_device_free(r->bandOffsets);
     gs_device_free(r->bandTotal);
     r->shPerSplat = nullptr;
     r->bandMask = nullptr;
-    r->bandCounts = r->bandOffsets = nullptr;
+    r->bandCounts = r->bandOffsets = r->bandSlotPrefix = nullptr;
     r->bandTotal = nullptr;
 }
 void ensureSortTemp(GsRenderer* r, size_t required)
@@ -638,6 +639,7 @@ void allocateSceneIntermediates(GsRenderer* r, int32_t n)
     const size_t waves = (((size_t) n + kWave - 1) / kWave) * (size_t) r->views;
     r->bandMask = (unsigned long long*) gs_device_alloc(sizeof(unsigned long long) * waves);
     r->bandCounts = (int32_t*) gs_device_alloc(sizeof(int32_t) * waves);
+    r->bandSlotPrefix = (int32_t*) gs_device_alloc(sizeof(int32_t) * waves);
     r->bandOffsets = (int32_t*) gs_device_alloc(sizeof(int32_t) * waves);
     r->bandTotal = (int64_t*) gs_device_alloc(sizeof(int64_t));
     // Demo.cpp:325: 8 pairs per splat to start with; grown on demand.
@@ -940,7 +942,7 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         {
             launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation,
                                 binned ? (float2*) r->clipXY : nullptr, nullptr, nullptr, nullptr, r->depthKey[0],
-                                (uint32_t*) r->order[0], nullptr, nullptr, nullptr, binned ? nullptr : r->tileRange, 2 * scr.totalTiles,
+                                (uint32_t*) r->order[0], nullptr, nullptr, nullptr, nullptr, binned ? nullptr : r->tileRange, 2 * scr.totalTiles,
                                 (float4*) r->tileRecord, (float4*) r->rasterRecord);
         }
         else
@@ -948,9 +950,9 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
             // clip data for every splat + keep-mask, then an order-preserving compaction of (depth key, index)
             launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation,
                                 binned ? (float2*) r->clipXY : nullptr, r->clipZ, nullptr, nullptr, nullptr, nullptr, r->bandMask,
-                                r->bandCounts, nullptr, binned ? nullptr : r->tileRange, 2 * scr.totalTiles, (float4*) r->tileRecord,
+                                r->bandSlotPrefix, r->bandCounts, nullptr, binned ? nullptr : r->tileRange, 2 * scr.totalTiles, (float4*) r->tileRecord,
                                 (float4*) r->rasterRecord);
-            launchBandCompaction(g.stream, n, 1, r->bandMask, r->bandCounts, r->bandOffsets, r->bandTotal, r->clipZ, r->depthKey[0],
+            launchBandCompaction(g.stream, n, 1, r->bandMask, r->bandSlotPrefix, r->bandCounts, r->bandOffsets, r->bandTotal, r->clipZ, r->depthKey[0],
                                  (uint32_t*) r->order[0]);
             countDevice = (const int*) r->bandTotal; // low 32 bits of the little-endian int64 total
         }
@@ -1195,16 +1197,16 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool bin
         if (!(g_ablation & 1))
             launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
                                 binned ? (float2*) r->clipXY : nullptr, nullptr, nullptr, nullptr, r->depthKey[0],
-                                (uint32_t*) r->order[0], nullptr, nullptr, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord,
+                                (uint32_t*) r->order[0], nullptr, nullptr, nullptr, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord,
                                 (float4*) r->rasterRecord, views);
     }
     else
     {
         launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
                             binned ? (float2*) r->clipXY : nullptr, r->clipZ, nullptr, nullptr, nullptr, nullptr, r->bandMask,
-                            r->bandCounts, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord, (float4*) r->rasterRecord,
+                            r->bandSlotPrefix, r->bandCounts, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord, (float4*) r->rasterRecord,
                             views);
-        launchBandCompaction(g.stream, n, views, r->bandMask, r->bandCounts, r->bandOffsets, r->bandTotal, r->clipZ, r->depthKey[0],
+        launchBandCompaction(g.stream, n, views, r->bandMask, r->bandSlotPrefix, r->bandCounts, r->bandOffsets, r->bandTotal, r->clipZ, r->depthKey[0],
                              (uint32_t*) r->order[0]);
         countDevice = (const int*) r->bandTotal;
         if (r->shDegree != 0 && !lazy)

@@ -247,18 +247,15 @@ __device__ __forceinline__ bool bandCandidate(const float4 pd, const float4 sr, 
 #define GS_CLIP_EARLY_BAND_TEST 1 // A/B and audit builds: 0 = every splat goes through the projection proper
 #endif
 
-// BAND = false: one splat per lane, every splat projected and stored (the single-GPU frame, the staged API).
-// BAND = true (multi-GPU band cull): the workgroup first rules out what it can with the early test, compacts the candidates of its
-// 256 splats in LDS and runs the projection proper on those only -- with 8 bands ~85 % of the splats stop after ~100 instructions
-// instead of ~700, and the candidates fill one wave instead of four.  Per wave of splats: the 64-bit mask of the kept ones; per
-// workgroup: their number (the compaction's scan runs over workgroups).
-template <bool BAND>
+constexpr int kBandItems = 4;                 // splats per lane of the band-cull kernel
+constexpr int kBandBlock = 256 * kBandItems;  // splats per workgroup; the compaction's scan runs over these blocks
+constexpr int kBandSlots = kBandBlock / kWave; // 64-splat slots (one kept mask each) per workgroup
+
+// Every splat projected and stored, one per lane (the single-GPU frame, the staged API).
 __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr, ClipCamera camArg, const FrameParams* __restrict__ params,
                                                             const float4* __restrict__ position,
                                                             const float4* __restrict__ scaleAndRotation, ClipOutputs o,
-                                                            unsigned long long* __restrict__ bandMask,
-                                                            int32_t* __restrict__ bandBlockCounts, int32_t* __restrict__ rangeTable,
-                                                            int rangeEntries)
+                                                            int32_t* __restrict__ rangeTable, int rangeEntries)
 {
     const int index = blockIdx.x * blockDim.x + threadIdx.x; // splat of the scene
     const int view = blockIdx.y;                              // gs_renderer_set_views: one grid row per camera
@@ -267,84 +264,135 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
     if (rangeTable != nullptr)
         for (int i = view * (int) (gridDim.x * blockDim.x) + index; i < rangeEntries; i += (int) (gridDim.x * gridDim.y * blockDim.x))
             rangeTable[i] = -1;
+    if (index >= count) return;
     const ClipCamera cam = params ? params[view].camera : camArg; // device-resident when the frame is a captured graph
-    if constexpr (!BAND)
+    // results are stored under the "virtual splat" view * count + index
+    (void) projectSplat<false>(position[index], scaleAndRotation[index], cam, scr, view * count + index, o);
+}
+
+// Multi-GPU band cull: a workgroup takes 1024 splats, four per lane (all eight loads of a lane in flight at once), rules out what it
+// can with the early test, stashes the candidates' inputs in LDS and runs the projection proper on those only -- with 8 bands
+// ~85 % of the splats stop after ~100 instructions instead of ~700, and the candidates fill one or two waves instead of sixteen.
+// Leaves, per slot of 64 splats, the 64-bit mask of the kept ones and the number of kept splats in the workgroup's earlier slots;
+// per workgroup, its number of kept splats (the compaction scans these).
+__global__ __launch_bounds__(256) void splatClipBandKernel(int count, Screen scr, ClipCamera camArg, const FrameParams* __restrict__ params,
+                                                            const float4* __restrict__ position,
+                                                            const float4* __restrict__ scaleAndRotation, ClipOutputs o,
+                                                            unsigned long long* __restrict__ bandMask, int32_t* __restrict__ bandSlotPrefix,
+                                                            int32_t* __restrict__ bandBlockCounts, int32_t* __restrict__ rangeTable,
+                                                            int rangeEntries)
+{
+    __shared__ float4 stashPosition[kBandBlock];
+    __shared__ float4 stashScaleRotation[kBandBlock];
+    __shared__ int stashLocal[kBandBlock];
+    __shared__ int slotCandidates[kBandSlots];
+    __shared__ unsigned long long keptMask[kBandSlots];
+    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
+    const int view = blockIdx.y;
+    if (rangeTable != nullptr)
     {
-        if (index >= count) return;
-        // results are stored under the "virtual splat" view * count + index
-        (void) projectSplat<false>(position[index], scaleAndRotation[index], cam, scr, view * count + index, o);
+        const int flat = (view * (int) gridDim.x + (int) blockIdx.x) * 256 + t;
+        for (int i = flat; i < rangeEntries; i += (int) (gridDim.x * gridDim.y) * 256) rangeTable[i] = -1;
     }
-    else
+    const int blockBase = blockIdx.x * kBandBlock;
+    if (blockBase >= count) return; // whole workgroup
+    const ClipCamera cam = params ? params[view].camera : camArg;
+
+    // local splat j * 256 + t sits in slot j * 4 + wave at bit `lane`
+    float4 pd[kBandItems], sr[kBandItems];
+#pragma unroll
+    for (int j = 0; j != kBandItems; ++j)
     {
-        __shared__ int candidates[256];
-        __shared__ int waveCandidates[4];
-        __shared__ unsigned long long keptMask[4];
-        const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
-        const int blockBase = blockIdx.x * blockDim.x;
-        if (blockBase >= count) return; // whole workgroup
-        bool candidate = false;
-        if (index < count)
-        {
+        const int splat = blockBase + j * 256 + t;
+        const bool live = splat < count;
+        pd[j] = live ? position[splat] : make_float4(0.f, 0.f, 0.f, 0.f);
+        sr[j] = live ? scaleAndRotation[splat] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    bool candidate[kBandItems];
+    unsigned long long votes[kBandItems];
+#pragma unroll
+    for (int j = 0; j != kBandItems; ++j)
+    {
 #if GS_CLIP_EARLY_BAND_TEST
-            candidate = bandCandidate(position[index], scaleAndRotation[index], cam, scr);
+        candidate[j] = blockBase + j * 256 + t < count && bandCandidate(pd[j], sr[j], cam, scr);
 #else
-            candidate = true;
+        candidate[j] = blockBase + j * 256 + t < count;
 #endif
-        }
-        const unsigned long long votes = __ballot(candidate);
+        votes[j] = __ballot(candidate[j]);
         if (lane == 0)
         {
-            waveCandidates[wave] = __popcll(votes);
-            keptMask[wave] = 0ull;
+            slotCandidates[j * 4 + wave] = __popcll(votes[j]);
+            keptMask[j * 4 + wave] = 0ull;
         }
-        __syncthreads();
-        int before = 0, total = 0;
+    }
+    __syncthreads();
+    int total = 0, before[kBandItems];
 #pragma unroll
-        for (int w = 0; w != 4; ++w)
+    for (int slot = 0; slot != kBandSlots; ++slot)
+    {
+        const int c = slotCandidates[slot];
+#pragma unroll
+        for (int j = 0; j != kBandItems; ++j)
+            if (slot == j * 4 + wave) before[j] = total; // (compile-time slot, run-time wave: one compare per pair)
+        total += c;
+    }
+    const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
+#pragma unroll
+    for (int j = 0; j != kBandItems; ++j)
+    {
+        if (candidate[j])
         {
-            const int c = waveCandidates[w];
-            before += (w < wave) ? c : 0;
-            total += c;
+            const int at = before[j] + __popcll(votes[j] & lower);
+            stashPosition[at] = pd[j];
+            stashScaleRotation[at] = sr[j];
+            stashLocal[at] = j * 256 + t;
         }
-        const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
-        if (candidate) candidates[before + __popcll(votes & lower)] = t;
-        __syncthreads();
-        if (t < total) // whole waves drop out here: `total` is typically below 64
+    }
+    __syncthreads();
+    for (int c = t; c < total; c += 256) // whole waves drop out: `total` is typically one or two waves' worth
+    {
+        // (the candidates' inputs wait in LDS: reading them again from memory -- cache hits, twice the workgroups per CU -- measured
+        // 58.6 against 48.4 us for a 4-view chain of an 8-way band at C3)
+        const int local = stashLocal[c];
+        if (projectSplat<true>(stashPosition[c], stashScaleRotation[c], cam, scr, view * count + blockBase + local, o))
+            atomicOr(&keptMask[local >> 6], 1ull << (local & (kWave - 1)));
+    }
+    __syncthreads();
+    const int slotsPerView = (count + kWave - 1) / kWave, blocksPerView = (count + kBandBlock - 1) / kBandBlock;
+    if (t < kBandSlots)
+    {
+        // slot s of the workgroup holds the splats blockBase + 64 s .. + 63 in STORAGE order: j = s / 4 covers local 256 j ..., so the
+        // storage-order slot index of (j, wave) is j * 4 + wave -- the same number
+        int prefix = 0;
+        for (int s = 0; s < t; ++s) prefix += __popcll(keptMask[s]);
+        if (blockBase + t * kWave < count)
         {
-            const int local = candidates[t];
-            const int splat = blockBase + local;
-            if (projectSplat<true>(position[splat], scaleAndRotation[splat], cam, scr, view * count + splat, o))
-                atomicOr(&keptMask[local >> 6], 1ull << (local & (kWave - 1)));
+            bandMask[view * slotsPerView + (blockBase >> 6) + t] = keptMask[t];
+            bandSlotPrefix[view * slotsPerView + (blockBase >> 6) + t] = prefix;
         }
-        __syncthreads();
-        const int wavesPerView = (count + kWave - 1) / kWave, blocksPerView = (count + 255) / 256;
-        if (t < 4 && blockBase + t * kWave < count) bandMask[view * wavesPerView + (blockBase >> 6) + t] = keptMask[t];
-        if (t == 0)
-            bandBlockCounts[view * blocksPerView + blockIdx.x] =
-                __popcll(keptMask[0]) + __popcll(keptMask[1]) + __popcll(keptMask[2]) + __popcll(keptMask[3]);
+        if (t == kBandSlots - 1) bandBlockCounts[view * blocksPerView + blockIdx.x] = prefix + __popcll(keptMask[t]);
     }
 }
 
 // Order-preserving compaction of the splats flagged by the band cull: depth key + (virtual) splat index of every kept splat at
-// blockOffsets[workgroup of 256 splats] + (kept splats of the workgroup's earlier waves) + (kept lanes below it).
+// blockOffsets[block of 1024 splats] + (kept splats of the block's earlier slots) + (kept lanes below it).
 __global__ __launch_bounds__(256) void compactBandKernel(int count, const unsigned long long* __restrict__ bandMask,
-                                                          const int32_t* __restrict__ blockOffsets, const float* __restrict__ clipZ,
-                                                          uint32_t* __restrict__ depthKey, uint32_t* __restrict__ splatOrder)
+                                                          const int32_t* __restrict__ bandSlotPrefix, const int32_t* __restrict__ blockOffsets,
+                                                          const float* __restrict__ clipZ, uint32_t* __restrict__ depthKey,
+                                                          uint32_t* __restrict__ splatOrder)
 {
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= count) return;
     const int view = blockIdx.y;
     const int out = view * count + index; // virtual splat (see the clip kernel)
-    const int wavesPerView = (count + kWave - 1) / kWave, blocksPerView = (count + 255) / 256;
-    const int firstWave = view * wavesPerView + (int) blockIdx.x * 4, wave = (int) threadIdx.x >> 6;
+    const int slotsPerView = (count + kWave - 1) / kWave, blocksPerView = (count + kBandBlock - 1) / kBandBlock;
+    const int slot = view * slotsPerView + (index >> 6);
     const int lane = index & (kWave - 1);
-    const unsigned long long mask = bandMask[firstWave + wave];
+    const unsigned long long mask = bandMask[slot]; // wave-uniform: scalar loads
     if ((mask >> lane) & 1ull)
     {
-        int pos = blockOffsets[view * blocksPerView + blockIdx.x];
-        for (int w = 0; w < wave; ++w) pos += __popcll(bandMask[firstWave + w]); // wave-uniform: scalar loads
         const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
-        pos += __popcll(mask & lower);
+        const int pos = blockOffsets[view * blocksPerView + index / kBandBlock] + bandSlotPrefix[slot] + __popcll(mask & lower);
         depthKey[pos] = compactDepthKey(clipZ[out]);
         splatOrder[pos] = (uint32_t) out;
     }
@@ -384,31 +432,33 @@ void launchUnpackEllipse(hipStream_t stream, int count, const float4* tileRecord
     if (count > 0) hipLaunchKernelGGL(unpackEllipseKernel, dim3((count + 255) / 256), dim3(256), 0, stream, count, tileRecord, screenEllipse);
 }
 
-void launchBandCompaction(hipStream_t stream, int count, int views, const unsigned long long* bandMask, const int32_t* bandBlockCounts,
-                          int32_t* bandBlockOffsets, int64_t* bandTotal, const float* clipZ, uint32_t* depthKey, uint32_t* splatOrder)
+void launchBandCompaction(hipStream_t stream, int count, int views, const unsigned long long* bandMask, const int32_t* bandSlotPrefix,
+                          const int32_t* bandBlockCounts, int32_t* bandBlockOffsets, int64_t* bandTotal, const float* clipZ,
+                          uint32_t* depthKey, uint32_t* splatOrder)
 {
     if (count <= 0) return;
-    const int blocks = (count + 255) / 256;
+    const int blocks = (count + kBandBlock - 1) / kBandBlock;
     launchScanInt32(stream, blocks * views, bandBlockCounts, bandBlockOffsets, bandTotal);
-    hipLaunchKernelGGL(compactBandKernel, dim3(blocks, views), dim3(256), 0, stream, count, bandMask, bandBlockOffsets, clipZ, depthKey,
-                       splatOrder);
+    hipLaunchKernelGGL(compactBandKernel, dim3((count + 255) / 256, views), dim3(256), 0, stream, count, bandMask, bandSlotPrefix,
+                       bandBlockOffsets, clipZ, depthKey, splatOrder);
 }
 
 void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const ClipCamera& cam, const float4* position,
                          const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic,
-                         uint32_t* depthKey, uint32_t* splatOrder, unsigned long long* bandMask, int32_t* bandBlockCounts,
-                         const FrameParams* paramsDevice, int32_t* rangeTableToClear, int rangeEntries, float4* tileRecord,
-                         float4* rasterRecord, int views)
+                         uint32_t* depthKey, uint32_t* splatOrder, unsigned long long* bandMask, int32_t* bandSlotPrefix,
+                         int32_t* bandBlockCounts, const FrameParams* paramsDevice, int32_t* rangeTableToClear, int rangeEntries,
+                         float4* tileRecord, float4* rasterRecord, int views)
 {
     if (count <= 0) return;
-    const dim3 grid((count + 255) / 256, views), block(256); // views > 1: cameras from paramsDevice[view], results under view * count + splat
+    // views > 1: cameras from paramsDevice[view], results under view * count + splat
     const ClipOutputs o{clipXY, clipZ, screenEllipse, conic, depthKey, splatOrder, tileRecord, rasterRecord};
     if (bandMask != nullptr)
-        hipLaunchKernelGGL(splatClipDataKernel<true>, grid, block, 0, stream, count, scr, cam, paramsDevice, position, scaleAndRotation, o,
-                           bandMask, bandBlockCounts, rangeTableToClear, rangeEntries);
+        hipLaunchKernelGGL(splatClipBandKernel, dim3((count + kBandBlock - 1) / kBandBlock, views), dim3(256), 0, stream, count, scr, cam,
+                           paramsDevice, position, scaleAndRotation, o, bandMask, bandSlotPrefix, bandBlockCounts, rangeTableToClear,
+                           rangeEntries);
     else
-        hipLaunchKernelGGL(splatClipDataKernel<false>, grid, block, 0, stream, count, scr, cam, paramsDevice, position, scaleAndRotation, o,
-                           (unsigned long long*) nullptr, (int32_t*) nullptr, rangeTableToClear, rangeEntries);
+        hipLaunchKernelGGL(splatClipDataKernel, dim3((count + 255) / 256, views), dim3(256), 0, stream, count, scr, cam, paramsDevice, position,
+                           scaleAndRotation, o, rangeTableToClear, rangeEntries);
 }
 
 } // namespace gs

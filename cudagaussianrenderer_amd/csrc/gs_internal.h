@@ -75,7 +75,8 @@ void launchSphericalHarmonics(hipStream_t stream, int count, int degree, int shC
 void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const ClipCamera& cam, const float4* position,
                          const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic,
                          uint32_t* depthKeyOrNull, uint32_t* splatOrderOrNull, unsigned long long* bandMaskOrNull = nullptr,
-                         int32_t* bandBlockCountsOrNull = nullptr, const FrameParams* paramsDeviceOrNull = nullptr,
+                         int32_t* bandSlotPrefixOrNull = nullptr, int32_t* bandBlockCountsOrNull = nullptr,
+                         const FrameParams* paramsDeviceOrNull = nullptr,
                          int32_t* rangeTableToClearOrNull = nullptr, int rangeEntries = 0, float4* tileRecordOrNull = nullptr,
                          float4* rasterRecordOrNull = nullptr, int views = 1);
 // screenEllipse[i] = (cos, sin, extent x, extent y) from the 32-byte tile records the clip kernel can write instead.
@@ -83,11 +84,12 @@ void launchUnpackEllipse(hipStream_t stream, int count, const float4* tileRecord
 // positionClipSpaceXY / Z / conic from the 32-byte raster records (cx, cy, conic.x, conic.y | conic.z, depth, 0, 0) the clip kernel can
 // write instead of the three arrays (what the raster gathers per list entry is then ONE memory sector instead of two).
 void launchUnpackRasterRecord(hipStream_t stream, int count, const float4* rasterRecord, float2* clipXY, float* clipZ, float4* conic);
-// Band cull (multi-GPU): the clip kernel flags the splats whose tile AABB reaches this GPU's rows (one 64-bit mask per 64 splats,
-// one count per workgroup of 256); this scans the counts and writes the kept splats' depth keys and (virtual) indices, order
-// preserved, and their number to *bandTotal.
-void launchBandCompaction(hipStream_t stream, int count, int views, const unsigned long long* bandMask, const int32_t* bandBlockCounts,
-                          int32_t* bandBlockOffsets, int64_t* bandTotal, const float* clipZ, uint32_t* depthKey, uint32_t* splatOrder);
+// Band cull (multi-GPU): the clip kernel flags the splats whose tile AABB reaches this GPU's rows (per 64 splats one 64-bit mask
+// and the kept splats before them in their block of 1024, one count per block); this scans the block counts and writes the kept
+// splats' depth keys and (virtual) indices, order preserved, and their number to *bandTotal.
+void launchBandCompaction(hipStream_t stream, int count, int views, const unsigned long long* bandMask, const int32_t* bandSlotPrefix,
+                          const int32_t* bandBlockCounts, int32_t* bandBlockOffsets, int64_t* bandTotal, const float* clipZ,
+                          uint32_t* depthKey, uint32_t* splatOrder);
 // Exclusive scan of n int32 on the device (one workgroup), total as int64.
 void launchScanInt32(hipStream_t stream, int n, const int32_t* in, int32_t* out, int64_t* total);
 // SH colour for the splats of a device-side index list only; coefficients in the [splat][shCount] layout.

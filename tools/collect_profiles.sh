@@ -10,7 +10,7 @@ cp $G/${TAG}_stats_serial/stats_kernel_stats.csv profiles/${TAG}_kernel_stats_se
 cp $G/${TAG}_pmc_FETCH_SIZE.txt profiles/${TAG}_pmc_fetch_size_kb.txt
 cp $G/${TAG}_pmc_WRITE_SIZE.txt profiles/${TAG}_pmc_write_size_kb.txt
 cat $G/${TAG}_pmc_SQ_BUSY_CYCLES.txt $G/${TAG}_pmc_SQ_ACTIVE_INST_LDS.txt $G/${TAG}_pmc_SQ_WAIT_ANY.txt > profiles/${TAG}_pmc_sq_counters.txt
-for f in band_sim ablation frame_pump raster_trace raster_trace_low_opacity micro_valu_lds_rate micro_graph_streams micro_atomic_rate micro_graph_memset; do
+for f in band_sim band_chain_kernels ablation frame_pump raster_trace raster_trace_low_opacity micro_valu_lds_rate micro_graph_streams micro_atomic_rate micro_graph_memset; do
   [ -f $G/${TAG}_$f.txt ] && cp $G/${TAG}_$f.txt profiles/${TAG}_$f.txt
 done
 python3 - "$TAG" <<'PY'
