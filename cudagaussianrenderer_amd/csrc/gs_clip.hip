@@ -208,47 +208,7 @@ __device__ __forceinline__ bool projectSplat(const float4 pd, const float4 sr, c
     return true;
 }
 
-// Band cull, early test: can this splat be ruled out WITHOUT the projection proper?  Exact part: a centre outside the frustum
-// gets clip = -128 and extents * 0, whose tile AABB is empty whatever the ellipse (gs_aabb.h) -- never kept.  Conservative part:
-// the AABB's half-height in clip units is |sin| eX + |cos| eY <= sqrt(eX^2 + eY^2) = f sqrt(lambda0 + lambda1) <= f sqrt(A + C),
-// A + C = |M^T a|^2 + |M^T b|^2 + 2 bump <= |M|_F^2 (|a|^2 + |b|^2) + 2 bump with M = R S, a, b the rows of J W; the bound is
-// evaluated in plain floats with 2 % on the radicand and 0.02 tile rows of slack for the rounding of either side, and anything
-// not finite compares false, i.e. stays a candidate.  Candidates go through projectSplat<true>, which decides exactly.
-__device__ __forceinline__ bool bandCandidate(const float4 pd, const float4 sr, const ClipCamera& cam, const Screen& scr)
-{
-    const ViewTerms t = viewTerms(pd, cam);
-    if (!t.inside) return false;
-    const uint32_t bits = __float_as_uint(sr.w);
-    const float k = 2.0f / 255.0f;
-    const float qx = (float) ((bits >> 24) & 0xFFu) * k - 1.0f, qy = (float) ((bits >> 16) & 0xFFu) * k - 1.0f;
-    const float qz = (float) ((bits >> 8) & 0xFFu) * k - 1.0f, qw = (float) (bits & 0xFFu) * k - 1.0f;
-    const float qxx = qx * qx, qyy = qy * qy, qzz = qz * qz;
-    const float qxz = qx * qz, qxy = qx * qy, qyz = qy * qz;
-    const float qwx = qw * qx, qwy = qw * qy, qwz = qw * qz;
-    const float r00 = 1.0f - 2.0f * (qyy + qzz), r01 = 2.0f * (qxy + qwz), r02 = 2.0f * (qxz - qwy);
-    const float r10 = 2.0f * (qxy - qwz), r11 = 1.0f - 2.0f * (qxx + qzz), r12 = 2.0f * (qyz + qwx);
-    const float r20 = 2.0f * (qxz + qwy), r21 = 2.0f * (qyz - qwx), r22 = 1.0f - 2.0f * (qxx + qyy);
-    const float frobenius = sr.x * sr.x * (r00 * r00 + r01 * r01 + r02 * r02) + sr.y * sr.y * (r10 * r10 + r11 * r11 + r12 * r12) +
-                            sr.z * sr.z * (r20 * r20 + r21 * r21 + r22 * r22); // |R S|_F^2 = trace(Sigma)
-    const float* v = cam.view;
-    const float a0 = t.scaleX * v[0] + t.shearX * v[2], a1 = t.scaleX * v[4] + t.shearX * v[6], a2 = t.scaleX * v[8] + t.shearX * v[10];
-    const float b0 = t.scaleY * v[1] + t.shearY * v[2], b1 = t.scaleY * v[5] + t.shearY * v[6], b2 = t.scaleY * v[9] + t.shearY * v[10];
-    const float rows = (a0 * a0 + a1 * a1 + a2 * a2) + (b0 * b0 + b1 * b1 + b2 * b2);
-    const float traceBound = frobenius * rows + 2.0f * scr.traceBump;          // >= covA + covC >= lambda0 + lambda1
-    const float reach = scr.extentFactor * sqrtf(traceBound * 1.02f + 1e-12f); // >= the AABB's half-height, clip units
-    const float centreRow = (t.clipY + 1.0f) * 0.5f * scr.tilesPerScreenY;     // tile-row coordinate of the centre (gs_aabb.h)
-    const float reachRows = reach * 0.5f * scr.tilesPerScreenY;
-    const bool below = centreRow + reachRows < (float) scr.rowBegin - 0.02f; // the AABB ends before the band's first row
-    const bool above = centreRow - reachRows > (float) scr.rowEnd + 0.02f;   // ... or starts behind its last
-    return !(below || above);
-}
-
-#ifndef GS_CLIP_EARLY_BAND_TEST
-#define GS_CLIP_EARLY_BAND_TEST 1 // A/B and audit builds: 0 = every splat goes through the projection proper
-#endif
-
-constexpr int kBandItems = 4;                 // splats per lane of the band-cull kernel
-constexpr int kBandBlock = 256 * kBandItems;  // splats per workgroup; the compaction's scan runs over these blocks
+constexpr int kBandBlock = 256;                // splats per workgroup of the band-cull kernel; the compaction's scan runs over these blocks
 constexpr int kBandSlots = kBandBlock / kWave; // 64-splat slots (one kept mask each) per workgroup
 
 // Every splat projected and stored, one per lane (the single-GPU frame, the staged API).
@@ -270,11 +230,13 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
     (void) projectSplat<false>(position[index], scaleAndRotation[index], cam, scr, view * count + index, o);
 }
 
-// Multi-GPU band cull: a workgroup takes 1024 splats, four per lane (all eight loads of a lane in flight at once), rules out what it
-// can with the early test, stashes the candidates' inputs in LDS and runs the projection proper on those only -- with 8 bands
-// ~85 % of the splats stop after ~100 instructions instead of ~700, and the candidates fill one or two waves instead of sixteen.
+// Multi-GPU band cull: the same projection, but a splat whose tile AABB does not reach this GPU's tile rows stores nothing.
 // Leaves, per slot of 64 splats, the 64-bit mask of the kept ones and the number of kept splats in the workgroup's earlier slots;
 // per workgroup, its number of kept splats (the compaction scans these).
+// (Tried and dropped: a cheap conservative bound on the AABB's height first -- trace(Sigma) |J W|_F^2 -- with the candidates of a
+// 256- or 1024-splat workgroup compacted in LDS and only those projected.  24 % of the splats of a centre band of the 8-way split
+// are candidates, the projection work falls to a third -- and the kernel takes as long as before: 48.4 - 58.6 us for a 4-view chain
+// against 47.1 us for this one; loads alone are 20 us of it, and the compacted second phase runs at low occupancy.)
 __global__ __launch_bounds__(256) void splatClipBandKernel(int count, Screen scr, ClipCamera camArg, const FrameParams* __restrict__ params,
                                                             const float4* __restrict__ position,
                                                             const float4* __restrict__ scaleAndRotation, ClipOutputs o,
@@ -282,100 +244,34 @@ __global__ __launch_bounds__(256) void splatClipBandKernel(int count, Screen scr
                                                             int32_t* __restrict__ bandBlockCounts, int32_t* __restrict__ rangeTable,
                                                             int rangeEntries)
 {
-    __shared__ float4 stashPosition[kBandBlock];
-    __shared__ float4 stashScaleRotation[kBandBlock];
-    __shared__ int stashLocal[kBandBlock];
-    __shared__ int slotCandidates[kBandSlots];
-    __shared__ unsigned long long keptMask[kBandSlots];
+    __shared__ int slotKept[kBandSlots];
     const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
+    const int index = blockIdx.x * blockDim.x + t;
     const int view = blockIdx.y;
     if (rangeTable != nullptr)
-    {
-        const int flat = (view * (int) gridDim.x + (int) blockIdx.x) * 256 + t;
-        for (int i = flat; i < rangeEntries; i += (int) (gridDim.x * gridDim.y) * 256) rangeTable[i] = -1;
-    }
+        for (int i = view * (int) (gridDim.x * blockDim.x) + index; i < rangeEntries; i += (int) (gridDim.x * gridDim.y * blockDim.x))
+            rangeTable[i] = -1;
     const int blockBase = blockIdx.x * kBandBlock;
     if (blockBase >= count) return; // whole workgroup
     const ClipCamera cam = params ? params[view].camera : camArg;
-
-    // local splat j * 256 + t sits in slot j * 4 + wave at bit `lane`
-    float4 pd[kBandItems], sr[kBandItems];
-#pragma unroll
-    for (int j = 0; j != kBandItems; ++j)
-    {
-        const int splat = blockBase + j * 256 + t;
-        const bool live = splat < count;
-        pd[j] = live ? position[splat] : make_float4(0.f, 0.f, 0.f, 0.f);
-        sr[j] = live ? scaleAndRotation[splat] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    bool candidate[kBandItems];
-    unsigned long long votes[kBandItems];
-#pragma unroll
-    for (int j = 0; j != kBandItems; ++j)
-    {
-#if GS_CLIP_EARLY_BAND_TEST
-        candidate[j] = blockBase + j * 256 + t < count && bandCandidate(pd[j], sr[j], cam, scr);
-#else
-        candidate[j] = blockBase + j * 256 + t < count;
-#endif
-        votes[j] = __ballot(candidate[j]);
-        if (lane == 0)
-        {
-            slotCandidates[j * 4 + wave] = __popcll(votes[j]);
-            keptMask[j * 4 + wave] = 0ull;
-        }
-    }
+    bool kept = false;
+    if (index < count) kept = projectSplat<true>(position[index], scaleAndRotation[index], cam, scr, view * count + index, o);
+    const unsigned long long mask = __ballot(kept);
+    if (lane == 0) slotKept[wave] = __popcll(mask);
     __syncthreads();
-    int total = 0, before[kBandItems];
-#pragma unroll
-    for (int slot = 0; slot != kBandSlots; ++slot)
+    if (lane == 0 && blockBase + wave * kWave < count)
     {
-        const int c = slotCandidates[slot];
-#pragma unroll
-        for (int j = 0; j != kBandItems; ++j)
-            if (slot == j * 4 + wave) before[j] = total; // (compile-time slot, run-time wave: one compare per pair)
-        total += c;
-    }
-    const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
-#pragma unroll
-    for (int j = 0; j != kBandItems; ++j)
-    {
-        if (candidate[j])
-        {
-            const int at = before[j] + __popcll(votes[j] & lower);
-            stashPosition[at] = pd[j];
-            stashScaleRotation[at] = sr[j];
-            stashLocal[at] = j * 256 + t;
-        }
-    }
-    __syncthreads();
-    for (int c = t; c < total; c += 256) // whole waves drop out: `total` is typically one or two waves' worth
-    {
-        // (the candidates' inputs wait in LDS: reading them again from memory -- cache hits, twice the workgroups per CU -- measured
-        // 58.6 against 48.4 us for a 4-view chain of an 8-way band at C3)
-        const int local = stashLocal[c];
-        if (projectSplat<true>(stashPosition[c], stashScaleRotation[c], cam, scr, view * count + blockBase + local, o))
-            atomicOr(&keptMask[local >> 6], 1ull << (local & (kWave - 1)));
-    }
-    __syncthreads();
-    const int slotsPerView = (count + kWave - 1) / kWave, blocksPerView = (count + kBandBlock - 1) / kBandBlock;
-    if (t < kBandSlots)
-    {
-        // slot s of the workgroup holds the splats blockBase + 64 s .. + 63 in STORAGE order: j = s / 4 covers local 256 j ..., so the
-        // storage-order slot index of (j, wave) is j * 4 + wave -- the same number
+        const int slotsPerView = (count + kWave - 1) / kWave, blocksPerView = (count + kBandBlock - 1) / kBandBlock;
         int prefix = 0;
-        for (int s = 0; s < t; ++s) prefix += __popcll(keptMask[s]);
-        if (blockBase + t * kWave < count)
-        {
-            bandMask[view * slotsPerView + (blockBase >> 6) + t] = keptMask[t];
-            bandSlotPrefix[view * slotsPerView + (blockBase >> 6) + t] = prefix;
-        }
-        if (t == kBandSlots - 1) bandBlockCounts[view * blocksPerView + blockIdx.x] = prefix + __popcll(keptMask[t]);
+        for (int s = 0; s < wave; ++s) prefix += slotKept[s];
+        bandMask[view * slotsPerView + (blockBase >> 6) + wave] = mask;
+        bandSlotPrefix[view * slotsPerView + (blockBase >> 6) + wave] = prefix;
+        if (wave == 0) bandBlockCounts[view * blocksPerView + blockIdx.x] = slotKept[0] + slotKept[1] + slotKept[2] + slotKept[3];
     }
 }
 
 // Order-preserving compaction of the splats flagged by the band cull: depth key + (virtual) splat index of every kept splat at
-// blockOffsets[block of 1024 splats] + (kept splats of the block's earlier slots) + (kept lanes below it).
+// blockOffsets[block of 256 splats] + (kept splats of the block's earlier slots) + (kept lanes below it).
 __global__ __launch_bounds__(256) void compactBandKernel(int count, const unsigned long long* __restrict__ bandMask,
                                                           const int32_t* __restrict__ bandSlotPrefix, const int32_t* __restrict__ blockOffsets,
                                                           const float* __restrict__ clipZ, uint32_t* __restrict__ depthKey,

@@ -85,7 +85,7 @@ void launchUnpackEllipse(hipStream_t stream, int count, const float4* tileRecord
 // write instead of the three arrays (what the raster gathers per list entry is then ONE memory sector instead of two).
 void launchUnpackRasterRecord(hipStream_t stream, int count, const float4* rasterRecord, float2* clipXY, float* clipZ, float4* conic);
 // Band cull (multi-GPU): the clip kernel flags the splats whose tile AABB reaches this GPU's rows (per 64 splats one 64-bit mask
-// and the kept splats before them in their block of 1024, one count per block); this scans the block counts and writes the kept
+// and the kept splats before them in their block of 256, one count per block); this scans the block counts and writes the kept
 // splats' depth keys and (virtual) indices, order preserved, and their number to *bandTotal.
 void launchBandCompaction(hipStream_t stream, int count, int views, const unsigned long long* bandMask, const int32_t* bandSlotPrefix,
                           const int32_t* bandBlockCounts, int32_t* bandBlockOffsets, int64_t* bandTotal, const float* clipZ,

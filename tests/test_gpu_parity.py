@@ -482,10 +482,10 @@ def test_band_cull_is_invisible(gs, tmp_path, degree):
 
 
 @pytest.mark.parametrize("log_scale_mean", [-4.0, -3.0, -1.5])
-def test_band_cull_early_test_drops_nothing(gs, tmp_path, log_scale_mean):
-    """The band cull rules most splats out with a cheap conservative bound before the projection proper (gs_clip.hip:
-    bandCandidate).  Whatever it drops must be something the exact test drops too: for narrow and wide bands, small to
-    screen-filling splats and several cameras, the band's pair list with the cull equals the list without it, entry for entry."""
+def test_band_cull_drops_nothing(gs, tmp_path, log_scale_mean):
+    """Whatever the band cull of a multi-GPU rank drops must be something that emits no pair in the band: for narrow and wide
+    bands, small to screen-filling splats and several cameras, the band's pair list with the cull (compacted splat list, slot
+    prefixes, block scan) equals the list without it, entry for entry."""
     from cudagaussianrenderer_amd import scenes
 
     w, h = 960, 544
