@@ -379,6 +379,7 @@ def main():
     ap.add_argument("--own-scene-copies", action="store_true", help="every renderer uploads its own copy of the scene instead of sharing renderer 0's read-only buffers")
     ap.add_argument("--ablate", type=int, default=-1, help="diagnostics: leave stages out of the timed frames (bit 0 clip, 1 depth sort, 2 count, 3 emit, 4 tile sort, 5 ranges, 6 raster; 0 = none, the reference point); prints frames/s only")
     ap.add_argument("--views-per-chain", type=int, default=0, help="frames rendered by one replay of the captured chain (gs_renderer_set_views, 1..4); 0 = 1 on one GPU, 4 on a rank of a multi-GPU run")
+    ap.add_argument("--spin-up", type=float, default=1.0, help="seconds of untimed rendering before the W warm-up frames: a handful of warm-up frames leaves the clocks, the host threads and the streams cold (20 timed frames after 5 warm-up frames: 4 600 frames/s without, 5 200 with 0.25 s or more -- the rate 512 timed frames give either way)")
     ap.add_argument("--inflight", type=int, default=0, help="frames in flight per GPU (renderers on separate HIP streams); 0 = 4 (the measured optimum with 8 hardware queues)")
     args = ap.parse_args()
 
@@ -459,6 +460,19 @@ def main():
     depth = args.inflight if args.inflight > 0 else 4
 
     rig = Rig(ctx, ply, cameras, bands, depth, args)
+    if args.spin_up > 0:
+        # untimed: keep the GPU rendering for a while before the W warm-up frames (a freshly leased box starts from idle clocks)
+        t_spin = time.perf_counter()
+        while True:
+            rig.run_frames(256)
+            rig.sync_all()
+            done = time.perf_counter() - t_spin >= args.spin_up
+            if world > 1:  # every rank must leave after the same number of frames (each frame is a matched send/receive set)
+                flag = torch.tensor([1 if done else 0], dtype=torch.int32, device=("cpu" if args.rehearse else device))
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                done = bool(int(flag.item()))
+            if done:
+                break
     if args.ablate >= 0:
         # marginal cost of stages in the pipelined loop: the renderers are primed with complete frames, then re-capture without
         # the masked stages (list sizes and buffers stay valid, the images are garbage)
@@ -518,7 +532,7 @@ def main():
                 "splats": N, "width": W, "height": H, "sh_degree": args.sh_degree, "views": len(cameras),
                 "pairs_per_frame": round(p_mean), "consumed_pairs_per_frame": round(pc_mean), "nonempty_tiles": round(nonempty),
                 "log_scale_mean": args.log_scale_mean, "opacity_mean_raw": args.opacity_mean, "seed": args.seed,
-                "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": device_name(lib), "frames_in_flight": depth, "frames_per_chain": rig.V,
+                "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": device_name(lib), "frames_in_flight": depth, "frames_per_chain": rig.V, "untimed_spin_up_s": args.spin_up,
                 "frames_in_timed_region": rig.frames_timed,
                 "captured_frames": not args.no_graph,
                 "colours": "on demand in the raster kernel (no SH pass)" if on_demand else "SH pass over all splats",
