@@ -184,8 +184,8 @@ class Rig:
         import torch
 
         with torch.cuda.stream(self.streams[d]):
-            for v in range(self.V):  # one grouped send/receive set per frame
-                self.ctx["multigpu"].gather_bands(self.framebuffers[d][v], self.bands, self.ctx["rank"], self.ctx["world"], comm=self.ctx["comm"])
+            # the V images of the chain: ONE grouped send/receive set (gs_gather_bands_views)
+            self.ctx["multigpu"].gather_bands(self.framebuffers[d], self.bands, self.ctx["rank"], self.ctx["world"], comm=self.ctx["comm"])
 
     def run_frames(self, count):
         """At least `count` more frames (whole chains of V): frame j's bands -> rank 0 (one grouped RCCL send/recv set, receives

@@ -120,15 +120,26 @@ extern "C" void gs_comm_destroy(GsComm* c)
 // ONE GPU, so that the run-time binding, the call signatures and the stream handling are exercised where only one GPU exists.
 extern "C" int gs_debug_rccl_self_exchange(void* dst, const void* src, size_t bytes, void* hipStream)
 {
+    return gs_debug_rccl_self_exchange_parts(dst, src, bytes, 1, hipStream);
+}
+
+// `parts` send/receive pairs with the same peer inside ONE group (what a chain of several views asks of the root and of every sender).
+extern "C" int gs_debug_rccl_self_exchange_parts(void* dst, const void* src, size_t bytes, int parts, void* hipStream)
+{
     const Rccl& r = rccl();
     if (!r.ok) return -1;
+    if (parts < 1 || bytes % (size_t) parts != 0) return -1;
     ncclUniqueId id;
     if (!check(r.getUniqueId(&id), "ncclGetUniqueId")) return -2;
     ncclComm_t comm = nullptr;
     if (!check(r.commInitRank(&comm, 1, id, 0), "ncclCommInitRank")) return -2;
+    const size_t part = bytes / (size_t) parts;
     bool ok = check(r.groupStart(), "ncclGroupStart");
-    ok = ok && check(r.send(src, bytes, ncclUint8, 0, comm, (hipStream_t) hipStream), "ncclSend");
-    ok = ok && check(r.recv(dst, bytes, ncclUint8, 0, comm, (hipStream_t) hipStream), "ncclRecv");
+    for (int p = 0; ok && p != parts; ++p)
+    {
+        ok = ok && check(r.send((const char*) src + part * (size_t) p, part, ncclUint8, 0, comm, (hipStream_t) hipStream), "ncclSend");
+        ok = ok && check(r.recv((char*) dst + part * (size_t) p, part, ncclUint8, 0, comm, (hipStream_t) hipStream), "ncclRecv");
+    }
     ok = check(r.groupEnd(), "ncclGroupEnd") && ok;
     if (hipStreamSynchronize((hipStream_t) hipStream) != hipSuccess) ok = false;
     (void) r.commDestroy(comm);
@@ -151,27 +162,38 @@ extern "C" void gs_band_pixel_rows(int tileRowBegin, int tileRowEnd, int height,
 
 extern "C" int gs_gather_bands(GsComm* c, uint8_t* backBuffer, int width, int height, const int32_t* tileRowBands, int root, void* hipStream)
 {
-    if (!c || !backBuffer || !tileRowBands || root < 0 || root >= c->world) return -1;
+    return gs_gather_bands_views(c, backBuffer, width, height, 1, tileRowBands, root, hipStream);
+}
+
+// The bands of `views` images stored one after another (gs_renderer_set_views), ONE grouped send/receive set for all of them.
+extern "C" int gs_gather_bands_views(GsComm* c, uint8_t* backBuffer, int width, int height, int views, const int32_t* tileRowBands, int root,
+                                     void* hipStream)
+{
+    if (!c || !backBuffer || !tileRowBands || root < 0 || root >= c->world || views < 1) return -1;
     if (c->world == 1) return 0;
-    const size_t rowBytes = (size_t) width * 4;
+    const size_t rowBytes = (size_t) width * 4, imageBytes = rowBytes * (size_t) height;
     hipStream_t stream = (hipStream_t) hipStream;
     const Rccl& r = rccl();
     bool ok = check(r.groupStart(), "ncclGroupStart");
-    if (c->rank == root)
+    for (int v = 0; ok && v != views; ++v)
     {
-        for (int src = 0; ok && src != c->world; ++src)
+        uint8_t* image = backBuffer + imageBytes * (size_t) v;
+        if (c->rank == root)
         {
-            if (src == root) continue;
-            int a, b;
-            gs_band_pixel_rows(tileRowBands[2 * src], tileRowBands[2 * src + 1], height, &a, &b);
-            if (b > a) ok = check(r.recv(backBuffer + rowBytes * (size_t) a, rowBytes * (size_t) (b - a), ncclUint8, src, c->comm, stream), "ncclRecv");
+            for (int src = 0; ok && src != c->world; ++src)
+            {
+                if (src == root) continue;
+                int a, b;
+                gs_band_pixel_rows(tileRowBands[2 * src], tileRowBands[2 * src + 1], height, &a, &b);
+                if (b > a) ok = check(r.recv(image + rowBytes * (size_t) a, rowBytes * (size_t) (b - a), ncclUint8, src, c->comm, stream), "ncclRecv");
+            }
         }
-    }
-    else
-    {
-        int a, b;
-        gs_band_pixel_rows(tileRowBands[2 * c->rank], tileRowBands[2 * c->rank + 1], height, &a, &b);
-        if (b > a) ok = check(r.send(backBuffer + rowBytes * (size_t) a, rowBytes * (size_t) (b - a), ncclUint8, root, c->comm, stream), "ncclSend");
+        else
+        {
+            int a, b;
+            gs_band_pixel_rows(tileRowBands[2 * c->rank], tileRowBands[2 * c->rank + 1], height, &a, &b);
+            if (b > a) ok = check(r.send(image + rowBytes * (size_t) a, rowBytes * (size_t) (b - a), ncclUint8, root, c->comm, stream), "ncclSend");
+        }
     }
     // the group is always closed, also after a failed call inside it
     ok = check(r.groupEnd(), "ncclGroupEnd") && ok;

@@ -38,14 +38,16 @@ class BandComm:
         self.rank, self.world = rank, world
 
     def gather(self, framebuffer, bands, root=0, stream=None):
+        """framebuffer: (H, W, 4), or (V, H, W, 4) for the V images of a chain of views -- one grouped send/receive set either way."""
         import torch
 
         flat = (C.c_int32 * (2 * len(bands)))(*[int(v) for b in bands for v in b])
         s = stream if stream is not None else torch.cuda.current_stream(framebuffer.device).cuda_stream
-        h, w = int(framebuffer.shape[0]), int(framebuffer.shape[1])
-        rc = _capi.load().gs_gather_bands(self.handle, framebuffer.data_ptr(), w, h, flat, root, s)
+        views = int(framebuffer.shape[0]) if framebuffer.dim() == 4 else 1
+        h, w = int(framebuffer.shape[-3]), int(framebuffer.shape[-2])
+        rc = _capi.load().gs_gather_bands_views(self.handle, framebuffer.data_ptr(), w, h, views, flat, root, s)
         if rc != 0:
-            raise RuntimeError(f"gs_gather_bands failed ({rc})")
+            raise RuntimeError(f"gs_gather_bands_views failed ({rc})")
 
     def close(self):
         if self.handle:
@@ -59,7 +61,8 @@ def pixel_rows(band, height):
 
 
 def gather_bands(framebuffer, bands, rank, world, root=0, comm=None):
-    """framebuffer: (H, W, 4) uint8 tensor, contiguous; every rank has filled rows pixel_rows(bands[rank]).
+    """framebuffer: (H, W, 4) uint8 tensor, contiguous (or (V, H, W, 4): the V images of a chain of views); every rank has filled
+    rows pixel_rows(bands[rank]).
 
     Returns after the transfers are ordered on the current stream (GPU) or complete (CPU); on `root` the
     framebuffer then holds the whole frame.  No-op for world == 1.  With `comm` (a BandComm) the transfers are the library's
@@ -69,7 +72,11 @@ def gather_bands(framebuffer, bands, rank, world, root=0, comm=None):
     if world == 1:
         return
     if comm is not None and framebuffer.is_cuda:
-        comm.gather(framebuffer, bands, root)
+        comm.gather(framebuffer, bands, root)  # (V, H, W, 4): the images of a chain of views in ONE grouped set
+        return
+    if framebuffer.dim() == 4:
+        for image in framebuffer:
+            gather_bands(image, bands, rank, world, root, comm)
         return
     height = framebuffer.shape[0]
     if framebuffer.is_cuda and dist.get_backend() == "gloo":

@@ -332,9 +332,15 @@ int gs_comm_world(const GsComm* comm);
 void gs_band_pixel_rows(int tileRowBegin, int tileRowEnd, int height, int* rowBegin, int* rowEnd);
 /* tileRowBands: 2 * world int32 (begin, end per rank).  Returns 0, -1 on bad arguments, -2 on an RCCL error. */
 int gs_gather_bands(GsComm* comm, uint8_t* deviceBackBuffer, int width, int height, const int32_t* tileRowBands, int root, void* hipStream);
+/* The same for the `views` images of a renderer set to several views per chain (gs_renderer_set_views: the images follow one another
+ * in the back buffer): ONE grouped send/receive set for all of them. */
+int gs_gather_bands_views(GsComm* comm, uint8_t* backBuffer, int width, int height, int views, const int32_t* tileRowBands, int root,
+                          void* hipStream);
 /* Diagnostics: a one-rank RCCL communicator sends `bytes` from src to dst (both device memory) through the grouped ncclSend/ncclRecv
  * path gs_gather_bands uses, on one GPU; blocks until done.  0 = ok, -1 RCCL not loadable, -2 RCCL error. */
 int gs_debug_rccl_self_exchange(void* dst, const void* src, size_t bytes, void* hipStream);
+/* ... with the block cut into `parts` send/receive pairs inside one group (several operations per peer, as gs_gather_bands_views issues). */
+int gs_debug_rccl_self_exchange_parts(void* dst, const void* src, size_t bytes, int parts, void* hipStream);
 
 const char* gs_version(void);
 

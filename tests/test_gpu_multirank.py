@@ -68,6 +68,11 @@ dst = gs.DeviceBuffer(np.zeros_like(rows))
 rc = lib.gs_debug_rccl_self_exchange(dst.ptr, src.ptr, rows.nbytes, None)
 assert rc == 0, rc
 assert np.array_equal(dst.copy_to(dtype=np.uint8).reshape(rows.shape), rows)
+# four send/receive pairs with one peer inside one group: what a chain of four views asks of gs_gather_bands_views
+dst4 = gs.DeviceBuffer(np.zeros_like(rows))
+rc = lib.gs_debug_rccl_self_exchange_parts(dst4.ptr, src.ptr, rows.nbytes, 4, None)
+assert rc == 0, rc
+assert np.array_equal(dst4.copy_to(dtype=np.uint8).reshape(rows.shape), rows)
 print("exchanged", rows.nbytes)
 """
 
