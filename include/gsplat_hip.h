@@ -269,7 +269,9 @@ void gs_renderer_set_graph(GsRenderer* r, int enabled);
  * holds the V images one after another (an external one must be that large); gs_renderer_back_buffer_view(r, v) is view v's.
  * gs_renderer_render_views takes V cameras; it needs captured frames (gs_renderer_set_graph), the two-level pipeline and colours
  * that do not need a per-view SH pass (SH degree 0, 1 or 3) and returns -3 otherwise; overflow of the pair list is handled as for
- * single frames (all V frames are rendered again).  Returns 0 on success. */
+ * single frames (all V frames are rendered again).  Returns 0 on success.  After a chain of V > 1 views gs_renderer_buffers describes
+ * the chain, not a frame: the pair list holds the pairs of all views (values are virtual splat indices v*N + i, ranges of view v start
+ * at entry 2*v*T of tileRange), and the per-splat arrays it unpacks are view 0's. */
 int gs_renderer_set_views(GsRenderer* r, int views);
 int gs_renderer_views(const GsRenderer* r);
 int gs_renderer_render_views(GsRenderer* r, const GsCameraData* cameras);
