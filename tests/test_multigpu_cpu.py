@@ -66,3 +66,47 @@ def test_band_split_and_gather_matches_single_process(tmp_path, world, width, he
     cam = gsref.camera_from_bounds([-4] * 3, [4] * 3, width, height)
     want, _, _ = gsref.render(pos, sr, col, None, 0, 0, cam, width, height)
     assert np.array_equal(got, want)
+
+
+def _views_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from cudagaussianrenderer_amd import multigpu, scenes
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        views, height, width = 3, 200, 64
+        bands = scenes.tile_row_bands((height + 15) // 16, world)
+        a, b = multigpu.pixel_rows(bands[rank], height)
+        fb = torch.zeros((views, height, width, 4), dtype=torch.uint8)
+        for v in range(views):
+            fb[v, a:b] = 10 * (v + 1) + rank  # what this rank "rendered" of view v
+        multigpu.gather_bands(fb, bands, rank, world)  # (V, H, W, 4): the images of one chain of views
+        dist.barrier()
+        if rank == 0:
+            np.save(out_path, fb.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_of_a_chain_of_views(tmp_path):
+    """bench.py on N > 1 renders several frames per chain of kernels (gs_renderer_set_views) and gathers their images together: the
+    stacked (V, H, W, 4) form of gather_bands must put every rank's rows of every view into rank 0's stack."""
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, ROOT)
+    from cudagaussianrenderer_amd import multigpu, scenes
+
+    world, views, height = 2, 3, 200
+    out = str(tmp_path / "views.npy")
+    mp.spawn(_views_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    bands = scenes.tile_row_bands((height + 15) // 16, world)
+    for v in range(views):
+        for rank in range(world):
+            a, b = multigpu.pixel_rows(bands[rank], height)
+            assert (got[v, a:b] == 10 * (v + 1) + rank).all()
