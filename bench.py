@@ -187,7 +187,7 @@ class Rig:
             # the V images of the chain: ONE grouped send/receive set (gs_gather_bands_views)
             self.ctx["multigpu"].gather_bands(self.framebuffers[d], self.bands, self.ctx["rank"], self.ctx["world"], comm=self.ctx["comm"])
 
-    def run_frames(self, count):
+    def run_frames(self, count, gather=True):
         """At least `count` more frames (whole chains of V): frame j's bands -> rank 0 (one grouped RCCL send/recv set, receives
         land directly in the framebuffer rows), ordered on the chain's own stream so the next use of that renderer waits for it.
         Returns the number of frames rendered."""
@@ -197,7 +197,8 @@ class Rig:
 
         def collect(chain, future):
             future.result()
-            self._gather(chain % self.depth)
+            if gather:
+                self._gather(chain % self.depth)
 
         chains = (count + self.V - 1) // self.V
         for chain in range(self.next_chain, self.next_chain + chains):
@@ -208,6 +209,17 @@ class Rig:
             collect(*inflight.popleft())
         self.next_chain += chains
         return chains * self.V
+
+    def local_frame_ms(self, frames):
+        """This rank's own steady-state time per frame for its band (no gather, no barrier): what the band re-cut balances."""
+        import torch
+
+        self.run_frames(frames // 4, gather=False)
+        torch.cuda.synchronize(self.ctx["device"])
+        t0 = time.perf_counter()
+        done = self.run_frames(frames, gather=False)
+        torch.cuda.synchronize(self.ctx["device"])
+        return 1e3 * (time.perf_counter() - t0) / done
 
     def sync_all(self):
         import torch
@@ -371,6 +383,7 @@ def main():
     ap.add_argument("--ppl", type=int, default=0, help="raster pixels per lane override (1,2,4)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel individually instead of replaying a captured frame")
     ap.add_argument("--even-bands", action="store_true", help="multi-GPU: equal-height bands instead of cost-balanced ones")
+    ap.add_argument("--rebalance", type=int, default=2, help="multi-GPU: re-cut the cost-balanced bands this many times from the ranks' measured band times (untimed set-up)")
     ap.add_argument("--pipeline", type=int, default=1, help="1 two-level sort (default, fastest at C3), 2 binned tile lists (no pair sort)")
     ap.add_argument("--band-cull", type=int, default=0, help="0 auto (compact the visible splats on strict bands only), 1 always, 2 never")
     ap.add_argument("--epanechnikov", action="store_true", help="the reference's EPANECHNIKOV_KERNEL option (footprint sqrt(7) sigma, density 1 - q/7)")
@@ -460,6 +473,37 @@ def main():
     depth = args.inflight if args.inflight > 0 else 4
 
     rig = Rig(ctx, ply, cameras, bands, depth, args)
+    band_times = None
+    if world > 1 and not args.even_bands and args.rebalance > 0:
+        # The cost model does not know the kernels' fixed costs: re-cut the bands from what every rank MEASURES for its own band
+        # (untimed set-up: a few hundred frames without gather, times shared with an all-gather so that every rank derives the same
+        # bands), keep the cut with the smallest slowest band.  Rows of a band that took longer than the mean get more weight
+        # (exponent 2: only part of a band's time follows its rows).  Also absorbs speed differences between the GPUs.
+        cost = row_cost.copy()
+        best = None
+        for it in range(args.rebalance + 1):
+            mine = torch.tensor([rig.local_frame_ms(256)], dtype=torch.float64, device=("cpu" if args.rehearse else device))
+            everyone = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(everyone, mine)
+            times = [float(t.item()) for t in everyone]
+            if best is None or max(times) < best[0]:
+                best = (max(times), bands, times)
+            if it == args.rebalance:
+                break
+            mean = sum(times) / len(times)
+            for (a, b), t in zip(bands, times):
+                cost[a:b] *= (t / mean) ** 2.0
+            recut = scenes.balanced_tile_row_bands(cost, world)
+            if recut == bands:
+                break
+            bands = recut
+            rig.close()
+            rig = Rig(ctx, ply, cameras, bands, depth, args)
+        if bands != best[1]:
+            bands = best[1]
+            rig.close()
+            rig = Rig(ctx, ply, cameras, bands, depth, args)
+        band_times = [round(t, 4) for t in best[2]]
     if args.spin_up > 0:
         # untimed: keep the GPU rendering for a while before the W warm-up frames (a freshly leased box starts from idle clocks)
         t_spin = time.perf_counter()
@@ -538,7 +582,7 @@ def main():
                 "colours": "on demand in the raster kernel (no SH pass)" if on_demand else "SH pass over all splats",
                 "footprint": "epanechnikov" if args.epanechnikov else "gaussian",
                 "pipeline": {1: "two_level", 2: "binned"}.get(args.pipeline, str(args.pipeline)),
-                "tile_row_bands": [list(b) for b in bands], "ingest_s": round(t_ingest, 2),
+                "tile_row_bands": [list(b) for b in bands], "band_ms_measured_by_its_rank": band_times, "ingest_s": round(t_ingest, 2),
                 "dist_backend": backend, "dist_world_size": world, "rehearsal_on_one_gpu": bool(args.rehearse),
                 "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
                 "gather": None if world == 1 else ("gs_gather_bands: grouped ncclSend/ncclRecv through the C ABI" if comm is not None

@@ -20,6 +20,8 @@ ap.add_argument("--sort-backend", type=int, default=1, help="0 rocPRIM, 1 native
 ap.add_argument("--ppl", type=int, default=2, help="raster pixels per lane")
 ap.add_argument("--pipeline", type=int, default=1)
 ap.add_argument("--views", type=int, default=1, help="cameras per chain of kernels (gs_renderer_set_views)")
+ap.add_argument("--rebalance", type=int, default=0, help="iterations of re-cutting the bands from their measured times")
+ap.add_argument("--gamma", type=float, default=2.0)
 ap.add_argument("--ablate", type=int, default=0, help="gs_debug_set_ablation mask for the timed frames (diagnostic: stages left out)")
 args = ap.parse_args()
 W, H = 1920, 1080
@@ -46,11 +48,8 @@ cal.close()
 D = args.inflight
 gs.lib().gs_debug_set_ablation(args.ablate)
 shared_streams = [torch.cuda.Stream() for _ in range(D)]
-for world in [int(x) for x in args.worlds.split(",")]:
+def measure(world, bands):
     times = []
-
-    bands = scenes.balanced_tile_row_bands(row_cost, world) if args.balanced else scenes.tile_row_bands(ty, world)
-    print('bands', bands)
     for band in bands:
         streams = shared_streams
         rs = []
@@ -83,6 +82,23 @@ for world in [int(x) for x in args.worlds.split(",")]:
         times.append(1e3 * (time.perf_counter() - t) / args.frames)
         for r in rs:
             r.close()
-    worst = max(times)
-    base = base or worst
-    print(f"world {world}: per-band ms {[round(x, 3) for x in times]} -> slowest {worst:.3f} ms, speed-up vs 1 GPU {base / worst:.2f}x (gather not included)")
+    return times
+
+
+for world in [int(x) for x in args.worlds.split(",")]:
+    cost = row_cost.copy()
+    bands = scenes.balanced_tile_row_bands(cost, world) if args.balanced else scenes.tile_row_bands(ty, world)
+    for it in range(args.rebalance + 1):
+        print('bands', bands)
+        times = measure(world, bands)
+        worst = max(times)
+        base = base or worst
+        print(f"world {world}: per-band ms {[round(x, 3) for x in times]} -> slowest {worst:.3f} ms, speed-up vs 1 GPU {base / worst:.2f}x (gather not included)")
+        if world == 1 or it == args.rebalance:
+            break
+        # re-cut: the rows of a band that took longer than the mean get proportionally more weight (gamma > 1: only part of a band's
+        # time follows its rows)
+        mean = sum(times) / len(times)
+        for (a, b), t in zip(bands, times):
+            cost[a:b] *= (t / mean) ** args.gamma
+        bands = scenes.balanced_tile_row_bands(cost, world)

@@ -23,6 +23,8 @@ tools/pmc_pass.sh $TAG "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTI
 tools/pmc_pass.sh $TAG "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES SQ_INST_CYCLES_VMEM"
 echo "pmc done"
 for v in 1 2 4; do echo "--- frames per chain: $v"; GPU_MAX_HW_QUEUES=8 python3 tools/band_sim.py --worlds 1,2,4,8 --frames 2048 --inflight 4 --views $v 2>/dev/null | grep -E "world|bands"; done > $OUT/${TAG}_band_sim.txt; echo "band_sim rc=$?"
+echo "--- frames per chain: 4, 8 GPUs, bands re-cut twice from their measured times (bench.py --rebalance 2)" >> $OUT/${TAG}_band_sim.txt
+GPU_MAX_HW_QUEUES=8 python3 tools/band_sim.py --worlds 8 --frames 2048 --inflight 4 --views 4 --rebalance 2 2>/dev/null | grep -E "world|bands" >> $OUT/${TAG}_band_sim.txt
 for v in 1 4; do echo "=== tile rows 29..34 (a centre band of the 8-way split), $v frame(s) per chain"; tools/band_profile.sh 29 34 $v; done > $OUT/${TAG}_band_chain_kernels.txt 2>&1; echo "band chain rc=$?"
 tools/ablation.sh 2>/dev/null | grep ablate > $OUT/${TAG}_ablation.txt
 PUMP_MASKS=0 PUMP_DEPTHS=1,2,3,4 python3 tools/frame_pump.py 2>/dev/null | grep inflight > $OUT/${TAG}_frame_pump.txt
