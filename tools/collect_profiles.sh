@@ -2,6 +2,7 @@
 # usage: tools/collect_profiles.sh r02   -- copies the summaries tools/profile_round.sh left in gpurun_out/ into profiles/
 TAG=${1:-r02}
 G=gpurun_out
+[ -s $G/${TAG}_bench_c3.json ] && [ -s $G/${TAG}_pmc_FETCH_SIZE.txt ] || { echo "no $TAG outputs under $G (was gpurun_out/ copied back?)"; exit 1; }
 tail -1 $G/${TAG}_bench_c3.json > profiles/${TAG}_bench_c3.json
 tail -1 $G/${TAG}_bench_under_rocprof.json > profiles/${TAG}_bench_under_rocprof_pipelined.json
 tail -1 $G/${TAG}_bench_under_rocprof_serial.json > profiles/${TAG}_bench_under_rocprof_serial.json

@@ -11,10 +11,11 @@ mkdir -p $OUT
 cd $ROOT
 python3 bench.py > $OUT/${TAG}_bench_c3.json 2> $OUT/${TAG}_bench_c3.err; echo "bench rc=$?"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o stats -- python3 $ROOT/bench.py --steps 256 --warmup 32 --cpu-frames 0 --no-extra > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_stats.err; echo "stats rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -o stats -- python3 $ROOT/bench.py --steps 256 --warmup 32 --cpu-frames 0 --no-extra --spin-up 0 > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_stats.err; echo "stats rc=$?"
+# (--spin-up 0: the untimed second of rendering would put ~80 000 more kernel records into every trace)
 # the same frames one at a time (one frame in flight, plain launches): per-kernel averages without overlap from other frames,
 # comparable with the per-stage HIP-event times bench.py reports in "stages" / "roofline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_serial -o stats -- python3 $ROOT/bench.py --steps 256 --warmup 32 --cpu-frames 0 --no-extra --inflight 1 --no-graph > $OUT/${TAG}_bench_under_rocprof_serial.json 2> $OUT/${TAG}_stats_serial.err; echo "serial stats rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_serial -o stats -- python3 $ROOT/bench.py --steps 256 --warmup 32 --cpu-frames 0 --no-extra --spin-up 0 --inflight 1 --no-graph > $OUT/${TAG}_bench_under_rocprof_serial.json 2> $OUT/${TAG}_stats_serial.err; echo "serial stats rc=$?"
 cd $ROOT
 tools/pmc_pass.sh $TAG "FETCH_SIZE"
 tools/pmc_pass.sh $TAG "WRITE_SIZE"
