@@ -384,7 +384,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel individually instead of replaying a captured frame")
     ap.add_argument("--even-bands", action="store_true", help="multi-GPU: equal-height bands instead of cost-balanced ones")
     ap.add_argument("--rebalance", type=int, default=2, help="multi-GPU: re-cut the cost-balanced bands this many times from the ranks' measured band times (untimed set-up)")
-    ap.add_argument("--pipeline", type=int, default=1, help="1 two-level sort (default, fastest at C3), 2 binned tile lists (no pair sort)")
+    ap.add_argument("--pipeline", type=int, default=1, help="1 two-level sort (default), 0 the reference's stage order (one 64-bit sort of all pairs)")
     ap.add_argument("--band-cull", type=int, default=0, help="0 auto (compact the visible splats on strict bands only), 1 always, 2 never")
     ap.add_argument("--epanechnikov", action="store_true", help="the reference's EPANECHNIKOV_KERNEL option (footprint sqrt(7) sigma, density 1 - q/7)")
     ap.add_argument("--gather", choices=["library", "torch"], default="library", help="multi-GPU framebuffer gather: the library's grouped ncclSend/ncclRecv (gs_gather_bands) or torch.distributed point-to-point operations")
@@ -581,7 +581,7 @@ def main():
                 "captured_frames": not args.no_graph,
                 "colours": "on demand in the raster kernel (no SH pass)" if on_demand else "SH pass over all splats",
                 "footprint": "epanechnikov" if args.epanechnikov else "gaussian",
-                "pipeline": {1: "two_level", 2: "binned"}.get(args.pipeline, str(args.pipeline)),
+                "pipeline": {1: "two_level", 0: "reference"}.get(args.pipeline, str(args.pipeline)),
                 "tile_row_bands": [list(b) for b in bands], "band_ms_measured_by_its_rank": band_times, "ingest_s": round(t_ingest, 2),
                 "dist_backend": backend, "dist_world_size": world, "rehearsal_on_one_gpu": bool(args.rehearse),
                 "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),

@@ -18,7 +18,6 @@ FOOTPRINT_GAUSSIAN = 0      # exp(-q/2), 3 sigma extent
 FOOTPRINT_EPANECHNIKOV = 1  # the reference's EPANECHNIKOV_KERNEL option: 1 - q/7, sqrt(7) sigma extent
 PIPELINE_REFERENCE = 0  # the reference's stage order: one 64-bit tile|depth radix sort of all pairs
 PIPELINE_TWO_LEVEL = 1  # default: depth-sort the splats, emit, stable-sort the pairs on the tile bits
-PIPELINE_BINNED = 2     # depth-sort the splats, then write every hit straight to its slot of the per-tile lists (no pair sort)
 
 
 def lib():

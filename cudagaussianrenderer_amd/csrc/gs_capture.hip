@@ -1,0 +1,285 @@
+// gs_capture.hip -- the C ABI of include/gsplat_hip.h, part 3: captured frames (hipGraph replay) and frames per chain.
+//
+// The two-level frame with every list size left on the device (the pair count feeds the tile sort and the range kernel
+// through pointers, grids are sized for the list capacity), so the frame has no host round trip and can be captured once
+// and replayed as ONE graph launch per frame.  The camera travels in a small device struct that a memcpy node refreshes.
+// The pair total reaches the host through a host-mapped word in the middle of the frame; a frame whose demand exceeds the
+// list capacity is rendered again with a larger list before the call returns (never handed out truncated).
+#include <atomic>
+#include <chrono>
+#include <cstring>
+
+#include "gs_state.h"
+
+using namespace gs;
+
+namespace gs
+{
+std::mutex g_captureMutex;
+namespace
+{
+// host-side cost of captured frames (diagnostic, gs_debug_host_times): time inside hipGraphLaunch, time waiting for the pair total
+std::atomic<long long> g_hostLaunchNs{0}, g_hostAwaitNs{0}, g_hostFrames{0};
+
+int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool lazy, int slot)
+{
+    const RasterColourSource lazySource = colourSource(r, nullptr, r->paramsDevice);
+    const RasterColourSource* lazyColours = lazy ? &lazySource : nullptr;
+    const int n = r->splatCount;
+    // Several views per chain: V grid rows in the clip, compaction and raster kernels; everything in between works on the
+    // n * V virtual splats and V * totalTiles virtual tiles as if they were one frame's (gs_internal.h: kMaxViews).
+    const int views = r->views;
+    const int nv = n * views;
+    const int virtualTiles = scr.totalTiles * views;
+    const int tileKeyBytes = virtualTiles > 65536 ? 4 : 2;
+    const int tBits = tileBits(virtualTiles);
+    const float3 unused = make_float3(0.f, 0.f, 0.f);
+    ClipCamera unusedCamera{};
+
+    GS_CHECK(hipMemcpyAsync(r->paramsDevice, r->paramsHost + slot * kMaxViews, sizeof(FrameParams) * views, hipMemcpyHostToDevice, g.stream));
+    // the range table is reset to -1 by the clip kernel (one node less than a memset; see gs_ranges.hip)
+    int32_t* clearTable = r->tileRange;
+    const int clearEntries = 2 * virtualTiles;
+#ifdef GS_DEBUG_MEMSET_NODE
+    // audit build (tools/micro/graph_memset.hip): the table is cleared by a memset NODE instead
+    if (clearTable != nullptr) GS_CHECK(hipMemsetAsync(clearTable, 0xFF, sizeof(int32_t) * (size_t) clearEntries, g.stream));
+    clearTable = nullptr;
+#endif
+    if (r->shDegree != 0 && !cull && !lazy)
+        launchSphericalHarmonics(g.stream, n, r->shDegree, r->shCount, (const float4*) r->position, r->sh, unused, (float4*) r->color,
+                                 r->paramsDevice);
+    const int* countDevice = nullptr;
+    if (!cull)
+    {
+        if (!(g_ablation & 1))
+            launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
+                                nullptr, nullptr, nullptr, nullptr, r->depthKey[0],
+                                (uint32_t*) r->order[0], nullptr, nullptr, nullptr, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord,
+                                (float4*) r->rasterRecord, views);
+    }
+    else
+    {
+        launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
+                            nullptr, r->clipZ, nullptr, nullptr, nullptr, nullptr, r->bandMask,
+                            r->bandSlotPrefix, r->bandCounts, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord, (float4*) r->rasterRecord,
+                            views);
+        launchBandCompaction(g.stream, n, views, r->bandMask, r->bandSlotPrefix, r->bandCounts, r->bandOffsets, r->bandTotal, r->clipZ, r->depthKey[0],
+                             (uint32_t*) r->order[0]);
+        countDevice = (const int*) r->bandTotal;
+        if (r->shDegree != 0 && !lazy)
+            launchSphericalHarmonicsGather(g.stream, n, countDevice, r->shDegree, r->shCount, r->order[0], (const float4*) r->position,
+                                           r->shPerSplat, unused, (float4*) r->color, r->paramsDevice);
+    }
+    r->radix.countDevice = countDevice;
+    r->scratch.countDevice = countDevice;
+    const int orderSel = (g_ablation & 2) ? 0 : launchRadixSortPairs(g.stream, r->radix, 4, r->depthKey[0], r->depthKey[1], r->order[0], r->order[1], nv, 0, kDepthKeyBits);
+    const uint32_t* order = (const uint32_t*) r->order[orderSel];
+    if (!(g_ablation & 4)) launchTileListFastCount(g.stream, nv, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch);
+    if (!(g_ablation & 8))
+        launchTileListFastEmit(g.stream, nv, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],
+                               tileKeyBytes, r->values[0], r->tileListCapacity, views > 1 ? n : 0);
+    // tile sort + ranges on the device-side pair count (low word of the int64 total), grids sized for the capacity
+    const int* pairCount = (const int*) r->scratch.total;
+    r->radix.countDevice = pairCount;
+    r->scratch.countDevice = nullptr;
+    const int sel = (g_ablation & 16) ? 0
+                                      : launchRadixSortPairs(g.stream, r->radix, tileKeyBytes, r->keys[0], r->keys[1], r->values[0], r->values[1],
+                                                             r->tileListCapacity, 0, tBits);
+    r->radix.countDevice = nullptr;
+    if (!(g_ablation & 32)) launchTileRanges(g.stream, r->tileListCapacity, tileKeyBytes, r->keys[sel], r->tileRange, pairCount);
+    if (!(g_ablation & 64))
+        launchRasterize(g.stream, scr, r->tileRange, r->values[sel], (const float2*) r->clipXY, (const float4*) r->conic,
+                        (const float4*) r->color, (uchar4*) r->backBuffer, nullptr, true, lazyColours, (const float4*) r->rasterRecord, views, n);
+    r->graphSelector = sel;
+    r->graphKeyBytes = tileKeyBytes;
+    return 0;
+}
+
+// The pair total of a captured frame lands in a host-mapped word (written by the emit pass).
+// The host arms the word with -1 before the launch and waits for the frame's own value: a few microseconds of polling in
+// the middle of the frame, long before its raster kernel ends.
+// The wait is bounded twice over: any stream status other than "not ready" ends it (a faulted queue never writes the word, and
+// hipStreamQuery then reports the fault for ever), and so does the wall clock (gs_debug_set_await_timeout, 30 s by default) -- both
+// the reference's way (CudaErrorCheck.cpp:2-11): print and exit, so that a fault on one rank of a multi-GPU job ends the job instead
+// of leaving a host thread spinning.
+double g_awaitTimeoutSeconds = 30.0;
+
+int64_t awaitPairTotal(GsRenderer* r)
+{
+    volatile int64_t* word = r->scratch.totalHost;
+    std::chrono::steady_clock::time_point t0;
+    for (unsigned spins = 0;; ++spins)
+    {
+        const int64_t v = *word;
+        if (v >= 0) return v;
+        if ((spins & 63u) == 63u)
+        {
+            const hipError_t status = hipStreamQuery(g.stream);
+            if (status == hipSuccess)
+            {
+                // the whole frame is done: every write of it is visible by now
+                const int64_t w = *word;
+                if (w >= 0) return w;
+                int64_t fromDevice = 0; // (no host-mapped address: the total was left in device memory)
+                GS_CHECK(hipMemcpy(&fromDevice, r->scratch.total, sizeof(int64_t), hipMemcpyDeviceToHost));
+                return fromDevice;
+            }
+            if (status != hipErrorNotReady)
+            {
+                printf("HIP error at %s %d: %s (stream status while waiting for a captured frame's pair total)\n", __FILE__, __LINE__,
+                       hipGetErrorString(status));
+                exit(EXIT_FAILURE);
+            }
+            if (spins == 63u) t0 = std::chrono::steady_clock::now();
+            else if ((spins & 0xFFFFu) == 0xFFFFu &&
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > g_awaitTimeoutSeconds)
+            {
+                printf("gsplat_hip: no pair total from a captured frame after %.1f s (stream still busy): giving up\n", g_awaitTimeoutSeconds);
+                exit(EXIT_FAILURE);
+            }
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+}
+} // namespace
+
+// `cameras`: r->views of them (one frame per view, rendered by one chain).
+int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
+{
+    if (!r->hasStream && g.stream == nullptr)
+    {
+        // the null stream cannot be captured: a renderer without a stream of its own gets one
+        GS_CHECK(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+        r->hasStream = true;
+        r->ownsStream = true;
+        GS_CHECK(hipDeviceSynchronize()); // uploads and earlier frames issued on the null stream
+    }
+    StreamScope scope(r);
+    const Screen scr = makeScreen(r->width, r->height, r->rowBegin, r->rowEnd);
+    const int n = r->splatCount;
+    const bool strictBand = scr.rowBegin > 0 || scr.rowEnd < scr.tilesY;
+    const bool cull = n > 0 && (r->bandCull == GS_BAND_CULL_ON || (r->bandCull == GS_BAND_CULL_AUTO && strictBand));
+
+    // No wait for the previous frame of this renderer: it may still be sorting or rasterising (render() returned when its pair
+    // total was known).  What this call overwrites is the OTHER parameter slot, last read by the frame before the previous one,
+    // which is complete -- the previous frame's emit pass ran behind it on the same stream and its total has been seen.
+    if (r->paramsDevice == nullptr)
+    {
+        std::lock_guard<std::mutex> lock(g_captureMutex);
+        GS_CHECK(hipMalloc((void**) &r->paramsDevice, sizeof(FrameParams) * kMaxViews));
+        GS_CHECK(hipHostMalloc((void**) &r->paramsHost, 2 * kMaxViews * sizeof(FrameParams), hipHostMallocDefault));
+    }
+    const bool lazy = useLazyColours(r);
+
+    FrameParams fp[kMaxViews] = {};
+    for (int v = 0; v != r->views; ++v)
+    {
+        const GsCameraData* camera = cameras + v;
+        std::memcpy(fp[v].camera.view, camera->view, sizeof(fp[v].camera.view));
+        fp[v].camera.fovCotX = camera->fovCotangent[0];
+        fp[v].camera.fovCotY = camera->fovCotangent[1];
+        fp[v].camera.depthScale = camera->depthScaleBias[0];
+        fp[v].camera.depthBias = camera->depthScaleBias[1];
+        for (int k = 0; k != 3; ++k) fp[v].cameraPosition[k] = r->lastCameraPosition[k] = camera->position[k];
+    }
+    r->colourStale = lazy;
+
+    // A frame whose pair demand exceeds the list capacity is NOT handed out (the reference would show it truncated and double
+    // the list for the next one, Demo.cpp:357-366,447): the list is grown, the frame re-captured and the SAME camera rendered
+    // again, so every frame that leaves this function is complete.
+    for (;;)
+    {
+        if (r->graphValid && (r->graphCapacity != r->tileListCapacity || r->graphSplats != n || r->graphRowBegin != scr.rowBegin ||
+                              r->graphRowEnd != scr.rowEnd || r->graphCull != (int) cull ||
+                              r->graphFootprint != scr.epanechnikov || r->graphLazy != (int) lazy || r->graphAblation != g_ablation))
+            r->graphValid = false;
+        if (!r->graphValid)
+        {
+            GS_CHECK(hipStreamSynchronize(g.stream)); // frames of the old instances drain before these are destroyed
+            std::lock_guard<std::mutex> lock(g_captureMutex);
+            // allocate everything the frame needs BEFORE capturing (no allocation may happen inside a capture)
+            ensureTileListFastScratch(r->scratch, n * r->views);
+            ensureRadixScratch(r->radix, n * r->views);
+            ensureRadixScratch(r->radix, r->tileListCapacity);
+            for (int slot = 0; slot != 2; ++slot)
+            {
+                if (r->graphExec[slot]) (void) hipGraphExecDestroy(r->graphExec[slot]);
+                if (r->graph[slot]) (void) hipGraphDestroy(r->graph[slot]);
+                r->graphExec[slot] = nullptr;
+                r->graph[slot] = nullptr;
+                GS_CHECK(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+                enqueueCapturableFrame(r, scr, cull, lazy, slot);
+                GS_CHECK(hipStreamEndCapture(g.stream, &r->graph[slot]));
+                GS_CHECK(hipGraphInstantiate(&r->graphExec[slot], r->graph[slot], nullptr, nullptr, 0));
+            }
+            r->graphValid = true;
+            r->graphCapacity = r->tileListCapacity;
+            r->graphSplats = n;
+            r->graphRowBegin = scr.rowBegin;
+            r->graphRowEnd = scr.rowEnd;
+            r->graphCull = (int) cull;
+            r->graphFootprint = scr.epanechnikov;
+            r->graphLazy = (int) lazy;
+            r->graphAblation = g_ablation;
+        }
+        const int slot = r->graphSlot;
+        r->graphSlot ^= 1;
+        for (int v = 0; v != r->views; ++v) r->paramsHost[slot * kMaxViews + v] = fp[v];
+        *r->scratch.totalHost = -1; // armed; the previous frame has left its total (seen by the host), nothing else writes the word
+        const auto hostT0 = std::chrono::steady_clock::now();
+        GS_CHECK(hipGraphLaunch(r->graphExec[slot], g.stream));
+        const auto hostT1 = std::chrono::steady_clock::now();
+        r->selector = r->graphSelector;
+        r->keyBytes = r->graphKeyBytes;
+
+        const int64_t demand = awaitPairTotal(r);
+        const auto hostT2 = std::chrono::steady_clock::now();
+        g_hostLaunchNs.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(hostT1 - hostT0).count(), std::memory_order_relaxed);
+        g_hostAwaitNs.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(hostT2 - hostT1).count(), std::memory_order_relaxed);
+        g_hostFrames.fetch_add(1, std::memory_order_relaxed);
+        g.lastDemand = demand;
+        r->tileListSize = (int32_t) std::min<int64_t>(demand, r->tileListCapacity);
+        if (demand <= r->tileListCapacity) return 0;
+        if (demand > 0x7FFFFFFF) return -2;
+        GS_CHECK(hipStreamSynchronize(g.stream)); // the truncated frame drains before its buffers are replaced
+        {
+            std::lock_guard<std::mutex> lock(g_captureMutex);
+            growTileListIfNeeded(r, demand);
+        }
+        r->graphValid = false;
+        r->capturedRetries += 1;
+    }
+}
+} // namespace gs
+
+extern "C" void gs_renderer_set_graph(GsRenderer* r, int enabled)
+{
+    r->useGraph = enabled != 0;
+    r->graphValid = false;
+}
+
+extern "C" int gs_renderer_captured_retries(const GsRenderer* r) { return r->capturedRetries; }
+extern "C" void gs_debug_set_ablation(int mask) { g_ablation = mask; }
+extern "C" void gs_debug_set_await_timeout(double seconds) { g_awaitTimeoutSeconds = seconds > 0.0 ? seconds : 30.0; }
+extern "C" long long gs_debug_host_times(double* launchMicroseconds, double* awaitMicroseconds, int reset)
+{
+    const long long frames = g_hostFrames.load();
+    if (launchMicroseconds) *launchMicroseconds = frames ? 1e-3 * (double) g_hostLaunchNs.load() / (double) frames : 0.0;
+    if (awaitMicroseconds) *awaitMicroseconds = frames ? 1e-3 * (double) g_hostAwaitNs.load() / (double) frames : 0.0;
+    if (reset) g_hostLaunchNs = 0, g_hostAwaitNs = 0, g_hostFrames = 0;
+    return frames;
+}
+
+extern "C" int gs_renderer_render_views(GsRenderer* r, const GsCameraData* cameras)
+{
+    if (r == nullptr || cameras == nullptr) return -1;
+    if (r->views == 1) return gs_renderer_render(r, cameras, 0, nullptr);
+    const bool coloursPerView = r->shDegree != 0 && !useLazyColours(r); // an SH pass would need one colour buffer per view
+    if (!r->useGraph || r->pipeline != GS_PIPELINE_TWO_LEVEL || cfg.sortBackend != GS_SORT_BACKEND_NATIVE || cfg.collectRasterStats ||
+        r->splatCount <= 0 || coloursPerView || !radixSortSupported(4, r->splatCount * r->views))
+        return -3;
+    return renderCaptured(r, cameras);
+}
+

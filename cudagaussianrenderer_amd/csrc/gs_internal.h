@@ -152,15 +152,6 @@ struct RadixScratch
     // Optional device-side element count (<= the host-side n the grids are sized for); set per call by the renderer
     // when the splat list was culled on the device, nullptr otherwise.
     const int* countDevice = nullptr;
-    // single-kernel passes (decoupled look-back): per-pass digit totals, one status granule per (tile, digit), the
-    // ticket counter and its running base, the launch epoch, and a device word set when a bounded spin gave up
-    bool onesweep = false; // measured slower than the three-kernel pass on MI355X; kept selectable
-    unsigned* digitCounts = nullptr;
-    unsigned long long* status = nullptr;
-    unsigned* ticket = nullptr;
-    unsigned* error = nullptr;
-    unsigned ticketBase = 0, epoch = 0;
-    int capacityStatusTiles = 0;
 };
 bool radixSortSupported(int keyBytes, int n);
 void ensureRadixScratch(RadixScratch& s, int n);
@@ -173,29 +164,6 @@ int launchRadixSortPairs(hipStream_t stream, RadixScratch& s, int keyBytes, void
 // sizeDevice (optional): the list length lives on the device (captured frame); `size` is then the upper bound the grid covers.
 void launchTileRanges(hipStream_t stream, int size, int keyBytes, const void* keys, int32_t* tileRange,
                       const int* sizeDevice = nullptr);
-
-// Binned tile lists (gs_bins.hip): depth-sorted splats -> final per-tile lists + ranges, no pair sort.
-constexpr int kBinMaxTiles = 8192; // LDS cursor table: 4 bytes per band tile and wave
-struct BinScratch
-{
-    uint16_t* counts = nullptr;    // [rows][stride] hits of a row of sorted splats per tile
-    uint32_t* offsets = nullptr;   // [rows][stride] exclusive scan of counts over the rows
-    int32_t* rowFlags = nullptr;   // [rows]
-    int32_t* tileTotals = nullptr; // [stride]
-    uint32_t* tileStart = nullptr; // [stride]
-    int rowsCapacity = 0, strideCapacity = 0;
-    const float4* tileRecord = nullptr; // optional packed (centre, ellipse) records: read instead of clipXY + screenEllipse
-};
-bool binsSupported(const Screen& scr);
-int binBatchesFor(int bandTiles);
-void ensureBinScratch(BinScratch& s, int splats, int bandTiles, int batches);
-void freeBinScratch(BinScratch& s);
-void launchBinCountScan(hipStream_t stream, int count, const int* countDevice, const Screen& scr, const uint32_t* order,
-                        const float2* clipXY, const float4* screenEllipse, const BinScratch& s, int batches);
-// Writes values (at most `capacity`), the band's rows of tileRange, *total (+ the host-mapped copy when given).
-void launchBinEmit(hipStream_t stream, int count, const int* countDevice, const Screen& scr, const uint32_t* order, const float2* clipXY,
-                   const float4* screenEllipse, const BinScratch& s, int batches, int32_t* values, int capacity, int32_t* tileRange,
-                   int64_t* total, int64_t* totalHostMapped);
 
 // Where the raster kernel gets an entry's colour when it is NOT read from the colour buffer: the splat's coefficient row
 // ([splat][shCount] layout) and position, evaluated when the entry is staged (gs_raster.hip, template parameter SH).

@@ -368,287 +368,6 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
     }
 }
 
-// ================================================================================================================
-// Single-kernel passes ("onesweep"): the tile digit counts are chained between workgroups inside the scatter kernel
-// (decoupled look-back), so a pass is ONE kernel and the keys are read once per pass; the per-pass digit totals of
-// ALL passes come from one up-front histogram kernel.
-//
-// Inter-workgroup protocol (MI355X: per-XCD L2s are not coherent, so nothing but the granule itself is handed over):
-//   status[tile][digit] is ONE naturally aligned 8-byte granule {epoch:30 | kind:2 | value:32}, written with a relaxed
-//   agent-scope atomic store and polled with relaxed agent-scope atomic loads -- the data IS the flag.  kind 1 = the
-//   tile's own digit count (published BEFORE the tile starts to look back), kind 2 = the inclusive prefix.  `epoch`
-//   changes with every launch, so the array is never cleared.  Logical tile indices are tickets drawn from an atomic
-//   counter when a workgroup starts, so every predecessor of a waiting workgroup is already running or done and will
-//   publish without waiting for anybody: the wait is bounded.  Spins are bounded anyway; a timeout sets `*error`.
-// ================================================================================================================
-constexpr unsigned kKindAggregate = 1u, kKindInclusive = 2u;
-constexpr int kSpinLimit = 1 << 24;
-
-__device__ __forceinline__ unsigned long long packGranule(unsigned epoch, unsigned kind, unsigned value)
-{
-    return ((unsigned long long) (epoch & 0x3FFFFFFFu) << 34) | ((unsigned long long) kind << 32) | (unsigned long long) value;
-}
-
-// Digit counts of up to four 8-bit passes in one read of the keys: counts[pass][256] (zeroed by the caller).
-template <typename K, int ITEMS>
-__global__ __launch_bounds__(kThreads) void radixGlobalHistogramKernel(const K* __restrict__ keys, int nHost,
-                                                                        const int* __restrict__ nDevice, int beginBit, int endBit,
-                                                                        unsigned* __restrict__ counts)
-{
-    constexpr int kTile = kThreads * ITEMS;
-    __shared__ unsigned hist[4][kDigits];
-    const int t = threadIdx.x;
-    const int n = nDevice ? min(*nDevice, nHost) : nHost;
-    const int base = blockIdx.x * kTile;
-    if (base >= n) return;
-    const int passes = (endBit - beginBit + 7) / 8;
-    for (int p = 0; p != 4; ++p) hist[p][t] = 0;
-    __syncthreads();
-    K key[ITEMS];
-#pragma unroll
-    for (int r = 0; r != ITEMS; ++r)
-    {
-        const int i = base + r * kThreads + t;
-        key[r] = (i < n) ? keys[i] : K(0);
-    }
-#pragma unroll
-    for (int r = 0; r != ITEMS; ++r)
-    {
-        if (base + r * kThreads + t < n)
-        {
-            for (int p = 0; p < passes; ++p)
-            {
-                const int shift = beginBit + 8 * p;
-                const int bits = min(8, endBit - shift);
-                atomicAdd(&hist[p][(int) ((key[r] >> shift) & ((1 << bits) - 1))], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    for (int p = 0; p < passes; ++p)
-    {
-        const unsigned c = hist[p][t];
-        if (c != 0) atomicAdd(&counts[p * kDigits + t], c);
-    }
-}
-
-template <typename K, int BITS, int ITEMS>
-__global__ __launch_bounds__(kThreads) void radixOnesweepKernel(const K* __restrict__ keysIn, const int32_t* __restrict__ valuesIn,
-                                                                 K* __restrict__ keysOut, int32_t* __restrict__ valuesOut, int nHost,
-                                                                 const int* __restrict__ nDevice, int shift,
-                                                                 const unsigned* __restrict__ digitCounts,
-                                                                 unsigned long long* __restrict__ status, unsigned* __restrict__ ticket,
-                                                                 unsigned ticketBase, unsigned epoch, unsigned* __restrict__ error)
-{
-    constexpr int kTile = kThreads * ITEMS;
-    constexpr int kDigitMask = (1 << BITS) - 1;
-    __shared__ int cnt[kWaves][kDigits];
-    __shared__ int localBase[kDigits];
-    __shared__ int globalBase[kDigits];
-    __shared__ int waveSums[2][kWaves];
-    __shared__ int sTile;
-    __shared__ K sKeys[kTile];
-    __shared__ int32_t sVals[kTile];
-
-    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
-    if (t == 0) sTile = (int) (atomicAdd(ticket, 1u) - ticketBase); // logical tile = arrival order
-    __syncthreads();
-    const int tile = sTile;
-    const int base = tile * kTile;
-    const int n = nDevice ? min(*nDevice, nHost) : nHost;
-    if (base >= n) return; // tickets past the data: nobody ever looks back at them
-    const int tileCount = min(kTile, n - base);
-
-    K key[ITEMS];
-    int32_t val[ITEMS];
-#pragma unroll
-    for (int r = 0; r != ITEMS; ++r)
-    {
-        const int i = base + wave * (kWave * ITEMS) + r * kWave + lane;
-        const bool valid = i < n;
-        key[r] = valid ? keysIn[i] : K(0);
-        val[r] = valid ? valuesIn[i] : 0;
-    }
-    const int digitTotal = (int) digitCounts[t];
-#pragma unroll
-    for (int w = 0; w != kWaves; ++w) cnt[w][t] = 0;
-    __syncthreads();
-
-    const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
-    unsigned long long match[ITEMS];
-#pragma unroll
-    for (int r = 0; r != ITEMS; ++r)
-    {
-        const bool valid = base + wave * (kWave * ITEMS) + r * kWave + lane < n;
-        match[r] = matchDigit<BITS>((int) ((key[r] >> shift) & kDigitMask), valid);
-    }
-    int rank[ITEMS];
-#pragma unroll
-    for (int r = 0; r != ITEMS; ++r)
-    {
-        const unsigned long long m = match[r];
-        const int digit = (int) ((key[r] >> shift) & kDigitMask);
-        const bool valid = m != 0ull;
-        const int leader = valid ? (__ffsll((long long) m) - 1) : lane;
-        int old = 0;
-        if (valid && lane == leader)
-        {
-            old = cnt[wave][digit];
-            cnt[wave][digit] = old + __popcll(m);
-        }
-        old = __shfl(old, leader);
-        rank[r] = old + __popcll(m & lower);
-        __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-
-    // ---- lane t owns digit t: tile count, publish, look back, publish inclusive -------------------------
-    {
-        int sum = 0;
-#pragma unroll
-        for (int w = 0; w != kWaves; ++w)
-        {
-            const int c = cnt[w][t];
-            cnt[w][t] = sum;
-            sum += c;
-        }
-        unsigned long long* mine = status + (size_t) tile * kDigits + t;
-        __hip_atomic_store(mine, packGranule(epoch, tile == 0 ? kKindInclusive : kKindAggregate, (unsigned) sum), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        unsigned exclusive = 0;
-        if (tile > 0)
-        {
-            for (int b = tile - 1; b >= 0; --b)
-            {
-                const unsigned long long* other = status + (size_t) b * kDigits + t;
-                unsigned long long g = 0;
-                int spins = 0;
-                for (;;)
-                {
-                    g = __hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((unsigned) (g >> 34) == (epoch & 0x3FFFFFFFu) && ((g >> 32) & 3ull) != 0ull) break;
-                    if (++spins > kSpinLimit)
-                    {
-                        atomicExch(error, 1u); // bounded: give up (wrong order, no hang); the host reports it
-                        g = packGranule(epoch, kKindInclusive, 0);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                exclusive += (unsigned) g;
-                if (((g >> 32) & 3ull) == kKindInclusive) break;
-            }
-            __hip_atomic_store(mine, packGranule(epoch, kKindInclusive, exclusive + (unsigned) sum), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        }
-
-        int inclLocal = sum, inclGlobal = digitTotal;
-#pragma unroll
-        for (int delta = 1; delta < kWave; delta <<= 1)
-        {
-            const int a = __shfl_up(inclLocal, delta);
-            const int b = __shfl_up(inclGlobal, delta);
-            if (lane >= delta)
-            {
-                inclLocal += a;
-                inclGlobal += b;
-            }
-        }
-        if (lane == kWave - 1)
-        {
-            waveSums[0][wave] = inclLocal;
-            waveSums[1][wave] = inclGlobal;
-        }
-        __syncthreads();
-        int beforeLocal = 0, beforeGlobal = 0;
-#pragma unroll
-        for (int w = 0; w != kWaves; ++w)
-        {
-            beforeLocal += (w < wave) ? waveSums[0][w] : 0;
-            beforeGlobal += (w < wave) ? waveSums[1][w] : 0;
-        }
-        localBase[t] = beforeLocal + inclLocal - sum;
-        globalBase[t] = beforeGlobal + inclGlobal - digitTotal + (int) exclusive;
-    }
-    __syncthreads();
-
-#pragma unroll
-    for (int r = 0; r != ITEMS; ++r)
-    {
-        if (match[r] != 0ull)
-        {
-            const int digit = (int) ((key[r] >> shift) & kDigitMask);
-            const int slot = localBase[digit] + cnt[wave][digit] + rank[r];
-            sKeys[slot] = key[r];
-            sVals[slot] = val[r];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r != ITEMS; ++r)
-    {
-        const int j = r * kThreads + t;
-        if (j < tileCount)
-        {
-            const K k = sKeys[j];
-            const int digit = (int) ((k >> shift) & kDigitMask);
-            const int pos = globalBase[digit] + (j - localBase[digit]);
-            keysOut[pos] = k;
-            valuesOut[pos] = sVals[j];
-        }
-    }
-}
-
-template <typename K, int ITEMS>
-int sortOnesweepItems(hipStream_t stream, K* keys0, K* keys1, int32_t* values0, int32_t* values1, int n, int beginBit, int endBit,
-                      RadixScratch& s)
-{
-    constexpr int kTile = kThreads * ITEMS;
-    const int numTiles = (n + kTile - 1) / kTile;
-    GS_CHECK(hipMemsetAsync(s.digitCounts, 0, sizeof(unsigned) * 4 * kDigits, stream));
-    constexpr int kHistItems = 16;
-    const int histBlocks = (n + kThreads * kHistItems - 1) / (kThreads * kHistItems);
-    hipLaunchKernelGGL((radixGlobalHistogramKernel<K, kHistItems>), dim3(histBlocks), dim3(kThreads), 0, stream, keys0, n, s.countDevice,
-                       beginBit, endBit, s.digitCounts);
-    int sel = 0, pass = 0;
-    for (int shift = beginBit; shift < endBit; shift += 8, ++pass)
-    {
-        const int bits = std::min(8, endBit - shift);
-        K* kin = sel ? keys1 : keys0;
-        K* kout = sel ? keys0 : keys1;
-        int32_t* vin = sel ? values1 : values0;
-        int32_t* vout = sel ? values0 : values1;
-        s.epoch += 1;
-        const unsigned* counts = s.digitCounts + pass * kDigits;
-#define GS_ONESWEEP(B)                                                                                                             \
-    hipLaunchKernelGGL((radixOnesweepKernel<K, B, ITEMS>), dim3(numTiles), dim3(kThreads), 0, stream, kin, vin, kout, vout, n,     \
-                       s.countDevice, shift, counts, s.status, s.ticket, s.ticketBase, s.epoch, s.error)
-        switch (bits)
-        {
-        case 1: GS_ONESWEEP(1); break;
-        case 2: GS_ONESWEEP(2); break;
-        case 3: GS_ONESWEEP(3); break;
-        case 4: GS_ONESWEEP(4); break;
-        case 5: GS_ONESWEEP(5); break;
-        case 6: GS_ONESWEEP(6); break;
-        case 7: GS_ONESWEEP(7); break;
-        default: GS_ONESWEEP(8); break;
-        }
-#undef GS_ONESWEEP
-        s.ticketBase += (unsigned) numTiles; // every launched workgroup draws exactly one ticket
-        sel ^= 1;
-    }
-    return sel;
-}
-
-template <typename K>
-int sortOnesweepT(hipStream_t stream, K* keys0, K* keys1, int32_t* values0, int32_t* values1, int n, int beginBit, int endBit,
-                  RadixScratch& s)
-{
-    if (n <= kSmallLimit) return sortOnesweepItems<K, kItemsSmall>(stream, keys0, keys1, values0, values1, n, beginBit, endBit, s);
-    return sortOnesweepItems<K, kItemsLarge>(stream, keys0, keys1, values0, values1, n, beginBit, endBit, s);
-}
-
 int itemsPerLane(int n) { return n <= kSmallLimit ? kItemsSmall : kItemsLarge; }
 
 template <typename K, int BITS, int ITEMS>
@@ -740,24 +459,6 @@ void ensureRadixScratch(RadixScratch& s, int n)
         s.capacityEntries = entries;
     }
     if (s.chunkTotals == nullptr) GS_CHECK(hipMalloc((void**) &s.chunkTotals, sizeof(int32_t) * 2 * kDigits));
-    if (s.digitCounts == nullptr)
-    {
-        GS_CHECK(hipMalloc((void**) &s.digitCounts, sizeof(unsigned) * 4 * kDigits));
-        GS_CHECK(hipMalloc((void**) &s.ticket, sizeof(unsigned)));
-        GS_CHECK(hipMalloc((void**) &s.error, sizeof(unsigned)));
-        GS_CHECK(hipMemset(s.ticket, 0, sizeof(unsigned)));
-        GS_CHECK(hipMemset(s.error, 0, sizeof(unsigned)));
-        s.ticketBase = 0;
-        s.epoch = 0;
-    }
-    if (numTiles > s.capacityStatusTiles)
-    {
-        if (s.status) GS_CHECK(hipFree(s.status));
-        const size_t bytes = sizeof(unsigned long long) * (size_t) std::max(numTiles, 1) * kDigits;
-        GS_CHECK(hipMalloc((void**) &s.status, bytes));
-        GS_CHECK(hipMemset(s.status, 0, bytes)); // epoch 0 is never used, so a zeroed granule is "not ready"
-        s.capacityStatusTiles = numTiles;
-    }
 }
 
 void freeRadixScratch(RadixScratch& s)
@@ -765,10 +466,6 @@ void freeRadixScratch(RadixScratch& s)
     if (s.table) (void) hipFree(s.table);
     if (s.scanned) (void) hipFree(s.scanned);
     if (s.chunkTotals) (void) hipFree(s.chunkTotals);
-    if (s.digitCounts) (void) hipFree(s.digitCounts);
-    if (s.status) (void) hipFree(s.status);
-    if (s.ticket) (void) hipFree(s.ticket);
-    if (s.error) (void) hipFree(s.error);
     s = RadixScratch{};
 }
 
@@ -777,12 +474,6 @@ int launchRadixSortPairs(hipStream_t stream, RadixScratch& s, int keyBytes, void
 {
     if (n <= 0 || endBit <= beginBit) return 0;
     ensureRadixScratch(s, n);
-    if (s.onesweep && endBit - beginBit <= 32)
-    {
-        if (keyBytes == 2)
-            return sortOnesweepT<uint16_t>(stream, (uint16_t*) keys0, (uint16_t*) keys1, values0, values1, n, beginBit, endBit, s);
-        return sortOnesweepT<uint32_t>(stream, (uint32_t*) keys0, (uint32_t*) keys1, values0, values1, n, beginBit, endBit, s);
-    }
     if (keyBytes == 2) return sortT<uint16_t>(stream, (uint16_t*) keys0, (uint16_t*) keys1, values0, values1, n, beginBit, endBit, s);
     return sortT<uint32_t>(stream, (uint32_t*) keys0, (uint32_t*) keys1, values0, values1, n, beginBit, endBit, s);
 }

@@ -29,10 +29,7 @@ namespace
 {
 
 constexpr int kBatch = 64; // entries staged per LDS fill; two vote chunks
-// blockIdx -> tile mapping (A/B builds: -DGS_RASTER_BLOCKS_2D=0 for round 1's runs of 8 tiles in a row, other block shapes)
-#ifndef GS_RASTER_BLOCKS_2D
-#define GS_RASTER_BLOCKS_2D 1
-#endif
+// blockIdx -> tile mapping: block shape dealt to one XCD (A/B builds may override)
 #ifndef GS_RASTER_BLOCK_W
 #define GS_RASTER_BLOCK_W 8
 #define GS_RASTER_BLOCK_H 4
@@ -92,7 +89,6 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
     __shared__ __attribute__((aligned(16))) float sAlpha[kBatch];
 
     // XCD-aware remap: workgroups b, b+8, b+16, ... share an XCD (round-robin dispatch).
-#if GS_RASTER_BLOCKS_2D
     // The band is cut into blocks of 8 x 4 tiles (BH at most the band's height); block j belongs to XCD j % 8 and an XCD walks its
     // blocks one after another, so a splat that overlaps neighbouring tiles in BOTH directions is gathered through ONE of the
     // eight L2s (they are not coherent with each other: what two XCDs both need is fetched from HBM twice).  Measured at C3
@@ -113,17 +109,6 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
         if (tx >= scr.tilesX || ty >= rows) return;
         tile = firstTile + ty * scr.tilesX + tx;
     }
-#else
-    // Round 1's mapping: inside every group of 64 consecutive tiles each XCD takes a run of 8 neighbouring tiles of one row, the
-    // groups themselves interleave over the XCDs.
-    int wg = blockIdx.x;
-    {
-        const int group = wg & ~63, inGroup = wg & 63;
-        const int remapped = group + (inGroup & 7) * 8 + (inGroup >> 3);
-        if (group + 64 <= numTiles) wg = remapped; // the ragged last group keeps the identity map
-    }
-    const int tile = firstTile + wg;
-#endif
     const unsigned long long traceStart = trace ? wall_clock64() : 0ull; // diagnostics only (gs_debug_set_raster_trace)
 
     // Several views per chain (gs_renderer_set_views): grid row v renders view v -- its ranges are the virtual tiles
@@ -350,13 +335,9 @@ void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileR
     const int firstTile = scr.rowBegin * scr.tilesX;
     const int numTiles = (scr.rowEnd - scr.rowBegin) * scr.tilesX;
     if (numTiles <= 0) return;
-    int gridTiles = numTiles;
-    if (GS_RASTER_BLOCKS_2D)
-    {
-        const int rows = scr.rowEnd - scr.rowBegin, bh = rows < GS_RASTER_BLOCK_H ? rows : GS_RASTER_BLOCK_H;
-        const int blocks = ((scr.tilesX + GS_RASTER_BLOCK_W - 1) / GS_RASTER_BLOCK_W) * ((rows + bh - 1) / bh);
-        gridTiles = ((blocks + 7) / 8) * 8 * GS_RASTER_BLOCK_W * bh; // every XCD walks the same number of blocks
-    }
+    const int rows = scr.rowEnd - scr.rowBegin, bh = rows < GS_RASTER_BLOCK_H ? rows : GS_RASTER_BLOCK_H;
+    const int blocks = ((scr.tilesX + GS_RASTER_BLOCK_W - 1) / GS_RASTER_BLOCK_W) * ((rows + bh - 1) / bh);
+    const int gridTiles = ((blocks + 7) / 8) * 8 * GS_RASTER_BLOCK_W * bh; // every XCD walks the same number of blocks
     RasterColourSource lazy{};
     if (lazyColours != nullptr) lazy = *lazyColours;
 #define GS_LAUNCH_RASTER(PPL, EPAN, SH)                                                                                                  \

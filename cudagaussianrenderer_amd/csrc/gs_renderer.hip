@@ -1,0 +1,710 @@
+// gs_renderer.hip -- the C ABI of include/gsplat_hip.h, part 2: the one-call renderer (Demo.cpp:314-331 buffers, :352-479 frame).
+//
+// Two pipelines produce the same frame:
+//   GS_PIPELINE_REFERENCE  the reference's stage order through the eight staged calls above: pairs keyed by
+//                          (tile << 32 | depth), one 64-bit radix sort over all pairs (44-47 key bits);
+//   GS_PIPELINE_TWO_LEVEL  (default) sort the SPLATS by the 32-bit depth key first (N elements), emit the
+//                          pairs in that order keyed by the tile index only, then one stable sort on the
+//                          13-15 tile bits.  The resulting value list is identical (same total order, ties by
+//                          splat index) while the radix-sort traffic drops from ~152 B to ~30 B per pair;
+// The latter leaves the SH pass out when the raster kernel can evaluate colours on demand (useLazyColours below),
+// keeps centre + ellipse in one 32-byte record per splat, and resets the range table from inside the clip kernel.
+#include <algorithm>
+#include <cstring>
+
+#include "gs_state.h"
+
+using namespace gs;
+
+namespace gs
+{
+// Colours on demand: the two-level frames skip the SH pass and let the raster kernel evaluate the colour of every
+// list entry it stages ("Colours on demand").  Needs the [splat][shCount] coefficient copy and a degree whose
+// rows are 16-byte multiples; GS_NO_LAZY_SH=1 keeps the reference's stage order.
+bool useLazyColours(const GsRenderer* r)
+{
+    static const bool disabled = getenv("GS_NO_LAZY_SH") != nullptr;
+    return !disabled && r->shDegree != 0 && r->shPerSplat != nullptr && r->pipeline != GS_PIPELINE_REFERENCE &&
+           rasterCanEvaluateColours(r->shDegree, r->shCount);
+}
+RasterColourSource colourSource(const GsRenderer* r, const float* cameraPosition, const FrameParams* paramsDevice)
+{
+    RasterColourSource src;
+    src.degree = r->shDegree;
+    src.shCount = r->shCount;
+    src.position = (const float4*) r->position;
+    src.shPerSplat = r->shPerSplat;
+    if (cameraPosition) src.cameraPosition = make_float3(cameraPosition[0], cameraPosition[1], cameraPosition[2]);
+    src.params = paramsDevice;
+    return src;
+}
+
+namespace
+{
+void freeTileList(GsRenderer* r)
+{
+    for (int i = 0; i != 2; ++i)
+    {
+        gs_device_free(r->keys[i]);
+        gs_device_free(r->values[i]);
+        r->keys[i] = nullptr;
+        r->values[i] = nullptr;
+    }
+}
+void allocTileList(GsRenderer* r, int32_t capacity)
+{
+    freeTileList(r);
+    for (int i = 0; i != 2; ++i)
+    {
+        r->keys[i] = (uint64_t*) gs_device_alloc(sizeof(uint64_t) * (size_t) capacity);
+        r->values[i] = (int32_t*) gs_device_alloc(sizeof(int32_t) * (size_t) capacity);
+    }
+    r->tileListCapacity = capacity;
+}
+void freeScene(GsRenderer* r)
+{
+    if (r->sceneShared)
+    {
+        // the read-only inputs are the owner's
+        r->position = r->scaleAndRotation = r->sh = r->shPerSplat = nullptr;
+        r->sceneShared = false;
+    }
+    float** bufs[] = {&r->position, &r->scaleAndRotation, &r->color,   &r->sh,         &r->clipXY,
+                      &r->clipZ,    &r->conic,            &r->ellipse, &r->tileRecord, &r->rasterRecord};
+    for (float** b : bufs)
+    {
+        gs_device_free(*b);
+        *b = nullptr;
+    }
+    for (int i = 0; i != 2; ++i)
+    {
+        gs_device_free(r->depthKey[i]);
+        gs_device_free(r->order[i]);
+        r->depthKey[i] = nullptr;
+        r->order[i] = nullptr;
+    }
+    gs_device_free(r->shPerSplat);
+    gs_device_free(r->bandMask);
+    gs_device_free(r->bandCounts);
+    gs_device_free(r->bandSlotPrefix);
+    gs_device_free(r->bandOffsets);
+    gs_device_free(r->bandTotal);
+    r->shPerSplat = nullptr;
+    r->bandMask = nullptr;
+    r->bandCounts = r->bandOffsets = r->bandSlotPrefix = nullptr;
+    r->bandTotal = nullptr;
+}
+void ensureSortTemp(GsRenderer* r, size_t required)
+{
+    if (required > r->sortTempBytes)
+    {
+        gs_device_free(r->sortTemp);
+        r->sortTemp = gs_device_alloc(required);
+        r->sortTempBytes = required;
+    }
+}
+} // namespace
+bool growTileListIfNeeded(GsRenderer* r, int64_t demand)
+{
+    if (demand <= r->tileListCapacity) return false;
+    int64_t cap = r->tileListCapacity > 0 ? r->tileListCapacity : 1;
+    while (cap < demand) cap <<= 1; // Demo.cpp:360
+    cap = std::min<int64_t>(cap, 0x7FFFFFFF);
+    allocTileList(r, (int32_t) cap);
+    return true;
+}
+} // namespace gs
+
+extern "C" GsRenderer* gs_renderer_create(int width, int height)
+{
+    GsRenderer* r = new GsRenderer{};
+    const Screen scr = makeScreen(width, height, 0, 0);
+    r->width = scr.width;
+    r->height = scr.height;
+    r->tileRange = (int32_t*) gs_device_alloc(sizeof(int32_t) * 2 * (size_t) scr.totalTiles);
+    GS_CHECK(hipMemset(r->tileRange, 0xFF, sizeof(int32_t) * 2 * (size_t) scr.totalTiles));
+    r->backBufferOwned = (uint8_t*) gs_device_alloc((size_t) scr.width * scr.height * 4);
+    r->backBuffer = r->backBufferOwned;
+    GS_CHECK(hipMemset(r->backBufferOwned, 0, (size_t) scr.width * scr.height * 4)); // rows outside a band stay zero
+    r->timer = gs_timer_create();
+    GS_CHECK(hipEventCreate(&r->frameStart));
+    GS_CHECK(hipEventCreate(&r->frameStop));
+    GS_CHECK(hipEventCreateWithFlags(&r->countReady, hipEventDisableTiming));
+    return r;
+}
+
+extern "C" void gs_renderer_destroy(GsRenderer* r)
+{
+    if (!r) return;
+    {
+        StreamScope scope(r);
+        GS_CHECK(hipStreamSynchronize(g.stream));
+    }
+    freeScene(r);
+    freeTileList(r);
+    gs_device_free(r->tileRange);
+    gs_device_free(r->backBufferOwned);
+    gs_device_free(r->sortTemp);
+    freeTileListScratch(r->scratch);
+    freeRadixScratch(r->radix);
+    for (int k = 0; k != 2; ++k)
+    {
+        if (r->graphExec[k]) (void) hipGraphExecDestroy(r->graphExec[k]);
+        if (r->graph[k]) (void) hipGraphDestroy(r->graph[k]);
+    }
+    if (r->ownsStream) (void) hipStreamDestroy(r->stream);
+    if (r->paramsDevice) (void) hipFree(r->paramsDevice);
+    if (r->paramsHost) (void) hipHostFree(r->paramsHost);
+    if (r->consumed) (void) hipFree(r->consumed);
+    gs_timer_destroy(r->timer);
+    for (GsTimer* t : r->asyncTimers) gs_timer_destroy(t);
+    (void) hipEventDestroy(r->frameStart);
+    (void) hipEventDestroy(r->frameStop);
+    (void) hipEventDestroy(r->countReady);
+    delete r;
+}
+
+extern "C" void gs_renderer_set_tile_rows(GsRenderer* r, int begin, int end)
+{
+    if (begin != r->rowBegin || end != r->rowEnd)
+    {
+        // ranges of tiles that leave the band must not linger
+        StreamScope scope(r);
+        GS_CHECK(hipStreamSynchronize(g.stream));
+        const Screen scr = makeScreen(r->width, r->height, 0, 0);
+        GS_CHECK(hipMemset(r->tileRange, 0xFF, sizeof(int32_t) * 2 * (size_t) scr.totalTiles));
+    }
+    r->rowBegin = begin;
+    r->rowEnd = end;
+}
+
+extern "C" void gs_renderer_set_pipeline(GsRenderer* r, int pipeline)
+{
+    r->pipeline = pipeline == GS_PIPELINE_REFERENCE ? pipeline : GS_PIPELINE_TWO_LEVEL;
+    r->graphValid = false;
+}
+
+extern "C" int gs_renderer_colours_on_demand(const GsRenderer* r) { return useLazyColours(r) ? 1 : 0; }
+
+extern "C" void gs_renderer_set_band_cull(GsRenderer* r, int mode)
+{
+    r->bandCull = (mode == GS_BAND_CULL_ON || mode == GS_BAND_CULL_OFF) ? mode : GS_BAND_CULL_AUTO;
+}
+
+namespace
+{
+// Everything a renderer owns per scene besides the read-only inputs: per-splat intermediates and the list buffers.
+void allocateSceneIntermediates(GsRenderer* r, int32_t n)
+{
+    const size_t f4 = sizeof(float) * 4 * (size_t) n;
+    r->color = (float*) gs_device_alloc(f4);
+    r->conic = (float*) gs_device_alloc(f4);
+    r->ellipse = (float*) gs_device_alloc(f4);
+    r->clipXY = (float*) gs_device_alloc(sizeof(float) * 2 * (size_t) n);
+    // per-view results (clip data of the "virtual splats" view * n + i, their depth keys and order, the band-cull masks): x views
+    const size_t nv = (size_t) n * (size_t) r->views;
+    r->clipZ = (float*) gs_device_alloc(sizeof(float) * nv);
+    r->tileRecord = (float*) gs_device_alloc(sizeof(float) * 8 * nv);
+    r->rasterRecord = (float*) gs_device_alloc(sizeof(float) * 8 * nv);
+    r->scratch.tileRecord = (const float4*) r->tileRecord;
+    for (int i = 0; i != 2; ++i)
+    {
+        r->depthKey[i] = (uint32_t*) gs_device_alloc(sizeof(uint32_t) * nv);
+        r->order[i] = (int32_t*) gs_device_alloc(sizeof(int32_t) * nv);
+    }
+    const size_t waves = (((size_t) n + kWave - 1) / kWave) * (size_t) r->views;
+    r->bandMask = (unsigned long long*) gs_device_alloc(sizeof(unsigned long long) * waves);
+    r->bandCounts = (int32_t*) gs_device_alloc(sizeof(int32_t) * waves);
+    r->bandSlotPrefix = (int32_t*) gs_device_alloc(sizeof(int32_t) * waves);
+    r->bandOffsets = (int32_t*) gs_device_alloc(sizeof(int32_t) * waves);
+    r->bandTotal = (int64_t*) gs_device_alloc(sizeof(int64_t));
+    // Demo.cpp:325: 8 pairs per splat to start with; grown on demand.
+#ifndef GS_INITIAL_LIST_FACTOR
+#define GS_INITIAL_LIST_FACTOR 8
+#endif
+    const int64_t initial = std::min<int64_t>((int64_t) std::max(n, 1) * GS_INITIAL_LIST_FACTOR * r->views, 0x7FFFFFFF);
+    if (r->tileListCapacity < initial) allocTileList(r, (int32_t) initial);
+}
+} // namespace
+
+extern "C" int gs_renderer_set_scene(GsRenderer* r, int32_t n, const float* position4, const float* scaleAndRotation4,
+                                     const float* color4, const float* sh, int shDegree, int shCount)
+{
+    if (n < 0 || (shDegree != 0 && sh == nullptr)) return -1;
+    StreamScope scope(r);
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    freeScene(r);
+    r->graphValid = false;
+    r->splatCount = n;
+    r->shDegree = shDegree;
+    r->shCount = shCount;
+    const size_t f4 = sizeof(float) * 4 * (size_t) n;
+    r->position = (float*) gs_device_alloc(f4);
+    r->scaleAndRotation = (float*) gs_device_alloc(f4);
+    allocateSceneIntermediates(r, n);
+    gs_device_upload(r->position, position4, f4);
+    gs_device_upload(r->scaleAndRotation, scaleAndRotation4, f4);
+    gs_device_upload(r->color, color4, f4);
+    if (shDegree != 0)
+    {
+        // Demo.cpp:291-296
+        const size_t total = gs_realigned_sh_size(GS_SH_GROUP_SIZE, shCount, n);
+        std::vector<float> aligned(total);
+        gs_realign_spherical_harmonics(sh, aligned.data(), GS_SH_GROUP_SIZE, shCount, n);
+        r->sh = (float*) gs_device_alloc(total * sizeof(float));
+        gs_device_upload(r->sh, aligned.data(), total * sizeof(float));
+        // second copy in the file's [splat][shCount] layout for the band-culled (gathered) SH evaluation
+        r->shPerSplat = (float*) gs_device_alloc(sizeof(float) * (size_t) n * shCount);
+        gs_device_upload(r->shPerSplat, sh, sizeof(float) * (size_t) n * shCount);
+    }
+    return 0;
+}
+
+// Several renderers of one scene (frames in flight): the read-only inputs -- position, scale/rotation, both coefficient layouts --
+// exist once, in the owner; the sharer allocates only its own intermediates and lists (0.3 instead of 0.75 GB at C3) and copies the
+// static colours device to device.  The owner must outlive its sharers and keep its scene.
+extern "C" int gs_renderer_share_scene(GsRenderer* r, const GsRenderer* owner)
+{
+    if (r == nullptr || owner == nullptr || r == owner || owner->sceneShared) return -1;
+    StreamScope scope(r);
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    freeScene(r);
+    r->graphValid = false;
+    const int32_t n = owner->splatCount;
+    r->splatCount = n;
+    r->shDegree = owner->shDegree;
+    r->shCount = owner->shCount;
+    r->position = owner->position;
+    r->scaleAndRotation = owner->scaleAndRotation;
+    r->sh = owner->sh;
+    r->shPerSplat = owner->shPerSplat;
+    r->sceneShared = true;
+    allocateSceneIntermediates(r, n);
+    if (n > 0) GS_CHECK(hipMemcpy(r->color, owner->color, sizeof(float) * 4 * (size_t) n, hipMemcpyDeviceToDevice));
+    return 0;
+}
+
+extern "C" uint8_t* gs_renderer_back_buffer(GsRenderer* r) { return r->backBuffer; }
+extern "C" uint8_t* gs_renderer_back_buffer_view(GsRenderer* r, int view)
+{
+    if (view < 0 || view >= r->views) return nullptr;
+    return r->backBuffer + (size_t) view * r->width * r->height * 4;
+}
+extern "C" int gs_renderer_views(const GsRenderer* r) { return r->views; }
+
+// Several cameras per chain of kernels (header: gs_renderer_set_views).  Before the scene is set: the per-view intermediates are
+// sized there.
+extern "C" int gs_renderer_set_views(GsRenderer* r, int views)
+{
+    if (views < 1 || views > kMaxViews || r->position != nullptr) return -1;
+    if (views == r->views) return 0;
+    StreamScope scope(r);
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    const Screen scr = makeScreen(r->width, r->height, 0, 0);
+    const bool external = r->backBuffer != r->backBufferOwned;
+    gs_device_free(r->tileRange);
+    gs_device_free(r->backBufferOwned);
+    r->views = views;
+    r->tileRange = (int32_t*) gs_device_alloc(sizeof(int32_t) * 2 * (size_t) scr.totalTiles * views);
+    GS_CHECK(hipMemset(r->tileRange, 0xFF, sizeof(int32_t) * 2 * (size_t) scr.totalTiles * views));
+    r->backBufferOwned = (uint8_t*) gs_device_alloc((size_t) scr.width * scr.height * 4 * views);
+    GS_CHECK(hipMemset(r->backBufferOwned, 0, (size_t) scr.width * scr.height * 4 * views)); // rows outside a band stay zero
+    if (!external) r->backBuffer = r->backBufferOwned;
+    r->graphValid = false;
+    return 0;
+}
+extern "C" void gs_renderer_set_back_buffer(GsRenderer* r, uint8_t* p) { r->backBuffer = p ? p : r->backBufferOwned; }
+
+extern "C" void gs_renderer_read_back_buffer(GsRenderer* r, uint8_t* hostRgba)
+{
+    StreamScope scope(r);
+    gs_device_download(hostRgba, r->backBuffer, (size_t) r->width * r->height * 4);
+}
+extern "C" int gs_renderer_read_back_buffer_view(GsRenderer* r, int view, uint8_t* hostRgba)
+{
+    if (view < 0 || view >= r->views) return -1;
+    StreamScope scope(r);
+    gs_device_download(hostRgba, r->backBuffer + (size_t) view * r->width * r->height * 4, (size_t) r->width * r->height * 4);
+    return 0;
+}
+
+extern "C" void gs_renderer_buffers(GsRenderer* r, GsRendererBuffers* out)
+{
+    out->position = r->position;
+    out->scaleAndRotation = r->scaleAndRotation;
+    out->color = r->color;
+    out->sphericalHarmonics = r->sh;
+    out->positionClipSpaceXY = r->clipXY;
+    out->positionClipSpaceZ = r->clipZ;
+    out->conic = r->conic;
+    out->screenEllipse = r->ellipse;
+    if (r->tileRecord != nullptr && r->pipeline != GS_PIPELINE_REFERENCE && r->splatCount > 0)
+    {
+        // the two-level frames keep ellipses, centres and conics only inside the packed records: unpack them for the caller
+        StreamScope scope(r);
+        launchUnpackEllipse(g.stream, r->splatCount, (const float4*) r->tileRecord, (float4*) r->ellipse);
+        launchUnpackRasterRecord(g.stream, r->splatCount, (const float4*) r->rasterRecord, (float2*) r->clipXY, r->clipZ, (float4*) r->conic);
+        GS_CHECK(hipStreamSynchronize(g.stream));
+    }
+    if (r->colourStale && r->shDegree != 0 && r->splatCount > 0)
+    {
+        // the last frame evaluated colours inside the raster kernel: run the SH pass once for the caller
+        StreamScope scope(r);
+        launchSphericalHarmonics(g.stream, r->splatCount, r->shDegree, r->shCount, (const float4*) r->position, r->sh,
+                                 make_float3(r->lastCameraPosition[0], r->lastCameraPosition[1], r->lastCameraPosition[2]), (float4*) r->color);
+        GS_CHECK(hipStreamSynchronize(g.stream));
+        r->colourStale = false;
+    }
+    out->tileRange = r->tileRange;
+    out->keys = r->keys[r->selector];
+    out->values = r->values[r->selector];
+    if (r->useGraph && r->graphValid && r->scratch.totalHost != nullptr)
+    {
+        // captured frames keep the pair count on the device; fetch the last frame's for the caller
+        StreamScope scope(r);
+        GS_CHECK(hipStreamSynchronize(g.stream));
+        r->tileListSize = (int32_t) std::min<int64_t>(*r->scratch.totalHost, r->tileListCapacity);
+        out->keys = r->keys[r->selector];
+        out->values = r->values[r->selector];
+    }
+    out->splatCount = r->splatCount;
+    out->tileListSize = r->tileListSize;
+    out->keyBytes = r->keyBytes;
+}
+
+extern "C" void gs_renderer_set_stream(GsRenderer* r, void* stream)
+{
+    r->stream = (hipStream_t) stream;
+    r->hasStream = true;
+}
+
+// First half of a frame: clears, SH, clip data, (band cull,) depth sort of the splats, pair count + scan, and the
+// emit pass launched with the current list capacity. Returns without waiting for anything.
+extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int timed)
+{
+    if (r->pending) return -3;
+    StreamScope scope(r);
+    FrameState& f = r->frame;
+    f = FrameState{};
+    f.scr = makeScreen(r->width, r->height, r->rowBegin, r->rowEnd);
+    const Screen& scr = f.scr;
+    // timed: 0 = no stage timers; 1 = the reference's blocking timer after every stage; 2 = one non-blocking
+    // event pair per stage, accumulated and read later with gs_renderer_collect_stage_times.
+    GsTimer** stageTimers = f.stageTimers;
+    if (timed == 1)
+        for (int i = 0; i != kStageTimers; ++i) stageTimers[i] = r->timer;
+    else if (timed == 2)
+    {
+        while (r->asyncTimers.size() < r->asyncUsed + kStageTimers)
+        {
+            GsTimer* t = gs_timer_create();
+            gs_timer_set_blocking(t, 0);
+            r->asyncTimers.push_back(t);
+        }
+        for (int i = 0; i != kStageTimers; ++i) stageTimers[i] = r->asyncTimers[r->asyncUsed + i];
+        // stages that do not run this frame must still hold a valid (zero-length) interval
+        for (int i = 0; i != kStageTimers; ++i)
+        {
+            gs_timer_start(stageTimers[i]);
+            gs_timer_stop(stageTimers[i]);
+        }
+        r->asyncUsed += kStageTimers;
+        r->asyncFrames += 1;
+    }
+    f.blocking = timed == 1;
+    const bool blocking = f.blocking;
+    GsFrameStats& st = f.st;
+    const int n = r->splatCount;
+    const bool twoLevel = r->pipeline != GS_PIPELINE_REFERENCE;
+
+    GS_CHECK(hipEventRecord(r->frameStart, g.stream));
+
+    // Clears (Demo.cpp:399,403). Only this GPU's band of the back buffer; the whole range table.
+    const size_t rowBytes = (size_t) r->width * 4;
+    const int pixelRowBegin = scr.rowBegin * kTileSize;
+    const int pixelRowEnd = std::min(scr.rowEnd * kTileSize, r->height);
+    // (two-level pipeline: the raster kernel zeroes the tiles that have no work itself, no 8 MB memset)
+    if (pixelRowEnd > pixelRowBegin && !twoLevel)
+        gs_device_memset(r->backBuffer + rowBytes * pixelRowBegin, 0, rowBytes * (size_t) (pixelRowEnd - pixelRowBegin));
+    // (two-level pipeline: the clip kernel resets the range table on the side)
+    if (!twoLevel || n <= 0) gs_device_memset(r->tileRange, 0xFF, sizeof(int32_t) * 2 * (size_t) scr.totalTiles);
+
+    // Demo.cpp:406-430
+    GsGlobalArgs args{};
+    args.cameraData = *camera;
+    args.position = r->position;
+    args.scaleAndRotation = r->scaleAndRotation;
+    args.color = r->color;
+    args.sphericalHarmonicsDegree = r->shDegree;
+    args.sphericalHarmonicsCount = r->shCount;
+    args.sphericalHarmonics = r->sh;
+    args.positionClipSpaceXY = r->clipXY;
+    args.positionClipSpaceZ = r->clipZ;
+    args.conic = r->conic;
+    args.screenEllipse = r->ellipse;
+    args.splatCount = n;
+    args.backBuffer = r->backBuffer;
+    args.tileRange = r->tileRange;
+    args.width = r->width;
+    args.height = r->height;
+    args.tileRowBegin = scr.rowBegin;
+    args.tileRowEnd = scr.rowEnd;
+    gs_set_global_args(&args);
+
+    // Band cull: with a strict sub-band of tile rows (one rank of a multi-GPU split) only the splats whose tile AABB
+    // reaches the band go through SH evaluation, the depth sort and the tile-list passes.
+    const bool strictBand = scr.rowBegin > 0 || scr.rowEnd < scr.tilesY;
+    const bool cull = twoLevel && n > 0 && cfg.sortBackend == GS_SORT_BACKEND_NATIVE &&
+                      (r->bandCull == GS_BAND_CULL_ON || (r->bandCull == GS_BAND_CULL_AUTO && strictBand));
+
+    f.lazyColours = useLazyColours(r);
+    for (int k = 0; k != 3; ++k) f.cameraPosition[k] = r->lastCameraPosition[k] = camera->position[k];
+    if (r->shDegree != 0 && !cull && !f.lazyColours) // Demo.cpp:432
+    {
+        gs_evaluate_spherical_harmonics(stageTimers[0], n);
+        if (blocking) st.msSphericalHarmonics = gs_timer_elapsed_ms(stageTimers[0]);
+    }
+
+    if (!twoLevel)
+    {
+        // ---- the reference's stage order, through the staged calls (whole frame here; finish() only reports) ----
+        gs_evaluate_splat_clip_data(stageTimers[1], n);
+        if (blocking) st.msClipData = gs_timer_elapsed_ms(stageTimers[1]);
+
+        // Count first and grow if needed, instead of rendering a truncated frame and doubling for the next
+        // one (Demo.cpp:357-366,447).
+        gs_timer_start(stageTimers[2]);
+        launchTileListCount(g.stream, n, scr, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch);
+        GS_CHECK(hipStreamSynchronize(g.stream)); // pair count readback, as GaussianRender.cu:793
+        const int64_t demand = *r->scratch.totalHost;
+        g.lastDemand = demand;
+        if (demand > 0x7FFFFFFF) return -2;
+        if (growTileListIfNeeded(r, demand)) st.grewTileList = 1;
+        const int32_t size = (int32_t) demand;
+        launchTileListEmit(g.stream, n, scr, (const float2*) r->clipXY, r->clipZ, (const float4*) r->ellipse, r->scratch, r->keys[0],
+                           r->values[0], r->tileListCapacity);
+        gs_timer_stop(stageTimers[2]);
+        if (blocking) st.msBuildTileList = gs_timer_elapsed_ms(stageTimers[2]);
+
+        GsDoubleBufferU64 keys{{r->keys[0], r->keys[1]}, 0};
+        GsDoubleBufferI32 values{{r->values[0], r->values[1]}, 0};
+        gs_sort_tile_list(stageTimers[3], size, &r->sortTemp, &r->sortTempBytes, &keys, &values); // Demo.cpp:458
+        if (blocking) st.msSortTileList = gs_timer_elapsed_ms(stageTimers[3]);
+        r->selector = keys.selector;
+        r->keyBytes = 8;
+
+        GsTileListArgs tl{keys.buffers[keys.selector], values.buffers[values.selector], size, r->tileListCapacity};
+        gs_set_tile_list_args(&tl); // Demo.cpp:463-466
+        if (size != 0)              // Demo.cpp:469
+        {
+            gs_evaluate_tile_range(stageTimers[4], size);
+            if (blocking) st.msTileRanges = gs_timer_elapsed_ms(stageTimers[4]);
+        }
+        f.size = size;
+        f.listDone = true;
+    }
+    else
+    {
+        // ---- two-level sort ------------------------------------------------------------------------
+        f.tileKeyBytes = scr.totalTiles > 65536 ? 4 : 2;
+
+        gs_timer_start(stageTimers[1]);
+        const int* countDevice = nullptr;
+        if (!cull)
+        {
+            launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation,
+                                nullptr, nullptr, nullptr, nullptr, r->depthKey[0],
+                                (uint32_t*) r->order[0], nullptr, nullptr, nullptr, nullptr, r->tileRange, 2 * scr.totalTiles,
+                                (float4*) r->tileRecord, (float4*) r->rasterRecord);
+        }
+        else
+        {
+            // clip data for every splat + keep-mask, then an order-preserving compaction of (depth key, index)
+            launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation,
+                                nullptr, r->clipZ, nullptr, nullptr, nullptr, nullptr, r->bandMask,
+                                r->bandSlotPrefix, r->bandCounts, nullptr, r->tileRange, 2 * scr.totalTiles, (float4*) r->tileRecord,
+                                (float4*) r->rasterRecord);
+            launchBandCompaction(g.stream, n, 1, r->bandMask, r->bandSlotPrefix, r->bandCounts, r->bandOffsets, r->bandTotal, r->clipZ, r->depthKey[0],
+                                 (uint32_t*) r->order[0]);
+            countDevice = (const int*) r->bandTotal; // low 32 bits of the little-endian int64 total
+        }
+        gs_timer_stop(stageTimers[1]);
+        if (blocking) st.msClipData = gs_timer_elapsed_ms(stageTimers[1]);
+        if (cull && r->shDegree != 0 && !f.lazyColours)
+        {
+            // SH colour of the kept splats only (list = the compacted, still index-ordered order[0])
+            gs_timer_start(stageTimers[0]);
+            const float* cp = camera->position;
+            launchSphericalHarmonicsGather(g.stream, n, countDevice, r->shDegree, r->shCount, r->order[0], (const float4*) r->position,
+                                           r->shPerSplat, make_float3(cp[0], cp[1], cp[2]), (float4*) r->color);
+            gs_timer_stop(stageTimers[0]);
+            if (blocking) st.msSphericalHarmonics = gs_timer_elapsed_ms(stageTimers[0]);
+        }
+        r->radix.countDevice = countDevice;
+        r->scratch.countDevice = countDevice;
+
+        // (1) splats by depth: 32-bit keys, N elements
+        int orderSel = 0;
+        gs_timer_start(stageTimers[6]);
+        const bool native = cfg.sortBackend == GS_SORT_BACKEND_NATIVE;
+        if (n > 0)
+        {
+            if (native && radixSortSupported(4, n))
+                orderSel = launchRadixSortPairs(g.stream, r->radix, 4, r->depthKey[0], r->depthKey[1], r->order[0], r->order[1], n, 0, kDepthKeyBits);
+            else
+            {
+                ensureSortTemp(r, sortTempBytes(4, n, 0, kDepthKeyBits));
+                orderSel = launchSortPairs(g.stream, r->sortTemp, r->sortTempBytes, 4, r->depthKey[0], r->depthKey[1], r->order[0],
+                                           r->order[1], 0, n, 0, kDepthKeyBits);
+            }
+        }
+        gs_timer_stop(stageTimers[6]);
+        f.orderSel = orderSel;
+        const uint32_t* order = (const uint32_t*) r->order[orderSel];
+
+        // (2) pairs in depth order, keyed by tile. The emit pass is launched with the current capacity while the
+        // pair count travels to the host, so the readback (GaussianRender.cu:793) costs no GPU idle time.
+        gs_timer_start(stageTimers[2]);
+        launchTileListFastCount(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch);
+        launchTileListFastEmit(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],
+                               f.tileKeyBytes, r->values[0], r->tileListCapacity);
+        GS_CHECK(hipEventRecord(r->countReady, g.stream)); // the emit pass leaves the pair total
+        gs_timer_stop(stageTimers[2]);
+    }
+    r->pending = true;
+    return 0;
+}
+
+// Second half: wait for the pair count (long since on the host), grow and re-emit in the rare overflow case, tile
+// sort, ranges, raster.
+extern "C" int gs_renderer_finish(GsRenderer* r, GsFrameStats* stats)
+{
+    if (!r->pending) return -3;
+    StreamScope scope(r);
+    FrameState& f = r->frame;
+    const Screen& scr = f.scr;
+    GsTimer** stageTimers = f.stageTimers;
+    const bool blocking = f.blocking;
+    GsFrameStats& st = f.st;
+    const int n = r->splatCount;
+    r->pending = false;
+
+    if (!f.listDone)
+    {
+        const int tBits = tileBits(scr.totalTiles);
+        const uint32_t* order = (const uint32_t*) r->order[f.orderSel];
+        GS_CHECK(hipEventSynchronize(r->countReady));
+        const int64_t demand = *r->scratch.totalHost;
+        g.lastDemand = demand;
+        if (demand > 0x7FFFFFFF) return -2;
+        if (growTileListIfNeeded(r, demand))
+        {
+            // the list did not fit: re-emit into the larger buffers (rare; the first frames of a scene)
+            st.grewTileList = 1;
+            launchTileListFastEmit(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch,
+                                   r->keys[0], f.tileKeyBytes, r->values[0], r->tileListCapacity);
+        }
+        if (blocking) st.msBuildTileList = gs_timer_elapsed_ms(stageTimers[2]);
+        r->radix.countDevice = nullptr;
+        r->scratch.countDevice = nullptr;
+        const int32_t size = (int32_t) demand;
+
+        // (3) stable sort of the pairs on the tile bits only
+        const bool native = cfg.sortBackend == GS_SORT_BACKEND_NATIVE;
+        gs_timer_start(stageTimers[3]);
+        int sel = 0;
+        if (size > 0)
+        {
+            if (native && radixSortSupported(f.tileKeyBytes, size))
+                sel = launchRadixSortPairs(g.stream, r->radix, f.tileKeyBytes, r->keys[0], r->keys[1], r->values[0], r->values[1], size, 0,
+                                           tBits);
+            else
+            {
+                ensureSortTemp(r, sortTempBytes(f.tileKeyBytes, size, 0, tBits));
+                sel = launchSortPairs(g.stream, r->sortTemp, r->sortTempBytes, f.tileKeyBytes, r->keys[0], r->keys[1], r->values[0],
+                                      r->values[1], 0, size, 0, tBits);
+            }
+        }
+        gs_timer_stop(stageTimers[3]);
+        if (blocking) st.msSortTileList = gs_timer_elapsed_ms(stageTimers[3]) + gs_timer_elapsed_ms(stageTimers[6]);
+        r->selector = sel;
+        r->keyBytes = f.tileKeyBytes;
+
+        gs_timer_start(stageTimers[4]);
+        launchTileRanges(g.stream, size, f.tileKeyBytes, r->keys[sel], r->tileRange);
+        gs_timer_stop(stageTimers[4]);
+        if (blocking) st.msTileRanges = gs_timer_elapsed_ms(stageTimers[4]);
+        f.size = size;
+    }
+    const int32_t size = f.size;
+    r->tileListSize = size;
+    st.tileListSize = size;
+    st.tileListCapacity = r->tileListCapacity;
+
+    // raster (direct launch: no global argument state, so renderers can interleave their halves)
+    unsigned long long* consumed = nullptr;
+    if (cfg.collectRasterStats)
+    {
+        if (r->consumed == nullptr) GS_CHECK(hipMalloc((void**) &r->consumed, sizeof(unsigned long long)));
+        consumed = r->consumed;
+        GS_CHECK(hipMemsetAsync(consumed, 0, sizeof(unsigned long long), g.stream));
+    }
+    gs_timer_start(stageTimers[5]);
+    const RasterColourSource lazySource = colourSource(r, f.cameraPosition, nullptr);
+    launchRasterize(g.stream, scr, r->tileRange, r->values[r->selector], (const float2*) r->clipXY, (const float4*) r->conic,
+                    (const float4*) r->color, (uchar4*) r->backBuffer, consumed, r->pipeline != GS_PIPELINE_REFERENCE,
+                    f.lazyColours ? &lazySource : nullptr, r->pipeline != GS_PIPELINE_REFERENCE ? (const float4*) r->rasterRecord : nullptr);
+    r->colourStale = f.lazyColours;
+    gs_timer_stop(stageTimers[5]);
+    if (hipGetLastError() != hipSuccess) printf("kernel error renderDepthBuffer\n");
+    if (blocking) st.msRasterize = gs_timer_elapsed_ms(stageTimers[5]);
+
+    GS_CHECK(hipEventRecord(r->frameStop, g.stream));
+    r->asyncPairs += (r->asyncFrames > 0) ? size : 0;
+    if (stats)
+    {
+        GS_CHECK(hipEventSynchronize(r->frameStop));
+        GS_CHECK(hipEventElapsedTime(&st.msFrame, r->frameStart, r->frameStop));
+        if (consumed != nullptr)
+        {
+            unsigned long long v = 0;
+            GS_CHECK(hipMemcpy(&v, consumed, sizeof(v), hipMemcpyDeviceToHost));
+            st.consumedPairs = (int64_t) v;
+        }
+        *stats = st;
+    }
+    return 0;
+}
+
+extern "C" int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsFrameStats* stats)
+{
+    // Captured path: plain frames (no stage timers, no stats) of the two-level pipeline on the native sort.
+    if (r->useGraph && timed == 0 && stats == nullptr && r->pipeline != GS_PIPELINE_REFERENCE &&
+        cfg.sortBackend == GS_SORT_BACKEND_NATIVE && !cfg.collectRasterStats && r->splatCount > 0 && r->views == 1)
+        return renderCaptured(r, camera);
+    r->graphValid = false; // the regular path re-sizes scratch as it likes
+    const int rc = gs_renderer_begin(r, camera, timed);
+    if (rc != 0) return rc;
+    return gs_renderer_finish(r, stats);
+}
+
+// r->views frames by ONE chain of kernels (header: gs_renderer_set_views); captured frames of the two-level pipeline only.
+
+extern "C" int gs_renderer_collect_stage_times(GsRenderer* r, GsFrameStats* sums)
+{
+    // Sums over the frames rendered with timed == 2 since the last call; resets the accumulation.
+    StreamScope scope(r);
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    GsFrameStats s{};
+    float* slots[kStageTimers] = {&s.msSphericalHarmonics, &s.msClipData, &s.msBuildTileList, &s.msSortTileList, &s.msTileRanges,
+                                  &s.msRasterize, &s.msSortTileList};
+    for (size_t i = 0; i != r->asyncUsed; ++i) *slots[i % kStageTimers] += gs_timer_elapsed_ms(r->asyncTimers[i]);
+    s.tileListSize = r->asyncPairs;
+    const int frames = r->asyncFrames;
+    r->asyncUsed = 0;
+    r->asyncFrames = 0;
+    r->asyncPairs = 0;
+    if (sums) *sums = s;
+    return frames;
+}
+

@@ -1,0 +1,158 @@
+// gs_state.h -- host-side state shared by the translation units behind the C ABI: gs_capi.hip (library state, timers, device
+// buffers, the eight staged calls), gs_renderer.hip (the one-call renderer) and gs_capture.hip (captured frames).  Not installed.
+#pragma once
+
+#include <mutex>
+#include <vector>
+
+#include "gs_internal.h"
+
+// Utilities.h:155-187
+struct GsTimer
+{
+    hipEvent_t start, stop;
+    float elapsedMs;
+    int blocking;
+};
+
+namespace gs
+{
+
+void setRasterPixelsPerLane(int ppl);
+int rasterPixelsPerLane();
+void setRasterTrace(unsigned long long* deviceBufferOrNull);
+
+extern int g_footprint; // process-wide, like the reference's #define
+extern int g_ablation;  // diagnostics: stages left out of captured frames (gs_debug_set_ablation)
+
+// The reference keeps these in __constant__ symbols (GaussianRender.cu:42-43); here they are a host
+// copy and every launch passes what its kernel needs by value.
+struct State
+{
+    GsGlobalArgs global{};
+    GsTileListArgs tileList{};
+    hipStream_t stream = nullptr;
+    gs::TileListScratch scratch;
+    gs::RadixScratch radix;
+    int64_t lastDemand = 0;
+};
+// One state per host thread: like the reference, the staged calls are not re-entrant, but each host thread may drive
+// its own renderer / staged sequence on its own stream (bench.py runs one thread per frame in flight).
+extern thread_local State g;
+
+// Process-wide settings.
+struct Settings
+{
+    int sortBackend = GS_SORT_BACKEND_NATIVE;
+    bool collectRasterStats = false;
+    unsigned long long* consumedDevice = nullptr; // counter of the staged gs_rasterize_tile
+};
+extern Settings cfg;
+
+Screen currentScreen();
+ClipCamera currentCamera();
+void reportLaunch(const char* stage);
+
+constexpr int kStageTimers = 7; // sh, clip, tile list, pair sort, ranges, raster, depth sort (added to the sort total)
+// What begin() leaves for finish().
+struct FrameState
+{
+    Screen scr{};
+    GsTimer* stageTimers[kStageTimers] = {};
+    bool blocking = false;
+    bool listDone = false; // reference pipeline: the sorted list and ranges were produced in begin()
+    int orderSel = 0, tileKeyBytes = 2;
+    bool lazyColours = false; // colours are evaluated by the raster kernel, entry by entry (no SH pass this frame)
+    float cameraPosition[3] = {0.f, 0.f, 0.f};
+    int32_t size = 0;
+    GsFrameStats st{};
+};
+
+} // namespace gs
+
+struct GsRenderer
+{
+    int width = 0, height = 0, rowBegin = 0, rowEnd = 0;
+    int pipeline = GS_PIPELINE_TWO_LEVEL;
+    int32_t splatCount = 0, shDegree = 0, shCount = 0;
+    float *position = nullptr, *scaleAndRotation = nullptr, *color = nullptr, *sh = nullptr;
+    float *clipXY = nullptr, *clipZ = nullptr, *conic = nullptr, *ellipse = nullptr;
+    bool colourStale = false;   // the last frame evaluated its colours inside the raster kernel: r->color is not current
+    float lastCameraPosition[3] = {0.f, 0.f, 0.f};
+    float* tileRecord = nullptr; // 8 floats per splat: clip x, y, cos, sin, extent x, y, 0, 0 (one memory sector)
+    float* rasterRecord = nullptr; // 8 floats per splat: clip x, y, conic x, y, z, 0, 0, 0 (what the raster gathers per list entry)
+    bool sceneShared = false; // position, scaleAndRotation, sh, shPerSplat belong to another renderer (gs_renderer_share_scene)
+    uint32_t* depthKey[2] = {nullptr, nullptr};
+    int32_t* order[2] = {nullptr, nullptr};
+    // band cull (multi-GPU): per-splat coefficients in the [splat][shCount] layout for gathered SH evaluation,
+    // one keep-mask and count per 64 splats, their scan, and the kept-splat count (device scalar)
+    float* shPerSplat = nullptr;
+    // per-renderer stream and scratch, so that several renderers can have frames in flight at once
+    hipStream_t stream = nullptr;
+    bool hasStream = false;
+    gs::TileListScratch scratch;
+    gs::RadixScratch radix;
+    unsigned long long* consumed = nullptr;
+    // captured frame (hipGraph): the whole two-level frame as one graph launch, list sizes kept on the device
+    bool useGraph = false, graphValid = false, ownsStream = false;
+    // TWO instances of the captured frame, each reading the camera from its own pinned slot: a frame can be launched while the
+    // previous one of this renderer is still running (its slot is not touched), so the stream never runs dry between frames
+    hipGraph_t graph[2] = {nullptr, nullptr};
+    hipGraphExec_t graphExec[2] = {nullptr, nullptr};
+    int graphSlot = 0; // instance of the NEXT launch
+    int views = 1;     // cameras per captured chain (gs_renderer_set_views)
+    gs::FrameParams* paramsDevice = nullptr;
+    gs::FrameParams* paramsHost = nullptr; // pinned, two slots
+    int graphCapacity = 0, graphSplats = 0, graphRowBegin = -1, graphRowEnd = -1, graphCull = -1, graphFootprint = -1, graphLazy = -1, graphAblation = 0, graphSelector = 0, graphKeyBytes = 2;
+    bool pending = false; // begin() issued, finish() not yet
+    int capturedRetries = 0; // captured frames rendered again because their pair demand exceeded the list capacity
+    gs::FrameState frame;
+    unsigned long long* bandMask = nullptr;
+    int32_t *bandCounts = nullptr, *bandOffsets = nullptr, *bandSlotPrefix = nullptr;
+    int64_t* bandTotal = nullptr;
+    int bandCull = GS_BAND_CULL_AUTO;
+    int32_t* tileRange = nullptr;
+    uint8_t* backBufferOwned = nullptr;
+    uint8_t* backBuffer = nullptr;
+    int32_t tileListCapacity = 0;
+    uint64_t* keys[2] = {nullptr, nullptr}; // 64-bit keys, or 16/32-bit tile indices in the same storage
+    int32_t* values[2] = {nullptr, nullptr};
+    int selector = 0;
+    int keyBytes = 8;
+    int32_t tileListSize = 0;
+    void* sortTemp = nullptr;
+    size_t sortTempBytes = 0;
+    GsTimer* timer = nullptr;
+    hipEvent_t frameStart = nullptr, frameStop = nullptr, countReady = nullptr;
+    // timed == 2: non-blocking per-stage event pairs, kStageTimers per frame, read by gs_renderer_collect_stage_times
+    std::vector<GsTimer*> asyncTimers;
+    size_t asyncUsed = 0;
+    int64_t asyncPairs = 0;
+    int asyncFrames = 0;
+};
+
+namespace gs
+{
+// The launchers enqueue on g.stream; a renderer that was given its own stream borrows the slot for the call, so that
+// several renderers (frames in flight) can be driven from one host thread on different streams.
+struct StreamScope
+{
+    hipStream_t saved;
+    explicit StreamScope(GsRenderer* r) : saved(g.stream)
+    {
+        if (r->hasStream) g.stream = r->stream;
+    }
+    ~StreamScope() { g.stream = saved; }
+};
+
+// ---- helpers of the renderer shared with the captured path (gs_renderer.hip) ----
+bool useLazyColours(const GsRenderer* r);
+RasterColourSource colourSource(const GsRenderer* r, const float* cameraPosition, const FrameParams* paramsDevice);
+bool growTileListIfNeeded(GsRenderer* r, int64_t demand);
+// Captured path (gs_capture.hip).  `cameras`: r->views of them (one frame per view, rendered by one chain).
+int renderCaptured(GsRenderer* r, const GsCameraData* cameras);
+// Allocation / legacy-stream work of one host thread must not overlap another thread's stream capture: set-up and capture
+// are serialised process-wide (they happen once per renderer; replays take no lock).
+extern std::mutex g_captureMutex;
+
+} // namespace gs

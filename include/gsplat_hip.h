@@ -131,7 +131,6 @@ int64_t gs_last_raster_consumed_pairs(void);
  * the pairs). NATIVE = the three-kernel LSD sort of gs_radix.hip (default), ROCPRIM = rocPRIM's device sort. */
 #define GS_SORT_BACKEND_ROCPRIM 0
 #define GS_SORT_BACKEND_NATIVE 1
-#define GS_SORT_BACKEND_ONESWEEP 2 /* NATIVE with one kernel per pass (decoupled look-back); slower on MI355X, kept for comparison */
 void gs_set_sort_backend(int backend);
 /* The reference's compile-time option `#define EPANECHNIKOV_KERNEL` (GaussianRender.cu:8-9, README.md:133-136) as a
  * run-time switch: footprint extent sqrt(7) sigma instead of 3 sigma (.cu:298-302), density 1 - q/7 instead of exp(-q/2)
@@ -228,14 +227,9 @@ void gs_renderer_set_tile_rows(GsRenderer* r, int tileRowBegin, int tileRowEnd);
 void gs_renderer_set_band_cull(GsRenderer* r, int mode);
 #define GS_PIPELINE_REFERENCE 0
 #define GS_PIPELINE_TWO_LEVEL 1
-/* BINNED: same depth sort of the splats, then every (splat, tile) hit is written straight to its final slot of the
- * per-tile lists (count per row of sorted splats and tile, column scan, emit through per-tile LDS cursors): no pair
- * sort and no range search; values and tileRange are identical to the other two pipelines, there is no key array
- * (GsRendererBuffers.keys is meaningless, keyBytes 0).  Bands of more than 8192 tiles fall back to TWO_LEVEL. */
-#define GS_PIPELINE_BINNED 2
 void gs_renderer_set_pipeline(GsRenderer* r, int pipeline);
 /* 1 when the renderer's frames evaluate SH colours on demand inside the raster kernel instead of running the SH pass over all
- * splats (two-level / binned pipelines, SH degree 1 or 3, two pixels per lane; GS_NO_LAZY_SH=1 in the environment turns it
+ * splats (two-level pipeline, SH degree 1 or 3, two pixels per lane; GS_NO_LAZY_SH=1 in the environment turns it
  * off).  Same colours bit for bit (one shared routine); a frame consumes only the front of its lists -- 88 K distinct splats
  * of 1 M at BASELINE.json configs[2] -- so most of the reference's evaluateSphericalHarmonics work is never needed.
  * GsRendererBuffers.color is brought up to date (one SH pass) when gs_renderer_buffers is called. */
@@ -254,7 +248,7 @@ int gs_renderer_share_scene(GsRenderer* r, const GsRenderer* owner);
  *   timed == 2: one non-blocking event pair per stage on the stream; read the sums later with
  *               gs_renderer_collect_stage_times (the frames are not slowed by host waits). */
 int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsFrameStats* statsOrNull);
-/* Captured frames: gs_renderer_render (timed == 0, stats == NULL, TWO_LEVEL or BINNED pipeline, native sort) replays the whole
+/* Captured frames: gs_renderer_render (timed == 0, stats == NULL, TWO_LEVEL pipeline, native sort) replays the whole
  * frame as ONE hipGraph launch; list sizes stay on the device, the camera is refreshed by a memcpy node.  The call returns once
  * the frame's pair total has reached the host (mid-frame, through a host-mapped word); the next call may follow at once (two
  * instances of the graph with a camera slot each, so the stream always holds the next frame).  A frame whose demand exceeds the list
@@ -280,6 +274,10 @@ int gs_renderer_read_back_buffer_view(GsRenderer* r, int view, uint8_t* hostRgba
 /* Diagnostics (bench.py --ablate): leave stages out of the captured frames -- bit 0 clip, 1 depth sort, 2 pair count, 3 pair emit,
  * 4 tile sort, 5 ranges, 6 raster -- to measure what each stage costs the pipelined frame rate.  The images are garbage. */
 void gs_debug_set_ablation(int mask);
+/* A captured frame hands its pair total to the host in the middle of the frame; the host waits for it at most this long (default
+ * 30 s) and gives up at once when the stream reports anything but "not ready" -- print + exit, the reference's convention for a
+ * failed runtime call (CudaErrorCheck.cpp:2-11), so that a faulted GPU ends the process instead of hanging it. */
+void gs_debug_set_await_timeout(double seconds);
 /* Diagnostics (tools/frame_pump): host-side cost of the captured frames of this process since the last reset -- average microseconds
  * per frame inside hipGraphLaunch and waiting for the frame's pair total; returns the number of frames averaged over. */
 long long gs_debug_host_times(double* launchMicroseconds, double* awaitMicroseconds, int reset);
@@ -300,7 +298,7 @@ uint8_t* gs_renderer_back_buffer(GsRenderer* r);
 void gs_renderer_set_back_buffer(GsRenderer* r, uint8_t* deviceBackBufferOrNull);
 /* Copy the back buffer to host (blocking). */
 void gs_renderer_read_back_buffer(GsRenderer* r, uint8_t* hostRgba);
-/* Device pointers of the per-splat intermediates, for tests/inspection.  The two-level / binned frames keep centre, depth, conic and
+/* Device pointers of the per-splat intermediates, for tests/inspection.  The two-level frames keep centre, depth, conic and
  * ellipse inside two packed 32-byte records per splat; this call unpacks them into the reference's arrays (and brings the colour buffer
  * up to date when the colours were evaluated on demand). */
 typedef struct GsRendererBuffers

@@ -408,13 +408,10 @@ def test_full_size_properties(gs, tmp_path_factory, n, w, h):
                                                       # 9-bit digits (512 bins, two per lane): 27 bits = 3 x 9 (the depth codes), 18 = 2 x 9, 9 = 1 x 9
                                                       (4, 1_000_003, 0, 27, False), (4, 200_000, 5, 23, False), (4, 300_000, 0, 9, True),
                                                       (4, 2_500_000, 0, 26, False), (2, 9_001, 3, 12, False)])
-@pytest.mark.parametrize("backend", [1, 2])
-def test_native_radix_sort_bit_exact(gs, key_bytes, n, begin, end, skew, backend):
-    """The renderer's own LSD radix sort (three-kernel passes, and the single-kernel look-back variant): stable,
-    bit-exact against numpy's stable argsort on the masked key."""
-    import ctypes as C
-
-    gs.lib().gs_set_sort_backend(backend)
+def test_native_radix_sort_bit_exact(gs, key_bytes, n, begin, end, skew):
+    """The renderer's own LSD radix sort (histogram / column scan / scatter passes): stable, bit-exact against numpy's stable
+    argsort on the masked key."""
+    gs.lib().gs_set_sort_backend(1)
 
     rng = np.random.default_rng(n)
     dt = np.uint16 if key_bytes == 2 else np.uint32
@@ -440,7 +437,7 @@ def test_sort_backends_give_identical_frames(gs):
     pos, sr, col = _procedural(gs, 100000, seed=21, min_scale=0.005, max_scale=0.1)
     cam = gs.camera_from_bounds([-4] * 3, [4] * 3, 1280, 720)
     out = []
-    for backend in (0, 1, 2):  # rocPRIM, native, native with look-back passes
+    for backend in (0, 1):  # rocPRIM, native
         gs.lib().gs_set_sort_backend(backend)
         r = gs.Renderer(1280, 720)
         r.set_scene(pos, sr, col)
@@ -538,7 +535,7 @@ def test_captured_frames_equal_regular_frames(gs, tmp_path):
 def test_captured_frames_never_hand_out_a_truncated_frame(gs):
     """A captured frame whose pair demand exceeds the list capacity is rendered again with a grown list before render()
     returns (no incomplete frames; the reference would show the truncated frame, Demo.cpp:447): the FIRST
-    frame already equals the regular path's, for the two-level and the binned pipeline, and later frames need no retry."""
+    frame already equals the regular path's, and later frames need no retry."""
     w = h = 512
     pos, sr, col = _procedural(gs, 3000, seed=9, min_scale=0.3, max_scale=1.5)  # ~40 pairs per splat >> the 8 provisioned
     cam = gs.camera_from_bounds([-4] * 3, [4] * 3, w, h)
@@ -549,7 +546,7 @@ def test_captured_frames_never_hand_out_a_truncated_frame(gs):
     want_values = ref.download(ref.buffers().values, st.tileListSize, np.int32)
     assert st.tileListSize > 8 * 3000 and st.grewTileList == 1
     ref.close()
-    for pipeline in (gs.PIPELINE_TWO_LEVEL, gs.PIPELINE_BINNED):
+    for pipeline in (gs.PIPELINE_TWO_LEVEL,):
         r = gs.Renderer(w, h, pipeline=pipeline)
         r.set_graph(True)
         r.set_scene(pos, sr, col)
@@ -654,7 +651,7 @@ def test_epanechnikov_footprint(gs, gsref, tmp_path, degree):
             gsref.set_footprint(footprint == gs.FOOTPRINT_EPANECHNIKOV)
             want, rst, _ = gsref.render(*scene[:3], sh_al, ply["shDegree"], ply["shCount"], cam, w, h)
             per_pipeline = []
-            for pipeline in (gs.PIPELINE_REFERENCE, gs.PIPELINE_TWO_LEVEL, gs.PIPELINE_BINNED):
+            for pipeline in (gs.PIPELINE_REFERENCE, gs.PIPELINE_TWO_LEVEL):
                 r = gs.Renderer(w, h, pipeline=pipeline)
                 r.set_scene(*scene)
                 st = r.render(cam, stats=True)
@@ -665,8 +662,6 @@ def test_epanechnikov_footprint(gs, gsref, tmp_path, degree):
             for img, size, values in per_pipeline:
                 _assert_image_close(img, want, f"footprint={footprint}")
                 assert abs(size - rst.tileListSize) <= max(4, 2e-5 * rst.tileListSize)
-            assert np.array_equal(per_pipeline[1][2], per_pipeline[2][2])  # two-level and binned lists: identical
-            assert np.array_equal(per_pipeline[1][0], per_pipeline[2][0])
             captured.render(cam)  # the footprint is part of the captured kernels' arguments: must re-capture
             assert np.array_equal(captured.read_image(), per_pipeline[1][0])
             images[footprint] = (per_pipeline[1][0], ell.copy())
@@ -688,7 +683,7 @@ def test_renderer_empty_scene_and_scene_swap(gs, graph):
     w, h = 320, 200
     cam = gs.camera_from_bounds([-4] * 3, [4] * 3, w, h)
     empty = np.zeros((0, 4), np.float32)
-    for pipeline in (gs.PIPELINE_REFERENCE, gs.PIPELINE_TWO_LEVEL, gs.PIPELINE_BINNED):
+    for pipeline in (gs.PIPELINE_REFERENCE, gs.PIPELINE_TWO_LEVEL):
         r = gs.Renderer(w, h, pipeline=pipeline)
         r.set_graph(graph)
         r.set_scene(empty, empty, empty)
@@ -714,7 +709,7 @@ def test_renderer_empty_scene_and_scene_swap(gs, graph):
 
 @pytest.mark.parametrize("degree", [1, 2, 3])
 def test_colours_on_demand_equal_the_sh_pass(gs, tmp_path, degree):
-    """Two-level / binned frames of a degree-1 or degree-3 scene evaluate colours inside the raster kernel instead of running
+    """Two-level frames of a degree-1 or degree-3 scene evaluate colours inside the raster kernel instead of running
     the SH pass; the reference-shaped pipeline always runs it.  Same bytes in the image, and the colour buffer handed out by
     gs_renderer_buffers equals the SH pass's.  (Degree 2: rows of 27 floats -- the SH pass stays, everything still agrees.)"""
     w, h = 800, 448
@@ -725,7 +720,7 @@ def test_colours_on_demand_equal_the_sh_pass(gs, tmp_path, degree):
 
     cams = [gs.camera_from_pose(p, q, w, h) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 3)]
     results = {}
-    for pipeline in (gs.PIPELINE_REFERENCE, gs.PIPELINE_TWO_LEVEL, gs.PIPELINE_BINNED):
+    for pipeline in (gs.PIPELINE_REFERENCE, gs.PIPELINE_TWO_LEVEL):
         r = gs.Renderer(w, h, pipeline=pipeline)
         r.set_scene(*scene)
         assert r.colours_on_demand() == (pipeline != gs.PIPELINE_REFERENCE and degree in (1, 3))
@@ -737,7 +732,7 @@ def test_colours_on_demand_equal_the_sh_pass(gs, tmp_path, degree):
             frames.append((image, colour))
         r.close()
         results[pipeline] = frames
-    for pipeline in (gs.PIPELINE_TWO_LEVEL, gs.PIPELINE_BINNED):
+    for pipeline in (gs.PIPELINE_TWO_LEVEL,):
         for (img_ref, col_ref), (img, col) in zip(results[gs.PIPELINE_REFERENCE], results[pipeline]):
             assert np.array_equal(img, img_ref)
             assert np.array_equal(col, col_ref)
@@ -813,7 +808,7 @@ def _renderer_lists(gs, scene, cam, w, h):
     """Sorted value list + image of every renderer pipeline, and of a captured frame."""
     out = {}
     for name, pipeline, graph in (("reference", gs.PIPELINE_REFERENCE, False), ("two_level", gs.PIPELINE_TWO_LEVEL, False),
-                                  ("binned", gs.PIPELINE_BINNED, False), ("captured", gs.PIPELINE_TWO_LEVEL, True)):
+                                  ("captured", gs.PIPELINE_TWO_LEVEL, True)):
         r = gs.Renderer(w, h, pipeline=pipeline)
         r.set_graph(graph)
         r.set_scene(scene["position"], scene["scaleAndRotation"], scene["color"])
@@ -944,7 +939,7 @@ def test_edge_whole_chunks_out_of_frustum(gs, gsref):
         assert not np.isin(values, np.nonzero(culled)[0]).any(), name
         assert abs(len(values) - len(sv)) <= 2, name
         _assert_image_close(image, want, name)
-    assert np.array_equal(lists["two_level"][0], lists["binned"][0]) and np.array_equal(lists["two_level"][0], lists["captured"][0])
+    assert np.array_equal(lists["two_level"][0], lists["captured"][0])
 
 
 def test_renderers_sharing_one_scene(gs, tmp_path):

@@ -13,13 +13,14 @@ for D in 1 4; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/band_stats_d$D -o stats -- $ROOT/tools/frame_pump /tmp/gs_pump/scene.ply /tmp/gs_pump/cams.bin 1920 1080 $RB $RE $D 512 1 0 $VIEWS > $OUT/band_stats_d$D.json 2> $OUT/band_stats_d$D.err
   echo "inflight $D rc=$?"; cat $OUT/band_stats_d$D.json
   f=$(find $OUT/band_stats_d$D -name "*kernel_stats.csv" | head -1)
-  python3 - "$f" <<'PY'
+  python3 - "$f" $((512 + 8 * D)) <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 for r in rows:
     print(f'{r["Name"][:70]:70s} calls {int(r["Calls"]):6d} avg {float(r["AverageNs"])/1e3:7.2f} us  {100*float(r["TotalDurationNs"])/tot:5.1f} %')
-print("kernel time per frame (544 frames):", round(tot / 544 / 1e3, 1), "us")
+frames = int(sys.argv[2])  # frame_pump: 8 * D warm-up frames + 512 timed ones
+print(f"kernel time per frame ({frames} frames):", round(tot / frames / 1e3, 1), "us")
 PY
 done
 rm -f /tmp/gs_pump/scene.ply

@@ -16,7 +16,7 @@ ap.add_argument("--cull", type=int, default=0)
 ap.add_argument("--inflight", type=int, default=3)
 ap.add_argument("--balanced", type=int, default=1)
 ap.add_argument("--graph", type=int, default=1)
-ap.add_argument("--sort-backend", type=int, default=1, help="0 rocPRIM, 1 native, 2 onesweep")
+ap.add_argument("--sort-backend", type=int, default=1, help="0 rocPRIM, 1 native")
 ap.add_argument("--ppl", type=int, default=2, help="raster pixels per lane")
 ap.add_argument("--pipeline", type=int, default=1)
 ap.add_argument("--views", type=int, default=1, help="cameras per chain of kernels (gs_renderer_set_views)")

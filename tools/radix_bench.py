@@ -12,7 +12,7 @@ ap.add_argument("--bits", type=int, default=13)
 ap.add_argument("--key-bytes", type=int, default=2)
 ap.add_argument("--reps", type=int, default=50)
 ap.add_argument("--random", type=int, default=0)
-ap.add_argument("--backend", type=int, default=1, help="1 native, 2 onesweep, 3 native with fused column scan")
+ap.add_argument("--backend", type=int, default=1, help="1 native, 0 rocPRIM")
 args = ap.parse_args()
 rng = np.random.default_rng(1)
 n = args.n
