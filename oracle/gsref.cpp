@@ -158,6 +158,11 @@ V3 normalize3(V3 v)
     float inv = 1.0f / std::sqrt(dot3(v, v));
     return V3{v.x * inv, v.y * inv, v.z * inv};
 }
+V2 normalize2(V2 v)
+{
+    float inv = 1.0f / std::sqrt(dot2(v, v));
+    return V2{v.x * inv, v.y * inv};
+}
 
 // ----------------------------------------------------------------------------------------------
 // Resolution generalisation (DESIGN.md "Resolution rules"); at 1024x1024 every value equals the
@@ -503,9 +508,7 @@ extern "C" void gsref_evaluate_splat_clip_data(int32_t count, const float* posit
         float lambda1 = gmax(0.0f, mid - radius);
 
         // .cu:290 normalize(vec2(b, lambda0 - a)); eigenVector1 (.cu:292) is dead code.
-        V2 ev{clipCovariance.m[1][0], lambda0 - clipCovariance.m[0][0]};
-        float inv = 1.0f / std::sqrt(dot2(ev, ev));
-        V2 eigenVector0{ev.x * inv, ev.y * inv};
+        V2 eigenVector0 = normalize2(V2{clipCovariance.m[1][0], lambda0 - clipCovariance.m[0][0]});
 
         // .cu:295-301
         float angle = std::atan2(eigenVector0.y, eigenVector0.x);
@@ -1098,5 +1101,65 @@ extern "C" void gsref_free_ply(GsRefPly* ply)
     std::free(ply->sh);
     ply->position4 = ply->scaleAndRotation4 = ply->color4 = ply->sh = nullptr;
 }
+
+// ----------------------------------------------------------------------------------------------
+// Test hooks: the glm restatements above, one by one, so that tests/test_oracle_golden.py can hold each of them bit for bit to
+// what glm 1.0.1 itself returns (tests/golden/glm_ops.json, written by tests/golden/make_golden.py from oracle/glm_ops_driver.cpp
+// compiled against the reference's vendored glm).  Matrices are column-major, m[col][row] at index 3*col + row (4*col + row).
+// ----------------------------------------------------------------------------------------------
+namespace
+{
+M3 loadM3(const float* p)
+{
+    M3 r;
+    for (int c = 0; c != 3; ++c)
+        for (int row = 0; row != 3; ++row) r.m[c][row] = p[c * 3 + row];
+    return r;
+}
+void storeM3(const M3& a, float* p)
+{
+    for (int c = 0; c != 3; ++c)
+        for (int row = 0; row != 3; ++row) p[c * 3 + row] = a.m[c][row];
+}
+} // namespace
+
+extern "C" void gsref_glm_mat3_cast(const float xyzw[4], float out[9]) { storeM3(mat3Cast(xyzw[0], xyzw[1], xyzw[2], xyzw[3]), out); }
+extern "C" void gsref_glm_mat3_mul(const float a[9], const float b[9], float out[9]) { storeM3(mul(loadM3(a), loadM3(b)), out); }
+extern "C" void gsref_glm_mat3_transpose(const float a[9], float out[9]) { storeM3(transpose(loadM3(a)), out); }
+extern "C" void gsref_glm_mat3_sandwich(const float a[9], const float b[9], float out[9])
+{
+    const M3 A = loadM3(a), B = loadM3(b);
+    storeM3(mul(mul(A, transpose(B)), transpose(A)), out); // as the clip stage writes it (.cu:264)
+}
+extern "C" void gsref_glm_mat4_mul_vec4(const float m[16], const float v[4], float out[4])
+{
+    const V4 r = mul(loadM4(m), V4{v[0], v[1], v[2], v[3]});
+    out[0] = r.x, out[1] = r.y, out[2] = r.z, out[3] = r.w;
+}
+extern "C" void gsref_glm_mat3_of_mat4(const float m[16], float out[9]) { storeM3(upper3(loadM4(m)), out); }
+extern "C" void gsref_glm_normalize2(const float v[2], float out[2])
+{
+    const V2 r = normalize2(V2{v[0], v[1]});
+    out[0] = r.x, out[1] = r.y;
+}
+extern "C" void gsref_glm_normalize3(const float v[3], float out[3])
+{
+    const V3 r = normalize3(V3{v[0], v[1], v[2]});
+    out[0] = r.x, out[1] = r.y, out[2] = r.z;
+}
+extern "C" float gsref_glm_atan2(float y, float x) { return std::atan2(y, x); }
+extern "C" float gsref_glm_max(float a, float b) { return gmax(a, b); }
+extern "C" float gsref_glm_min(float a, float b) { return gmin(a, b); }
+extern "C" float gsref_glm_step(float edge, float x) { return gstep(edge, x); }
+extern "C" float gsref_glm_mix(float x, float y, float a) { return gmix(x, y, a); }
+extern "C" float gsref_glm_clamp01(float x) { return gclamp01(x); }
+extern "C" int gsref_glm_clampi(int x, int lo, int hi) { return gclampi(x, lo, hi); }
+extern "C" float gsref_glm_length2(const float v[2]) { return dot2(V2{v[0], v[1]}, V2{v[0], v[1]}); }
+extern "C" float gsref_glm_dot2(const float a[2], const float b[2]) { return dot2(V2{a[0], a[1]}, V2{b[0], b[1]}); }
+extern "C" float gsref_glm_sqrt(float x) { return std::sqrt(x); }
+extern "C" float gsref_glm_cos(float x) { return std::cos(x); }
+extern "C" float gsref_glm_sin(float x) { return std::sin(x); }
+extern "C" float gsref_glm_floor(float x) { return std::floor(x); }
+extern "C" float gsref_glm_ceil(float x) { return std::ceil(x); }
 
 extern "C" int gsref_hardware_concurrency(void) { return (int) std::thread::hardware_concurrency(); }

@@ -16,6 +16,9 @@ Outputs (data only -- inputs and expected outputs):
   tests/golden/encode_vec4.json                         encodeVec4 known answers
   tests/golden/camera_default_pose.json                 CameraControls::setBounds poses + CameraData constants
   tests/golden/sh_basis.json                            Y_lm, l<=4, at sample directions
+  tests/golden/glm_ops.json                             the glm 1.0.1 primitives the clip / tile-list / key code calls (GaussianRender.cu:215-320,
+                                                        351-436,452,537-551), evaluated by glm itself (oracle/_ref/libglmops.so = oracle/glm_ops_driver.cpp
+                                                        against the reference's vendored headers) on seeded inputs; float bit patterns in and out
 
 Run:  make -C oracle && python tests/golden/make_golden.py
 """
@@ -197,12 +200,126 @@ def make_sh_fixture():
         json.dump({"order": "k = l*l + (m + l), l = 0..4", "samples": rows}, f, indent=1)
 
 
+# name -> (input kinds, output kind); a kind is a float-array length, "f" (float scalar) or "i" (int scalar).  tests/test_oracle_golden.py
+# binds the oracle's gsref_glm_<name> hooks with the same table (stored in the fixture).
+GLM_OPS = {
+    "mat3_cast": ([4], 9), "mat3_mul": ([9, 9], 9), "mat3_transpose": ([9], 9), "mat3_sandwich": ([9, 9], 9),
+    "mat4_mul_vec4": ([16, 4], 4), "mat3_of_mat4": ([16], 9), "normalize2": ([2], 2), "normalize3": ([3], 3),
+    "atan2": (["f", "f"], "f"), "max": (["f", "f"], "f"), "min": (["f", "f"], "f"), "step": (["f", "f"], "f"),
+    "mix": (["f", "f", "f"], "f"), "clamp01": (["f"], "f"), "clampi": (["i", "i", "i"], "i"), "length2": ([2], "f"),
+    "dot2": ([2, 2], "f"), "sqrt": (["f"], "f"), "cos": (["f"], "f"), "sin": (["f"], "f"), "floor": (["f"], "f"), "ceil": (["f"], "f"),
+}
+
+
+def bind_glm_ops(lib, prefix):
+    """ctypes signatures of `<prefix><name>` for every entry of GLM_OPS; returns {name: callable(list of inputs) -> output}."""
+    fp = C.POINTER(C.c_float)
+
+    def make(name, ins, out):
+        fn = getattr(lib, prefix + name)
+        fn.argtypes = [fp if isinstance(k, int) else (C.c_float if k == "f" else C.c_int) for k in ins] + ([fp] if isinstance(out, int) else [])
+        fn.restype = None if isinstance(out, int) else (C.c_float if out == "f" else C.c_int)
+
+        def call(args):
+            conv = []
+            for k, a in zip(ins, args):
+                if isinstance(k, int):
+                    conv.append(np.ascontiguousarray(a, np.float32))
+                else:
+                    conv.append(C.c_float(np.float32(a)) if k == "f" else int(a))
+            cargs = [a.ctypes.data_as(fp) if isinstance(a, np.ndarray) else a for a in conv]
+            if isinstance(out, int):
+                res = np.zeros(out, np.float32)
+                fn(*cargs, res.ctypes.data_as(fp))
+                return res
+            r = fn(*cargs)
+            return np.float32(r) if out == "f" else int(r)
+        return call
+    return {name: make(name, ins, out) for name, (ins, out) in GLM_OPS.items()}
+
+
+def glm_op_inputs():
+    """Seeded inputs per primitive: the value ranges the pipeline feeds them plus the edge cases it can reach."""
+    rng = np.random.default_rng(20251004)
+    f32 = np.float32
+
+    def quats(n):
+        q = [np.array(b, f32) / f32(255.0) * f32(2.0) - f32(1.0) for b in rng.integers(0, 256, size=(n, 4))]  # decodeVec4(...)*2-1: not normalised
+        q += [np.array(v, f32) for v in ([0, 0, 0, 1], [1, 1, 1, -1], [-1, -1, -1, -1], [0, 0, 0, 0], [2, 0, 0, 0], [1e-3, 0, 0, 1e-3])]
+        q += list(rng.standard_normal((20, 4)).astype(f32))
+        return q
+
+    def mats(n, k, scale=1.0):
+        return [(rng.standard_normal(k) * scale).astype(f32) for _ in range(n)]
+    diag = []
+    for s in rng.uniform(0.005, 0.5, size=(30, 3)):
+        m = np.zeros(9, f32)
+        m[0], m[4], m[8] = s
+        diag.append(m)
+    cov = []
+    for a in mats(40, 9, 0.3):
+        cov.append((a.reshape(3, 3) @ a.reshape(3, 3).T).astype(f32).reshape(9))
+    vecs2 = [np.array(v, f32) for v in ([0, 0], [0, 1e-20], [1e-30, 1e-30], [3e19, 4e19], [-0.0, 0.0], [1, 0], [0, -1], [1e-12, 0], [0, 2.5e-7])]
+    vecs2 += list((rng.standard_normal((60, 2)) * 10.0 ** rng.uniform(-9, 2, size=(60, 1))).astype(f32))
+    scal = [f32(v) for v in (0, -0.0, 1, -1, 0.5, 1e-12, -1e-12, 1e12, -1e12, np.nan, np.inf, -np.inf, 128, -128, 0.99999994, 1.0000001, -1.0000001)]
+    scal += list(rng.standard_normal(40).astype(f32)) + list((rng.standard_normal(20) * 100).astype(f32))
+    pairs = [(a, b) for a in scal[:17] for b in scal[:17]][::3] + list(zip(scal[17:], scal[:17:-1]))
+    angles = [f32(v) for v in (0, -0.0, np.pi, -np.pi, np.pi / 2, -np.pi / 2, 3.1415927, 1e-8, 100.0, -1e4)] + list(rng.uniform(-np.pi, np.pi, 60).astype(f32))
+    unit = [np.array([np.cos(t), np.sin(t)], f32) for t in rng.uniform(-np.pi, np.pi, 60)]
+    return {
+        "mat3_cast": [[q] for q in quats(120)],
+        "mat3_mul": [[a, b] for a, b in zip(mats(60, 9), mats(60, 9))] + [[a, d] for a, d in zip(mats(30, 9), diag)],
+        "mat3_transpose": [[a] for a in mats(20, 9)],
+        "mat3_sandwich": [[a, c] for a, c in zip(mats(40, 9, 0.5), cov)],
+        "mat4_mul_vec4": [[m, np.append(v, f32(1.0))] for m, v in zip(mats(60, 16), mats(60, 3, 4.0))],
+        "mat3_of_mat4": [[m] for m in mats(10, 16)],
+        "normalize2": [[v] for v in vecs2],
+        "normalize3": [[v] for v in mats(40, 3, 5.0)] + [[np.zeros(3, f32)]],
+        "atan2": [[v[1], v[0]] for v in unit] + [[a, b] for a, b in pairs[:60]],
+        "max": [list(p) for p in pairs], "min": [list(p) for p in pairs], "step": [list(p) for p in pairs],
+        "mix": [[f32(-128.0), x, a] for x in scal[:30] for a in (f32(0.0), f32(1.0))] + [[a, b, f32(t)] for (a, b), t in zip(pairs[:40], rng.uniform(0, 1, 40))],
+        "clamp01": [[x] for x in scal] + [[f32(v)] for v in rng.uniform(-0.5, 1.5, 40)],
+        "clampi": [[int(x), 0, int(hi)] for x in rng.integers(-300, 400, 60) for hi in (64, 120)][::2] + [[-2147483648, 0, 68], [2147483647, 0, 240]],
+        "length2": [[v] for v in vecs2], "dot2": [[a, b] for a, b in zip(vecs2, vecs2[::-1])],
+        "sqrt": [[f32(abs(float(x)))] for x in scal if np.isfinite(x)] + [[f32(1e-12)], [f32(7.0)]],
+        "cos": [[a] for a in angles], "sin": [[a] for a in angles],
+        "floor": [[f32(v)] for v in rng.uniform(-3, 130, 50)] + [[f32(-0.0)], [f32(63.999996)], [f32(np.nan)], [f32(64.0)]],
+        "ceil": [[f32(v)] for v in rng.uniform(-3, 130, 50)] + [[f32(-0.5)], [f32(64.000004)], [f32(np.nan)], [f32(64.0)]],
+    }
+
+
+def make_glm_ops_fixture():
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libglmops.so"))
+    ops = bind_glm_ops(lib, "glmops_")
+
+    def bits(v):
+        if isinstance(v, (int, np.integer)) and not isinstance(v, np.floating):
+            return int(v)
+        return [int(b) for b in np.atleast_1d(np.asarray(v, np.float32)).view(np.uint32)]
+    out = {"what": "glm 1.0.1 primitives evaluated by glm itself (oracle/glm_ops_driver.cpp, g++ -O2 -ffp-contract=off, scalar code path); "
+                   "floats are IEEE-754 bit patterns (uint32), ints are plain", "signatures": {k: [v[0], v[1]] for k, v in GLM_OPS.items()}, "cases": {}}
+    total = 0
+    for name, cases in glm_op_inputs().items():
+        rows = []
+        for args in cases:
+            rows.append({"in": [bits(a) for a in args], "out": bits(ops[name](args))})
+        out["cases"][name] = rows
+        total += len(rows)
+    with open(os.path.join(HERE, "glm_ops.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print(f"glm_ops.json: {total} cases over {len(out['cases'])} primitives")
+
+
 def main():
+    if "--only-glm" in sys.argv:
+        make_glm_ops_fixture()
+        return
     up = load_upstream()
     make_ply_fixtures(up)
     make_encode_fixture(up)
     make_camera_fixture(up)
     make_sh_fixture()
+    make_glm_ops_fixture()
     print("golden fixtures written to", HERE)
 
 

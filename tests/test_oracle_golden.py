@@ -138,3 +138,47 @@ def test_epanechnikov_footprint_known_answers(gsref):
     far = (q > 7.5) & (img_g[..., 3] == 255) & (img_e[..., 3] == 255)
     if far.any():
         assert img_e[..., 0][far].max() == 0
+
+
+def test_glm_primitives_match_glm_itself_bit_for_bit(gsref, golden_dir):
+    """The hand-written glm restatements of oracle/gsref.cpp (mat3_cast of un-normalised quaternions, mat3*mat3, transpose,
+    mat4*vec4, (mat3) of a mat4, normalize incl. (0,0), atan(y,x), max/min/step/mix/clamp, length2/dot, sqrt/cos/sin/floor/ceil) against
+    glm 1.0.1's own results on ~1 800 inputs (tests/golden/glm_ops.json, generated by tests/golden/make_golden.py from
+    oracle/glm_ops_driver.cpp compiled against the reference's vendored glm).  Bit patterns, NaN payloads aside."""
+    import ctypes as C
+
+    fixture = json.load(open(os.path.join(golden_dir, "glm_ops.json")))
+    lib = C.CDLL(os.path.join(os.path.dirname(golden_dir), os.pardir, "oracle", "libgsref.so"))
+    fp = C.POINTER(C.c_float)
+    assert len(fixture["cases"]) == len(fixture["signatures"]) >= 22
+    checked = 0
+    for name, (ins, out) in fixture["signatures"].items():
+        fn = getattr(lib, "gsref_glm_" + name)
+        fn.argtypes = [fp if isinstance(k, int) else (C.c_float if k == "f" else C.c_int) for k in ins] + ([fp] if isinstance(out, int) else [])
+        fn.restype = None if isinstance(out, int) else (C.c_float if out == "f" else C.c_int)
+        rows = fixture["cases"][name]
+        assert len(rows) >= 10, name
+        for row in rows:
+            args, keep = [], []
+            for kind, value in zip(ins, row["in"]):
+                if kind == "i":
+                    args.append(int(value))
+                    continue
+                arr = np.array(value, np.uint32).view(np.float32)
+                keep.append(arr)
+                args.append(arr.ctypes.data_as(fp) if isinstance(kind, int) else C.c_float(arr[0]))
+            if isinstance(out, int):
+                res = np.zeros(out, np.float32)
+                fn(*args, res.ctypes.data_as(fp))
+                got = res.view(np.uint32)
+            elif out == "f":
+                got = np.array([fn(*args)], np.float32).view(np.uint32)
+            else:
+                assert fn(*args) == row["out"], (name, row)
+                checked += 1
+                continue
+            want = np.array(row["out"], np.uint32)
+            nan_both = np.isnan(got.view(np.float32)) & np.isnan(want.view(np.float32))  # sign/payload of a NaN is not pinned
+            assert np.array_equal(got[~nan_both], want[~nan_both]), (name, row, got.tolist())
+            checked += 1
+    assert checked >= 1800
