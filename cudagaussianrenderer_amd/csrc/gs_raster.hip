@@ -29,6 +29,20 @@ namespace
 {
 
 constexpr int kBatch = 64; // entries staged per LDS fill; two vote chunks
+// Diagnostics build (-DGS_RASTER_PHASE_TRACE): with a trace buffer set, thread 0 of every tile sums the 100 MHz ticks it spends in
+// each phase of the loop -- waiting for the gather, staging (SH evaluation + LDS writes), barriers, blending, voting -- and leaves the
+// five sums in place of the regular trace record (tools/raster_lone_tile.py --phases).
+#ifdef GS_RASTER_PHASE_TRACE
+#define GS_PHASE(k)                                       \
+    do                                                    \
+    {                                                     \
+        const unsigned long long now_ = wall_clock64();   \
+        phase[k] += now_ - phaseT;                        \
+        phaseT = now_;                                    \
+    } while (0)
+#else
+#define GS_PHASE(k)
+#endif
 // blockIdx -> tile mapping: block shape dealt to one XCD (A/B builds may override)
 #ifndef GS_RASTER_BLOCK_W
 #define GS_RASTER_BLOCK_W 8
@@ -170,10 +184,15 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
 #pragma unroll
         for (int m = 0; m != kRowQuads; ++m) gRow[m] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // The list entry (a splat index) of the batch AFTER the one being gathered is already on its way: a gather is two dependent
+    // loads (index, then the splat's records), and a tile that runs alone on its SIMD -- the kernel's tail -- would otherwise wait
+    // for both, one after the other, once per batch (measured: 62-70 ns per entry for a lone tile whatever its arithmetic costs).
+    int nextSrc = (t < kBatch && t < count) ? values[first + t] : 0;
     auto gather = [&](int base) {
+        const int src = nextSrc;
+        if (t < kBatch && base + kBatch + t < count) nextSrc = values[first + base + kBatch + t]; // GaussianRender.cu:957-960
         if (t < kBatch && base + t < count)
         {
-            const int src = values[first + base + t]; // GaussianRender.cu:957-960
             if (rasterRecord != nullptr)
             {
                 // the renderer: centre and conic from ONE 32-byte record (one memory sector); wave-uniform branch
@@ -202,10 +221,18 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
     // the conic is staged pre-scaled: exp(-q/2) = exp2(q * -0.5 log2 e); Epanechnikov: 1 - q/7 = 1 + q * (-1/7)
     constexpr float kHalfLog2e = EPAN ? (-1.0f / 7.0f) : (-0.5f * 1.4426950408889634f);
     int base = 0, consumed = 0;
+#ifdef GS_RASTER_PHASE_TRACE
+    unsigned long long phase[6] = {0, 0, 0, 0, 0, 0}, phaseT = wall_clock64();
+#endif
     for (;;)
     {
         const int n = min(count - base, kBatch);
         __syncthreads(); // every wave is done reading the previous batch
+        GS_PHASE(0);
+#ifdef GS_RASTER_PHASE_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GS_PHASE(1);
+#endif
         if (t < kBatch)
         {
             // Entries past the end of the list are staged as all-zero records: opacity 0 makes them exact no-ops
@@ -220,7 +247,9 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
             sB[t] = live ? make_float4(gConic.z * kHalfLog2e, gColor.x, gColor.y, gColor.z) : make_float4(0.f, 0.f, 0.f, 0.f);
             sAlpha[t] = live ? gColor.w : 0.0f;
         }
+        GS_PHASE(2);
         __syncthreads();
+        GS_PHASE(0);
         if (base + kBatch < count) gather(base + kBatch); // in flight while this batch is blended
 
         bool stop = false;
@@ -269,12 +298,15 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
                 }
             }
             consumed = base + chunk + m;
+            GS_PHASE(3);
             // GaussianRender.cu:995: stop when no pixel of the tile has T > 0.02 (off-screen pixels of a
             // partial edge tile do not vote).
             bool alive = false;
 #pragma unroll
             for (int p = 0; p != PPL; ++p) alive |= onScreen[p] && PV::get(tr, p) > 0.02f;
-            if (!anyInBlock<THREADS>(alive))
+            const bool any = anyInBlock<THREADS>(alive);
+            GS_PHASE(4);
+            if (!any)
             {
                 stop = true;
                 break;
@@ -285,6 +317,17 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
     }
 
     if (consumedPairs != nullptr && t == 0) atomicAdd(consumedPairs, (unsigned long long) consumed);
+#ifdef GS_RASTER_PHASE_TRACE
+    if (trace != nullptr && t == 0)
+    {
+        // ticks in barriers, waiting for the gather, staging, blending | voting, consumed entries
+        trace[4 * (size_t) tile + 0] = (phase[0] << 32) | phase[1];
+        trace[4 * (size_t) tile + 1] = (phase[2] << 32) | phase[3];
+        trace[4 * (size_t) tile + 2] = phase[4];
+        trace[4 * (size_t) tile + 3] = ((unsigned long long) blockIdx.x << 32) | (unsigned long long) consumed;
+        trace = nullptr;
+    }
+#endif
     if (trace != nullptr && t == 0)
     {
         // per tile: start and end on the 100 MHz wall clock, list length, consumed entries
