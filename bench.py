@@ -129,6 +129,8 @@ class Rig:
 
         gs, lib = ctx["gs"], ctx["lib"]
         self.ctx, self.ply, self.cameras, self.bands, self.depth = ctx, ply, cameras, bands, depth
+        self.beat = ctx.get("beat", lambda what: None)
+        self.frames_timed = 0
         self.W, self.H = args.width, args.height
         world, rank, device = ctx["world"], ctx["rank"], ctx["device"]
         self.band = bands[rank]
@@ -181,11 +183,21 @@ class Rig:
             self.renderers[d].render_views(cams)
 
     def _gather(self, d):
+        """The V images of renderer d's chain -> rank 0: ONE grouped send/receive set (gs_gather_bands_views) on the chain's own stream,
+        through slot d's OWN communicator -- RCCL orders the operations of a communicator, so one communicator shared by the frames in
+        flight would tie their streams together.  Always called from the main thread, in chain order, on every rank alike.  A failed
+        enqueue ends this rank at once (exit 4): its peers would otherwise wait in their half of the exchange for ever, and the
+        launcher tears the job down when a rank exits."""
         import torch
 
-        with torch.cuda.stream(self.streams[d]):
-            # the V images of the chain: ONE grouped send/receive set (gs_gather_bands_views)
-            self.ctx["multigpu"].gather_bands(self.framebuffers[d], self.bands, self.ctx["rank"], self.ctx["world"], comm=self.ctx["comm"])
+        comms = self.ctx["comms"]
+        try:
+            with torch.cuda.stream(self.streams[d]):
+                self.ctx["multigpu"].gather_bands(self.framebuffers[d], self.bands, self.ctx["rank"], self.ctx["world"],
+                                                  comm=comms[d % len(comms)] if comms else None)
+        except Exception as exc:  # noqa: BLE001
+            print(f"bench.py: rank {self.ctx['rank']}: band gather failed on slot {d}: {exc}", file=sys.stderr, flush=True)
+            os._exit(4)
 
     def run_frames(self, count, gather=True):
         """At least `count` more frames (whole chains of V): frame j's bands -> rank 0 (one grouped RCCL send/recv set, receives
@@ -199,6 +211,7 @@ class Rig:
             future.result()
             if gather:
                 self._gather(chain % self.depth)
+            self.beat(f"chain {chain}")
 
         chains = (count + self.V - 1) // self.V
         for chain in range(self.next_chain, self.next_chain + chains):
@@ -231,23 +244,46 @@ class Rig:
         torch.cuda.synchronize(self.ctx["device"])
 
     def timed_run(self, steps, warmup):
-        """W untimed warm-up frames, then `steps` frames between barrier + synchronize pairs; max over ranks.  With V frames per
-        chain both counts are rounded UP to whole chains: the timed region then holds ceil(steps / V) * V >= steps frames of work
-        (self.frames_timed) while the caller still divides `steps` by the time -- never in the measurement's favour."""
-        import torch
-        import torch.distributed as dist
-
-        self.run_frames(warmup)
-        self.sync_all()
-        t0 = time.perf_counter()
-        self.frames_timed = self.run_frames(steps)
-        self.sync_all()
-        elapsed = time.perf_counter() - t0
-        if self.ctx["world"] > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=("cpu" if self.ctx["rehearse"] else self.ctx["device"]))
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        """multigpu.timed_frames on this rig: seconds of the timed region (MAX over ranks); self.frames_timed = frames in it,
+        self.own_seconds = this rank's own clock around the same region."""
+        elapsed, self.frames_timed, self.own_seconds = self.ctx["multigpu"].timed_frames(self, steps, warmup, self.ctx["world"],
+                                                                                         self.ctx["tensor_device"])
         return elapsed
+
+    def serial_frames(self, frames, sync_each):
+        """One renderer, one frame after the other (captured frames): seconds per frame.  sync_each = the reference's loop
+        (Demo.cpp:478: cudaDeviceSynchronize after every frame); without it render() returns when the frame's pair total is known
+        and the next frame is launched behind it on the same stream."""
+        import torch
+
+        r, stream = self.renderers[0], self.streams[0]
+        for phase in range(2):
+            torch.cuda.synchronize(self.ctx["device"])
+            t0 = time.perf_counter()
+            for i in range(frames if phase else max(8, frames // 8)):
+                r.render(self.cameras[i % len(self.cameras)])
+                if sync_each:
+                    stream.synchronize()
+            torch.cuda.synchronize(self.ctx["device"])
+        return (time.perf_counter() - t0) / frames
+
+    def gather_ms(self, chains):
+        """HIP-event time of the gather alone, chains one at a time on renderer 0 (milliseconds per chain): what the exchange costs
+        this rank when nothing overlaps it."""
+        import torch
+
+        stream = self.streams[0]
+        total = 0.0
+        for c in range(chains):
+            self.pools[0].submit(self._render, 0, c).result()
+            start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record(stream)
+            self._gather(0)
+            stop.record(stream)
+            stop.synchronize()
+            total += start.elapsed_time(stop)
+            self.beat(f"gather timing {c}")
+        return total / max(chains, 1)
 
     def stage_times(self, steps):
         """The same frames again on ONE renderer, back to back, with one non-blocking HIP-event pair per stage recorded on
@@ -258,7 +294,10 @@ class Rig:
         with torch.cuda.stream(self.streams[0]):
             for i in range(steps):
                 r.render(self.cameras[i % len(self.cameras)], timed=2)
-                self.ctx["multigpu"].gather_bands(self.framebuffers[0][0], self.bands, self.ctx["rank"], self.ctx["world"], comm=self.ctx["comm"])
+                comms = self.ctx["comms"]
+                self.ctx["multigpu"].gather_bands(self.framebuffers[0][0], self.bands, self.ctx["rank"], self.ctx["world"],
+                                                  comm=comms[0] if comms else None)
+                self.beat(f"stage timing {i}")
             frames, sums = r.collect_stage_times()
         return {"sh": sums.msSphericalHarmonics / frames, "clip": sums.msClipData / frames, "tile_list": sums.msBuildTileList / frames,
                 "sort": sums.msSortTileList / frames, "ranges": sums.msTileRanges / frames, "raster": sums.msRasterize / frames}
@@ -383,6 +422,7 @@ def main():
     ap.add_argument("--ppl", type=int, default=0, help="raster pixels per lane override (1,2,4)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel individually instead of replaying a captured frame")
     ap.add_argument("--even-bands", action="store_true", help="multi-GPU: equal-height bands instead of cost-balanced ones")
+    ap.add_argument("--rebalance-frames", type=int, default=256, help="multi-GPU: frames every rank times its band over per re-cut round")
     ap.add_argument("--rebalance", type=int, default=2, help="multi-GPU: re-cut the cost-balanced bands this many times from the ranks' measured band times (untimed set-up)")
     ap.add_argument("--pipeline", type=int, default=1, help="1 two-level sort (default), 0 the reference's stage order (one 64-bit sort of all pairs)")
     ap.add_argument("--band-cull", type=int, default=0, help="0 auto (compact the visible splats on strict bands only), 1 always, 2 never")
@@ -393,6 +433,7 @@ def main():
     ap.add_argument("--ablate", type=int, default=-1, help="diagnostics: leave stages out of the timed frames (bit 0 clip, 1 depth sort, 2 count, 3 emit, 4 tile sort, 5 ranges, 6 raster; 0 = none, the reference point); prints frames/s only")
     ap.add_argument("--views-per-chain", type=int, default=0, help="frames rendered by one replay of the captured chain (gs_renderer_set_views, 1..4); 0 = 1 on one GPU, 4 on a rank of a multi-GPU run")
     ap.add_argument("--spin-up", type=float, default=1.0, help="seconds of untimed rendering before the W warm-up frames: a handful of warm-up frames leaves the clocks, the host threads and the streams cold (20 timed frames after 5 warm-up frames: 4 600 frames/s without, 5 200 with 0.25 s or more -- the rate 512 timed frames give either way)")
+    ap.add_argument("--watchdog", type=float, default=180.0, help="multi-GPU: seconds without progress after which a rank prints where it was and exits 5 (0 = off)")
     ap.add_argument("--inflight", type=int, default=0, help="frames in flight per GPU (renderers on separate HIP streams); 0 = 4 (the measured optimum with 8 hardware queues)")
     args = ap.parse_args()
 
@@ -421,37 +462,48 @@ def main():
     lib = gs.lib()  # fails loudly if libgsplat_hip.so is missing
     lib.gs_set_device(local_rank)
     backend = None
+    depth = args.inflight if args.inflight > 0 else 4
+    multigpu_watchdog = multigpu.Watchdog(args.watchdog if world > 1 else 0, rank)
+    beat = multigpu_watchdog.beat
     if world > 1:
+        from datetime import timedelta
+
+        # collectives that cannot complete (a peer died) raise after this long instead of waiting for the default half hour
+        limit = timedelta(seconds=max(60.0, 2.0 * args.watchdog)) if args.watchdog > 0 else None
         if args.rehearse:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", **({"timeout": limit} if limit else {}))
         else:
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, **({"timeout": limit} if limit else {}))
         backend = dist.get_backend()
         assert dist.get_world_size() == args.gpus
+    beat("process group up")
     lib.gs_set_stream(torch.cuda.current_stream(device).cuda_stream)
     if args.ppl:
         lib.gs_set_raster_pixels_per_lane(args.ppl)
     if args.epanechnikov:
         gs.set_footprint(gs.FOOTPRINT_EPANECHNIKOV)
-    # the band gather's own communicator (RCCL through the C ABI); torch.distributed stays the bootstrap, barrier and timing reduce
-    comm, gather_note = None, None
+    # The band gather's own communicators (RCCL through the C ABI), ONE PER FRAME IN FLIGHT: slot d's chains are gathered on slot d's
+    # stream through slot d's communicator, so RCCL never sees a communicator on two streams.  torch.distributed stays the bootstrap,
+    # barrier and timing reduce.  BandComm either succeeds on every rank or raises on every rank (its own agreement collectives), so
+    # all ranks take the same path here.
+    comms, gather_note = [], None
     if world > 1 and not args.rehearse and args.gather == "library":
         try:
-            comm = multigpu.BandComm(rank, world, device)
-        except Exception as exc:  # e.g. librccl.so not loadable: every rank must then take the same path
-            gather_note = f"gs_comm_create failed on rank {rank}: {exc}"
-        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=device)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
-            if comm is not None:
-                comm.close()
-            comm = None
-            gather_note = gather_note or "gs_comm_create failed on another rank"
+            for d in range(depth):
+                comms.append(multigpu.BandComm(rank, world, device))
+                beat(f"communicator {d}")
+        except RuntimeError as exc:
+            gather_note = f"communicator {len(comms)} of {depth}: {exc}"
+            for c in comms:
+                c.close()
+            comms = []
+    tensor_device = "cpu" if args.rehearse else device
     ctx = {"gs": gs, "lib": lib, "multigpu": multigpu, "scenes": scenes, "rank": rank, "world": world, "local_rank": local_rank,
-           "device": device, "rehearse": args.rehearse, "comm": comm}
+           "device": device, "rehearse": args.rehearse, "comms": comms, "beat": beat, "tensor_device": tensor_device}
 
     W, H, N = args.width, args.height, args.splats
     ply, t_ingest = make_scene(ctx, args, args.opacity_mean)
+    beat("scene ingested")
     tiles_x, tiles_y = gs.tile_counts(W, H)
     cameras = [gs.camera_from_pose(p, q, W, H) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], args.views)]
     bands = scenes.tile_row_bands(tiles_y, world)
@@ -470,53 +522,23 @@ def main():
             row_cost += counts.sum(1) + 6.0 * np.minimum(counts, 256.0).sum(1)
         cal.close()
         bands = scenes.balanced_tile_row_bands(row_cost, world)
-    depth = args.inflight if args.inflight > 0 else 4
+    beat("bands cut")
+
+    def log(message):
+        if rank == 0:
+            print("bench.py: " + message, file=sys.stderr, flush=True)
 
     rig = Rig(ctx, ply, cameras, bands, depth, args)
+    beat("rig ready")
     band_times = None
     if world > 1 and not args.even_bands and args.rebalance > 0:
-        # The cost model does not know the kernels' fixed costs: re-cut the bands from what every rank MEASURES for its own band
-        # (untimed set-up: a few hundred frames without gather, times shared with an all-gather so that every rank derives the same
-        # bands), keep the cut with the smallest slowest band.  Rows of a band that took longer than the mean get more weight
-        # (exponent 2: only part of a band's time follows its rows).  Also absorbs speed differences between the GPUs.
-        cost = row_cost.copy()
-        best = None
-        for it in range(args.rebalance + 1):
-            mine = torch.tensor([rig.local_frame_ms(256)], dtype=torch.float64, device=("cpu" if args.rehearse else device))
-            everyone = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(everyone, mine)
-            times = [float(t.item()) for t in everyone]
-            if best is None or max(times) < best[0]:
-                best = (max(times), bands, times)
-            if it == args.rebalance:
-                break
-            mean = sum(times) / len(times)
-            for (a, b), t in zip(bands, times):
-                cost[a:b] *= (t / mean) ** 2.0
-            recut = scenes.balanced_tile_row_bands(cost, world)
-            if recut == bands:
-                break
-            bands = recut
-            rig.close()
-            rig = Rig(ctx, ply, cameras, bands, depth, args)
-        if bands != best[1]:
-            bands = best[1]
-            rig.close()
-            rig = Rig(ctx, ply, cameras, bands, depth, args)
-        band_times = [round(t, 4) for t in best[2]]
-    if args.spin_up > 0:
-        # untimed: keep the GPU rendering for a while before the W warm-up frames (a freshly leased box starts from idle clocks)
-        t_spin = time.perf_counter()
-        while True:
-            rig.run_frames(256)
-            rig.sync_all()
-            done = time.perf_counter() - t_spin >= args.spin_up
-            if world > 1:  # every rank must leave after the same number of frames (each frame is a matched send/receive set)
-                flag = torch.tensor([1 if done else 0], dtype=torch.int32, device=("cpu" if args.rehearse else device))
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-                done = bool(int(flag.item()))
-            if done:
-                break
+        # re-cut the bands from the ranks' measured band times (multigpu.rebalance_bands; untimed set-up)
+        rig, bands, times = multigpu.rebalance_bands(lambda b: Rig(ctx, ply, cameras, b, depth, args), rig, bands, row_cost, world,
+                                                     args.rebalance, tensor_device, frames=args.rebalance_frames, log=log)
+        band_times = [round(t, 4) for t in times]
+    # untimed: keep the GPU rendering for a while before the W warm-up frames (a freshly leased box starts from idle clocks)
+    multigpu.spin_up(rig, args.spin_up, world, tensor_device)
+    beat("spun up")
     if args.ablate >= 0:
         # marginal cost of stages in the pipelined loop: the renderers are primed with complete frames, then re-capture without
         # the masked stages (list sizes and buffers stay valid, the images are garbage)
@@ -528,6 +550,33 @@ def main():
         rig.close()
         return
     elapsed = rig.timed_run(args.steps, args.warmup)
+    beat("timed region done")
+
+    # ---- what the throughput costs, and whether it lasts (N = 1) -- and where an N-rank run spends its time (N > 1) ----
+    latency, per_rank = None, None
+    if world == 1 and not args.no_graph:
+        serial = rig.serial_frames(256, sync_each=False)
+        synced = rig.serial_frames(256, sync_each=True)
+        t0 = time.perf_counter()
+        frames = 0
+        while time.perf_counter() - t0 < 1.5:  # >= 1.5 s of the pipelined loop, timed as a whole
+            frames += rig.run_frames(512)
+            rig.sync_all()
+        sustained_s = time.perf_counter() - t0
+        latency = {
+            "one_frame_in_flight": {"frames_per_s": round(1.0 / serial, 1), "ms": round(1e3 * serial, 4),
+                                    "what": "ONE renderer on one stream, captured frames back to back (render() returns when the frame's pair total "
+                                            "is known; the next frame is launched behind it)"},
+            "one_frame_then_sync": {"frames_per_s": round(1.0 / synced, 1), "ms": round(1e3 * synced, 4),
+                                    "what": "the reference's loop (Demo.cpp:394-479): one frame, then a device synchronise, then the next camera"},
+            "sustained": {"frames_per_s": round(frames / sustained_s, 1), "frames": frames, "seconds": round(sustained_s, 3),
+                          "what": "the pipelined loop of `value` over >= 1.5 s, synchronised every 512 frames"},
+        }
+    if world > 1:
+        chain_gather_ms = rig.gather_ms(8)
+        per_rank = {"timed_region_s_own_clock": [round(v, 5) for v in multigpu.all_gather_floats(rig.own_seconds, world, tensor_device)],
+                    "gather_ms_per_chain_alone": [round(v, 4) for v in multigpu.all_gather_floats(chain_gather_ms, world, tensor_device)]}
+        beat("per-rank report")
 
     # ---- N > 1: one more frame through the same path, compared on rank 0 with a full-frame render of its own --------
     gathered_ok = None
@@ -576,7 +625,10 @@ def main():
                 "splats": N, "width": W, "height": H, "sh_degree": args.sh_degree, "views": len(cameras),
                 "pairs_per_frame": round(p_mean), "consumed_pairs_per_frame": round(pc_mean), "nonempty_tiles": round(nonempty),
                 "log_scale_mean": args.log_scale_mean, "opacity_mean_raw": args.opacity_mean, "seed": args.seed,
-                "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": device_name(lib), "frames_in_flight": depth, "frames_per_chain": rig.V, "untimed_spin_up_s": args.spin_up,
+                "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": device_name(lib), "frames_in_flight": depth, "frames_per_chain": rig.V, "frames_ahead": depth * rig.V,
+                "frames_ahead_what": "cameras the caller must hand over before the first image of them is complete (frames per chain x chains in flight); "
+                                     "the reference's loop is 1 -- extra.latency has that figure",
+                "untimed_spin_up_s": args.spin_up,
                 "frames_in_timed_region": rig.frames_timed,
                 "captured_frames": not args.no_graph,
                 "colours": "on demand in the raster kernel (no SH pass)" if on_demand else "SH pass over all splats",
@@ -585,8 +637,9 @@ def main():
                 "tile_row_bands": [list(b) for b in bands], "band_ms_measured_by_its_rank": band_times, "ingest_s": round(t_ingest, 2),
                 "dist_backend": backend, "dist_world_size": world, "rehearsal_on_one_gpu": bool(args.rehearse),
                 "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
-                "gather": None if world == 1 else ("gs_gather_bands: grouped ncclSend/ncclRecv through the C ABI" if comm is not None
+                "gather": None if world == 1 else (f"gs_gather_bands: grouped ncclSend/ncclRecv through the C ABI, {len(comms)} communicators (one per frame in flight)" if comms
                                                    else "torch.distributed point-to-point" + (f" (fallback: {gather_note})" if gather_note else "")),
+                "per_rank": per_rank,
                 "gathered_frame_equals_single_gpu_frame": gathered_ok,
             },
             "roofline": {
@@ -608,6 +661,8 @@ def main():
             "stages": stages,
             "gpu_ms_sum_of_stages": round(sum(stage_ms.values()), 4),
         }
+        if world == 1:
+            result["extra"] = {"latency": latency}
         if args.cpu_frames > 0 and world == 1:
             gpu_images = [rig.image(i) for i in range(min(args.cpu_frames, len(cameras)))]
             result["cpu_baseline"], result["parity"] = cpu_baseline_and_parity(ply, cameras, W, H, args.cpu_frames, gpu_images, pairs_per_view,
@@ -625,18 +680,19 @@ def main():
         p2, pc2, ne2, _ = rig2.list_sizes()
         st2, ab2, mb2, ms2, _ = stage_report(rig2, args, ms2, p2, pc2, ne2, band_tiles, band_h)
         a2 = ab2["raster"] / 1e9 / (ms2["raster"] / 1e3)
-        result["extra"] = {"low_opacity_scene": {
+        result["extra"]["low_opacity_scene"] = {
             "what": "same generator with raw opacity mean -3 (alpha ~0.05): P_c/P ~ 27 %, the raster kernel is the dominant stage",
             "opacity_mean_raw": -3.0, "value": round(steps2 / el2, 2), "unit": "frames/s", "steps": steps2, "ms_per_step": round(1e3 * el2 / steps2, 4),
             "pairs_per_frame": round(p2), "consumed_pairs_per_frame": round(pc2),
             "raster_ms": round(ms2["raster"], 4), "raster_algorithmic_GBps": round(a2, 1), "raster_frac": round(a2 / HBM_PEAK_GBS, 5),
-            "stages_ms": {k: round(v, 4) for k, v in ms2.items()}}}
+            "stages_ms": {k: round(v, 4) for k, v in ms2.items()}}
         rig2.close()
 
+    multigpu_watchdog.stop()
     if world > 1:
         dist.barrier()
-        if comm is not None:
-            comm.close()
+        for c in comms:
+            c.close()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))

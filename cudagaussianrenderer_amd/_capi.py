@@ -202,6 +202,7 @@ SIGNATURES = {
     "gs_gather_bands": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
     "gs_debug_rccl_self_exchange": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "gs_debug_rccl_self_exchange_parts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "gs_debug_rccl_self_exchange_streams": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "gs_gather_bands_views": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
     "gs_version": (C.c_char_p, []),
 }

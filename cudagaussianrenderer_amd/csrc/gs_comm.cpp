@@ -146,6 +146,43 @@ extern "C" int gs_debug_rccl_self_exchange_parts(void* dst, const void* src, siz
     return ok ? 0 : -2;
 }
 
+// What bench.py does with several frames in flight: `comms` communicators (of one rank each here), every one used on a stream of its
+// own, all exchanges in flight at once, two rounds so that every communicator is used again while the others are busy.  Slice k of the
+// block travels through communicator k.
+extern "C" int gs_debug_rccl_self_exchange_streams(void* dst, const void* src, size_t bytes, int comms)
+{
+    const Rccl& r = rccl();
+    if (!r.ok) return -1;
+    if (comms < 1 || comms > 8 || bytes % (size_t) comms != 0) return -1;
+    std::vector<ncclComm_t> comm((size_t) comms, nullptr);
+    std::vector<hipStream_t> stream((size_t) comms, nullptr);
+    bool ok = true;
+    for (int k = 0; ok && k != comms; ++k)
+    {
+        ncclUniqueId id;
+        ok = check(r.getUniqueId(&id), "ncclGetUniqueId") && check(r.commInitRank(&comm[k], 1, id, 0), "ncclCommInitRank") &&
+             hipStreamCreateWithFlags(&stream[k], hipStreamNonBlocking) == hipSuccess;
+    }
+    const size_t slice = bytes / (size_t) comms;
+    for (int round = 0; ok && round != 2; ++round)
+        for (int k = 0; ok && k != comms; ++k)
+        {
+            // round 0 moves the slice to its place, round 1 moves it again from there (same bytes): both must complete in order on stream k
+            const char* from = round == 0 ? (const char*) src + slice * (size_t) k : (const char*) dst + slice * (size_t) k;
+            ok = check(r.groupStart(), "ncclGroupStart");
+            ok = ok && check(r.send(from, slice, ncclUint8, 0, comm[k], stream[k]), "ncclSend");
+            ok = ok && check(r.recv((char*) dst + slice * (size_t) k, slice, ncclUint8, 0, comm[k], stream[k]), "ncclRecv");
+            ok = check(r.groupEnd(), "ncclGroupEnd") && ok;
+        }
+    for (int k = 0; k != comms; ++k)
+    {
+        if (stream[k] && hipStreamSynchronize(stream[k]) != hipSuccess) ok = false;
+        if (comm[k]) (void) r.commDestroy(comm[k]);
+        if (stream[k]) (void) hipStreamDestroy(stream[k]);
+    }
+    return ok ? 0 : -2;
+}
+
 extern "C" int gs_comm_rank(const GsComm* c) { return c ? c->rank : -1; }
 extern "C" int gs_comm_world(const GsComm* c) { return c ? c->world : 0; }
 

@@ -17,25 +17,40 @@ from .scenes import tile_row_bands  # noqa: F401  (re-exported)
 class BandComm:
     """The library's RCCL communicator for the band gather (include/gsplat_hip.h: gs_comm_*, gs_gather_bands): one rank per
     process and GPU.  The 128-byte RCCL unique id is created on rank 0 and handed to the others through torch.distributed
-    (which is only the bootstrap here: the per-frame transfers are the library's own grouped ncclSend/ncclRecv)."""
+    (which is only the bootstrap here: the per-frame transfers are the library's own grouped ncclSend/ncclRecv).
+
+    Every rank takes part in the same collectives whatever happens locally: rank 0 broadcasts a status byte with the id (a failed
+    gs_comm_unique_id travels as status 0 instead of leaving the other ranks inside the broadcast), and after gs_comm_create the
+    ranks agree (MIN) on whether everybody has a communicator -- so either all ranks get a BandComm or all of them raise."""
 
     def __init__(self, rank, world, device=None):
         import torch
 
         lib = _capi.load()
         buf = C.create_string_buffer(128)
-        if world > 1:
-            ident = torch.zeros(128, dtype=torch.uint8, device=device if device is not None else "cpu")
-            if rank == 0:
-                if lib.gs_comm_unique_id(buf) != 0:
-                    raise RuntimeError("gs_comm_unique_id failed (librccl.so not loadable?)")
-                ident.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
-            dist.broadcast(ident, src=0)
-            buf = C.create_string_buffer(bytes(ident.cpu().numpy().tobytes()), 128)
-        self.handle = lib.gs_comm_create(rank, world, buf)
-        if not self.handle:
-            raise RuntimeError("gs_comm_create failed")
+        self.handle = None
         self.rank, self.world = rank, world
+        if world > 1:
+            where = device if device is not None else "cpu"
+            packet = torch.zeros(129, dtype=torch.uint8, device=where)  # [0] = status, [1:] = the id
+            if rank == 0 and lib.gs_comm_unique_id(buf) == 0:
+                packet.copy_(torch.frombuffer(bytearray(b"\x01" + buf.raw), dtype=torch.uint8))
+            dist.broadcast(packet, src=0)
+            host = packet.cpu().numpy().tobytes()
+            if host[0] != 1:
+                raise RuntimeError("gs_comm_unique_id failed on rank 0 (librccl.so not loadable?)")
+            buf = C.create_string_buffer(host[1:], 128)
+        handle = lib.gs_comm_create(rank, world, buf)
+        if world > 1:
+            ok = torch.tensor([1 if handle else 0], dtype=torch.int32, device=where)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if handle:
+                    lib.gs_comm_destroy(handle)
+                raise RuntimeError("gs_comm_create failed" + ("" if not handle else " on another rank"))
+        elif not handle:
+            raise RuntimeError("gs_comm_create failed")
+        self.handle = handle
 
     def gather(self, framebuffer, bands, root=0, stream=None):
         """framebuffer: (H, W, 4), or (V, H, W, 4) for the V images of a chain of views -- one grouped send/receive set either way."""
@@ -118,3 +133,138 @@ def gather_bands(framebuffer, bands, rank, world, root=0, comm=None):
 
 
 _OPS_CACHE = {}
+
+
+# ---- the control flow of an N-rank run (used by bench.py with GPU renderers, and by tests/test_multigpu_cpu.py with the CPU oracle) ----
+#
+# A "rig" is whatever renders this rank's band: it offers run_frames(count, gather=True) -> frames rendered, sync_all(),
+# local_frame_ms(frames) -> this rank's own milliseconds per frame without the gather, close().  Every function below is a fixed
+# sequence of collectives that all ranks enter in the same order whatever their local results: decisions are taken from all-gathered
+# or all-reduced values only, so no rank can leave a loop that another rank is still in.
+def all_gather_floats(value, world, tensor_device):
+    """[value of rank 0, ..., value of rank world-1], the same list on every rank."""
+    import torch
+
+    if world == 1:
+        return [float(value)]
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=tensor_device)
+    everyone = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(everyone, mine)
+    return [float(t.item()) for t in everyone]
+
+
+def rebalance_bands(make_rig, rig, bands, row_cost, world, rounds, tensor_device, frames=256, log=None):
+    """Re-cut cost-balanced bands from what every rank MEASURES for its own band (untimed set-up).  The cost model behind the first
+    cut does not know the kernels' fixed costs; here the rows of a band that took longer than the mean get more weight (exponent 2:
+    only part of a band's time follows its rows), the cut with the smallest slowest band is kept.  Also absorbs speed differences
+    between the GPUs.  make_rig(bands) builds a rig for a new cut; returns (rig, bands, per-rank milliseconds of the kept cut)."""
+    from .scenes import balanced_tile_row_bands
+
+    cost = [float(c) for c in row_cost]
+    best = None
+    for it in range(rounds + 1):
+        times = all_gather_floats(rig.local_frame_ms(frames), world, tensor_device)
+        if log:
+            log(f"rebalance round {it}: bands {bands} ms {[round(t, 4) for t in times]}")
+        if best is None or max(times) < best[0]:
+            best = (max(times), bands, times)
+        if it == rounds:
+            break
+        mean = sum(times) / len(times)
+        for (a, b), t in zip(bands, times):
+            for y in range(a, b):
+                cost[y] *= (t / mean) ** 2.0
+        recut = balanced_tile_row_bands(cost, world)
+        if recut == bands:
+            break
+        bands = recut
+        rig.close()
+        rig = make_rig(bands)
+    if bands != best[1]:
+        bands = best[1]
+        rig.close()
+        rig = make_rig(bands)
+    return rig, bands, best[2]
+
+
+def spin_up(rig, seconds, world, tensor_device, chunk=256):
+    """Untimed rendering for about `seconds` (a freshly leased GPU starts from idle clocks); with several ranks everybody leaves after
+    the same number of frames -- each frame is a matched send/receive set -- i.e. when the SLOWEST clock says the time is up."""
+    import time
+
+    import torch
+
+    if seconds <= 0:
+        return 0
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        frames += rig.run_frames(chunk)
+        rig.sync_all()
+        done = time.perf_counter() - t0 >= seconds
+        if world > 1:
+            flag = torch.tensor([1 if done else 0], dtype=torch.int32, device=tensor_device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            done = bool(int(flag.item()))
+        if done:
+            return frames
+
+
+def timed_frames(rig, steps, warmup, world, tensor_device):
+    """W untimed warm-up frames, then `steps` frames between barrier + synchronize pairs (rig.sync_all); MAX over ranks.  With V frames
+    per chain both counts are rounded UP to whole chains by the rig: the timed region then holds >= steps frames of work while the
+    caller still divides `steps` by the time -- never in the measurement's favour.  Returns (seconds, frames in the timed region,
+    this rank's own seconds)."""
+    import time
+
+    import torch
+
+    rig.run_frames(warmup)
+    rig.sync_all()
+    t0 = time.perf_counter()
+    frames = rig.run_frames(steps)
+    rig.sync_all()
+    mine = time.perf_counter() - t0
+    elapsed = mine
+    if world > 1:
+        t = torch.tensor([mine], dtype=torch.float64, device=tensor_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, frames, mine
+
+
+class Watchdog:
+    """A rank that makes no progress for `seconds` prints where it was and ends the process (exit code 5): under a launcher
+    (torch.distributed.run) the other ranks are then torn down too, so a hang anywhere in an N-rank job -- a peer that died, a
+    collective that never completes -- becomes a diagnosable failure instead of a run that waits for ever.  `beat(what)` marks
+    progress; the thread is a daemon and costs nothing between beats."""
+
+    def __init__(self, seconds, rank, stream=None):
+        import sys
+        import threading
+        import time
+
+        self.seconds, self.rank, self.what, self.last = float(seconds), rank, "start", time.monotonic()
+        self._stop = threading.Event()
+        self._out = stream if stream is not None else sys.stderr
+        if self.seconds > 0:
+            self._thread = threading.Thread(target=self._watch, name="gsplat-watchdog", daemon=True)
+            self._thread.start()
+
+    def beat(self, what):
+        import time
+
+        self.what, self.last = what, time.monotonic()
+
+    def _watch(self):
+        import os
+        import time
+
+        while not self._stop.wait(min(1.0, self.seconds / 4)):
+            idle = time.monotonic() - self.last
+            if idle > self.seconds:
+                print(f"gsplat watchdog: rank {self.rank} made no progress for {idle:.0f} s in '{self.what}': giving up (exit 5)",
+                      file=self._out, flush=True)
+                os._exit(5)
+
+    def stop(self):
+        self._stop.set()

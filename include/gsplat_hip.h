@@ -341,6 +341,9 @@ int gs_gather_bands_views(GsComm* comm, uint8_t* backBuffer, int width, int heig
 int gs_debug_rccl_self_exchange(void* dst, const void* src, size_t bytes, void* hipStream);
 /* ... with the block cut into `parts` send/receive pairs inside one group (several operations per peer, as gs_gather_bands_views issues). */
 int gs_debug_rccl_self_exchange_parts(void* dst, const void* src, size_t bytes, int parts, void* hipStream);
+/* ... through `comms` (1..8) communicators, each on a stream of its own, all in flight at once and each used twice: how a host with
+ * several frames in flight drives the gather (one communicator per frame in flight, never one communicator on two streams). */
+int gs_debug_rccl_self_exchange_streams(void* dst, const void* src, size_t bytes, int comms);
 
 const char* gs_version(void);
 

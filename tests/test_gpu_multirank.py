@@ -14,20 +14,32 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("ranks", [2, 3])
-def test_bench_multirank_rehearsal(ranks):
+@pytest.mark.parametrize("ranks,width,height,splats", [(2, 1920, 1080, 200000), (3, 1920, 1080, 200000),
+                                                       # the widest rehearsals the GPU box allows (six processes on the card, this one included):
+                                                       # 1080p with its half-height last tile row, and 4K (135 tile rows)
+                                                       (5, 1920, 1080, 120000), (5, 3840, 2160, 200000)])
+def test_bench_multirank_rehearsal(ranks, width, height, splats):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
            "--master-port", str(29600 + ranks), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "24", "--warmup", "6",
-           "--splats", "200000", "--cpu-frames", "0", "--rehearse"]
-    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
+           "--splats", str(splats), "--width", str(width), "--height", str(height), "--cpu-frames", "0", "--rehearse",
+           "--rebalance-frames", "64", "--spin-up", "0.2"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     result = json.loads(line)
+    cfg = result["config"]
     assert result["n_gpus"] == ranks and result["steps"] == 24 and result["value"] > 0
     assert result["scaling"] == "strong"
-    assert len(result["config"]["tile_row_bands"]) == ranks
-    assert result["config"]["gathered_frame_equals_single_gpu_frame"] is True
+    bands = cfg["tile_row_bands"]
+    assert len(bands) == ranks and bands[0][0] == 0 and bands[-1][1] == (height + 15) // 16
+    assert all(b[1] > b[0] for b in bands) and all(bands[i][1] == bands[i + 1][0] for i in range(ranks - 1))
+    assert cfg["gathered_frame_equals_single_gpu_frame"] is True
+    assert cfg["frames_per_chain"] == 4 and cfg["frames_ahead"] == 16 and cfg["frames_in_timed_region"] >= 24
+    assert len(cfg["band_ms_measured_by_its_rank"]) == ranks  # the re-cut ran: every rank reported its band time
+    per_rank = cfg["per_rank"]
+    assert len(per_rank["timed_region_s_own_clock"]) == ranks and len(per_rank["gather_ms_per_chain_alone"]) == ranks
+    assert all(v > 0 for v in per_rank["timed_region_s_own_clock"])
 
 
 def test_rccl_is_loadable_and_world_one_gather_is_a_noop():
@@ -73,6 +85,11 @@ dst4 = gs.DeviceBuffer(np.zeros_like(rows))
 rc = lib.gs_debug_rccl_self_exchange_parts(dst4.ptr, src.ptr, rows.nbytes, 4, None)
 assert rc == 0, rc
 assert np.array_equal(dst4.copy_to(dtype=np.uint8).reshape(rows.shape), rows)
+# four communicators on four streams, all in flight, each used twice: bench.py's one communicator per frame in flight
+dst5 = gs.DeviceBuffer(np.zeros_like(rows))
+rc = lib.gs_debug_rccl_self_exchange_streams(dst5.ptr, src.ptr, rows.nbytes, 4)
+assert rc == 0, rc
+assert np.array_equal(dst5.copy_to(dtype=np.uint8).reshape(rows.shape), rows)
 print("exchanged", rows.nbytes)
 """
 

@@ -738,6 +738,49 @@ def test_colours_on_demand_equal_the_sh_pass(gs, tmp_path, degree):
             assert np.array_equal(col, col_ref)
 
 
+@pytest.mark.parametrize("width,height,splats", [(1920, 1080, 150_000), (3840, 2160, 300_000)])
+def test_eight_bands_stitch_to_the_single_gpu_frame(gs, tmp_path, width, height, splats):
+    """BASELINE.json configs[3] / [4] in their 8-GPU shape, one GPU standing in for each rank in turn: eight cost-balanced bands of tile
+    rows (1080p: 68 rows, the last one half height; 4K: 135 rows), every band rendered the way a rank of bench.py --gpus 8 renders it
+    -- captured chains of V = 4 frames, band cull on -- and the rows each rank would send to rank 0 stitched together: byte-identical
+    to the frames one GPU renders alone, for all four views of two chains."""
+    from cudagaussianrenderer_amd import multigpu, scenes
+
+    ply = _ply_scene(gs, tmp_path, splats, 3, log_scale_mean=-3.4)
+    scene = (ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+    cams = [gs.camera_from_pose(p, q, width, height) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 8)]
+    tx, ty = gs.tile_counts(width, height)
+    single = gs.Renderer(width, height)
+    single.set_graph(True)
+    single.set_scene(*scene)
+    want, row_cost = [], np.zeros(ty)
+    for cam in cams:
+        single.render(cam)
+        want.append(single.read_image())
+        rng = single.download(single.buffers().tileRange, 2 * tx * ty, np.int32).reshape(ty, tx, 2)
+        counts = (rng[..., 1] - rng[..., 0]).astype(np.float64)
+        row_cost += counts.sum(1) + 6.0 * np.minimum(counts, 256.0).sum(1)  # bench.py's calibration cost
+    single.close()
+    assert all(img[..., :3].any() for img in want)
+    for bands in (scenes.balanced_tile_row_bands(row_cost, 8), scenes.tile_row_bands(ty, 8)):
+        assert len(bands) == 8 and bands[0][0] == 0 and bands[-1][1] == ty
+        stitched = np.zeros((8, height, width, 4), np.uint8)
+        for band in bands:
+            r = gs.Renderer(width, height, tile_rows=band, views=4)
+            r.set_graph(True)
+            r.set_scene(*scene)
+            a, b = multigpu.pixel_rows(band, height)
+            for chain in range(2):
+                r.render_views(cams[4 * chain:4 * chain + 4])
+                for v in range(4):
+                    img = r.read_image(view=v)
+                    assert not img[:a].any() and not img[b:].any()  # a rank touches only its own rows
+                    stitched[4 * chain + v, a:b] = img[a:b]
+            r.close()
+        for v in range(8):
+            assert np.array_equal(stitched[v], want[v]), (bands, v)
+
+
 # ---- full-size parity against the oracle (BASELINE.json configs[1], [2], [4]) ---------------------------------------------
 @pytest.mark.parametrize("config", ["C2", "C3", "C5"])
 def test_full_size_parity_with_oracle(gs, gsref, tmp_path_factory, config):
