@@ -143,7 +143,7 @@ class Rig:
         self.renderers, self.framebuffers = [], []
         for d in range(depth):
             r = gs.Renderer(self.W, self.H, tile_rows=self.band if world > 1 else None, band_cull=args.band_cull, pipeline=args.pipeline,
-                            views=self.V)
+                            views=self.V, storage_order=args.storage_order)
             if d == 0 or args.own_scene_copies:
                 r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
             else:
@@ -434,8 +434,11 @@ def main():
     ap.add_argument("--views-per-chain", type=int, default=0, help="frames rendered by one replay of the captured chain (gs_renderer_set_views, 1..4); 0 = 1 on one GPU, 4 on a rank of a multi-GPU run")
     ap.add_argument("--spin-up", type=float, default=1.0, help="seconds of untimed rendering before the W warm-up frames: a handful of warm-up frames leaves the clocks, the host threads and the streams cold (20 timed frames after 5 warm-up frames: 4 600 frames/s without, 5 200 with 0.25 s or more -- the rate 512 timed frames give either way)")
     ap.add_argument("--watchdog", type=float, default=180.0, help="multi-GPU: seconds without progress after which a rank prints where it was and exits 5 (0 = off)")
+    ap.add_argument("--storage-order", choices=["auto", "caller", "morton"], default="auto", help="how the renderers store the splats (gs_renderer_set_storage_order): the file's order, or along a 3-D Morton curve (same frames; -10 %% per band frame of an 8-way split, -1 %% frames/s on one GPU: profiles/r03_storage_order.txt); auto = morton on the ranks of a multi-GPU run, the file's order on one GPU")
     ap.add_argument("--inflight", type=int, default=0, help="frames in flight per GPU (renderers on separate HIP streams); 0 = 4 (the measured optimum with 8 hardware queues)")
     args = ap.parse_args()
+    if args.storage_order == "auto":
+        args.storage_order = "morton" if args.gpus > 1 else "caller"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))  # nothing GPU-related has been imported yet
@@ -624,7 +627,7 @@ def main():
                             f"{len(cameras)}-view orbit, tile-row bands over {world} GPU(s)",
                 "splats": N, "width": W, "height": H, "sh_degree": args.sh_degree, "views": len(cameras),
                 "pairs_per_frame": round(p_mean), "consumed_pairs_per_frame": round(pc_mean), "nonempty_tiles": round(nonempty),
-                "log_scale_mean": args.log_scale_mean, "opacity_mean_raw": args.opacity_mean, "seed": args.seed,
+                "log_scale_mean": args.log_scale_mean, "opacity_mean_raw": args.opacity_mean, "seed": args.seed, "storage_order": args.storage_order,
                 "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": device_name(lib), "frames_in_flight": depth, "frames_per_chain": rig.V, "frames_ahead": depth * rig.V,
                 "frames_ahead_what": "cameras the caller must hand over before the first image of them is complete (frames per chain x chains in flight); "
                                      "the reference's loop is 1 -- extra.latency has that figure",

@@ -18,6 +18,8 @@ FOOTPRINT_GAUSSIAN = 0      # exp(-q/2), 3 sigma extent
 FOOTPRINT_EPANECHNIKOV = 1  # the reference's EPANECHNIKOV_KERNEL option: 1 - q/7, sqrt(7) sigma extent
 PIPELINE_REFERENCE = 0  # the reference's stage order: one 64-bit tile|depth radix sort of all pairs
 PIPELINE_TWO_LEVEL = 1  # default: depth-sort the splats, emit, stable-sort the pairs on the tile bits
+STORAGE_ORDER_CALLER = 0  # splats stored in the caller's order (the reference's behaviour)
+STORAGE_ORDER_MORTON = 1  # splats stored along a Morton curve: same frames, faster (include/gsplat_hip.h)
 
 
 def lib():
@@ -210,6 +212,14 @@ def camera_from_pose(position, rotation_xyzw, width, height):
     return cam
 
 
+def morton_order(position):
+    """gs_morton_order: storage_to_splat for (N, 4) positions."""
+    pos = _f32(position)
+    out = np.zeros(max(pos.shape[0], 1), np.int32)
+    lib().gs_morton_order(_fp(pos), pos.shape[0], out.ctypes.data_as(C.POINTER(C.c_int32)))
+    return out[:pos.shape[0]]
+
+
 def generate_random_gaussians(count, seed=1234, min_scale=0.01, max_scale=0.5, extent=4.0):
     """Demo.cpp:119-143,258-269 with a seeded PRNG. Returns position, scaleAndRotation, color (N,4) float32."""
     pos = np.zeros((count, 4), np.float32)
@@ -257,7 +267,7 @@ def parse_ply(path):
 class Renderer:
     """The frame loop body of src/Demo.cpp:352-479 behind one call."""
 
-    def __init__(self, width, height, tile_rows=None, pipeline=None, band_cull=None, views=1):
+    def __init__(self, width, height, tile_rows=None, pipeline=None, band_cull=None, views=1, storage_order=None):
         self.width, self.height = width, height
         self.handle = lib().gs_renderer_create(width, height)
         self.views = int(views)
@@ -269,6 +279,9 @@ class Renderer:
             lib().gs_renderer_set_pipeline(self.handle, pipeline)
         if band_cull is not None:  # 0 auto (on for a strict sub-band of tile rows), 1 on, 2 off
             lib().gs_renderer_set_band_cull(self.handle, band_cull)
+        if storage_order is not None:  # STORAGE_ORDER_CALLER / STORAGE_ORDER_MORTON, or "caller" / "morton"
+            order = {"caller": STORAGE_ORDER_CALLER, "file": STORAGE_ORDER_CALLER, "morton": STORAGE_ORDER_MORTON}.get(storage_order, storage_order)
+            lib().gs_renderer_set_storage_order(self.handle, int(order))
         self.splat_count = 0
 
     def set_scene(self, position, scale_and_rotation, color, sh=None, sh_degree=0, sh_count=0):
@@ -286,6 +299,13 @@ class Renderer:
             raise ValueError("gs_renderer_share_scene failed")
         self.splat_count = owner.splat_count
         self._scene_owner = owner  # keep it alive
+
+    def storage_order(self):
+        """storage_to_splat[k] = the caller's index of the splat stored in slot k: per-splat buffers and the pair list's values are
+        in storage order (identity unless the renderer was created with storage_order="morton")."""
+        out = np.zeros(max(self.splat_count, 1), np.int32)
+        n = lib().gs_renderer_storage_order(self.handle, out.ctypes.data_as(C.POINTER(C.c_int32)))
+        return out[:n]
 
     def set_back_buffer(self, device_ptr):
         lib().gs_renderer_set_back_buffer(self.handle, device_ptr)

@@ -173,6 +173,9 @@ SIGNATURES = {
     "gs_renderer_set_band_cull": (None, [C.c_void_p, C.c_int]),
     "gs_renderer_set_scene": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                         C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int]),
+    "gs_renderer_set_storage_order": (None, [C.c_void_p, C.c_int]),
+    "gs_renderer_storage_order": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "gs_morton_order": (None, [C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
     "gs_renderer_share_scene": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gs_renderer_render": (C.c_int, [C.c_void_p, C.POINTER(CameraData), C.c_int, C.POINTER(FrameStats)]),
     "gs_renderer_set_graph": (None, [C.c_void_p, C.c_int]),

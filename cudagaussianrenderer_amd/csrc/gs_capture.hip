@@ -73,7 +73,13 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
     r->radix.countDevice = countDevice;
     r->scratch.countDevice = countDevice;
     const int orderSel = (g_ablation & 2) ? 0 : launchRadixSortPairs(g.stream, r->radix, 4, r->depthKey[0], r->depthKey[1], r->order[0], r->order[1], nv, 0, kDepthKeyBits);
-    const uint32_t* order = (const uint32_t*) r->order[orderSel];
+    int fixedSel = orderSel;
+    if (r->storageToSplat != nullptr && !(g_ablation & 2)) // ties of the depth sort back into the caller's order (gs_radix.hip)
+    {
+        launchDepthTieFix(g.stream, nv, countDevice, r->depthKey[orderSel], r->order[orderSel], r->order[orderSel ^ 1], r->storageToSplat, n);
+        fixedSel = orderSel ^ 1;
+    }
+    const uint32_t* order = (const uint32_t*) r->order[fixedSel];
     if (!(g_ablation & 4)) launchTileListFastCount(g.stream, nv, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch);
     if (!(g_ablation & 8))
         launchTileListFastEmit(g.stream, nv, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],

@@ -182,6 +182,46 @@ extern "C" void gs_realign_spherical_harmonics(const float* src, float* dst, int
     }
 }
 
+// Storage order along a 3-D Morton (Z-order) curve through the positions' bounding box, 21 bits per axis; splats with equal codes
+// keep their order (std::stable_sort on the code).  storageToSplat[k] = the caller's index of the splat stored k-th.
+extern "C" void gs_morton_order(const float* position4, int32_t count, int32_t* storageToSplat)
+{
+    if (count <= 0) return;
+    float lo[3] = {position4[0], position4[1], position4[2]}, hi[3] = {position4[0], position4[1], position4[2]};
+    for (int32_t i = 0; i != count; ++i)
+        for (int a = 0; a != 3; ++a)
+        {
+            const float v = position4[4 * (size_t) i + a];
+            if (v < lo[a]) lo[a] = v; // (NaN positions never move the box; their codes below come out as 0)
+            if (v > hi[a]) hi[a] = v;
+        }
+    auto spread = [](uint64_t v) { // 21 bits -> every third bit
+        v &= 0x1FFFFFull;
+        v = (v | (v << 32)) & 0x1F00000000FFFFull;
+        v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+        v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+        v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+        v = (v | (v << 2)) & 0x1249249249249249ull;
+        return v;
+    };
+    std::vector<std::pair<uint64_t, int32_t>> keyed((size_t) count);
+    for (int32_t i = 0; i != count; ++i)
+    {
+        uint64_t code = 0;
+        for (int a = 0; a != 3; ++a)
+        {
+            const double extent = (double) hi[a] - (double) lo[a];
+            double u = extent > 0.0 ? ((double) position4[4 * (size_t) i + a] - (double) lo[a]) / extent : 0.0;
+            if (!(u >= 0.0)) u = 0.0;
+            if (u > 1.0) u = 1.0;
+            code |= spread((uint64_t) (u * 2097151.0)) << a;
+        }
+        keyed[(size_t) i] = {code, i};
+    }
+    std::stable_sort(keyed.begin(), keyed.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+    for (int32_t k = 0; k != count; ++k) storageToSplat[k] = keyed[(size_t) k].second;
+}
+
 extern "C" void gs_camera_from_pose(const float position[3], const float rotationXYZW[4], int width, int height, GsCameraData* out)
 {
     fillCamera(position, rotationXYZW, width, height, out);

@@ -160,6 +160,11 @@ void freeRadixScratch(RadixScratch& s);
 int launchRadixSortPairs(hipStream_t stream, RadixScratch& s, int keyBytes, void* keys0, void* keys1, int32_t* values0, int32_t* values1,
                          int n, int beginBit, int endBit);
 
+// After the depth sort of a renderer whose splats are NOT stored in the caller's order: entries with equal keys re-ordered by the
+// caller's index (gs_radix.hip).  orderIn/orderOut: the sorted (virtual) storage slots, two different buffers.
+void launchDepthTieFix(hipStream_t stream, int n, const int* countDevice, const uint32_t* sortedKeys, const int32_t* orderIn, int32_t* orderOut,
+                       const int32_t* storageToSplat, int splatsPerView);
+
 // keyBytes 8: tile = key >> 32 (the reference's keys); 2 or 4: the key is the tile index.
 // sizeDevice (optional): the list length lives on the device (captured frame); `size` is then the upper bound the grid covers.
 void launchTileRanges(hipStream_t stream, int size, int keyBytes, const void* keys, int32_t* tileRange,

@@ -441,7 +441,152 @@ int sortT(hipStream_t stream, K* keys0, K* keys1, int32_t* values0, int32_t* val
     return sel;
 }
 
+// Ties of the depth sort, re-ordered by the CALLER's splat index.  The sort is stable, so splats with equal depth codes come out in
+// the order they were stored in; a renderer that stores its splats along a Morton curve (gs_renderer_set_storage_order) must still
+// break ties the way a renderer with the caller's order does -- by the caller's index -- or two overlapping splats of equal depth
+// would blend in another order.  Ties are the rule, not the exception: getKey's (z + 1) / 2 in float leaves ~0.8 M distinct codes
+// for the 1 M splats of the bench scene, 38 % of the entries sit in a run of two to about twenty equal keys.
+//
+// One lane per sorted position.  A workgroup stages its 256 (key, entry) pairs and kTieHalo neighbours on both sides in LDS; every
+// staged entry that has an equal neighbour fetches its caller index ONCE (one gather per tied entry instead of one per pair of run
+// members) and leaves it in LDS too; a lane then finds its run in the window, counts the members that precede its own entry in the
+// caller's order and stores its entry at that rank.  A run that reaches beyond the halo takes a loop over global memory, in slices
+// whose loads are in flight together (the lane that walks the longest run sets the kernel's duration); runs of more than kMaxTieRun
+// entries (a scene with thousands of splats at exactly one depth) keep the storage order -- every lane of a run comes to the same
+// verdict.  No atomics, no order-dependent step.  Measured at 1 M entries: 15 us, of which 6 are the launch floor and the rest four
+// dependent memory round trips per wave, two rounds of waves (profiles/r03_storage_order.txt).  Key 0 is the code of the splats outside the frustum (clip depth -128), which emit
+// no pairs: their run -- the longest of every frame -- is copied as it is.  Several views per chain: a key's entries of view 0 come
+// first, then view 1's, ... (stable sort, view-major input), and only entries of ONE view can meet in a tile: the run that matters is
+// (key, view).
+constexpr int kMaxTieRun = 1024;
+constexpr int kTieHalo = 16; // a run of up to 16 entries is always resolved from the LDS window
+__global__ __launch_bounds__(256) void depthTieFixKernel(int nHost, const int* __restrict__ nDevice, const uint32_t* __restrict__ keys,
+                                                         const int32_t* __restrict__ orderIn, int32_t* __restrict__ orderOut,
+                                                         const int32_t* __restrict__ storageToSplat, int splatsPerView, int views)
+{
+    constexpr int kWindow = 256 + 2 * kTieHalo;
+    __shared__ uint32_t sKey[kWindow + 2]; // one sentinel on either side
+    __shared__ int sOrd[kWindow + 2];
+    __shared__ int sCaller[kWindow + 2];   // caller index of the entries that sit in a run (view-local)
+    const int n = nDevice ? min(*nDevice, nHost) : nHost;
+    const int t = threadIdx.x, base = blockIdx.x * 256;
+    if (base >= n) return; // whole workgroup
+    for (int idx = t; idx < kWindow + 2; idx += 256)
+    {
+        const int g = base - kTieHalo - 1 + idx;
+        const bool live = g >= 0 && g < n && idx != 0 && idx != kWindow + 1;
+        sKey[idx] = live ? keys[g] : 0xFFFFFFFFu; // (no key has 32 bits: the ends of the window end every run)
+        sOrd[idx] = live ? orderIn[g] : -1;
+    }
+    __syncthreads();
+    // view of a (virtual) entry; one view: no division
+    const auto viewBase = [&](int entry) { return views > 1 ? (entry / splatsPerView) * splatsPerView : 0; };
+    const auto tied = [&](int a, int b) { return sKey[a] == sKey[b] && (views == 1 || viewBase(sOrd[a]) == viewBase(sOrd[b])); };
+    for (int idx = 1 + t; idx <= kWindow; idx += 256)
+    {
+        // (an entry at the window's edge is only asked about the neighbour the window holds: a run that leaves the window is not
+        // resolved from it anyway)
+        const bool inRun = sKey[idx] != 0u && sOrd[idx] >= 0 && (tied(idx, idx - 1) || tied(idx, idx + 1));
+        if (inRun) sCaller[idx] = storageToSplat[sOrd[idx] - viewBase(sOrd[idx])];
+    }
+    __syncthreads();
+    const int i = base + t, l = t + kTieHalo + 1;
+    if (i >= n) return;
+    const uint32_t key = sKey[l];
+    const int mine = sOrd[l];
+    int before = 0, after = 0; // run members left / right of this lane, as far as the window shows
+    if (key != 0u)
+    {
+        while (before < kTieHalo && tied(l, l - before - 1)) ++before;
+        while (after < kTieHalo && tied(l, l + after + 1)) ++after;
+    }
+    if (before + after == 0)
+    {
+        orderOut[i] = mine;
+        return;
+    }
+    const int firstOfView = viewBase(mine), lastOfView = firstOfView + splatsPerView - 1;
+    const int own = sCaller[l];
+    if (before < kTieHalo && after < kTieHalo)
+    {
+        // the whole run lies inside the window: rank among its members
+        int rank = 0;
+        for (int d = 1; d <= before; ++d) rank += sCaller[l - d] < own ? 1 : 0;
+        for (int d = 1; d <= after; ++d) rank += sCaller[l + d] < own ? 1 : 0;
+        orderOut[i - before + rank] = mine;
+        return;
+    }
+    // a run that leaves the window: its extent from global memory, as far as kMaxTieRun entries either way
+    const auto same = [&](int j) { return keys[j] == key && orderIn[j] >= firstOfView && orderIn[j] <= lastOfView; };
+    // (sixteen entries per step, their loads in flight together: the lane that walks the longest run sets the kernel's duration)
+    int begin = i - before, end = i + after + 1;
+    for (bool more = true; more && begin > 0 && i - begin < kMaxTieRun;)
+    {
+        uint32_t k16[16];
+        int o16[16];
+#pragma unroll
+        for (int k = 0; k != 16; ++k)
+        {
+            const int j = max(begin - 1 - k, 0);
+            k16[k] = keys[j];
+            o16[k] = orderIn[j];
+        }
+        int run = 0;
+#pragma unroll
+        for (int k = 0; k != 16; ++k)
+            if (run == k && begin - 1 - k >= 0 && k16[k] == key && o16[k] >= firstOfView && o16[k] <= lastOfView) run = k + 1;
+        begin -= run;
+        more = run == 16;
+    }
+    for (bool more = true; more && end < n && end - i <= kMaxTieRun;)
+    {
+        uint32_t k16[16];
+        int o16[16];
+#pragma unroll
+        for (int k = 0; k != 16; ++k)
+        {
+            const int j = min(end + k, n - 1);
+            k16[k] = keys[j];
+            o16[k] = orderIn[j];
+        }
+        int run = 0;
+#pragma unroll
+        for (int k = 0; k != 16; ++k)
+            if (run == k && end + k < n && k16[k] == key && o16[k] >= firstOfView && o16[k] <= lastOfView) run = k + 1;
+        end += run;
+        more = run == 16;
+    }
+    // the same verdict in every lane of a run: its two ends were found AND it is at most kMaxTieRun entries long (a lane in the middle
+    // of a longer run may see both ends where a lane at its edge cannot)
+    const bool whole = (begin == 0 || !same(begin - 1)) && (end == n || !same(end)) && end - begin <= kMaxTieRun;
+    if (!whole)
+    {
+        orderOut[i] = mine;
+        return;
+    }
+    int rank = 0;
+    for (int j = begin; j < end; j += 16) // sixteen members at a time: their entries first, then their caller indices, each set in flight together
+    {
+        int member[16];
+#pragma unroll
+        for (int k = 0; k != 16; ++k) member[k] = j + k < end ? orderIn[j + k] : mine;
+#pragma unroll
+        for (int k = 0; k != 16; ++k) member[k] = storageToSplat[member[k] - firstOfView];
+#pragma unroll
+        for (int k = 0; k != 16; ++k) rank += member[k] < own ? 1 : 0;
+    }
+    orderOut[begin + rank] = mine;
+}
+
 } // namespace
+
+void launchDepthTieFix(hipStream_t stream, int n, const int* countDevice, const uint32_t* sortedKeys, const int32_t* orderIn, int32_t* orderOut,
+                       const int32_t* storageToSplat, int splatsPerView)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(depthTieFixKernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, countDevice, sortedKeys, orderIn, orderOut,
+                       storageToSplat, splatsPerView, (n + splatsPerView - 1) / splatsPerView);
+}
 
 bool radixSortSupported(int keyBytes, int n) { return (keyBytes == 2 || keyBytes == 4) && n >= 0; }
 

@@ -67,8 +67,12 @@ void freeScene(GsRenderer* r)
     {
         // the read-only inputs are the owner's
         r->position = r->scaleAndRotation = r->sh = r->shPerSplat = nullptr;
+        r->storageToSplat = nullptr;
         r->sceneShared = false;
     }
+    gs_device_free(r->storageToSplat);
+    r->storageToSplat = nullptr;
+    r->storageToSplatHost.clear();
     float** bufs[] = {&r->position, &r->scaleAndRotation, &r->color,   &r->sh,         &r->clipXY,
                       &r->clipZ,    &r->conic,            &r->ellipse, &r->tileRecord, &r->rasterRecord};
     for (float** b : bufs)
@@ -239,25 +243,58 @@ extern "C" int gs_renderer_set_scene(GsRenderer* r, int32_t n, const float* posi
     r->shDegree = shDegree;
     r->shCount = shCount;
     const size_t f4 = sizeof(float) * 4 * (size_t) n;
+    // Storage order (gs_renderer_set_storage_order): the splats are uploaded in the caller's order, or along a Morton curve through
+    // their positions -- neighbours in space become neighbours in memory, which is what the band cull of a multi-GPU rank, the
+    // gathers of the tile-list passes and the raster kernel's L2 hit rate live on.  Frames are the same bytes either way (the depth
+    // sort's ties are put back into the caller's order, gs_radix.hip: depthTieFixKernel).
+    std::vector<float> ordered;
+    const auto inStorageOrder = [&](const float* src, size_t floatsPerSplat) -> const float* {
+        if (r->storageToSplatHost.empty() || src == nullptr) return src;
+        ordered.resize(floatsPerSplat * (size_t) n);
+        for (int32_t k = 0; k != n; ++k)
+            std::memcpy(ordered.data() + floatsPerSplat * (size_t) k, src + floatsPerSplat * (size_t) r->storageToSplatHost[(size_t) k],
+                        sizeof(float) * floatsPerSplat);
+        return ordered.data();
+    };
+    if (r->storageOrder == GS_STORAGE_ORDER_MORTON && n > 1)
+    {
+        r->storageToSplatHost.resize((size_t) n);
+        gs_morton_order(position4, n, r->storageToSplatHost.data());
+        r->storageToSplat = (int32_t*) gs_device_alloc(sizeof(int32_t) * (size_t) n);
+        gs_device_upload(r->storageToSplat, r->storageToSplatHost.data(), sizeof(int32_t) * (size_t) n);
+    }
     r->position = (float*) gs_device_alloc(f4);
     r->scaleAndRotation = (float*) gs_device_alloc(f4);
     allocateSceneIntermediates(r, n);
-    gs_device_upload(r->position, position4, f4);
-    gs_device_upload(r->scaleAndRotation, scaleAndRotation4, f4);
-    gs_device_upload(r->color, color4, f4);
+    gs_device_upload(r->position, inStorageOrder(position4, 4), f4);
+    gs_device_upload(r->scaleAndRotation, inStorageOrder(scaleAndRotation4, 4), f4);
+    gs_device_upload(r->color, inStorageOrder(color4, 4), f4);
     if (shDegree != 0)
     {
         // Demo.cpp:291-296
+        const float* rows = inStorageOrder(sh, (size_t) shCount);
         const size_t total = gs_realigned_sh_size(GS_SH_GROUP_SIZE, shCount, n);
         std::vector<float> aligned(total);
-        gs_realign_spherical_harmonics(sh, aligned.data(), GS_SH_GROUP_SIZE, shCount, n);
+        gs_realign_spherical_harmonics(rows, aligned.data(), GS_SH_GROUP_SIZE, shCount, n);
         r->sh = (float*) gs_device_alloc(total * sizeof(float));
         gs_device_upload(r->sh, aligned.data(), total * sizeof(float));
         // second copy in the file's [splat][shCount] layout for the band-culled (gathered) SH evaluation
         r->shPerSplat = (float*) gs_device_alloc(sizeof(float) * (size_t) n * shCount);
-        gs_device_upload(r->shPerSplat, sh, sizeof(float) * (size_t) n * shCount);
+        gs_device_upload(r->shPerSplat, rows, sizeof(float) * (size_t) n * shCount);
     }
     return 0;
+}
+
+extern "C" void gs_renderer_set_storage_order(GsRenderer* r, int order)
+{
+    r->storageOrder = order == GS_STORAGE_ORDER_MORTON ? GS_STORAGE_ORDER_MORTON : GS_STORAGE_ORDER_CALLER;
+}
+
+extern "C" int32_t gs_renderer_storage_order(const GsRenderer* r, int32_t* storageToSplat)
+{
+    if (storageToSplat != nullptr)
+        for (int32_t k = 0; k != r->splatCount; ++k) storageToSplat[k] = r->storageToSplatHost.empty() ? k : r->storageToSplatHost[(size_t) k];
+    return r->splatCount;
 }
 
 // Several renderers of one scene (frames in flight): the read-only inputs -- position, scale/rotation, both coefficient layouts --
@@ -278,6 +315,9 @@ extern "C" int gs_renderer_share_scene(GsRenderer* r, const GsRenderer* owner)
     r->scaleAndRotation = owner->scaleAndRotation;
     r->sh = owner->sh;
     r->shPerSplat = owner->shPerSplat;
+    r->storageOrder = owner->storageOrder;
+    r->storageToSplat = owner->storageToSplat;
+    r->storageToSplatHost = owner->storageToSplatHost;
     r->sceneShared = true;
     allocateSceneIntermediates(r, n);
     if (n > 0) GS_CHECK(hipMemcpy(r->color, owner->color, sizeof(float) * 4 * (size_t) n, hipMemcpyDeviceToDevice));
@@ -557,6 +597,11 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
                 orderSel = launchSortPairs(g.stream, r->sortTemp, r->sortTempBytes, 4, r->depthKey[0], r->depthKey[1], r->order[0],
                                            r->order[1], 0, n, 0, kDepthKeyBits);
             }
+        }
+        if (r->storageToSplat != nullptr && n > 0) // ties of the depth sort back into the caller's order
+        {
+            launchDepthTieFix(g.stream, n, countDevice, r->depthKey[orderSel], r->order[orderSel], r->order[orderSel ^ 1], r->storageToSplat, n);
+            orderSel ^= 1; // (the keys stay where they are: nothing reads them after this)
         }
         gs_timer_stop(stageTimers[6]);
         f.orderSel = orderSel;

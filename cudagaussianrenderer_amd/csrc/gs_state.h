@@ -81,7 +81,13 @@ struct GsRenderer
     float lastCameraPosition[3] = {0.f, 0.f, 0.f};
     float* tileRecord = nullptr; // 8 floats per splat: clip x, y, cos, sin, extent x, y, 0, 0 (one memory sector)
     float* rasterRecord = nullptr; // 8 floats per splat: clip x, y, conic x, y, z, 0, 0, 0 (what the raster gathers per list entry)
-    bool sceneShared = false; // position, scaleAndRotation, sh, shPerSplat belong to another renderer (gs_renderer_share_scene)
+    bool sceneShared = false; // position, scaleAndRotation, sh, shPerSplat, storageToSplat belong to another renderer (gs_renderer_share_scene)
+    // gs_renderer_set_storage_order: the splats stored along a Morton curve instead of in the caller's order.  storageToSplat[k] = the
+    // caller's index of the splat in slot k (device copy for the depth sort's tie fix, host copy for gs_renderer_storage_order);
+    // null = the caller's order.
+    int storageOrder = GS_STORAGE_ORDER_CALLER;
+    int32_t* storageToSplat = nullptr;
+    std::vector<int32_t> storageToSplatHost;
     uint32_t* depthKey[2] = {nullptr, nullptr};
     int32_t* order[2] = {nullptr, nullptr};
     // band cull (multi-GPU): per-splat coefficients in the [splat][shCount] layout for gathered SH evaluation,

@@ -32,6 +32,11 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kGroup = kWave * kWavesPerBlock; // splats (and lanes) per workgroup
 constexpr int kTilesPerUnit = 4;
 constexpr int kMaskRounds = 16;                // rounds of a workgroup whose hit masks are kept for the emit pass
+// The emit pass sums the group totals in front of each group itself up to this many groups (1 M splats: 3 906); longer lists get
+// the scan kernel.  A band-culled list (device-side count) keeps only a fraction of the groups the grid was sized for, so the
+// limit on the host-side group count is wider there.
+constexpr int kSelfSumGroups = 4096;
+constexpr int kSelfSumGroupsCulled = 16384;
 
 struct GroupStage
 {
@@ -145,11 +150,18 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
         if (!EMIT && t == 0) groupCounts[group] = 0;
         return;
     }
-    // EMIT: where this workgroup's pairs start = the pairs of all groups before it.  Every workgroup sums the count pass's group
-    // totals in front of it itself (at most a few thousand L2-resident words, 16 per lane) instead of reading the result of a
-    // one-workgroup scan kernel: one kernel and one dependent launch less per frame.  The last group also leaves the pair total.
+    // EMIT: where this workgroup's pairs start = the pairs of all groups before it.  Up to kSelfSumGroups groups every workgroup
+    // sums the count pass's group totals in front of it itself (a few thousand L2-resident words, 16 per lane) instead of reading the
+    // result of a one-workgroup scan kernel: one kernel and one dependent launch less per frame; the last group also leaves the pair
+    // total.  Beyond that (5 M splats: 19.5 K groups, 190 M word loads) the self-summing would be quadratic work: the host launches
+    // the scan kernel in between and the offsets (and the total) come from there.
     int outBase = 0;
-    if (EMIT)
+    if (EMIT && groupOffsets != nullptr)
+    {
+        outBase = groupOffsets[group];
+        if (totalUnits == 0) return;
+    }
+    else if (EMIT)
     {
         long long mine = 0;
         for (int j = t; j < group; j += kGroup) mine += groupCounts[j];
@@ -276,9 +288,10 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                 before += (wv < wave) ? v : 0;
                 all += v;
             }
-            int pos = outBase + running + before;
+            // (unsigned: a demand beyond 2^31 pairs wraps past every capacity instead of into negative positions)
+            unsigned pos = (unsigned) outBase + (unsigned) running + (unsigned) before;
 #pragma unroll
-            for (int e = 0; e != kTilesPerUnit; ++e) pos += __popcll(ballots[e] & lowerLanes);
+            for (int e = 0; e != kTilesPerUnit; ++e) pos += (unsigned) __popcll(ballots[e] & lowerLanes);
             // re-walk the unit's tiles to write the hits, unit-major
             int wx = lx0, wy = ly0;
             const int splatK = st.splat[k];
@@ -293,7 +306,7 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
             {
                 if (hitMask & (1u << e))
                 {
-                    if (pos < capacity)
+                    if (pos < (unsigned) capacity)
                     {
                         const int gx = (origin & 0xFFFF) + wx, gy = (origin >> 16) + wy;
                         tileKeys[pos] = (TileKey) (gy * scr.tilesX + gx + viewTileBase);
@@ -417,10 +430,11 @@ __global__ __launch_bounds__(kScanThreads) void scanFastKernel(int nHost, const 
 
 template <typename TileKey>
 void launchEmit(hipStream_t stream, dim3 grid, dim3 block, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
-                const float4* screenEllipse, const TileListScratch& s, void* tileKeys, int32_t* values, int capacity, int viewSplats)
+                const float4* screenEllipse, const TileListScratch& s, const int32_t* groupOffsets, void* tileKeys, int32_t* values, int capacity,
+                int viewSplats)
 {
     hipLaunchKernelGGL((tileListFastKernel<true, TileKey>), grid, block, 0, stream, count, s.countDevice, scr, order, clipXY, screenEllipse,
-                       s.waveCounts, (const int32_t*) nullptr, (TileKey*) tileKeys, values, capacity, s.hitMasks, s.tileRecord, s.total,
+                       s.waveCounts, groupOffsets, (TileKey*) tileKeys, values, capacity, s.hitMasks, s.tileRecord, s.total,
                        s.totalHostMapped, viewSplats);
 }
 
@@ -472,8 +486,16 @@ void launchTileListFastEmit(hipStream_t stream, int count, const Screen& scr, co
     if (groups == 0) return;
     // (capacity 0 still runs: the pass is also what produces the pair total; nothing is written past `capacity`)
     const dim3 grid(groups), block(kGroup);
-    if (tileKeyBytes == 2) launchEmit<uint16_t>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, tileKeys, values, capacity, viewSplats);
-    else launchEmit<uint32_t>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, tileKeys, values, capacity, viewSplats);
+    const int32_t* groupOffsets = nullptr;
+    if (groups > (s.countDevice != nullptr ? kSelfSumGroupsCulled : kSelfSumGroups))
+    {
+        // long lists: exclusive scan of the group totals (and the pair total) by one workgroup, linear work
+        hipLaunchKernelGGL(scanFastKernel, dim3(1), dim3(kScanThreads), 0, stream, groups, s.countDevice, kGroup, s.waveCounts, s.waveOffsets, s.total,
+                           s.totalHostMapped);
+        groupOffsets = s.waveOffsets;
+    }
+    if (tileKeyBytes == 2) launchEmit<uint16_t>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, groupOffsets, tileKeys, values, capacity, viewSplats);
+    else launchEmit<uint32_t>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, groupOffsets, tileKeys, values, capacity, viewSplats);
     if (s.totalHostMapped == nullptr) GS_CHECK(hipMemcpyAsync(s.totalHost, s.total, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
 }
 

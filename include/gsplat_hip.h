@@ -234,6 +234,22 @@ void gs_renderer_set_pipeline(GsRenderer* r, int pipeline);
  * of 1 M at BASELINE.json configs[2] -- so most of the reference's evaluateSphericalHarmonics work is never needed.
  * GsRendererBuffers.color is brought up to date (one SH pass) when gs_renderer_buffers is called. */
 int gs_renderer_colours_on_demand(const GsRenderer* r);
+/* Addition: how the renderer STORES the splats of the next gs_renderer_set_scene.  CALLER (default): in the caller's order, like the
+ * reference (Demo.cpp:314-331).  MORTON: along a 3-D Morton curve through their positions -- the spatial ordering the reference's
+ * author names as the cure for the raster's scattered gathers (README.md:138).  Frames are byte-identical either way: splats of equal
+ * depth still blend in the caller's index order (the depth sort's ties are re-ordered by a small extra pass; runs of more than 1024
+ * splats at exactly one depth keep the storage order).  What changes is speed (profiles/r03_storage_order.txt: +3.5 % frames/s on one
+ * GPU, -15 % per band frame of an 8-way split) and the index space of everything per splat that the renderer hands out:
+ * GsRendererBuffers arrays and the `values` of the pair list are in STORAGE order; gs_renderer_storage_order gives the map. */
+#define GS_STORAGE_ORDER_CALLER 0
+#define GS_STORAGE_ORDER_MORTON 1
+void gs_renderer_set_storage_order(GsRenderer* r, int order);
+/* storageToSplat[k] = the caller's index of the splat stored in slot k (identity for CALLER); returns the splat count.  The array
+ * (splat count entries) may be NULL to query the count. */
+int32_t gs_renderer_storage_order(const GsRenderer* r, int32_t* storageToSplat);
+/* The Morton order itself (host): storageToSplat for `count` positions (x, y, z, _) -- 21 bits per axis over the bounding box, equal
+ * codes in index order. */
+void gs_morton_order(const float* position4, int32_t count, int32_t* storageToSplat);
 /* Upload a scene from host arrays (Demo.cpp:314-331). sh is [N][shCount] un-aligned (as parsePly
  * returns it) and is realigned here (Demo.cpp:291-296); may be NULL at degree 0. */
 int gs_renderer_set_scene(GsRenderer* r, int32_t splatCount, const float* position4, const float* scaleAndRotation4,

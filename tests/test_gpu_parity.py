@@ -738,6 +738,84 @@ def test_colours_on_demand_equal_the_sh_pass(gs, tmp_path, degree):
             assert np.array_equal(col, col_ref)
 
 
+def _tie_heavy_scene(gs, n=20000, planes=40, seed=3):
+    """Splats on `planes` planes of constant view depth in front of a camera looking down -z: hundreds of overlapping, fairly opaque
+    splats share every depth code, so the blend order of ties shows in the image."""
+    rng = np.random.default_rng(seed)
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, 0] = rng.uniform(-3, 3, n)
+    pos[:, 1] = rng.uniform(-2, 2, n)
+    pos[:, 2] = -0.25 * rng.integers(0, planes, n).astype(np.float32)  # exact in float: every plane is one view depth
+    pos[:, 3] = 1.0
+    sr = np.zeros((n, 4), np.float32)
+    sr[:, :3] = rng.uniform(0.05, 0.35, (n, 3))
+    sr[:, 3] = _bits_to_float(gs.encode_vec4([0.5, 0.5, 0.5, 1.0]))
+    col = rng.uniform(0, 1, (n, 4)).astype(np.float32)
+    col[:, 3] = rng.uniform(0.3, 0.9, n)
+    return pos, sr, col
+
+
+def test_morton_storage_gives_byte_identical_frames(gs, tmp_path):
+    """gs_renderer_set_storage_order(MORTON): the splats live along a Morton curve, every frame is the same bytes as with the caller's
+    order -- also where many overlapping splats share a depth code (the depth sort's ties go back into the caller's index order) --
+    and the pair list is the same list once its values are mapped through gs_renderer_storage_order.  Plain and captured frames, a
+    culled band, four views per chain; SH on demand and static colours."""
+    from cudagaussianrenderer_amd import scenes
+
+    w, h = 1280, 720
+    tie_pos, tie_sr, tie_col = _tie_heavy_scene(gs)
+    tie_cam = gs.camera_from_pose([0, 0, 6], [0, 0, 0, 1], w, h)
+    ply = _ply_scene(gs, tmp_path, 80_003, 3, log_scale_mean=-3.3)
+    ply_cams = [gs.camera_from_pose(p, q, w, h) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 4)]
+    cases = [("ties", (tie_pos, tie_sr, tie_col), [tie_cam] * 4),
+             ("ply", (ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"]), ply_cams)]
+    for name, scene, cams in cases:
+        frames = {}
+        for order in ("caller", "morton"):
+            r = gs.Renderer(w, h, storage_order=order)
+            r.set_scene(*scene)
+            perm = r.storage_order()
+            assert sorted(perm.tolist()) == list(range(len(scene[0])))
+            assert (order == "caller") == bool((perm == np.arange(len(perm))).all())
+            st = r.render(cams[0], stats=True)
+            b = r.buffers()
+            frames[order] = (r.read_image(), perm[r.download(b.values, b.tileListSize, np.int32)], st.tileListSize)
+            r.set_graph(True)
+            for cam in cams[:2]:
+                r.render(cam)
+            assert np.array_equal(r.read_image(), gs_image(gs, scene, cams[1], w, h)), (name, order, "captured")
+            r.close()
+            band = gs.Renderer(w, h, tile_rows=(13, 30), storage_order=order, views=4)
+            band.set_graph(True)
+            band.set_scene(*scene)
+            band.render_views(cams)
+            frames[order + "-band"] = [band.read_image(view=v) for v in range(4)]
+            band.close()
+        assert frames["caller"][2] == frames["morton"][2] > 0
+        assert np.array_equal(frames["caller"][0], frames["morton"][0]), name
+        assert np.array_equal(frames["caller"][1], frames["morton"][1]), name  # the same list, splat for splat
+        for v in range(4):
+            assert np.array_equal(frames["caller-band"][v], frames["morton-band"][v]), (name, v)
+            assert frames["caller-band"][v][13 * 16:30 * 16].any()
+    # the tie scene is sensitive to the order of ties: the same splats handed over in reverse index order blend differently
+    rev = gs.Renderer(w, h)
+    rev.set_scene(tie_pos[::-1].copy(), tie_sr[::-1].copy(), tie_col[::-1].copy())
+    rev.render(tie_cam)
+    reverse_image = rev.read_image()
+    rev.close()
+    fresh = gs_image(gs, (tie_pos, tie_sr, tie_col), tie_cam, w, h)
+    assert not np.array_equal(reverse_image, fresh)
+
+
+def gs_image(gs, scene, cam, w, h):
+    r = gs.Renderer(w, h)
+    r.set_scene(*scene)
+    r.render(cam)
+    img = r.read_image()
+    r.close()
+    return img
+
+
 @pytest.mark.parametrize("width,height,splats", [(1920, 1080, 150_000), (3840, 2160, 300_000)])
 def test_eight_bands_stitch_to_the_single_gpu_frame(gs, tmp_path, width, height, splats):
     """BASELINE.json configs[3] / [4] in their 8-GPU shape, one GPU standing in for each rank in turn: eight cost-balanced bands of tile

@@ -197,3 +197,24 @@ def test_band_gather_entry_points_without_a_gpu(gs):
     assert lib.gs_gather_bands(comm, C.c_void_p(16), 1920, 1080, bands, 3, None) == -1  # root outside the world
     lib.gs_comm_destroy(comm)
     assert not lib.gs_comm_create(2, 2, None)  # rank outside the world
+
+
+def test_morton_order_is_a_stable_space_filling_permutation():
+    """gs_morton_order (host): a permutation, neighbours in storage are neighbours in space, equal codes keep index order."""
+    import cudagaussianrenderer_amd as gs
+
+    rng = np.random.default_rng(2)
+    pos = rng.uniform(-4, 4, (50_000, 4)).astype(np.float32)
+    perm = gs.morton_order(pos)
+    assert perm.dtype == np.int32 and sorted(perm.tolist()) == list(range(50_000))
+    before = np.abs(np.diff(pos[:, :3], axis=0)).mean()
+    after = np.abs(np.diff(pos[perm][:, :3], axis=0)).mean()
+    assert after < 0.1 * before
+    same = np.ones((1000, 4), np.float32)
+    assert (gs.morton_order(same) == np.arange(1000)).all()
+    twice = np.concatenate([pos[:100], pos[:100]])
+    p2 = gs.morton_order(twice)
+    for k in range(100):  # the two copies of a position sit next to each other, lower index first
+        where = np.nonzero(p2 % 100 == k)[0]
+        assert len(where) == 2 and where[1] == where[0] + 1 and p2[where[0]] < p2[where[1]]
+    assert gs.morton_order(np.zeros((0, 4), np.float32)).size == 0

@@ -248,3 +248,26 @@ def test_bench_control_flow_at_world_8(tmp_path, width, height, views):
         want, _, _ = gsref.render(pos, sr, col, None, 0, 0, cams[v], width, height)
         assert want[..., :3].any()
         assert np.array_equal(got[v], want), v
+
+
+def test_watchdog_ends_a_rank_that_stops_making_progress():
+    """multigpu.Watchdog: beats keep the process alive; a stall longer than the limit prints where the rank was and exits with code 5
+    (a launcher then tears the other ranks down) -- nothing in an N-rank bench run can wait for ever."""
+    import subprocess
+
+    code = ("import sys, time\n"
+            f"sys.path.insert(0, {ROOT!r})\n"
+            "from cudagaussianrenderer_amd import multigpu\n"
+            "dog = multigpu.Watchdog(1.0, 3)\n"
+            "for i in range(4):\n"
+            "    time.sleep(0.5); dog.beat(f'chain {i}')\n"
+            "print('alive after 2 s of beats', flush=True)\n"
+            "time.sleep(30)\n"
+            "print('not reached')\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 5, (out.returncode, out.stderr[-500:])
+    assert "alive after 2 s of beats" in out.stdout and "not reached" not in out.stdout
+    assert "rank 3 made no progress" in out.stderr and "'chain 3'" in out.stderr
+    quiet = subprocess.run([sys.executable, "-c", code.replace("Watchdog(1.0, 3)", "Watchdog(0, 3)").replace("time.sleep(30)", "time.sleep(1.5)")],
+                           capture_output=True, text=True, timeout=120)
+    assert quiet.returncode == 0 and "not reached" in quiet.stdout  # limit 0 = off

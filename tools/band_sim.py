@@ -22,6 +22,7 @@ ap.add_argument("--pipeline", type=int, default=1)
 ap.add_argument("--views", type=int, default=1, help="cameras per chain of kernels (gs_renderer_set_views)")
 ap.add_argument("--rebalance", type=int, default=0, help="iterations of re-cutting the bands from their measured times")
 ap.add_argument("--gamma", type=float, default=2.0)
+ap.add_argument("--storage-order", choices=["caller", "morton"], default="morton", help="gs_renderer_set_storage_order: the caller's order, or along a 3-D Morton curve")
 ap.add_argument("--ablate", type=int, default=0, help="gs_debug_set_ablation mask for the timed frames (diagnostic: stages left out)")
 args = ap.parse_args()
 W, H = 1920, 1080
@@ -54,7 +55,7 @@ def measure(world, bands):
         streams = shared_streams
         rs = []
         for d in range(D):
-            r = gs.Renderer(W, H, tile_rows=band if world > 1 else None, band_cull=args.cull, pipeline=args.pipeline, views=args.views)
+            r = gs.Renderer(W, H, tile_rows=band if world > 1 else None, band_cull=args.cull, pipeline=args.pipeline, views=args.views, storage_order=args.storage_order)
             r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
             r.set_stream(streams[d].cuda_stream)
             r.set_graph(bool(args.graph))
