@@ -385,20 +385,20 @@ def stage_report(rig, args, stage_ms, p_mean, pc_mean, nonempty, band_tiles, ban
 
 
 def offline_counters(args, world):
-    """PMC figures of the raster kernel from the committed counter passes (profiles/r02_pmc_raster.json: separate rocprofv3
+    """PMC figures of the raster kernel from the committed counter passes (profiles/r03_pmc_raster.json: separate rocprofv3
     --pmc passes of this very workload, tools/profile_round.sh).  Counters cannot be collected from inside the timed run, so
     they are attached only when the run IS that workload and the kernel sources are the ones the counters were collected
     with (source hash); otherwise every field is null."""
     empty = {"traffic": None, "valu_issue_frac": None, "waves_per_simd": None}
     default_scene = (world == 1 and args.splats == 1_000_000 and (args.width, args.height) == (1920, 1080) and args.sh_degree == 3
                      and args.seed == 1234 and args.opacity_mean == 1.0 and args.log_scale_mean == -3.6 and not args.epanechnikov)
-    path = os.path.join(ROOT, "profiles", "r02_pmc_raster.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_raster.json")
     if not default_scene or not os.path.exists(path):
         return empty
     with open(path) as f:
         d = json.load(f)
     if d.get("source_hash") != source_hash():
-        return dict(empty, counters_note=f"profiles/r02_pmc_raster.json was collected with other kernel sources ({d.get('source_hash')})")
+        return dict(empty, counters_note=f"profiles/r03_pmc_raster.json was collected with other kernel sources ({d.get('source_hash')})")
     out = {"traffic": round(d["traffic_bytes_per_launch"]), "traffic_unit": "bytes per launch", "traffic_source": d["traffic_source"],
            "valu_issue_frac": d.get("valu_issue_frac"), "waves_per_simd": d.get("waves_per_simd"), "counters_source": d.get("sq_source")}
     return out

@@ -1,6 +1,6 @@
 #!/bin/bash
-# usage: tools/collect_profiles.sh r02   -- copies the summaries tools/profile_round.sh left in gpurun_out/ into profiles/
-TAG=${1:-r02}
+# usage: tools/collect_profiles.sh r03   -- copies the summaries tools/profile_round.sh left in gpurun_out/ into profiles/
+TAG=${1:-r03}
 G=gpurun_out
 [ -s $G/${TAG}_bench_c3.json ] && [ -s $G/${TAG}_pmc_FETCH_SIZE.txt ] || { echo "no $TAG outputs under $G (was gpurun_out/ copied back?)"; exit 1; }
 tail -1 $G/${TAG}_bench_c3.json > profiles/${TAG}_bench_c3.json
@@ -12,8 +12,16 @@ cp $G/${TAG}_pmc_FETCH_SIZE.txt profiles/${TAG}_pmc_fetch_size_kb.txt
 cp $G/${TAG}_pmc_WRITE_SIZE.txt profiles/${TAG}_pmc_write_size_kb.txt
 cat $G/${TAG}_pmc_SQ_BUSY_CYCLES.txt $G/${TAG}_pmc_SQ_ACTIVE_INST_LDS.txt $G/${TAG}_pmc_SQ_WAIT_ANY.txt > profiles/${TAG}_pmc_sq_counters.txt
 for f in band_sim band_chain_kernels ablation frame_pump raster_trace raster_trace_low_opacity micro_valu_lds_rate micro_graph_streams micro_atomic_rate micro_graph_memset; do
-  [ -f $G/${TAG}_$f.txt ] && cp $G/${TAG}_$f.txt profiles/${TAG}_$f.txt
+  [ -s $G/${TAG}_$f.txt ] && cp $G/${TAG}_$f.txt profiles/${TAG}_$f.txt
 done
+[ -s $G/${TAG}_bench_other.jsonl ] && cp $G/${TAG}_bench_other.jsonl profiles/${TAG}_bench_other.jsonl
+# the low-opacity scene (raster-dominated) and BASELINE.json configs[4] on one GPU: serial kernel statistics + counter passes
+[ -s $G/${TAG}lo_stats_serial/stats_kernel_stats.csv ] && cp $G/${TAG}lo_stats_serial/stats_kernel_stats.csv profiles/${TAG}_kernel_stats_low_opacity_serial.csv
+[ -s $G/${TAG}lo_bench_under_rocprof_serial.json ] && tail -1 $G/${TAG}lo_bench_under_rocprof_serial.json > profiles/${TAG}_bench_under_rocprof_low_opacity_serial.json
+ls $G/${TAG}lo_pmc_*.txt > /dev/null 2>&1 && cat $G/${TAG}lo_pmc_FETCH_SIZE.txt $G/${TAG}lo_pmc_WRITE_SIZE.txt $G/${TAG}lo_pmc_SQ_BUSY_CYCLES.txt $G/${TAG}lo_pmc_SQ_ACTIVE_INST_LDS.txt > profiles/${TAG}_pmc_low_opacity.txt
+[ -s $G/${TAG}c5_stats_serial/stats_kernel_stats.csv ] && cp $G/${TAG}c5_stats_serial/stats_kernel_stats.csv profiles/${TAG}_kernel_stats_c5_serial.csv
+[ -s $G/${TAG}c5_bench_under_rocprof_serial.json ] && tail -1 $G/${TAG}c5_bench_under_rocprof_serial.json > profiles/${TAG}_bench_under_rocprof_c5_serial.json
+ls $G/${TAG}c5_pmc_*.txt > /dev/null 2>&1 && cat $G/${TAG}c5_pmc_FETCH_SIZE.txt $G/${TAG}c5_pmc_WRITE_SIZE.txt > profiles/${TAG}_pmc_c5.txt
 python3 - "$TAG" <<'PY'
 import json, sys
 sys.path.insert(0, ".")

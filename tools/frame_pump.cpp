@@ -1,6 +1,7 @@
 // frame_pump.cpp -- the pipelined frame loop of bench.py driven by NATIVE host threads (one per frame in flight) straight over
 // the C ABI, to separate what the GPU can do from what the Python harness adds (GIL, futures, ctypes marshalling).
-//   frame_pump scene.ply cams.bin W H rowBegin rowEnd inflight frames [graph=1] [mask=0] [views=1]
+//   frame_pump scene.ply cams.bin W H rowBegin rowEnd inflight frames [graph=1] [mask=0] [views=1] [storage=0]
+// storage: 0 = the splats stored in the file's order, 1 = along a Morton curve (gs_renderer_set_storage_order).
 // mask: 0 = plain streams; 1 = every stream restricted to its own share of the compute units, bits dealt round-robin
 // (bit i -> stream i % inflight: with the driver's XCC-interleaved mask layout a share of whole XCDs when inflight divides 8);
 // 2 = contiguous shares of the mask (bit i -> stream i / (256 / inflight)).
@@ -29,6 +30,7 @@ int main(int argc, char** argv)
     const int graph = argc > 9 ? std::atoi(argv[9]) : 1;
     const int maskMode = argc > 10 ? std::atoi(argv[10]) : 0;
     const int views = argc > 11 ? std::atoi(argv[11]) : 1; // cameras per chain of kernels (gs_renderer_set_views)
+    const int storage = argc > 12 ? std::atoi(argv[12]) : 0;
     std::vector<GsCameraData> cams;
     {
         std::FILE* f = std::fopen(argv[2], "rb");
@@ -52,6 +54,7 @@ int main(int argc, char** argv)
         rs[d] = gs_renderer_create(W, H);
         if (views > 1 && gs_renderer_set_views(rs[d], views) != 0) return 4;
         if (rowEnd > rowBegin) gs_renderer_set_tile_rows(rs[d], rowBegin, rowEnd);
+        gs_renderer_set_storage_order(rs[d], storage ? GS_STORAGE_ORDER_MORTON : GS_STORAGE_ORDER_CALLER);
         gs_renderer_set_scene(rs[d], ply.vertexCount, ply.position, ply.scaleAndRotation, ply.color, ply.sphericalHarmonics,
                               ply.sphericalHarmonicsDegree, ply.sphericalHarmonicsCount);
         if (maskMode == 0) (void) hipStreamCreateWithFlags(&streams[d], hipStreamNonBlocking);
@@ -91,9 +94,9 @@ int main(int argc, char** argv)
     const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count() / frames;
     double launchUs = 0.0, awaitUs = 0.0;
     (void) gs_debug_host_times(&launchUs, &awaitUs, 0);
-    std::printf("{\"inflight\": %d, \"views\": %d, \"rows\": [%d, %d], \"graph\": %d, \"cu_mask\": %d, \"ms_per_frame\": %.4f, \"frames_per_s\": %.1f, "
+    std::printf("{\"inflight\": %d, \"views\": %d, \"rows\": [%d, %d], \"graph\": %d, \"cu_mask\": %d, \"morton\": %d, \"ms_per_frame\": %.4f, \"frames_per_s\": %.1f, "
                 "\"host_us_in_graph_launch\": %.1f, \"host_us_awaiting_total\": %.1f}\n",
-                D, views, rowBegin, rowEnd, graph, maskMode, ms, 1e3 / ms, launchUs, awaitUs);
+                D, views, rowBegin, rowEnd, graph, maskMode, storage, ms, 1e3 / ms, launchUs, awaitUs);
     for (int d = 0; d != D; ++d) gs_renderer_destroy(rs[d]);
     gs_free_ply(&ply);
     return 0;
