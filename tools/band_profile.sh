@@ -22,5 +22,6 @@ for r in rows:
 frames = int(sys.argv[2])  # frame_pump: 8 * D warm-up frames + 512 timed ones
 print(f"kernel time per frame ({frames} frames):", round(tot / frames / 1e3, 1), "us")
 PY
+  find $OUT/band_stats_d$D -name "*kernel_trace.csv" -delete
 done
 rm -f /tmp/gs_pump/scene.ply

@@ -10,4 +10,5 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc $COUNTERS --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$first -o pmc -- python3 $ROOT/bench.py --steps 16 --warmup 4 --cpu-frames 0 --no-extra --spin-up 0 --inflight 1 --no-graph "$@" > $OUT/${TAG}_pmc_$first.json 2> $OUT/${TAG}_pmc_$first.err
 f=$(find $OUT/${TAG}_pmc_$first -name "*counter_collection.csv" | head -1)
 python3 $ROOT/tools/pmc_summary.py $f > $OUT/${TAG}_pmc_$first.txt
+rm -rf $OUT/${TAG}_pmc_$first   # the raw per-dispatch table (gpurun_out/ travels back only below 64 MiB); the per-kernel means stay
 grep -i raster $OUT/${TAG}_pmc_$first.txt

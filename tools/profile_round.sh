@@ -58,4 +58,6 @@ GPU_MAX_HW_QUEUES=8 python3 tools/band_sim.py --worlds 8 --frames 1024 --infligh
   echo "=== tile rows 29..34, 4 frames per chain, splats in the caller's order"; tools/band_profile.sh 29 34 4 0; } > $OUT/${TAG}_band_chain_kernels.txt 2>&1; echo "band chain rc=$?"
 PUMP_MASKS=0 PUMP_DEPTHS=1,2,3,4 python3 tools/frame_pump.py GPU_MAX_HW_QUEUES=8 2>/dev/null | grep inflight > $OUT/${TAG}_frame_pump.txt
 fi
+# the per-dispatch kernel traces are large (gpurun_out/ travels back only below 64 MiB): keep the per-kernel statistics
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
 ls $OUT | grep $TAG
