@@ -740,6 +740,7 @@ def cpu_baseline_and_parity(ply, cameras, W, H, views, gpu_images, gpu_pairs, ep
         img, st, dt = frame(i)
         all_s.append(dt)
         if i == 0:
+            first_image = img
             view0.append(dt)
             for f, _ in st._fields_:
                 if f.startswith("ms"):
@@ -752,6 +753,19 @@ def cpu_baseline_and_parity(ply, cameras, W, H, views, gpu_images, gpu_pairs, ep
         consumed_oracle.append(int(st.consumedPairs))
     while len(view0) < 3 and time.perf_counter() - t_leg < 30.0:
         view0.append(frame(0)[2])
+    # the same frame on several host cores (optional): every stage of the oracle on slices of its input, bit-identical
+    # output (tests/test_oracle_golden.py); best of three.  16 threads at most: a one-GPU box's share of its host's cores
+    threads = max(1, min(16, len(os.sched_getaffinity(0)), gsref.hardware_concurrency()))
+    all_cores = None
+    if threads > 1:
+        times = []
+        for _ in range(3):
+            t = time.perf_counter()
+            img_t, _, _ = gsref.render(ply["position"], ply["scaleAndRotation"], ply["color"], sh, ply["shDegree"], ply["shCount"], cameras[0], W, H,
+                                       threads=threads)
+            times.append(time.perf_counter() - t)
+        all_cores = {"value": round(1.0 / min(times), 3), "unit": "frames/s", "cores": threads, "best_ms": round(1e3 * min(times), 1),
+                     "same_image_as_one_thread": bool(np.array_equal(img_t, first_image))}
     done = len(pairs_oracle)
     best = min(view0)
     frac = gt1 / max(total, 1)
@@ -764,6 +778,7 @@ def cpu_baseline_and_parity(ply, cameras, W, H, views, gpu_images, gpu_pairs, ep
         "sample": f"view 0 of the same 1 M-splat scene at {W}x{H}, best of {len(view0)} full frames on one thread "
                   f"(views 0..{done - 1} rendered once each for the parity check), g++ -O3 without -ffast-math",
         "best_ms": round(1e3 * best, 1), "mean_ms_over_views": round(1e3 * sum(all_s) / len(all_s), 1), "ms_by_stage_view0": per_stage,
+        "all_cores": all_cores,
     }
     parity = {
         "against": "CPU oracle (oracle/gsref.cpp), full-size frames of this run", "views": done, "max_lsb": max_lsb, "frac_gt1": frac,

@@ -11,6 +11,7 @@
 #include "gsref.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -810,6 +811,157 @@ extern "C" int gsref_render(int32_t count, const float* position4, const float* 
     t = nowMs();
     st.consumedPairs = gsref_rasterize_tiles(width, height, 0, 0, tileRange.data(), values.data(), clipXY.data(), conic.data(),
                                              color4, backBuffer);
+    st.msRasterize = nowMs() - t;
+    st.msTotal = nowMs() - t0;
+    if (stats) *stats = st;
+    return 0;
+}
+
+// ----------------------------------------------------------------------------------------------
+// The same frame on several host threads (the optional all-core CPU baseline).  Orchestration only: every
+// stage is the serial routine above on a slice of its input -- splats in contiguous chunks (multiples of the 256-splat SH group),
+// the pair list concatenated in chunk order (= the serial emission order), a parallel stable merge sort (the stable order of a key
+// sequence is unique), tile rows handed out one at a time -- so the image and the list are the serial frame's, bit for bit
+// (tests/test_oracle_golden.py).
+// ----------------------------------------------------------------------------------------------
+namespace
+{
+template <typename F>
+void forChunks(int threads, int64_t count, int64_t align, F&& body) // body(chunk, begin, end), chunks in order, one thread each
+{
+    threads = std::max(1, threads);
+    int64_t per = (count + threads - 1) / threads;
+    per = (per + align - 1) / align * align;
+    std::vector<std::thread> pool;
+    int chunk = 0;
+    for (int64_t begin = 0; begin < count; begin += per, ++chunk)
+        pool.emplace_back([=, &body] { body(chunk, begin, std::min(count, begin + per)); });
+    for (auto& th : pool) th.join();
+}
+} // namespace
+
+extern "C" int gsref_render_threads(int32_t count, const float* position4, const float* scaleAndRotation4, float* color4,
+                                    const float* sh, int shDegree, int shCount, const GsRefCameraData* camera, int width,
+                                    int height, uint8_t* backBuffer, GsRefFrameStats* stats, int threads)
+{
+    if (threads <= 1) return gsref_render(count, position4, scaleAndRotation4, color4, sh, shDegree, shCount, camera, width, height, backBuffer, stats);
+    const ScreenInfo scr = makeScreen(width, height);
+    GsRefFrameStats st{};
+    const double t0 = nowMs();
+    std::memset(backBuffer, 0, (size_t) width * height * 4);
+    std::vector<int32_t> tileRange((size_t) scr.totalTiles * 2, -1);
+    std::vector<float> clipXY((size_t) count * 2), clipZ((size_t) count), ellipse((size_t) count * 4), conic((size_t) count * 4);
+
+    double t = nowMs();
+    if (shDegree != 0)
+    {
+        // chunks start on a multiple of 256 splats: the blocked coefficient layout of a chunk then starts at sh + begin * shCount
+        forChunks(threads, count, 256, [&](int, int64_t b, int64_t e) {
+            gsref_evaluate_spherical_harmonics((int32_t) (e - b), position4 + 4 * b, sh + (size_t) b * shCount, shDegree, shCount, camera->position,
+                                               color4 + 4 * b);
+        });
+        st.msSphericalHarmonics = nowMs() - t;
+    }
+    t = nowMs();
+    forChunks(threads, count, 256, [&](int, int64_t b, int64_t e) {
+        gsref_evaluate_splat_clip_data((int32_t) (e - b), position4 + 4 * b, scaleAndRotation4 + 4 * b, camera, width, height, clipXY.data() + 2 * b,
+                                       clipZ.data() + b, ellipse.data() + 4 * b, conic.data() + 4 * b);
+    });
+    st.msClipData = nowMs() - t;
+
+    t = nowMs();
+    std::vector<int64_t> chunkPairs((size_t) threads + 1, 0), chunkBegin((size_t) threads + 1, 0);
+    forChunks(threads, count, 256, [&](int c, int64_t b, int64_t e) {
+        chunkPairs[(size_t) c] = gsref_build_tile_list((int32_t) (e - b), clipXY.data() + 2 * b, clipZ.data() + b, ellipse.data() + 4 * b, width, height,
+                                                       0, 0, nullptr, nullptr, 0);
+    });
+    int64_t size = 0;
+    for (int c = 0; c <= threads; ++c)
+    {
+        chunkBegin[(size_t) c] = size;
+        size += c < threads ? chunkPairs[(size_t) c] : 0;
+    }
+    std::vector<uint64_t> keys((size_t) size);
+    std::vector<int32_t> values((size_t) size);
+    forChunks(threads, count, 256, [&](int c, int64_t b, int64_t e) {
+        const int64_t at = chunkBegin[(size_t) c], n = chunkPairs[(size_t) c];
+        gsref_build_tile_list((int32_t) (e - b), clipXY.data() + 2 * b, clipZ.data() + b, ellipse.data() + 4 * b, width, height, 0, 0, keys.data() + at,
+                              values.data() + at, n);
+        for (int64_t j = 0; j != n; ++j) values[(size_t) (at + j)] += (int32_t) b; // chunk-local splat index -> the scene's
+    });
+    st.msBuildTileList = (nowMs() - t) * 0.5;
+    st.tileListSize = size;
+
+    // parallel stable merge sort of the permutation (sorted runs per chunk, then pairwise merges of neighbours)
+    t = nowMs();
+    {
+        const int endBit = gsref_sort_end_bit(width, height);
+        const uint64_t mask = (endBit >= 64) ? ~0ull : ((1ull << endBit) - 1ull);
+        std::vector<int64_t> order((size_t) size), scratch((size_t) size);
+        std::iota(order.begin(), order.end(), 0);
+        const auto less = [&](int64_t a, int64_t b) { return (keys[(size_t) a] & mask) < (keys[(size_t) b] & mask); };
+        std::vector<int64_t> cut;
+        int64_t per = (size + threads - 1) / std::max(threads, 1);
+        per = std::max<int64_t>(per, 1);
+        for (int64_t b = 0; b < size; b += per) cut.push_back(b);
+        cut.push_back(size);
+        {
+            std::vector<std::thread> pool;
+            for (size_t c = 0; c + 1 < cut.size(); ++c)
+                pool.emplace_back([&, c] { std::stable_sort(order.begin() + cut[c], order.begin() + cut[c + 1], less); });
+            for (auto& th : pool) th.join();
+        }
+        while (cut.size() > 2)
+        {
+            std::vector<int64_t> next;
+            std::vector<std::thread> pool;
+            for (size_t c = 0; c + 1 < cut.size(); c += 2)
+            {
+                next.push_back(cut[c]);
+                if (c + 2 < cut.size())
+                    pool.emplace_back([&, c] {
+                        std::merge(order.begin() + cut[c], order.begin() + cut[c + 1], order.begin() + cut[c + 1], order.begin() + cut[c + 2],
+                                   scratch.begin() + cut[c], less); // std::merge is stable: ties take the left run first
+                        std::copy(scratch.begin() + cut[c], scratch.begin() + cut[c + 2], order.begin() + cut[c]);
+                    });
+            }
+            next.push_back(size);
+            for (auto& th : pool) th.join();
+            cut.swap(next);
+        }
+        std::vector<uint64_t> k((size_t) size);
+        std::vector<int32_t> v((size_t) size);
+        forChunks(threads, size, 1, [&](int, int64_t b, int64_t e) {
+            for (int64_t i = b; i != e; ++i)
+            {
+                k[(size_t) i] = keys[(size_t) order[(size_t) i]];
+                v[(size_t) i] = values[(size_t) order[(size_t) i]];
+            }
+        });
+        keys.swap(k);
+        values.swap(v);
+    }
+    st.msSortTileList = nowMs() - t;
+
+    t = nowMs();
+    gsref_evaluate_tile_ranges(size, keys.data(), tileRange.data());
+    st.msTileRanges = nowMs() - t;
+    for (int i = 0; i != scr.totalTiles; ++i) st.nonEmptyTiles += (tileRange[2 * i + 1] - tileRange[2 * i]) != 0;
+
+    t = nowMs();
+    {
+        std::atomic<int> nextRow{0};
+        std::atomic<long long> consumed{0};
+        std::vector<std::thread> pool;
+        for (int w = 0; w != threads; ++w)
+            pool.emplace_back([&] {
+                for (int row = nextRow.fetch_add(1); row < scr.tilesY; row = nextRow.fetch_add(1))
+                    consumed += gsref_rasterize_tiles(width, height, row, row + 1, tileRange.data(), values.data(), clipXY.data(), conic.data(), color4,
+                                                      backBuffer);
+            });
+        for (auto& th : pool) th.join();
+        st.consumedPairs = consumed.load();
+    }
     st.msRasterize = nowMs() - t;
     st.msTotal = nowMs() - t0;
     if (stats) *stats = st;

@@ -107,6 +107,11 @@ int64_t gsref_rasterize_tiles(int width, int height, int tileRowBegin, int tileR
 int gsref_render(int32_t count, const float* position4, const float* scaleAndRotation4, float* color4,
                  const float* sh, int shDegree, int shCount, const GsRefCameraData* camera, int width,
                  int height, uint8_t* backBuffer, GsRefFrameStats* stats);
+/* The same frame on `threads` host threads (the optional all-core baseline of SURVEY.md section 8(d)): every stage is the serial routine on
+ * a slice of its input, so image, list and counts are the serial frame's bit for bit. */
+int gsref_render_threads(int32_t count, const float* position4, const float* scaleAndRotation4, float* color4, const float* sh,
+                         int shDegree, int shCount, const GsRefCameraData* camera, int width, int height, uint8_t* backBuffer,
+                         GsRefFrameStats* stats, int threads);
 
 /* CameraControls.cpp:132-146 + 79-96 + Demo.cpp:377-392: default pose for a bounding box. */
 void gsref_camera_from_bounds(const float boundsMin[3], const float boundsMax[3], int width, int height,

@@ -197,8 +197,9 @@ def set_footprint(epanechnikov):
     lib().gsref_set_footprint(1 if epanechnikov else 0)
 
 
-def render(position, scale_and_rotation, color, sh_aligned, sh_degree, sh_count, camera, width, height):
-    """Demo.cpp:394-479 on the CPU. Returns (image HxWx4 uint8, FrameStats, colour actually used)."""
+def render(position, scale_and_rotation, color, sh_aligned, sh_degree, sh_count, camera, width, height, threads=1):
+    """Demo.cpp:394-479 on the CPU. Returns (image HxWx4 uint8, FrameStats, colour actually used).  threads > 1: the same frame, bit
+    for bit, with every stage spread over that many host threads (the all-core baseline)."""
     pos, pp = _f(position)
     sr, srp = _f(scale_and_rotation)
     col = np.ascontiguousarray(color, dtype=np.float32).copy()
@@ -208,8 +209,12 @@ def render(position, scale_and_rotation, color, sh_aligned, sh_degree, sh_count,
         sp = None
     img = np.zeros((height, width, 4), np.uint8)
     st = FrameStats()
-    rc = lib().gsref_render(pos.shape[0], pp, srp, _p(col, C.c_float), sp, int(sh_degree), int(sh_count),
-                            C.byref(camera), int(width), int(height), _p(img, C.c_uint8), C.byref(st))
+    if threads > 1:
+        rc = lib().gsref_render_threads(pos.shape[0], pp, srp, _p(col, C.c_float), sp, int(sh_degree), int(sh_count),
+                                        C.byref(camera), int(width), int(height), _p(img, C.c_uint8), C.byref(st), int(threads))
+    else:
+        rc = lib().gsref_render(pos.shape[0], pp, srp, _p(col, C.c_float), sp, int(sh_degree), int(sh_count),
+                                C.byref(camera), int(width), int(height), _p(img, C.c_uint8), C.byref(st))
     assert rc == 0
     return img, st, col
 

@@ -182,3 +182,25 @@ def test_glm_primitives_match_glm_itself_bit_for_bit(gsref, golden_dir):
             assert np.array_equal(got[~nan_both], want[~nan_both]), (name, row, got.tolist())
             checked += 1
     assert checked >= 1800
+
+
+@pytest.mark.parametrize("degree,threads", [(0, 3), (3, 8)])
+def test_threaded_oracle_frame_is_the_serial_frame(gsref, tmp_path, degree, threads):
+    """gsref_render_threads (the all-core CPU baseline of bench.py) only slices the serial stages' inputs: image, pair count, consumed
+    entries and non-empty tiles are the serial frame's, bit for bit -- ragged splat count (not a multiple of the 256-splat SH group),
+    1080p-shaped tiles (half-height last tile row)."""
+    import cudagaussianrenderer_amd as gs
+    from cudagaussianrenderer_amd import scenes
+
+    w, h = 480, 270
+    path = str(tmp_path / "s.ply")
+    scenes.write_synthetic_ply(path, 20_011, sh_degree=degree, seed=5, log_scale_mean=-3.0)
+    ply = gsref.parse_ply(path)
+    sh = gs.realign_spherical_harmonics(ply["sh"], ply["shCount"], ply["vertexCount"]) if degree else None
+    cam = gsref.camera_from_bounds(ply["boundsMin"], ply["boundsMax"], w, h)
+    args = (ply["position"], ply["scaleAndRotation"], ply["color"], sh, ply["shDegree"], ply["shCount"], cam, w, h)
+    want, st, col = gsref.render(*args)
+    got, st_t, col_t = gsref.render(*args, threads=threads)
+    assert want[..., :3].any() and st.tileListSize > 20_000
+    assert np.array_equal(got, want) and np.array_equal(col_t, col)
+    assert (st_t.tileListSize, st_t.consumedPairs, st_t.nonEmptyTiles) == (st.tileListSize, st.consumedPairs, st.nonEmptyTiles)
