@@ -44,7 +44,10 @@ cd $ROOT
 tools/pmc_pass.sh ${TAG}c5 "FETCH_SIZE" $C5
 tools/pmc_pass.sh ${TAG}c5 "WRITE_SIZE" $C5
 tools/bench_other.sh $TAG
-for m in valu_lds_rate graph_streams; do [ -x tools/micro/$m ] && timeout -k 5 200 tools/micro/$m > $OUT/${TAG}_micro_$m.txt 2>/dev/null; done
+# the micro benchmarks are built here from their sources (never a binary that happens to lie around)
+for m in valu_lds_rate graph_streams lds_atomic_order; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/micro/$m.hip -o /tmp/micro_$m -lpthread 2>/dev/null && timeout -k 5 200 /tmp/micro_$m > $OUT/${TAG}_micro_$m.txt 2>/dev/null
+done
 python3 tools/raster_trace.py --frames 3 2>/dev/null > $OUT/${TAG}_raster_trace.txt
 python3 tools/raster_trace.py --frames 3 --opacity-mean -3 2>/dev/null > $OUT/${TAG}_raster_trace_low_opacity.txt
 fi
