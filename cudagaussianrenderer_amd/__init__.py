@@ -276,13 +276,18 @@ class Renderer:
         if tile_rows is not None:
             lib().gs_renderer_set_tile_rows(self.handle, tile_rows[0], tile_rows[1])
         if pipeline is not None:
-            lib().gs_renderer_set_pipeline(self.handle, pipeline)
+            self.set_pipeline(pipeline)
         if band_cull is not None:  # 0 auto (on for a strict sub-band of tile rows), 1 on, 2 off
             lib().gs_renderer_set_band_cull(self.handle, band_cull)
         if storage_order is not None:  # STORAGE_ORDER_CALLER / STORAGE_ORDER_MORTON, or "caller" / "morton"
             order = {"caller": STORAGE_ORDER_CALLER, "file": STORAGE_ORDER_CALLER, "morton": STORAGE_ORDER_MORTON}.get(storage_order, storage_order)
             lib().gs_renderer_set_storage_order(self.handle, int(order))
         self.splat_count = 0
+
+    def set_pipeline(self, pipeline):
+        """PIPELINE_REFERENCE is refused while the renderer holds a scene stored in Morton order (it breaks depth ties by storage order)."""
+        if lib().gs_renderer_set_pipeline(self.handle, int(pipeline)) != 0:
+            raise ValueError("gs_renderer_set_pipeline: the reference-shaped pipeline cannot run on a scene stored in Morton order")
 
     def set_scene(self, position, scale_and_rotation, color, sh=None, sh_degree=0, sh_count=0):
         pos, sr, col = _f32(position), _f32(scale_and_rotation), _f32(color)

@@ -169,7 +169,7 @@ SIGNATURES = {
     "gs_renderer_create": (C.c_void_p, [C.c_int, C.c_int]),
     "gs_renderer_destroy": (None, [C.c_void_p]),
     "gs_renderer_set_tile_rows": (None, [C.c_void_p, C.c_int, C.c_int]),
-    "gs_renderer_set_pipeline": (None, [C.c_void_p, C.c_int]),
+    "gs_renderer_set_pipeline": (C.c_int, [C.c_void_p, C.c_int]),
     "gs_renderer_set_band_cull": (None, [C.c_void_p, C.c_int]),
     "gs_renderer_set_scene": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                         C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int]),

@@ -53,9 +53,9 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
     {
         if (!(g_ablation & 1))
             launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
-                                nullptr, nullptr, nullptr, nullptr, r->depthKey[0],
-                                (uint32_t*) r->order[0], nullptr, nullptr, nullptr, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord,
-                                (float4*) r->rasterRecord, views);
+                                nullptr, nullptr, nullptr, nullptr, r->splatToStorage != nullptr ? nullptr : r->depthKey[0],
+                                r->splatToStorage != nullptr ? nullptr : (uint32_t*) r->order[0], nullptr, nullptr, nullptr, r->paramsDevice, clearTable,
+                                clearEntries, (float4*) r->tileRecord, (float4*) r->rasterRecord, views);
     }
     else
     {
@@ -64,7 +64,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
                             r->bandSlotPrefix, r->bandCounts, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord, (float4*) r->rasterRecord,
                             views);
         launchBandCompaction(g.stream, n, views, r->bandMask, r->bandSlotPrefix, r->bandCounts, r->bandOffsets, r->bandTotal, r->clipZ, r->depthKey[0],
-                             (uint32_t*) r->order[0]);
+                             (uint32_t*) r->order[0], r->splatToStorage, r->bandMaskCaller);
         countDevice = (const int*) r->bandTotal;
         if (r->shDegree != 0 && !lazy)
             launchSphericalHarmonicsGather(g.stream, n, countDevice, r->shDegree, r->shCount, r->order[0], (const float4*) r->position,
@@ -72,14 +72,18 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
     }
     r->radix.countDevice = countDevice;
     r->scratch.countDevice = countDevice;
-    const int orderSel = (g_ablation & 2) ? 0 : launchRadixSortPairs(g.stream, r->radix, 4, r->depthKey[0], r->depthKey[1], r->order[0], r->order[1], nv, 0, kDepthKeyBits);
-    int fixedSel = orderSel;
-    if (r->storageToSplat != nullptr && !(g_ablation & 2)) // ties of the depth sort back into the caller's order (gs_radix.hip)
-    {
-        launchDepthTieFix(g.stream, nv, countDevice, r->depthKey[orderSel], r->order[orderSel], r->order[orderSel ^ 1], r->storageToSplat, n);
-        fixedSel = orderSel ^ 1;
-    }
-    const uint32_t* order = (const uint32_t*) r->order[fixedSel];
+    // (Morton storage, no cull: the sort's input is in the caller's order -- its first pass makes the keys from the caller-ordered
+    // positions and the cameras on the device; the culled list was compacted in that order already)
+    DepthKeySource keySource;
+    keySource.positionCaller = (const float4*) r->positionCaller;
+    keySource.params = r->paramsDevice;
+    keySource.splatsPerView = n;
+    const bool callerOrderedInput = !cull && r->splatToStorage != nullptr;
+    const int orderSel = (g_ablation & 2) ? 0
+                                          : launchRadixSortPairs(g.stream, r->radix, 4, r->depthKey[0], r->depthKey[1], r->order[0], r->order[1], nv, 0,
+                                                                 kDepthKeyBits, callerOrderedInput ? r->splatToStorage : nullptr,
+                                                                 callerOrderedInput ? &keySource : nullptr);
+    const uint32_t* order = (const uint32_t*) r->order[orderSel];
     if (!(g_ablation & 4)) launchTileListFastCount(g.stream, nv, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch);
     if (!(g_ablation & 8))
         launchTileListFastEmit(g.stream, nv, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],
@@ -88,11 +92,13 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
     const int* pairCount = (const int*) r->scratch.total;
     r->radix.countDevice = pairCount;
     r->scratch.countDevice = nullptr;
+    // (the last pass of the tile sort leaves the tile ranges: no range kernel, gs_radix.hip)
+    r->radix.rangeTableForLastPass = (g_ablation & 32) ? nullptr : r->tileRange;
     const int sel = (g_ablation & 16) ? 0
                                       : launchRadixSortPairs(g.stream, r->radix, tileKeyBytes, r->keys[0], r->keys[1], r->values[0], r->values[1],
                                                              r->tileListCapacity, 0, tBits);
     r->radix.countDevice = nullptr;
-    if (!(g_ablation & 32)) launchTileRanges(g.stream, r->tileListCapacity, tileKeyBytes, r->keys[sel], r->tileRange, pairCount);
+    r->radix.rangeTableForLastPass = nullptr;
     if (!(g_ablation & 64))
         launchRasterize(g.stream, scr, r->tileRange, r->values[sel], (const float2*) r->clipXY, (const float4*) r->conic,
                         (const float4*) r->color, (uchar4*) r->backBuffer, nullptr, true, lazyColours, (const float4*) r->rasterRecord, views, n);
@@ -114,6 +120,7 @@ int64_t awaitPairTotal(GsRenderer* r)
 {
     volatile int64_t* word = r->scratch.totalHost;
     std::chrono::steady_clock::time_point t0;
+    bool clockStarted = false; // (the spin counter wraps: the start of the wait is taken once)
     for (unsigned spins = 0;; ++spins)
     {
         const int64_t v = *word;
@@ -136,7 +143,11 @@ int64_t awaitPairTotal(GsRenderer* r)
                        hipGetErrorString(status));
                 exit(EXIT_FAILURE);
             }
-            if (spins == 63u) t0 = std::chrono::steady_clock::now();
+            if (!clockStarted)
+            {
+                t0 = std::chrono::steady_clock::now();
+                clockStarted = true;
+            }
             else if ((spins & 0xFFFFu) == 0xFFFFu &&
                      std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > g_awaitTimeoutSeconds)
             {

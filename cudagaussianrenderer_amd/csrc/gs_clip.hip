@@ -4,12 +4,23 @@
 // 32 B read + 44 B written per splat, one splat per lane with 16-byte coalesced loads/stores.
 // The arithmetic follows the reference's order (covariance = (R S)(R S)^T, para-perspective
 // Jacobian, J W Sigma^T (J W)^T, trace bump, eigen decomposition, conic = Sigma^-1) on plain floats;
-// glm's 3x3 products are written out so the symmetric halves are not recomputed.
+// glm's 3x3 products are written out, entry by entry in glm's left-to-right order (type_mat3x3.inl:486-520), so the
+// symmetric halves are not recomputed and the terms glm multiplies by a structural zero are left out (they only ever add +-0).
+//
+// Floating-point contraction is OFF in this file: every operation rounds as written, division and square root are
+// IEEE-correct (no -ffast-math), so centre, depth, conic and extents are the same IEEE values the CPU oracle computes with
+// glm's operand order (tests/test_gpu_parity.py: _check_clip compares them for equality).  The kernel is HBM-bound, the
+// unfused multiplies and adds cost nothing measurable (profiles/r04_clip_contract_off.txt).  It also makes the arithmetic
+// independent of the context it is inlined into: the band kernel, the full-frame kernel and the all-views kernel give
+// the same bits.
 //
 // One deliberate simplification: the reference stores (cos(atan2(e.y,e.x)), sin(atan2(e.y,e.x)))
 // of the NORMALISED principal eigenvector e; that is e itself, which is what is stored here.
 #include "gs_aabb.h"
+#include "gs_depth_key.h"
 #include "gs_internal.h"
+
+#pragma clang fp contract(off)
 
 namespace gs
 {
@@ -20,56 +31,6 @@ struct Sym3
 {
     float xx, xy, xz, yy, yz, zz;
 };
-
-// Quantised depth of getKey() (GaussianRender.cu:446-454; (uint32) of 2^32 saturated) re-coded on kDepthKeyBits = 27 bits.
-// q = floor(n * 2^32) with n a float in [0, 1] has at most 24 significant bits: for q >= 2^23 the bits below (top bit - 23)
-// are zero, so (class = top bit position - 22, the 23 bits after the top bit) is a lossless, order-preserving code; q < 2^23
-// is its own code (class 0); the saturated 0xFFFFFFFF of n == 1 (the only value with 32 significant bits) gets class 10.
-__device__ __forceinline__ uint32_t compactDepthKey(float clipDepth)
-{
-    const float n01 = fminf(fmaxf((clipDepth + 1.0f) * 0.5f, 0.0f), 1.0f);
-    const float scaled = n01 * 4294967296.0f;
-    if (scaled >= 4294967296.0f) return 10u << 23;
-    const uint32_t q = (uint32_t) scaled;
-    if (q < (1u << 23)) return q;
-    const int top = 31 - __clz((int) q);
-    return ((uint32_t) (top - 22) << 23) | ((q >> (top - 23)) & 0x7FFFFFu);
-}
-
-// View-space centre and the para-perspective terms every later step needs (GaussianRender.cu:227-259,265).  ONE routine for the
-// band cull's early test and for the projection proper, so that both see the same clip position bit for bit.
-struct ViewTerms
-{
-    float vx, vy, vz, zRcp, zRcpSqr, scaleX, scaleY, cotTrsX, cotTrsY, shearX, shearY;
-    float clipX, clipY, clipDepth;
-    bool inside; // centre-in-frustum test of GaussianRender.cu:316-321 (without its lambda1 term, which never fails: lambda1 >= 0)
-};
-__device__ __forceinline__ ViewTerms viewTerms(const float4 pd, const ClipCamera& cam)
-{
-    ViewTerms t;
-    // View-space centre (GaussianRender.cu:227); v[col*4+row].
-    const float* v = cam.view;
-    t.vx = (v[0] * pd.x + v[4] * pd.y) + (v[8] * pd.z + v[12]);
-    t.vy = (v[1] * pd.x + v[5] * pd.y) + (v[9] * pd.z + v[13]);
-    t.vz = (v[2] * pd.x + v[6] * pd.y) + (v[10] * pd.z + v[14]);
-    // Para-perspective Jacobian (GaussianRender.cu:236-259).
-    t.zRcp = 1.0f / t.vz;
-    t.zRcpSqr = t.zRcp * t.zRcp;
-    t.scaleX = -cam.fovCotX * t.zRcp;
-    t.scaleY = -cam.fovCotY * t.zRcp;
-    t.cotTrsX = cam.fovCotX * t.vx;
-    t.cotTrsY = cam.fovCotY * t.vy;
-    t.shearX = t.cotTrsX * t.zRcpSqr;
-    t.shearY = t.cotTrsY * t.zRcpSqr;
-    // Clip position = J * (view pos, 1) (GaussianRender.cu:265): x = scaleX*vx + shearX*vz + translationX.
-    t.clipX = (t.scaleX * t.vx + 0.0f * t.vy) + (t.shearX * t.vz + (-t.cotTrsX * t.zRcp));
-    t.clipY = (0.0f * t.vx + t.scaleY * t.vy) + (t.shearY * t.vz + (-t.cotTrsY * t.zRcp));
-    t.clipDepth = (0.0f * t.vx + 0.0f * t.vy) + (cam.depthScale * t.vz + cam.depthBias);
-    // Centre-in-frustum cull (GaussianRender.cu:316-321). step(edge,x) = x < edge ? 0 : 1, so NaN passes, as in glm.
-    t.inside = !(t.clipX < -1.0f) && !(1.0f < t.clipX) && !(t.clipY < -1.0f) && !(1.0f < t.clipY) && !(t.clipDepth < -1.0f) &&
-               !(1.0f < t.clipDepth);
-    return t;
-}
 
 // What the kernel writes per (virtual) splat; null pointers are outputs nobody asked for.
 struct ClipOutputs
@@ -165,9 +126,9 @@ __device__ __forceinline__ bool projectSplat(const float4 pd, const float4 sr, c
     const bool inside = t.inside && !(lambda1 < 0.0f);
     const float isVisible = inside ? 1.0f : 0.0f;
     // mix(-128, clip, v) = -128*(1-v) + clip*v ; extent *= v  (kept as arithmetic so inf/NaN propagate as in the reference)
-    clipX = -128.0f * (1.0f - isVisible) + clipX * isVisible;
-    clipY = -128.0f * (1.0f - isVisible) + clipY * isVisible;
-    clipDepth = -128.0f * (1.0f - isVisible) + clipDepth * isVisible;
+    clipX = mixInvisible(clipX, isVisible);
+    clipY = mixInvisible(clipY, isVisible);
+    clipDepth = mixInvisible(clipDepth, isVisible);
     extentX *= isVisible;
     extentY *= isVisible;
 
@@ -183,9 +144,10 @@ __device__ __forceinline__ bool projectSplat(const float4 pd, const float4 sr, c
     if (o.depthKey != nullptr)
     {
         // Quantised depth of getKey() (GaussianRender.cu:446-454) as a sort key of its own (27-bit code, see above), plus
-        // the identity permutation: the one-call renderer sorts SPLATS by depth before expanding them to tiles.
+        // the identity permutation: the one-call renderer sorts SPLATS by depth before expanding them to tiles.  (A renderer with
+        // Morton storage hands the sort its own input order -- caller index -> slot -- instead: no identity list, gs_radix.hip.)
         o.depthKey[out] = compactDepthKey(clipDepth);
-        o.splatOrder[out] = (uint32_t) out;
+        if (o.splatOrder != nullptr) o.splatOrder[out] = (uint32_t) out;
     }
     if (o.clipXY != nullptr) o.clipXY[out] = make_float2(clipX, clipY);
     if (o.clipZ != nullptr) o.clipZ[out] = clipDepth;
@@ -270,23 +232,59 @@ __global__ __launch_bounds__(256) void splatClipBandKernel(int count, Screen scr
     }
 }
 
+// Morton storage: the keep-masks of the band cull, re-gathered in the CALLER's order (lane = caller index c, one bit fetched from
+// the storage-ordered mask of slot splatToStorage[c]; the 0.5 MB of masks are L2-resident), with the same per-slot prefixes and
+// per-workgroup counts the clip kernel leaves in storage order.  The compaction then runs over the caller's order, the stable depth
+// sort keeps splats of equal depth code in it, and the frame is the one a renderer with the caller's storage order gives -- for any
+// number of equal codes (round 3 repaired the order after the sort, up to runs of 1024).
+__global__ __launch_bounds__(256) void bandCallerMaskKernel(int count, const int32_t* __restrict__ splatToStorage,
+                                                             const unsigned long long* __restrict__ bandMask,
+                                                             unsigned long long* __restrict__ callerMask, int32_t* __restrict__ bandSlotPrefix,
+                                                             int32_t* __restrict__ bandBlockCounts)
+{
+    __shared__ int slotKept[kBandSlots];
+    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
+    const int index = blockIdx.x * blockDim.x + t; // caller's index
+    const int view = blockIdx.y;
+    const int blockBase = blockIdx.x * kBandBlock;
+    const int slotsPerView = (count + kWave - 1) / kWave, blocksPerView = (count + kBandBlock - 1) / kBandBlock;
+    bool kept = false;
+    if (index < count)
+    {
+        const int stored = splatToStorage[index];
+        kept = ((bandMask[view * slotsPerView + (stored >> 6)] >> (stored & (kWave - 1))) & 1ull) != 0ull;
+    }
+    const unsigned long long mask = __ballot(kept);
+    if (lane == 0) slotKept[wave] = __popcll(mask);
+    __syncthreads();
+    if (lane == 0 && blockBase + wave * kWave < count)
+    {
+        int prefix = 0;
+        for (int s = 0; s < wave; ++s) prefix += slotKept[s];
+        callerMask[view * slotsPerView + (blockBase >> 6) + wave] = mask;
+        bandSlotPrefix[view * slotsPerView + (blockBase >> 6) + wave] = prefix;
+        if (wave == 0) bandBlockCounts[view * blocksPerView + blockIdx.x] = slotKept[0] + slotKept[1] + slotKept[2] + slotKept[3];
+    }
+}
+
 // Order-preserving compaction of the splats flagged by the band cull: depth key + (virtual) splat index of every kept splat at
-// blockOffsets[block of 256 splats] + (kept splats of the block's earlier slots) + (kept lanes below it).
+// blockOffsets[block of 256 splats] + (kept splats of the block's earlier slots) + (kept lanes below it).  With Morton storage the
+// masks are the caller-ordered ones and lane c compacts the splat stored in slot splatToStorage[c].
 __global__ __launch_bounds__(256) void compactBandKernel(int count, const unsigned long long* __restrict__ bandMask,
                                                           const int32_t* __restrict__ bandSlotPrefix, const int32_t* __restrict__ blockOffsets,
-                                                          const float* __restrict__ clipZ, uint32_t* __restrict__ depthKey,
-                                                          uint32_t* __restrict__ splatOrder)
+                                                          const float* __restrict__ clipZ, const int32_t* __restrict__ splatToStorage,
+                                                          uint32_t* __restrict__ depthKey, uint32_t* __restrict__ splatOrder)
 {
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= count) return;
     const int view = blockIdx.y;
-    const int out = view * count + index; // virtual splat (see the clip kernel)
     const int slotsPerView = (count + kWave - 1) / kWave, blocksPerView = (count + kBandBlock - 1) / kBandBlock;
     const int slot = view * slotsPerView + (index >> 6);
     const int lane = index & (kWave - 1);
     const unsigned long long mask = bandMask[slot]; // wave-uniform: scalar loads
     if ((mask >> lane) & 1ull)
     {
+        const int out = view * count + (splatToStorage != nullptr ? splatToStorage[index] : index); // virtual splat (see the clip kernel)
         const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
         const int pos = blockOffsets[view * blocksPerView + index / kBandBlock] + bandSlotPrefix[slot] + __popcll(mask & lower);
         depthKey[pos] = compactDepthKey(clipZ[out]);
@@ -328,15 +326,22 @@ void launchUnpackEllipse(hipStream_t stream, int count, const float4* tileRecord
     if (count > 0) hipLaunchKernelGGL(unpackEllipseKernel, dim3((count + 255) / 256), dim3(256), 0, stream, count, tileRecord, screenEllipse);
 }
 
-void launchBandCompaction(hipStream_t stream, int count, int views, const unsigned long long* bandMask, const int32_t* bandSlotPrefix,
-                          const int32_t* bandBlockCounts, int32_t* bandBlockOffsets, int64_t* bandTotal, const float* clipZ,
-                          uint32_t* depthKey, uint32_t* splatOrder)
+void launchBandCompaction(hipStream_t stream, int count, int views, const unsigned long long* bandMask, int32_t* bandSlotPrefix,
+                          int32_t* bandBlockCounts, int32_t* bandBlockOffsets, int64_t* bandTotal, const float* clipZ,
+                          uint32_t* depthKey, uint32_t* splatOrder, const int32_t* splatToStorage, unsigned long long* callerMask)
 {
     if (count <= 0) return;
     const int blocks = (count + kBandBlock - 1) / kBandBlock;
+    if (splatToStorage != nullptr)
+    {
+        // Morton storage: masks, slot prefixes and block counts once more, in the caller's order
+        hipLaunchKernelGGL(bandCallerMaskKernel, dim3(blocks, views), dim3(256), 0, stream, count, splatToStorage, bandMask, callerMask,
+                           bandSlotPrefix, bandBlockCounts);
+        bandMask = callerMask;
+    }
     launchScanInt32(stream, blocks * views, bandBlockCounts, bandBlockOffsets, bandTotal);
     hipLaunchKernelGGL(compactBandKernel, dim3((count + 255) / 256, views), dim3(256), 0, stream, count, bandMask, bandSlotPrefix,
-                       bandBlockOffsets, clipZ, depthKey, splatOrder);
+                       bandBlockOffsets, clipZ, splatToStorage, depthKey, splatOrder);
 }
 
 void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const ClipCamera& cam, const float4* position,

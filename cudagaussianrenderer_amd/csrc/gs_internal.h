@@ -74,7 +74,8 @@ void launchSphericalHarmonics(hipStream_t stream, int count, int degree, int shC
 
 void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const ClipCamera& cam, const float4* position,
                          const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic,
-                         uint32_t* depthKeyOrNull, uint32_t* splatOrderOrNull, unsigned long long* bandMaskOrNull = nullptr,
+                         uint32_t* depthKeyOrNull, uint32_t* splatOrderOrNull /* identity list beside the depth keys; may be null */,
+                         unsigned long long* bandMaskOrNull = nullptr,
                          int32_t* bandSlotPrefixOrNull = nullptr, int32_t* bandBlockCountsOrNull = nullptr,
                          const FrameParams* paramsDeviceOrNull = nullptr,
                          int32_t* rangeTableToClearOrNull = nullptr, int rangeEntries = 0, float4* tileRecordOrNull = nullptr,
@@ -86,10 +87,12 @@ void launchUnpackEllipse(hipStream_t stream, int count, const float4* tileRecord
 void launchUnpackRasterRecord(hipStream_t stream, int count, const float4* rasterRecord, float2* clipXY, float* clipZ, float4* conic);
 // Band cull (multi-GPU): the clip kernel flags the splats whose tile AABB reaches this GPU's rows (per 64 splats one 64-bit mask
 // and the kept splats before them in their block of 256, one count per block); this scans the block counts and writes the kept
-// splats' depth keys and (virtual) indices, order preserved, and their number to *bandTotal.
-void launchBandCompaction(hipStream_t stream, int count, int views, const unsigned long long* bandMask, const int32_t* bandSlotPrefix,
-                          const int32_t* bandBlockCounts, int32_t* bandBlockOffsets, int64_t* bandTotal, const float* clipZ,
-                          uint32_t* depthKey, uint32_t* splatOrder);
+// splats' depth keys and (virtual) indices, order preserved, and their number to *bandTotal.  Morton storage: splatToStorage
+// (caller's index -> storage slot) and a second mask array; the compaction then runs in the CALLER's order (gs_clip.hip).
+void launchBandCompaction(hipStream_t stream, int count, int views, const unsigned long long* bandMask, int32_t* bandSlotPrefix,
+                          int32_t* bandBlockCounts, int32_t* bandBlockOffsets, int64_t* bandTotal, const float* clipZ,
+                          uint32_t* depthKey, uint32_t* splatOrder, const int32_t* splatToStorageOrNull = nullptr,
+                          unsigned long long* callerMaskOrNull = nullptr);
 // Exclusive scan of n int32 on the device (one workgroup), total as int64.
 void launchScanInt32(hipStream_t stream, int n, const int32_t* in, int32_t* out, int64_t* total);
 // SH colour for the splats of a device-side index list only; coefficients in the [splat][shCount] layout.
@@ -109,6 +112,7 @@ struct TileListScratch
     // renderer's builder: hit masks of the count pass (one byte per lane and round, the first rounds of every group of
     // 256 splats), replayed by the emit pass instead of repeating the overlap tests
     uint8_t* hitMasks = nullptr;
+    void* boxRecords = nullptr; // int4 per depth-sorted splat: the tile box the count pass found, for the emit pass
     int32_t capacityMaskGroups = 0;
     // optional: (clip x, y, cos, sin | extent x, y, 0, 0) per splat as one 32-byte record (written by the clip kernel);
     // when set, the renderer's builders read it instead of clipXY + screenEllipse
@@ -152,18 +156,32 @@ struct RadixScratch
     // Optional device-side element count (<= the host-side n the grids are sized for); set per call by the renderer
     // when the splat list was culled on the device, nullptr otherwise.
     const int* countDevice = nullptr;
+    // Tile range table (int32[2 * tiles], preset to -1) that the LAST pass of the next sort fills from its scatter -- the key is then the
+    // tile index and no range kernel is needed (GaussianRender.cu:857-888); set per call by the renderer, null otherwise.
+    int32_t* rangeTableForLastPass = nullptr;
 };
 bool radixSortSupported(int keyBytes, int n);
 void ensureRadixScratch(RadixScratch& s, int n);
 void freeRadixScratch(RadixScratch& s);
+// First pass of the depth sort of a renderer with Morton storage: where the keys come from when they are made by the sort itself
+// (gs_radix.hip, KEYGEN): the caller-ordered positions and the camera(s).
+struct DepthKeySource
+{
+    const float4* positionCaller = nullptr; // position of the splat with caller index c
+    const FrameParams* params = nullptr;    // captured frames: the cameras live on the device, one per view
+    ClipCamera camera{};                    // otherwise
+    int splatsPerView = 0;
+};
 // Returns the selector (0/1) of the buffer pair holding the sorted data (input is buffer 0).
+// inputValues (optional, n entries, only read): the values of the input instead of values0.  keySource (optional; 27-bit depth sort
+// only): the input keys are not in keys0 yet -- the first pass computes key i from the caller-ordered positions and leaves it in keys0[i].
+// Together: element i = (depth code of the splat with caller index i, its storage slot inputValues[i]) -- the input is in the CALLER's
+// order, and a stable sort leaves equal keys in input order: ties blend in the caller's index order however the splats are stored.
 int launchRadixSortPairs(hipStream_t stream, RadixScratch& s, int keyBytes, void* keys0, void* keys1, int32_t* values0, int32_t* values1,
-                         int n, int beginBit, int endBit);
-
-// After the depth sort of a renderer whose splats are NOT stored in the caller's order: entries with equal keys re-ordered by the
-// caller's index (gs_radix.hip).  orderIn/orderOut: the sorted (virtual) storage slots, two different buffers.
-void launchDepthTieFix(hipStream_t stream, int n, const int* countDevice, const uint32_t* sortedKeys, const int32_t* orderIn, int32_t* orderOut,
-                       const int32_t* storageToSplat, int splatsPerView);
+                         int n, int beginBit, int endBit, const int32_t* inputValues = nullptr, const DepthKeySource* keySource = nullptr);
+// The same input sequence materialised from storage-ordered keys (for the rocPRIM backend, which has no such hook):
+// keysOut[i] = keysIn[inputOrder[i]], valuesOut[i] = inputOrder[i].
+void launchGatherSortInput(hipStream_t stream, int n, const uint32_t* keysIn, const int32_t* inputOrder, uint32_t* keysOut, int32_t* valuesOut);
 
 // keyBytes 8: tile = key >> 32 (the reference's keys); 2 or 4: the key is the tile index.
 // sizeDevice (optional): the list length lives on the device (captured frame); `size` is then the upper bound the grid covers.

@@ -1,5 +1,5 @@
 // gs_radix.hip -- stable LSD radix sort of (16/32-bit key, 32-bit value) pairs for the renderer's two sorts
-// (splats by 32-bit depth key; depth-ordered pairs by 13-15 tile bits).
+// (splats by the 27-bit depth code; depth-ordered pairs by 13-15 tile bits).
 //
 // rocPRIM's device radix sort stays behind the drop-in sortTileList (64-bit keys, gs_sort.hip).  For the
 // renderer's element counts (1 M splats, ~5 M pairs) it spends most of its time outside the streaming
@@ -13,6 +13,9 @@
 //                     running counters in LDS), reordered by digit in LDS, and written out as runs of consecutive
 //                     addresses (base = exclusive scan of the 256 digit totals + the scanned table entry).
 // HBM traffic per pass and element: key read twice, value read once, key + value written once.
+#include <type_traits>
+
+#include "gs_depth_key.h"
 #include "gs_internal.h"
 
 namespace gs
@@ -55,26 +58,48 @@ __device__ __forceinline__ unsigned long long matchDigit(int digit, bool valid)
 // table[digit][tile] (a single tile per workgroup would scatter 256 four-byte stores a row apart).
 constexpr int kHistTiles = 4;
 
-template <typename K, int BITS, int ITEMS>
-__global__ __launch_bounds__(kThreads) void radixHistogramKernel(const K* __restrict__ keys, int nHost, const int* __restrict__ nDevice, int shift,
-                                                                  int skewed, int32_t* __restrict__ table, int stride)
+// KEYGEN (first pass of the depth sort of a renderer with Morton storage): the keys do not exist yet -- element i = v * N + c is the
+// splat with CALLER index c in view v; its depth code is computed here from the caller-ordered copy of the positions
+// (gs_depth_key.h: the very routine the clip kernel uses) and stored to `keysOut` for the scatter of this pass.  The sort's
+// input is thereby in the caller's order without a single gathered or scattered access, and a stable sort leaves equal depth
+// codes in input order: ties blend in the caller's index order however the splats are stored.
+// A plain histogram workgroup (256 lanes) walks its kHistTiles tiles in turn.  Counting them side by side, one 256-lane quarter each,
+// was measured in round 4: the kernel is at its floor either way (5.6 against 5.7 us at 1 M keys) and the 1024-lane workgroups cost
+// the pipelined frame loop 3 % (profiles/r04_ab_histogram.txt) -- kept only for the key-generating variant, whose per-element
+// arithmetic (a projection and an IEEE division) would otherwise run four tiles deep on a wave that has its SIMD to itself.
+struct NoKeySource
 {
+};
+template <bool KEYGEN>
+constexpr int kHistThreadsFor = KEYGEN ? kThreads * 4 : kThreads;
+template <typename SOURCE>
+constexpr bool kIsKeySource = !std::is_same<SOURCE, NoKeySource>::value;
+
+template <typename K, int BITS, int ITEMS, typename SOURCE>
+__global__ __launch_bounds__(kHistThreadsFor<kIsKeySource<SOURCE>>) void radixHistogramKernel(
+    const K* __restrict__ keys, SOURCE source, K* __restrict__ keysOut, int nHost, const int* __restrict__ nDevice, int shift, int skewed,
+    int32_t* __restrict__ table, int stride)
+{
+    constexpr bool KEYGEN = kIsKeySource<SOURCE>;
+    constexpr int kHistThreads = kHistThreadsFor<KEYGEN>;
+    constexpr bool kParallelTiles = KEYGEN;
     constexpr int kTile = kThreads * ITEMS;
     constexpr int DIGITS = BITS > 8 ? 2 * kDigits : kDigits; // 9-bit digits: every lane owns two bins
+    static_assert(kHistTiles == 4, "four tiles per workgroup: one 16-byte table store per digit");
     __shared__ int hist[kHistTiles][DIGITS];
-    const int t = threadIdx.x;
+    const int t = threadIdx.x & (kThreads - 1); // lane within the tile's quarter
     // The element count may live on the device (the renderer's band-culled splat list): nHost is then only the
     // upper bound the grid was sized for; tiles past the real count do nothing.
     const int n = nDevice ? min(*nDevice, nHost) : nHost;
     const int firstTile = blockIdx.x * kHistTiles;
     if (firstTile * kTile >= n) return;
 #pragma unroll
-    for (int j = 0; j != kHistTiles; ++j)
-#pragma unroll
-        for (int d = t; d < DIGITS; d += kThreads) hist[j][d] = 0;
+    for (int d = threadIdx.x; d < kHistTiles * DIGITS; d += kHistThreads) (&hist[0][0])[d] = 0;
     __syncthreads();
-    for (int j = 0; j != kHistTiles; ++j)
+    constexpr int kTilesPerQuarter = kParallelTiles ? 1 : kHistTiles;
+    for (int turn = 0; turn != kTilesPerQuarter; ++turn)
     {
+        const int j = kParallelTiles ? (int) (threadIdx.x / kThreads) : turn;
         const int base = (firstTile + j) * kTile;
         if (base >= n) break;
         int* h = hist[j];
@@ -82,8 +107,8 @@ __global__ __launch_bounds__(kThreads) void radixHistogramKernel(const K* __rest
         // Counting does not care which lane sees which key: full tiles are read 16 bytes per lane (ITEMS consecutive keys
         // when they fill a multiple of 16 bytes), the ragged last tile element by element.
         constexpr bool kWide = (sizeof(K) * ITEMS) % 16 == 0;
-        const bool wide = kWide && base + kTile <= n;
-        if constexpr (kWide)
+        const bool wide = !KEYGEN && kWide && base + kTile <= n;
+        if constexpr (kWide && !KEYGEN)
         {
             if (wide)
             {
@@ -95,7 +120,42 @@ __global__ __launch_bounds__(kThreads) void radixHistogramKernel(const K* __rest
                 __builtin_memcpy(key, v, sizeof(key));
             }
         }
-        if (!wide)
+        if constexpr (KEYGEN)
+        {
+            float4 pos[ITEMS];
+            int view[ITEMS];
+            const auto viewOf = [&](int i) {
+                int v = 0;
+#pragma unroll
+                for (int w = 1; w != kMaxViews; ++w) v += (i >= w * source.splatsPerView) ? 1 : 0;
+                return v;
+            };
+#pragma unroll
+            for (int r = 0; r != ITEMS; ++r) // all loads in flight before the first use
+            {
+                const int i = base + r * kThreads + t;
+                view[r] = viewOf(i);
+                pos[r] = (i < n) ? source.positionCaller[i - view[r] * source.splatsPerView] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            // the camera: a kernel argument, or the device-resident one of the tile's view (captured frames) through scalar loads --
+            // only a tile that straddles two views of a chain reads it lane by lane
+            const int viewFirst = viewOf(base), viewLast = viewOf(min(base + kTile, n) - 1);
+            if (source.params == nullptr || viewFirst == viewLast)
+            {
+                const ClipCamera cam = source.params != nullptr ? source.params[__builtin_amdgcn_readfirstlane(viewFirst)].camera : source.camera;
+#pragma unroll
+                for (int r = 0; r != ITEMS; ++r) key[r] = (K) depthKeyOfSplat(pos[r], cam);
+            }
+            else
+            {
+#pragma unroll
+                for (int r = 0; r != ITEMS; ++r) key[r] = (K) depthKeyOfSplat(pos[r], source.params[view[r]].camera);
+            }
+#pragma unroll
+            for (int r = 0; r != ITEMS; ++r)
+                if (base + r * kThreads + t < n) keysOut[base + r * kThreads + t] = key[r];
+        }
+        else if (!wide)
         {
 #pragma unroll
             for (int r = 0; r != ITEMS; ++r) // all loads in flight before the first use
@@ -147,7 +207,7 @@ __global__ __launch_bounds__(kThreads) void radixHistogramKernel(const K* __rest
     __syncthreads();
     // [digit][tile]: every digit's row is contiguous for the scan; stride is a multiple of 4, so the quad is aligned
 #pragma unroll
-    for (int d = t; d < DIGITS; d += kThreads)
+    for (int d = threadIdx.x; d < DIGITS; d += kHistThreads)
         *reinterpret_cast<int4*>(table + (size_t) d * stride + firstTile) = make_int4(hist[0][d], hist[1][d], hist[2][d], hist[3][d]);
 }
 
@@ -206,7 +266,7 @@ template <typename K, int BITS, int ITEMS>
 __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restrict__ keysIn, const int32_t* __restrict__ valuesIn,
                                                                 K* __restrict__ keysOut, int32_t* __restrict__ valuesOut, int nHost, const int* __restrict__ nDevice,
                                                                 int shift, const int32_t* __restrict__ scanned,
-                                                                const int32_t* __restrict__ totals, int stride)
+                                                                const int32_t* __restrict__ totals, int stride, int32_t* __restrict__ rangeTable)
 {
     constexpr int kTile = kThreads * ITEMS;
     constexpr int kDigitMask = (1 << BITS) - 1;
@@ -364,6 +424,15 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
             const int pos = globalBase[digit] + (j - localBase[digit]);
             keysOut[pos] = k;
             valuesOut[pos] = sVals[j];
+            if (rangeTable != nullptr)
+            {
+                // The last pass of the renderer's tile sort finds the tile ranges itself (GaussianRender.cu:857-888; no range kernel):
+                // the workgroup's elements of one key sit together in LDS with ascending output positions, so the first of them
+                // bids for the range's begin (unsigned min against the preset -1 = 0xFFFFFFFF) and the last for its end (signed max
+                // against -1).  ~0.7 M fire-and-forget atomics per frame at C3; tiles without pairs keep (-1, -1) (Demo.cpp:403).
+                if (j == 0 || sKeys[j - 1] != k) atomicMin((unsigned*) &rangeTable[2 * (int) k], (unsigned) pos);
+                if (j == tileCount - 1 || sKeys[j + 1] != k) atomicMax(&rangeTable[2 * (int) k + 1], pos + 1);
+            }
         }
     }
 }
@@ -371,13 +440,24 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
 int itemsPerLane(int n) { return n <= kSmallLimit ? kItemsSmall : kItemsLarge; }
 
 template <typename K, int BITS, int ITEMS>
-void runPassItems(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, K* keysOut, int32_t* valuesOut, int n, int shift,
-                  bool skewed, RadixScratch& s)
+void runPassItems(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, const DepthKeySource* keySource, K* keysOut, int32_t* valuesOut, int n,
+                  int shift, bool skewed, RadixScratch& s, int32_t* lastPassRanges)
 {
     constexpr int kTile = kThreads * ITEMS;
     const int numTiles = (n + kTile - 1) / kTile;
     const int stride = (numTiles + 3) & ~3; // tiles per digit row of the tables
-    hipLaunchKernelGGL((radixHistogramKernel<K, BITS, ITEMS>), dim3((numTiles + kHistTiles - 1) / kHistTiles), dim3(kThreads), 0, stream, keysIn, n, s.countDevice, shift, skewed ? 1 : 0, s.table, stride);
+    const dim3 histGrid((numTiles + kHistTiles - 1) / kHistTiles);
+
+    if constexpr (sizeof(K) == 4 && BITS == kMaxDigitBits)
+    {
+        // the depth sort's first pass may have to make its keys itself (Morton storage): they land in keysIn, where the scatter reads them
+        if (keySource != nullptr)
+            hipLaunchKernelGGL((radixHistogramKernel<K, BITS, ITEMS, DepthKeySource>), histGrid, dim3(kHistThreadsFor<true>), 0, stream, keysIn, *keySource,
+                               const_cast<K*>(keysIn), n, s.countDevice, shift, 0, s.table, stride);
+    }
+    if (keySource == nullptr || !(sizeof(K) == 4 && BITS == kMaxDigitBits))
+        hipLaunchKernelGGL((radixHistogramKernel<K, BITS, ITEMS, NoKeySource>), histGrid, dim3(kHistThreadsFor<false>), 0, stream, keysIn, NoKeySource{},
+                           (K*) nullptr, n, s.countDevice, shift, skewed ? 1 : 0, s.table, stride);
 #ifndef GS_SCAN_ROW_LIMIT
 #define GS_SCAN_ROW_LIMIT 4096 // A/B builds: 0 = always 1024 lanes
 #endif
@@ -386,37 +466,38 @@ void runPassItems(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, 
     else
         hipLaunchKernelGGL(radixColumnScanKernel<1024>, dim3(BITS > 8 ? 2 * kDigits : kDigits), dim3(1024), 0, stream, n, s.countDevice, kTile, stride, s.table, s.scanned, s.chunkTotals);
     hipLaunchKernelGGL((radixScatterKernel<K, BITS, ITEMS>), dim3(8 * ((numTiles + 7) / 8)), dim3(kThreads), 0, stream, keysIn, valuesIn, keysOut,
-                       valuesOut, n, s.countDevice, shift, s.scanned, s.chunkTotals, stride);
+                       valuesOut, n, s.countDevice, shift, s.scanned, s.chunkTotals, stride, lastPassRanges);
 }
 
 template <typename K, int BITS>
-void runPass(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, K* keysOut, int32_t* valuesOut, int n, int shift,
-             bool skewed, RadixScratch& s)
+void runPass(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, const DepthKeySource* keySource, K* keysOut, int32_t* valuesOut, int n,
+             int shift, bool skewed, RadixScratch& s, int32_t* lastPassRanges)
 {
-    if (n <= kSmallLimit) runPassItems<K, BITS, kItemsSmall>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s);
-    else runPassItems<K, BITS, kItemsLarge>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s);
+    if (n <= kSmallLimit) runPassItems<K, BITS, kItemsSmall>(stream, keysIn, valuesIn, keySource, keysOut, valuesOut, n, shift, skewed, s, lastPassRanges);
+    else runPassItems<K, BITS, kItemsLarge>(stream, keysIn, valuesIn, keySource, keysOut, valuesOut, n, shift, skewed, s, lastPassRanges);
 }
 
 template <typename K>
-void runPassBits(hipStream_t stream, int bits, const K* keysIn, const int32_t* valuesIn, K* keysOut, int32_t* valuesOut, int n,
-                 int shift, bool skewed, RadixScratch& s)
+void runPassBits(hipStream_t stream, int bits, const K* keysIn, const int32_t* valuesIn, const DepthKeySource* keySource, K* keysOut, int32_t* valuesOut,
+                 int n, int shift, bool skewed, RadixScratch& s, int32_t* lastPassRanges)
 {
     switch (bits)
     {
-    case 1: runPass<K, 1>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
-    case 2: runPass<K, 2>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
-    case 3: runPass<K, 3>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
-    case 4: runPass<K, 4>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
-    case 5: runPass<K, 5>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
-    case 6: runPass<K, 6>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
-    case 7: runPass<K, 7>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
-    case 8: runPass<K, 8>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
-    default: runPass<K, 9>(stream, keysIn, valuesIn, keysOut, valuesOut, n, shift, skewed, s); break;
+    case 1: runPass<K, 1>(stream, keysIn, valuesIn, keySource, keysOut, valuesOut, n, shift, skewed, s, lastPassRanges); break;
+    case 2: runPass<K, 2>(stream, keysIn, valuesIn, keySource, keysOut, valuesOut, n, shift, skewed, s, lastPassRanges); break;
+    case 3: runPass<K, 3>(stream, keysIn, valuesIn, keySource, keysOut, valuesOut, n, shift, skewed, s, lastPassRanges); break;
+    case 4: runPass<K, 4>(stream, keysIn, valuesIn, keySource, keysOut, valuesOut, n, shift, skewed, s, lastPassRanges); break;
+    case 5: runPass<K, 5>(stream, keysIn, valuesIn, keySource, keysOut, valuesOut, n, shift, skewed, s, lastPassRanges); break;
+    case 6: runPass<K, 6>(stream, keysIn, valuesIn, keySource, keysOut, valuesOut, n, shift, skewed, s, lastPassRanges); break;
+    case 7: runPass<K, 7>(stream, keysIn, valuesIn, keySource, keysOut, valuesOut, n, shift, skewed, s, lastPassRanges); break;
+    case 8: runPass<K, 8>(stream, keysIn, valuesIn, keySource, keysOut, valuesOut, n, shift, skewed, s, lastPassRanges); break;
+    default: runPass<K, 9>(stream, keysIn, valuesIn, keySource, keysOut, valuesOut, n, shift, skewed, s, lastPassRanges); break;
     }
 }
 
 template <typename K>
-int sortT(hipStream_t stream, K* keys0, K* keys1, int32_t* values0, int32_t* values1, int n, int beginBit, int endBit, RadixScratch& s)
+int sortT(hipStream_t stream, K* keys0, K* keys1, int32_t* values0, int32_t* values1, int n, int beginBit, int endBit, RadixScratch& s,
+          const int32_t* inputValues, const DepthKeySource* keySource)
 {
     // As few passes as 9-bit digits allow (512 bins, two per lane: the 27-bit compact depth keys sort in three passes), the bits
     // spread evenly over them (13 tile bits -> 7 + 6, not 8 + 5): fewer digits per pass means longer runs of consecutive
@@ -430,162 +511,34 @@ int sortT(hipStream_t stream, K* keys0, K* keys1, int32_t* values0, int32_t* val
         const int bits = (left + (passes - pass) - 1) / (passes - pass);
         K* kin = sel ? keys1 : keys0;
         K* kout = sel ? keys0 : keys1;
-        int32_t* vin = sel ? values1 : values0;
+        // (first pass: the values may come from a constant list of the caller's -- it is only read)
+        const int32_t* vin = sel ? values1 : (pass == 0 && inputValues != nullptr ? inputValues : values0);
         int32_t* vout = sel ? values0 : values1;
         // the top digit of a multi-pass sort of tile indices is shared by most neighbours: count it through ballots
         const bool skewed = sizeof(K) == 2 && passes > 1 && pass == passes - 1 && bits < 8;
-        runPassBits<K>(stream, bits, kin, vin, kout, vout, n, shift, skewed, s);
+        runPassBits<K>(stream, bits, kin, vin, pass == 0 ? keySource : nullptr, kout, vout, n, shift, skewed, s,
+                       pass == passes - 1 ? s.rangeTableForLastPass : nullptr);
         shift += bits;
         sel ^= 1;
     }
     return sel;
 }
 
-// Ties of the depth sort, re-ordered by the CALLER's splat index.  The sort is stable, so splats with equal depth codes come out in
-// the order they were stored in; a renderer that stores its splats along a Morton curve (gs_renderer_set_storage_order) must still
-// break ties the way a renderer with the caller's order does -- by the caller's index -- or two overlapping splats of equal depth
-// would blend in another order.  Ties are the rule, not the exception: getKey's (z + 1) / 2 in float leaves ~0.8 M distinct codes
-// for the 1 M splats of the bench scene, 38 % of the entries sit in a run of two to about twenty equal keys.
-//
-// One lane per sorted position.  A workgroup stages its 256 (key, entry) pairs and kTieHalo neighbours on both sides in LDS; every
-// staged entry that has an equal neighbour fetches its caller index ONCE (one gather per tied entry instead of one per pair of run
-// members) and leaves it in LDS too; a lane then finds its run in the window, counts the members that precede its own entry in the
-// caller's order and stores its entry at that rank.  A run that reaches beyond the halo takes a loop over global memory, in slices
-// whose loads are in flight together (the lane that walks the longest run sets the kernel's duration); runs of more than kMaxTieRun
-// entries (a scene with thousands of splats at exactly one depth) keep the storage order -- every lane of a run comes to the same
-// verdict.  No atomics, no order-dependent step.  Measured at 1 M entries: 15 us, of which 6 are the launch floor and the rest four
-// dependent memory round trips per wave, two rounds of waves (profiles/r03_storage_order.txt).  Key 0 is the code of the splats outside the frustum (clip depth -128), which emit
-// no pairs: their run -- the longest of every frame -- is copied as it is.  Several views per chain: a key's entries of view 0 come
-// first, then view 1's, ... (stable sort, view-major input), and only entries of ONE view can meet in a tile: the run that matters is
-// (key, view).
-constexpr int kMaxTieRun = 1024;
-constexpr int kTieHalo = 16; // a run of up to 16 entries is always resolved from the LDS window
-__global__ __launch_bounds__(256) void depthTieFixKernel(int nHost, const int* __restrict__ nDevice, const uint32_t* __restrict__ keys,
-                                                         const int32_t* __restrict__ orderIn, int32_t* __restrict__ orderOut,
-                                                         const int32_t* __restrict__ storageToSplat, int splatsPerView, int views)
+__global__ __launch_bounds__(256) void gatherSortInputKernel(int n, const uint32_t* __restrict__ keysIn, const int32_t* __restrict__ inputOrder,
+                                                             uint32_t* __restrict__ keysOut, int32_t* __restrict__ valuesOut)
 {
-    constexpr int kWindow = 256 + 2 * kTieHalo;
-    __shared__ uint32_t sKey[kWindow + 2]; // one sentinel on either side
-    __shared__ int sOrd[kWindow + 2];
-    __shared__ int sCaller[kWindow + 2];   // caller index of the entries that sit in a run (view-local)
-    const int n = nDevice ? min(*nDevice, nHost) : nHost;
-    const int t = threadIdx.x, base = blockIdx.x * 256;
-    if (base >= n) return; // whole workgroup
-    for (int idx = t; idx < kWindow + 2; idx += 256)
-    {
-        const int g = base - kTieHalo - 1 + idx;
-        const bool live = g >= 0 && g < n && idx != 0 && idx != kWindow + 1;
-        sKey[idx] = live ? keys[g] : 0xFFFFFFFFu; // (no key has 32 bits: the ends of the window end every run)
-        sOrd[idx] = live ? orderIn[g] : -1;
-    }
-    __syncthreads();
-    // view of a (virtual) entry; one view: no division
-    const auto viewBase = [&](int entry) { return views > 1 ? (entry / splatsPerView) * splatsPerView : 0; };
-    const auto tied = [&](int a, int b) { return sKey[a] == sKey[b] && (views == 1 || viewBase(sOrd[a]) == viewBase(sOrd[b])); };
-    for (int idx = 1 + t; idx <= kWindow; idx += 256)
-    {
-        // (an entry at the window's edge is only asked about the neighbour the window holds: a run that leaves the window is not
-        // resolved from it anyway)
-        const bool inRun = sKey[idx] != 0u && sOrd[idx] >= 0 && (tied(idx, idx - 1) || tied(idx, idx + 1));
-        if (inRun) sCaller[idx] = storageToSplat[sOrd[idx] - viewBase(sOrd[idx])];
-    }
-    __syncthreads();
-    const int i = base + t, l = t + kTieHalo + 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t key = sKey[l];
-    const int mine = sOrd[l];
-    int before = 0, after = 0; // run members left / right of this lane, as far as the window shows
-    if (key != 0u)
-    {
-        while (before < kTieHalo && tied(l, l - before - 1)) ++before;
-        while (after < kTieHalo && tied(l, l + after + 1)) ++after;
-    }
-    if (before + after == 0)
-    {
-        orderOut[i] = mine;
-        return;
-    }
-    const int firstOfView = viewBase(mine), lastOfView = firstOfView + splatsPerView - 1;
-    const int own = sCaller[l];
-    if (before < kTieHalo && after < kTieHalo)
-    {
-        // the whole run lies inside the window: rank among its members
-        int rank = 0;
-        for (int d = 1; d <= before; ++d) rank += sCaller[l - d] < own ? 1 : 0;
-        for (int d = 1; d <= after; ++d) rank += sCaller[l + d] < own ? 1 : 0;
-        orderOut[i - before + rank] = mine;
-        return;
-    }
-    // a run that leaves the window: its extent from global memory, as far as kMaxTieRun entries either way
-    const auto same = [&](int j) { return keys[j] == key && orderIn[j] >= firstOfView && orderIn[j] <= lastOfView; };
-    // (sixteen entries per step, their loads in flight together: the lane that walks the longest run sets the kernel's duration)
-    int begin = i - before, end = i + after + 1;
-    for (bool more = true; more && begin > 0 && i - begin < kMaxTieRun;)
-    {
-        uint32_t k16[16];
-        int o16[16];
-#pragma unroll
-        for (int k = 0; k != 16; ++k)
-        {
-            const int j = max(begin - 1 - k, 0);
-            k16[k] = keys[j];
-            o16[k] = orderIn[j];
-        }
-        int run = 0;
-#pragma unroll
-        for (int k = 0; k != 16; ++k)
-            if (run == k && begin - 1 - k >= 0 && k16[k] == key && o16[k] >= firstOfView && o16[k] <= lastOfView) run = k + 1;
-        begin -= run;
-        more = run == 16;
-    }
-    for (bool more = true; more && end < n && end - i <= kMaxTieRun;)
-    {
-        uint32_t k16[16];
-        int o16[16];
-#pragma unroll
-        for (int k = 0; k != 16; ++k)
-        {
-            const int j = min(end + k, n - 1);
-            k16[k] = keys[j];
-            o16[k] = orderIn[j];
-        }
-        int run = 0;
-#pragma unroll
-        for (int k = 0; k != 16; ++k)
-            if (run == k && end + k < n && k16[k] == key && o16[k] >= firstOfView && o16[k] <= lastOfView) run = k + 1;
-        end += run;
-        more = run == 16;
-    }
-    // the same verdict in every lane of a run: its two ends were found AND it is at most kMaxTieRun entries long (a lane in the middle
-    // of a longer run may see both ends where a lane at its edge cannot)
-    const bool whole = (begin == 0 || !same(begin - 1)) && (end == n || !same(end)) && end - begin <= kMaxTieRun;
-    if (!whole)
-    {
-        orderOut[i] = mine;
-        return;
-    }
-    int rank = 0;
-    for (int j = begin; j < end; j += 16) // sixteen members at a time: their entries first, then their caller indices, each set in flight together
-    {
-        int member[16];
-#pragma unroll
-        for (int k = 0; k != 16; ++k) member[k] = j + k < end ? orderIn[j + k] : mine;
-#pragma unroll
-        for (int k = 0; k != 16; ++k) member[k] = storageToSplat[member[k] - firstOfView];
-#pragma unroll
-        for (int k = 0; k != 16; ++k) rank += member[k] < own ? 1 : 0;
-    }
-    orderOut[begin + rank] = mine;
+    const int src = inputOrder[i];
+    keysOut[i] = keysIn[src];
+    valuesOut[i] = src;
 }
 
 } // namespace
 
-void launchDepthTieFix(hipStream_t stream, int n, const int* countDevice, const uint32_t* sortedKeys, const int32_t* orderIn, int32_t* orderOut,
-                       const int32_t* storageToSplat, int splatsPerView)
+void launchGatherSortInput(hipStream_t stream, int n, const uint32_t* keysIn, const int32_t* inputOrder, uint32_t* keysOut, int32_t* valuesOut)
 {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(depthTieFixKernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, countDevice, sortedKeys, orderIn, orderOut,
-                       storageToSplat, splatsPerView, (n + splatsPerView - 1) / splatsPerView);
+    if (n > 0) hipLaunchKernelGGL(gatherSortInputKernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, keysIn, inputOrder, keysOut, valuesOut);
 }
 
 bool radixSortSupported(int keyBytes, int n) { return (keyBytes == 2 || keyBytes == 4) && n >= 0; }
@@ -615,12 +568,14 @@ void freeRadixScratch(RadixScratch& s)
 }
 
 int launchRadixSortPairs(hipStream_t stream, RadixScratch& s, int keyBytes, void* keys0, void* keys1, int32_t* values0, int32_t* values1,
-                         int n, int beginBit, int endBit)
+                         int n, int beginBit, int endBit, const int32_t* inputValues, const DepthKeySource* keySource)
 {
     if (n <= 0 || endBit <= beginBit) return 0;
     ensureRadixScratch(s, n);
-    if (keyBytes == 2) return sortT<uint16_t>(stream, (uint16_t*) keys0, (uint16_t*) keys1, values0, values1, n, beginBit, endBit, s);
-    return sortT<uint32_t>(stream, (uint32_t*) keys0, (uint32_t*) keys1, values0, values1, n, beginBit, endBit, s);
+    if (keyBytes == 2) return sortT<uint16_t>(stream, (uint16_t*) keys0, (uint16_t*) keys1, values0, values1, n, beginBit, endBit, s, inputValues, nullptr);
+    // (key generation is the depth sort's: 32-bit keys whose first pass is a 9-bit one)
+    if (keySource != nullptr && !(beginBit == 0 && endBit == kDepthKeyBits)) keySource = nullptr;
+    return sortT<uint32_t>(stream, (uint32_t*) keys0, (uint32_t*) keys1, values0, values1, n, beginBit, endBit, s, inputValues, keySource);
 }
 
 } // namespace gs

@@ -67,11 +67,14 @@ void freeScene(GsRenderer* r)
     {
         // the read-only inputs are the owner's
         r->position = r->scaleAndRotation = r->sh = r->shPerSplat = nullptr;
-        r->storageToSplat = nullptr;
+        r->splatToStorage = nullptr;
+        r->positionCaller = nullptr;
         r->sceneShared = false;
     }
-    gs_device_free(r->storageToSplat);
-    r->storageToSplat = nullptr;
+    gs_device_free(r->splatToStorage);
+    gs_device_free(r->positionCaller);
+    r->splatToStorage = nullptr;
+    r->positionCaller = nullptr;
     r->storageToSplatHost.clear();
     float** bufs[] = {&r->position, &r->scaleAndRotation, &r->color,   &r->sh,         &r->clipXY,
                       &r->clipZ,    &r->conic,            &r->ellipse, &r->tileRecord, &r->rasterRecord};
@@ -89,12 +92,13 @@ void freeScene(GsRenderer* r)
     }
     gs_device_free(r->shPerSplat);
     gs_device_free(r->bandMask);
+    gs_device_free(r->bandMaskCaller);
     gs_device_free(r->bandCounts);
     gs_device_free(r->bandSlotPrefix);
     gs_device_free(r->bandOffsets);
     gs_device_free(r->bandTotal);
     r->shPerSplat = nullptr;
-    r->bandMask = nullptr;
+    r->bandMask = r->bandMaskCaller = nullptr;
     r->bandCounts = r->bandOffsets = r->bandSlotPrefix = nullptr;
     r->bandTotal = nullptr;
 }
@@ -182,10 +186,16 @@ extern "C" void gs_renderer_set_tile_rows(GsRenderer* r, int begin, int end)
     r->rowEnd = end;
 }
 
-extern "C" void gs_renderer_set_pipeline(GsRenderer* r, int pipeline)
+extern "C" int gs_renderer_set_pipeline(GsRenderer* r, int pipeline)
 {
+    // The reference-shaped pipeline emits its pairs in storage order and breaks depth ties by it (one stable sort on tile | depth):
+    // with a scene stored along the Morton curve its frames would differ from the caller-order frames wherever splats of equal depth
+    // overlap.  A scene set while this pipeline is selected is stored in the caller's order whatever the storage option says; switching
+    // to it with a Morton-stored scene in place is refused.
+    if (pipeline == GS_PIPELINE_REFERENCE && r->splatToStorage != nullptr) return -1;
     r->pipeline = pipeline == GS_PIPELINE_REFERENCE ? pipeline : GS_PIPELINE_TWO_LEVEL;
     r->graphValid = false;
+    return 0;
 }
 
 extern "C" int gs_renderer_colours_on_demand(const GsRenderer* r) { return useLazyColours(r) ? 1 : 0; }
@@ -218,6 +228,7 @@ void allocateSceneIntermediates(GsRenderer* r, int32_t n)
     }
     const size_t waves = (((size_t) n + kWave - 1) / kWave) * (size_t) r->views;
     r->bandMask = (unsigned long long*) gs_device_alloc(sizeof(unsigned long long) * waves);
+    if (r->splatToStorage != nullptr) r->bandMaskCaller = (unsigned long long*) gs_device_alloc(sizeof(unsigned long long) * waves);
     r->bandCounts = (int32_t*) gs_device_alloc(sizeof(int32_t) * waves);
     r->bandSlotPrefix = (int32_t*) gs_device_alloc(sizeof(int32_t) * waves);
     r->bandOffsets = (int32_t*) gs_device_alloc(sizeof(int32_t) * waves);
@@ -245,8 +256,10 @@ extern "C" int gs_renderer_set_scene(GsRenderer* r, int32_t n, const float* posi
     const size_t f4 = sizeof(float) * 4 * (size_t) n;
     // Storage order (gs_renderer_set_storage_order): the splats are uploaded in the caller's order, or along a Morton curve through
     // their positions -- neighbours in space become neighbours in memory, which is what the band cull of a multi-GPU rank, the
-    // gathers of the tile-list passes and the raster kernel's L2 hit rate live on.  Frames are the same bytes either way (the depth
-    // sort's ties are put back into the caller's order, gs_radix.hip: depthTieFixKernel).
+    // gathers of the tile-list passes and the raster kernel's L2 hit rate live on.  Frames are the same bytes either way: the
+    // depth sort takes its input in the CALLER's order (its first pass makes the keys itself from a caller-ordered copy of the
+    // positions, gs_radix.hip), so the stable sort breaks ties by the caller's index.
+    // The reference-shaped pipeline emits its pairs in storage order and sorts them once on (tile | depth): it keeps the caller's order.
     std::vector<float> ordered;
     const auto inStorageOrder = [&](const float* src, size_t floatsPerSplat) -> const float* {
         if (r->storageToSplatHost.empty() || src == nullptr) return src;
@@ -256,12 +269,19 @@ extern "C" int gs_renderer_set_scene(GsRenderer* r, int32_t n, const float* posi
                         sizeof(float) * floatsPerSplat);
         return ordered.data();
     };
-    if (r->storageOrder == GS_STORAGE_ORDER_MORTON && n > 1)
+    if (r->storageOrder == GS_STORAGE_ORDER_MORTON && r->pipeline != GS_PIPELINE_REFERENCE && n > 1)
     {
         r->storageToSplatHost.resize((size_t) n);
         gs_morton_order(position4, n, r->storageToSplatHost.data());
-        r->storageToSplat = (int32_t*) gs_device_alloc(sizeof(int32_t) * (size_t) n);
-        gs_device_upload(r->storageToSplat, r->storageToSplatHost.data(), sizeof(int32_t) * (size_t) n);
+        // caller index -> (virtual) slot, once per view of a chain: the depth sort's input order
+        std::vector<int32_t> inverse((size_t) n * (size_t) r->views);
+        for (int v = 0; v != r->views; ++v)
+            for (int32_t k = 0; k != n; ++k) inverse[(size_t) v * n + (size_t) r->storageToSplatHost[(size_t) k]] = v * n + k;
+        r->splatToStorage = (int32_t*) gs_device_alloc(sizeof(int32_t) * inverse.size());
+        gs_device_upload(r->splatToStorage, inverse.data(), sizeof(int32_t) * inverse.size());
+        // ... and the positions in the caller's order, from which its first pass makes the keys (gs_radix.hip, KEYGEN)
+        r->positionCaller = (float*) gs_device_alloc(f4);
+        gs_device_upload(r->positionCaller, position4, f4);
     }
     r->position = (float*) gs_device_alloc(f4);
     r->scaleAndRotation = (float*) gs_device_alloc(f4);
@@ -316,9 +336,12 @@ extern "C" int gs_renderer_share_scene(GsRenderer* r, const GsRenderer* owner)
     r->sh = owner->sh;
     r->shPerSplat = owner->shPerSplat;
     r->storageOrder = owner->storageOrder;
-    r->storageToSplat = owner->storageToSplat;
+    if (owner->splatToStorage != nullptr && owner->views != r->views) return -1; // (the order list is laid out per view)
+    r->splatToStorage = owner->splatToStorage;
+    r->positionCaller = owner->positionCaller;
     r->storageToSplatHost = owner->storageToSplatHost;
     r->sceneShared = true;
+    if (r->splatToStorage != nullptr) r->pipeline = GS_PIPELINE_TWO_LEVEL; // (see gs_renderer_set_pipeline)
     allocateSceneIntermediates(r, n);
     if (n > 0) GS_CHECK(hipMemcpy(r->color, owner->color, sizeof(float) * 4 * (size_t) n, hipMemcpyDeviceToDevice));
     return 0;
@@ -552,10 +575,12 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         const int* countDevice = nullptr;
         if (!cull)
         {
+            // (Morton storage on the native sort: no keys from here -- the depth sort's first pass makes them in the caller's order)
+            const bool keysFromSort = r->splatToStorage != nullptr && cfg.sortBackend == GS_SORT_BACKEND_NATIVE && radixSortSupported(4, n);
             launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation,
-                                nullptr, nullptr, nullptr, nullptr, r->depthKey[0],
-                                (uint32_t*) r->order[0], nullptr, nullptr, nullptr, nullptr, r->tileRange, 2 * scr.totalTiles,
-                                (float4*) r->tileRecord, (float4*) r->rasterRecord);
+                                nullptr, nullptr, nullptr, nullptr, keysFromSort ? nullptr : r->depthKey[0],
+                                r->splatToStorage != nullptr ? nullptr : (uint32_t*) r->order[0], nullptr, nullptr, nullptr, nullptr, r->tileRange,
+                                2 * scr.totalTiles, (float4*) r->tileRecord, (float4*) r->rasterRecord);
         }
         else
         {
@@ -565,7 +590,7 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
                                 r->bandSlotPrefix, r->bandCounts, nullptr, r->tileRange, 2 * scr.totalTiles, (float4*) r->tileRecord,
                                 (float4*) r->rasterRecord);
             launchBandCompaction(g.stream, n, 1, r->bandMask, r->bandSlotPrefix, r->bandCounts, r->bandOffsets, r->bandTotal, r->clipZ, r->depthKey[0],
-                                 (uint32_t*) r->order[0]);
+                                 (uint32_t*) r->order[0], r->splatToStorage, r->bandMaskCaller);
             countDevice = (const int*) r->bandTotal; // low 32 bits of the little-endian int64 total
         }
         gs_timer_stop(stageTimers[1]);
@@ -589,19 +614,29 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         const bool native = cfg.sortBackend == GS_SORT_BACKEND_NATIVE;
         if (n > 0)
         {
+            // Morton storage, no cull: the sort's input is in the caller's order (the culled list was compacted in it already)
+            const int32_t* inputOrder = cull ? nullptr : r->splatToStorage;
             if (native && radixSortSupported(4, n))
-                orderSel = launchRadixSortPairs(g.stream, r->radix, 4, r->depthKey[0], r->depthKey[1], r->order[0], r->order[1], n, 0, kDepthKeyBits);
+            {
+                DepthKeySource keys;
+                keys.positionCaller = (const float4*) r->positionCaller;
+                keys.camera = currentCamera();
+                keys.splatsPerView = n;
+                orderSel = launchRadixSortPairs(g.stream, r->radix, 4, r->depthKey[0], r->depthKey[1], r->order[0], r->order[1], n, 0, kDepthKeyBits,
+                                                inputOrder, inputOrder != nullptr ? &keys : nullptr);
+            }
             else
             {
+                int inputSel = 0;
+                if (inputOrder != nullptr)
+                {
+                    launchGatherSortInput(g.stream, n, r->depthKey[0], inputOrder, r->depthKey[1], r->order[1]);
+                    inputSel = 1;
+                }
                 ensureSortTemp(r, sortTempBytes(4, n, 0, kDepthKeyBits));
                 orderSel = launchSortPairs(g.stream, r->sortTemp, r->sortTempBytes, 4, r->depthKey[0], r->depthKey[1], r->order[0],
-                                           r->order[1], 0, n, 0, kDepthKeyBits);
+                                           r->order[1], inputSel, n, 0, kDepthKeyBits);
             }
-        }
-        if (r->storageToSplat != nullptr && n > 0) // ties of the depth sort back into the caller's order
-        {
-            launchDepthTieFix(g.stream, n, countDevice, r->depthKey[orderSel], r->order[orderSel], r->order[orderSel ^ 1], r->storageToSplat, n);
-            orderSel ^= 1; // (the keys stay where they are: nothing reads them after this)
         }
         gs_timer_stop(stageTimers[6]);
         f.orderSel = orderSel;
@@ -661,8 +696,11 @@ extern "C" int gs_renderer_finish(GsRenderer* r, GsFrameStats* stats)
         if (size > 0)
         {
             if (native && radixSortSupported(f.tileKeyBytes, size))
+            {
+                r->radix.rangeTableForLastPass = r->tileRange; // the last pass leaves the tile ranges: no range kernel (gs_radix.hip)
                 sel = launchRadixSortPairs(g.stream, r->radix, f.tileKeyBytes, r->keys[0], r->keys[1], r->values[0], r->values[1], size, 0,
                                            tBits);
+            }
             else
             {
                 ensureSortTemp(r, sortTempBytes(f.tileKeyBytes, size, 0, tBits));
@@ -676,7 +714,8 @@ extern "C" int gs_renderer_finish(GsRenderer* r, GsFrameStats* stats)
         r->keyBytes = f.tileKeyBytes;
 
         gs_timer_start(stageTimers[4]);
-        launchTileRanges(g.stream, size, f.tileKeyBytes, r->keys[sel], r->tileRange);
+        if (r->radix.rangeTableForLastPass == nullptr) launchTileRanges(g.stream, size, f.tileKeyBytes, r->keys[sel], r->tileRange); // (rocPRIM backend)
+        r->radix.rangeTableForLastPass = nullptr;
         gs_timer_stop(stageTimers[4]);
         if (blocking) st.msTileRanges = gs_timer_elapsed_ms(stageTimers[4]);
         f.size = size;

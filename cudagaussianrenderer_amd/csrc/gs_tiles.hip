@@ -17,6 +17,7 @@
 // Floating-point contraction is OFF in this file: the overlap predicate is compared bit-for-bit with
 // the CPU oracle, so every operation must round exactly as written.
 #include "gs_internal.h"
+#include "gs_overlap_exact.h"
 
 #pragma clang fp contract(off)
 
@@ -26,48 +27,6 @@ namespace
 {
 
 constexpr int kWavesPerBlock = 4;
-
-struct EllipseD
-{
-    float cx, cy, ex, ey, cosA, sinA;
-};
-
-// CUDA __saturatef: clamp to [0,1], NaN -> 0.
-__device__ __forceinline__ float saturate(float x) { return (x != x) ? 0.0f : fminf(fmaxf(x, 0.0f), 1.0f); }
-
-// GaussianRender.cu:351-358
-__device__ __forceinline__ float2 toEllipse(const EllipseD& e, float px, float py)
-{
-    const float dx = px - e.cx, dy = py - e.cy;
-    return make_float2((dx * e.cosA + dy * e.sinA) / e.ex, (dy * e.cosA - dx * e.sinA) / e.ey);
-}
-
-// GaussianRender.cu:361-372
-__device__ __forceinline__ bool intersectsUnitCircle(float2 v0, float2 v1)
-{
-    const float dx = v1.x - v0.x, dy = v1.y - v0.y;
-    const float lengthSqr = dx * dx + dy * dy;
-    const float t = saturate((-v0.x * dx + -v0.y * dy) / lengthSqr);
-    const float px = v0.x + t * (v1.x - v0.x), py = v0.y + t * (v1.y - v0.y);
-    return px * px + py * py < 1.0f;
-}
-
-// GaussianRender.cu:375-405
-__device__ __forceinline__ bool ellipseRectOverlap(const EllipseD& e, float minX, float minY, float maxX, float maxY)
-{
-    bool overlaps = e.cx > minX && e.cx < maxX && e.cy > minY && e.cy < maxY;
-    const float2 c = toEllipse(e, minX + (maxX - minX) * 0.5f, minY + (maxY - minY) * 0.5f);
-    overlaps |= c.x * c.x + c.y * c.y < 1.0f;
-    const float2 p0 = toEllipse(e, minX, minY);
-    const float2 p1 = toEllipse(e, maxX, minY);
-    const float2 p2 = toEllipse(e, maxX, maxY);
-    const float2 p3 = toEllipse(e, minX, maxY);
-    overlaps |= intersectsUnitCircle(p0, p1);
-    overlaps |= intersectsUnitCircle(p1, p2);
-    overlaps |= intersectsUnitCircle(p2, p3);
-    overlaps |= intersectsUnitCircle(p3, p0);
-    return overlaps;
-}
 
 // glm min/max: min(x,y) = (y < x) ? y : x ; max(x,y) = (x < y) ? y : x  (NaN in y is ignored)
 __device__ __forceinline__ float gmin(float x, float y) { return (y < x) ? y : x; }
@@ -220,12 +179,12 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void tileListKernel(int coun
         const int gy = st.y0[k] + ly;
 
         // tile rectangle in clip space (GaussianRender.cu:656-664)
-        const float minX = (float) gx * scr.tileClipSizeX - 1.0f;
-        const float minY = (float) gy * scr.tileClipSizeY - 1.0f;
+        const float minX = tileClipMin(gx, scr.tileClipSizeX);
+        const float minY = tileClipMin(gy, scr.tileClipSizeY);
         const float maxX = minX + scr.tileClipSizeX;
         const float maxY = minY + scr.tileClipSizeY;
         const EllipseD ek{st.cx[k], st.cy[k], st.ex[k], st.ey[k], st.cosA[k], st.sinA[k]};
-        const bool hit = valid && ellipseRectOverlap(ek, minX, minY, maxX, maxY);
+        const bool hit = valid && ellipseRectOverlapExact(ek, minX, minY, maxX, maxY); // gs_overlap_exact.h
 
         const unsigned long long mask = __ballot(hit);
         if (EMIT)
@@ -305,6 +264,7 @@ void freeTileListScratch(TileListScratch& s)
     if (s.waveCounts) (void) hipFree(s.waveCounts);
     if (s.waveOffsets) (void) hipFree(s.waveOffsets);
     if (s.hitMasks) (void) hipFree(s.hitMasks);
+    if (s.boxRecords) (void) hipFree(s.boxRecords);
     if (s.total) (void) hipFree(s.total);
     if (s.totalHost) (void) hipHostFree(s.totalHost);
     s = TileListScratch{};

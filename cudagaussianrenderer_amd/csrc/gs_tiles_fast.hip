@@ -18,10 +18,24 @@
 //   * the ellipse/rectangle predicate is evaluated in the ellipse's unit-circle space with the affine map
 //     hoisted per splat (reciprocals instead of the reference's 14 divisions per test).  It is the same
 //     predicate -- centre-in-rect OR rect-centre-in-ellipse OR an edge within the unit circle
-//     (GaussianRender.cu:375-405) -- evaluated in a different floating-point order, so a pair whose
-//     overlap margin is at rounding level may differ from the oracle's; tests check exactly that.
+//     (GaussianRender.cu:375-405) -- evaluated in a different floating-point order, so its decision value (the
+//     smallest of the five squared distances, compared with 1) differs from the reference's by rounding.  A GUARD
+//     BAND makes the decisions the reference's all the same: a tile whose value lies within kGuard (1 + A) of 1 is
+//     decided again by the reference's own arithmetic (gs_overlap_exact.h, shared with gs_tiles.hip).  A is what the
+//     rounding errors of BOTH formulations scale with: the absolute terms of the two dot products that map the tile's
+//     corner into unit-circle space, before they cancel, plus the L1 size of the tile's edge vectors there.  The hot loop
+//     compares a unit's four values with ONE bound per splat: a tile whose value is near 1 has its closest point within
+//     the ellipse's larger extent of the centre, so its corner offset is at most (extent + tile) per axis -- A* bounds A for
+//     every such tile.  tools/guard_band_check.cpp runs both formulations on the host over 10^8 tiles of harsh ellipses
+//     (anisotropy up to 1000, extents 1e-4 .. 2 clip units, five resolutions): near the decision the two values are never
+//     further apart than 2.5e-6 (1 + A), in every range of A; kGuard = 1e-5 is four times that, no differing decision lies
+//     outside the band.  On the bench scene ~1 000 of 9 M tiles per frame are decided exactly and 1-4 decisions change
+//     (tools/guard_stats.py).  The "centre inside the rectangle" term is decided per SPLAT with the reference's arithmetic
+//     (which tile holds the centre) and is a single integer compare per tile.  The pair list is therefore the staged
+//     builder's, bit for bit (test_two_level_pipeline_equals_reference_pipeline asserts equality).
 #include "gs_aabb.h"
 #include "gs_internal.h"
+#include "gs_overlap_exact.h"
 
 namespace gs
 {
@@ -44,11 +58,20 @@ struct GroupStage
     int area[kGroup];   // AABB tiles
     int origin[kGroup]; // x0 | y0 << 16
     int w[kGroup];
-    float rcpW[kGroup];
+    int centreLocal[kGroup]; // local index (row-major in the box) of the tile that strictly contains the centre, or -1
     float4 centreM[kGroup]; // cx, cy, m00, m01
     float4 mInv[kGroup];    // m10, m11, 1/|u|^2, 1/|v|^2
     int splat[kGroup];
+    float guard[kGroup];    // kGuard (1 + A*): the splat-wide filter of the guard band
+    float4 ellipse[kGroup]; // cos, sin, extent x, y as the clip stage stored them: operands of the exact predicate inside the band
 };
+
+// Guard band of the cheap overlap decision (see the head of the file and tools/guard_band_check.cpp).
+constexpr float kGuard = 1.0e-5f;
+#ifdef GS_AB_GUARD_COUNT
+// diagnostics build: [0] units tested, [1] units that entered the band's slow side, [2] tiles decided exactly, [3] decisions changed
+__device__ unsigned long long g_guardStats[4];
+#endif
 
 // Squared distance of the origin to the segment q + t e, t in [0,1]: the edge comes within the unit circle when it is
 // below 1 (GaussianRender.cu:361-372).
@@ -59,13 +82,68 @@ __device__ __forceinline__ float edgeDistanceSquared(float qx, float qy, float e
     return fmaf(rx, rx, ry * ry);
 }
 
+// The rare side of the guard band: the tiles of one work unit whose cheap decision value is within kGuard (1 + A) of 1 (A from the
+// tile's own corner) are decided by the reference's predicate.  A lane gets here for about one unit in three thousand; the loop is
+// rolled and the predicate is the register-lean form, so that this path does not set the kernel's register count.
+__device__ __forceinline__ unsigned decideInsideGuardBand(unsigned hitMask, float4 dev4, float4 se, int local0, int areaK, int wk, float rcpW,
+                                                          int origin, float4 cm, float4 mi, float sx, float sy)
+{
+    const float ux = cm.z * sx, uy = mi.x * sx, vx = cm.w * sy, vy = mi.y * sy;
+    const float uvAbs = 1.0f + (fabsf(ux) + fabsf(uy)) + (fabsf(vx) + fabsf(vy));
+    const EllipseD ell{cm.x, cm.y, se.z, se.w, se.x, se.y};
+    static_assert(kTilesPerUnit == 4, "dev4 carries one value per tile of the unit");
+#pragma unroll 1
+    for (int e = 0; e != kTilesPerUnit; ++e)
+    {
+        const int local = local0 + e;
+        if (local >= areaK) break;
+        const int ly = (int) (((float) local + 0.5f) * rcpW), lx = local - ly * wk; // as the caller derives lx0, ly0
+        const int gx = (origin & 0xFFFF) + lx, gy = (origin >> 16) + ly;
+        const float minX = tileClipMin(gx, sx), minY = tileClipMin(gy, sy);
+        const float dx = fabsf(minX - cm.x), dy = fabsf(minY - cm.y);
+        const float a1 = uvAbs + ((fabsf(cm.z) + fabsf(mi.x)) * dx + (fabsf(cm.w) + fabsf(mi.y)) * dy);
+        const float dev = e == 0 ? dev4.x : e == 1 ? dev4.y : e == 2 ? dev4.z : dev4.w;
+        if (dev > kGuard * a1) continue; // certain (a NaN fails the comparison and is decided exactly)
+        const bool exact = ellipseRectOverlapExactRolled(ell, minX, minY, minX + sx, minY + sy);
+#ifdef GS_AB_GUARD_COUNT
+        atomicAdd(&g_guardStats[2], 1ull);
+        if (exact != ((hitMask >> e) & 1u)) atomicAdd(&g_guardStats[3], 1ull);
+#endif
+        hitMask = (hitMask & ~(1u << e)) | (exact ? (1u << e) : 0u);
+    }
+    return hitMask;
+}
+
+// Which tile strictly contains the centre along one axis, by the reference's arithmetic (GaussianRender.cu:382-386,656-664:
+// min = g * size - 1 and max = min + size, each rounded): the candidates around floor((c + 1) / size) are tested exactly.  Returns the
+// tile, -1 when none does (a centre on a boundary), -2 when two neighbours both do (their rounded intervals overlap by an ulp).
+__device__ __forceinline__ int centreTileOnAxis(float c, float size, float tilesPerScreen)
+{
+    const float guess = floorf((c + 1.0f) * 0.5f * tilesPerScreen);
+    if (!(guess > -4.0f && guess < 1.0e6f)) return -1; // off screen by far (or NaN): no tile of any box holds the centre
+    const int g0 = (int) guess;
+    int found = -1, count = 0;
+#pragma unroll
+    for (int g = g0 - 1; g <= g0 + 1; ++g)
+    {
+        const float lo = tileClipMin(g, size);
+        if (c > lo && c < lo + size)
+        {
+            found = g;
+            ++count;
+        }
+    }
+    return count == 1 ? found : (count == 0 ? -1 : -2);
+}
+
 template <bool EMIT, typename TileKey>
 __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, const int* __restrict__ countDevice, Screen scr, const uint32_t* __restrict__ order,
                                                              const float2* __restrict__ clipXY, const float4* __restrict__ screenEllipse,
                                                              int32_t* __restrict__ groupCounts, const int32_t* __restrict__ groupOffsets,
                                                              TileKey* __restrict__ tileKeys, int32_t* __restrict__ values, int capacity,
                                                              uint8_t* __restrict__ hitMasks, const float4* __restrict__ tileRecord,
-                                                             int64_t* __restrict__ total, int64_t* __restrict__ totalHostMapped, int viewSplats)
+                                                             int64_t* __restrict__ total, int64_t* __restrict__ totalHostMapped, int viewSplats,
+                                                             int4* __restrict__ boxRecords)
 {
     __shared__ GroupStage st;
     __shared__ int waveTotals[kWavesPerBlock];
@@ -75,22 +153,22 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
     const int wave = t >> 6, lane = t & (kWave - 1);
     const int group = blockIdx.x;
     const int count = countDevice ? min(*countDevice, countHost) : countHost; // device-side count: culled splat list
-    if (EMIT && count <= 0 && group == 0 && t == 0)
+    if (EMIT && groupOffsets == nullptr && count <= 0 && group == 0 && t == 0)
     {
-        // nothing reached the band: no workgroup gets as far as the pair total below
+        // nothing reached the band: no workgroup gets as far as the pair total below.  (With the scan kernel in front -- groupOffsets --
+        // the total is the scan's to write, once per frame: the host may re-arm the mapped word as soon as it has seen that value.)
         *total = 0;
         if (totalHostMapped != nullptr) *totalHostMapped = 0;
     }
     if (group * kGroup >= count) return; // whole workgroup
     const int sorted = group * kGroup + t;
 
-    int area = 0, x0 = 0, y0 = 0, w = 0, splat = 0;
-    float cx = 0.f, cy = 0.f, m00 = 0.f, m01 = 0.f, m10 = 0.f, m11 = 0.f, invUU = 0.f, invVV = 0.f;
-    if (sorted < count)
-    {
-        splat = (int) order[sorted];
+    // What a lane knows about its splat: the tile box (always) and the operands of the overlap tests (when tests will be run).
+    int area = 0, x0 = 0, y0 = 0, w = 0, splat = 0, centreLocal = -1;
+    float cx = 0.f, cy = 0.f, m00 = 0.f, m01 = 0.f, m10 = 0.f, m11 = 0.f, invUU = 0.f, invVV = 0.f, guard = 0.f;
+    float4 se = make_float4(0.f, 0.f, 0.f, 0.f); // cos, sin, extent.x, extent.y
+    const auto loadSplat = [&]() {
         float2 c;
-        float4 se; // cos, sin, extent.x, extent.y
         if (tileRecord != nullptr)
         {
             const float4 ra = tileRecord[2 * splat], rb = tileRecord[2 * splat + 1]; // one 32-byte sector
@@ -104,16 +182,13 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
         }
         cx = c.x;
         cy = c.y;
-        // AABB in tiles, exactly as gs_tiles.hip / GaussianRender.cu:408-436,537-551 (shared with the band cull).
-        const TileAabb box = splatTileAabb(cx, cy, se.x, se.y, se.z, se.w, scr);
-        x0 = box.x0;
-        y0 = box.y0;
-        w = box.x1 - box.x0;
-        const int h = box.y1 - box.y0;
-        area = (w > 0 && h > 0) ? w * h : 0;
+    };
+    const auto overlapOperands = [&]() {
         // Affine map clip space -> the ellipse's unit-circle space (GaussianRender.cu:351-358), hoisted:
         //   l = M (p - c),  M = diag(1/ex, 1/ey) * [[cos, sin], [-sin, cos]]
-        const float invEx = 1.0f / se.z, invEy = 1.0f / se.w;
+        // (hardware reciprocals, 1 ulp: these are the cheap formulation's own operands -- what they cost in accuracy is inside the
+        // guard band's margin, tools/guard_band_check.cpp perturbs them the same way)
+        const float invEx = __builtin_amdgcn_rcpf(se.z), invEy = __builtin_amdgcn_rcpf(se.w);
         m00 = se.x * invEx;
         m01 = se.y * invEx;
         m10 = -se.y * invEy;
@@ -121,8 +196,56 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
         // Images of the tile edges: u = M (sx, 0), v = M (0, sy).
         const float ux = m00 * scr.tileClipSizeX, uy = m10 * scr.tileClipSizeX;
         const float vx = m01 * scr.tileClipSizeY, vy = m11 * scr.tileClipSizeY;
-        invUU = 1.0f / fmaf(ux, ux, uy * uy);
-        invVV = 1.0f / fmaf(vx, vx, vy * vy);
+        invUU = __builtin_amdgcn_rcpf(fmaf(ux, ux, uy * uy));
+        invVV = __builtin_amdgcn_rcpf(fmaf(vx, vx, vy * vy));
+        // Splat-wide filter of the guard band (see the head of the file): the corner of a tile whose decision value can be near 1 lies
+        // within (larger extent + one tile) of the centre on either axis.
+        // (1.05: a value within the widest band still used, 0.05, of 1 belongs to a point within sqrt(1.1) extents)
+        const float reach = 1.05f * fmaxf(se.z, se.w);
+        float aStar = (fabsf(m00) + fabsf(m10)) * (reach + scr.tileClipSizeX) + (fabsf(m01) + fabsf(m11)) * (reach + scr.tileClipSizeY) +
+                      ((fabsf(ux) + fabsf(uy)) + (fabsf(vx) + fabsf(vy)));
+        aStar = fmaf(0.0f, invUU + invVV, aStar); // a non-finite reciprocal (degenerate extent) poisons the bound: every tile is then decided exactly
+        guard = kGuard * (1.0f + aStar);
+        if (!(guard <= 0.05f)) guard = __builtin_inff(); // absurd conditioning, NaN or inf: no unit of this splat passes the "certain" test below
+#ifdef GS_AB_GUARD_NEVER
+        guard = -1.0f; // A/B builds: the band is never entered (what the hot loop's share of the guard costs)
+#endif
+    };
+    if (sorted < count)
+    {
+        splat = (int) order[sorted];
+        if (!EMIT)
+        {
+            loadSplat();
+            // AABB in tiles, exactly as gs_tiles.hip / GaussianRender.cu:408-436,537-551 (shared with the band cull).
+            const TileAabb box = splatTileAabb(cx, cy, se.x, se.y, se.z, se.w, scr);
+            x0 = box.x0;
+            y0 = box.y0;
+            w = box.x1 - box.x0;
+            const int h = box.y1 - box.y0;
+            area = (w > 0 && h > 0) ? w * h : 0;
+            overlapOperands();
+            // The tile that holds the centre (GaussianRender.cu:382-386), found once per splat with the reference's rounding.
+            const int cgx = centreTileOnAxis(cx, scr.tileClipSizeX, scr.tilesPerScreenX), cgy = centreTileOnAxis(cy, scr.tileClipSizeY, scr.tilesPerScreenY);
+            if (cgx == -2 || cgy == -2) centreLocal = -2; // two candidate tiles an ulp apart: every tile of this splat goes to the exact predicate
+            else if (cgx >= box.x0 && cgx < box.x1 && cgy >= box.y0 && cgy < box.y1) centreLocal = (cgy - box.y0) * w + (cgx - box.x0);
+            // the box, for the emit pass: it replays the recorded hit masks and needs neither the splat's record nor any of the above
+            boxRecords[sorted] = make_int4(area, x0 | (y0 << 16), w, centreLocal);
+        }
+        else
+        {
+            const int4 b = boxRecords[sorted];
+            area = b.x;
+            x0 = b.y & 0xFFFF;
+            y0 = b.y >> 16;
+            w = b.z;
+            centreLocal = b.w;
+        }
+        if (centreLocal == -2)
+        {
+            guard = __builtin_inff();
+            centreLocal = -1;
+        }
     }
     const int units = (area + kTilesPerUnit - 1) / kTilesPerUnit;
 
@@ -182,14 +305,25 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
         if (totalUnits == 0) return;
     }
 
+    if (EMIT && totalUnits > kMaskRounds * kGroup && sorted < count)
+    {
+        // rounds past the recorded ones are tested again: only then does the emit pass need the splats themselves
+        // (uniform branch; a group of 256 splats with more than 4 096 work units is a handful of near, large splats)
+        const bool poisoned = guard > 1.0f;
+        loadSplat();
+        overlapOperands();
+        if (poisoned) guard = __builtin_inff();
+    }
     st.excl[t] = unitsBefore + incl - units;
     st.area[t] = area;
     st.origin[t] = x0 | (y0 << 16);
     st.w[t] = max(w, 1);
-    st.rcpW[t] = 1.0f / (float) max(w, 1);
+    st.centreLocal[t] = centreLocal;
     st.centreM[t] = make_float4(cx, cy, m00, m01);
     st.mInv[t] = make_float4(m10, m11, invUU, invVV);
     st.splat[t] = splat;
+    st.guard[t] = guard;
+    st.ellipse[t] = se;
     __syncthreads();
 
     int running = 0; // COUNT: hits of this wave so far; EMIT: hits of the whole workgroup in the rounds before this one
@@ -211,9 +345,11 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
         const int areaK = valid ? st.area[k] : 0;
         const int wk = st.w[k];
         const int origin = st.origin[k];
-        // local0 / wk through the reciprocal: the quotient's fractional part is at least 0.5/wk away from an
+        // local0 / wk through the (approximate, 1 ulp) reciprocal: the quotient's fractional part is at least 0.5/wk away from an
         // integer, far above the float error for local0 < 2^16.
-        const int ly0 = (int) (((float) local0 + 0.5f) * st.rcpW[k]);
+        const float rcpW = __builtin_amdgcn_rcpf((float) wk);
+        const int centreK = st.centreLocal[k];
+        const int ly0 = (int) (((float) local0 + 0.5f) * rcpW);
         const int lx0 = local0 - ly0 * wk;
 
         // The count pass leaves the four hit bits of every lane for its first kMaskRounds rounds; the emit pass replays
@@ -230,29 +366,35 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
             const float vx = cm.w * sy, vy = mi.y * sy; // v = M (0, sy)
             const float uv = fmaf(ux, vx, uy * vy);
             int lx = lx0, ly = ly0;
+            float dev[kTilesPerUnit]; // |decision value - 1| of the unit's tiles (tiles past the box: certain)
 #pragma unroll
             for (int e = 0; e != kTilesPerUnit; ++e)
             {
                 bool hit = false;
+                dev[e] = __builtin_inff();
                 if (local0 + e < areaK)
                 {
                     const int gx = (origin & 0xFFFF) + lx, gy = (origin >> 16) + ly;
-                    const float minX = (float) gx * sx - 1.0f, minY = (float) gy * sy - 1.0f; // GaussianRender.cu:656-664
-                    // centre inside the rectangle (strict, GaussianRender.cu:382-386)
-                    hit = cm.x > minX && cm.x < minX + sx && cm.y > minY && cm.y < minY + sy;
+                    // GaussianRender.cu:656-664, product and difference rounded as the reference rounds them: a fused g * s - 1 is up to
+                    // an ulp of 1 off, which the map into unit-circle space magnifies by 1 / extent -- more than the guard band allows for
+                    const float minX = tileClipMin(gx, sx), minY = tileClipMin(gy, sy);
+                    // centre inside the rectangle (strict, GaussianRender.cu:382-386): decided per splat, exactly (prologue)
+                    hit = local0 + e == centreK;
                     // corner q0 = M (min - c); the other corners are q0 + u, q0 + v, q0 + u + v
                     const float dx = minX - cm.x, dy = minY - cm.y;
                     const float q0x = fmaf(cm.z, dx, cm.w * dy), q0y = fmaf(mi.x, dx, mi.y * dy);
                     const float qcx = fmaf(0.5f, ux + vx, q0x), qcy = fmaf(0.5f, uy + vy, q0y);
                     // rectangle centre inside the ellipse (:389), or an edge within the unit circle (:392-402): the smallest of
-                    // the five squared distances decides (a NaN distance never wins a min, as it never passed the comparison)
+                    // the five squared distances decides
                     const float centre2 = fmaf(qcx, qcx, qcy * qcy);
                     const float q0u = fmaf(q0x, ux, q0y * uy), q0v = fmaf(q0x, vx, q0y * vy);
                     const float bottom2 = edgeDistanceSquared(q0x, q0y, ux, uy, q0u, mi.z);
                     const float right2 = edgeDistanceSquared(q0x + ux, q0y + uy, vx, vy, q0v + uv, mi.w);
                     const float top2 = edgeDistanceSquared(q0x + vx, q0y + vy, ux, uy, q0u + uv, mi.z);
                     const float left2 = edgeDistanceSquared(q0x, q0y, vx, vy, q0v, mi.w);
-                    hit |= fminf(fminf(fminf(bottom2, right2), fminf(top2, left2)), centre2) < 1.0f;
+                    const float decision = fminf(fminf(fminf(bottom2, right2), fminf(top2, left2)), centre2);
+                    hit |= decision < 1.0f;
+                    dev[e] = fabsf(decision - 1.0f);
                 }
                 hitMask |= hit ? (1u << e) : 0u;
                 // next local tile
@@ -263,6 +405,17 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                     ++ly;
                 }
             }
+            // Guard band: a decision value this close to 1 may fall on the other side in the reference's arithmetic.  First the
+            // splat-wide bound (one compare per unit); the few units that fail it look at each tile with the tile's own S and
+            // decide the ones inside the band with the reference's predicate, operation for operation (gs_overlap_exact.h).
+            // Every comparison is written so that a NaN (degenerate extents) lands on the exact side.
+#ifdef GS_AB_GUARD_COUNT
+            if (!EMIT && valid) atomicAdd(&g_guardStats[0], 1ull);
+            if (!EMIT && !(fminf(fminf(dev[0], dev[1]), fminf(dev[2], dev[3])) > st.guard[k])) atomicAdd(&g_guardStats[1], 1ull);
+#endif
+            if (!(fminf(fminf(dev[0], dev[1]), fminf(dev[2], dev[3])) > st.guard[k]))
+                hitMask = decideInsideGuardBand(hitMask, make_float4(dev[0], dev[1], dev[2], dev[3]), st.ellipse[k], local0, areaK, wk, rcpW, origin, cm,
+                                                mi, sx, sy);
             if (!EMIT && recorded) *maskSlot = (uint8_t) hitMask;
         }
         unsigned long long ballots[kTilesPerUnit];
@@ -435,10 +588,23 @@ void launchEmit(hipStream_t stream, dim3 grid, dim3 block, int count, const Scre
 {
     hipLaunchKernelGGL((tileListFastKernel<true, TileKey>), grid, block, 0, stream, count, s.countDevice, scr, order, clipXY, screenEllipse,
                        s.waveCounts, groupOffsets, (TileKey*) tileKeys, values, capacity, s.hitMasks, s.tileRecord, s.total,
-                       s.totalHostMapped, viewSplats);
+                       s.totalHostMapped, viewSplats, (int4*) s.boxRecords);
 }
 
 } // namespace
+
+#ifdef GS_AB_GUARD_COUNT
+extern "C" void gs_debug_guard_stats(unsigned long long out[4], int reset)
+{
+    GS_CHECK(hipDeviceSynchronize());
+    GS_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_guardStats), sizeof(unsigned long long) * 4));
+    if (reset)
+    {
+        const unsigned long long zero[4] = {0, 0, 0, 0};
+        GS_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_guardStats), zero, sizeof(zero)));
+    }
+}
+#endif
 
 void launchScanInt32(hipStream_t stream, int n, const int32_t* in, int32_t* out, int64_t* total)
 {
@@ -452,7 +618,9 @@ void ensureTileListFastScratch(TileListScratch& s, int count)
     if (groups > s.capacityMaskGroups)
     {
         if (s.hitMasks) GS_CHECK(hipFree(s.hitMasks));
+        if (s.boxRecords) GS_CHECK(hipFree(s.boxRecords));
         GS_CHECK(hipMalloc((void**) &s.hitMasks, (size_t) groups * kMaskRounds * kGroup));
+        GS_CHECK(hipMalloc(&s.boxRecords, (size_t) groups * kGroup * 16)); // (area, origin, width, centre tile) per sorted splat
         s.capacityMaskGroups = groups;
     }
 }
@@ -473,7 +641,7 @@ void launchTileListFastCount(hipStream_t stream, int count, const Screen& scr, c
         // leaves the pair total (no scan kernel in between)
         hipLaunchKernelGGL((tileListFastKernel<false, uint16_t>), dim3(groups), dim3(kGroup), 0, stream, count, s.countDevice, scr, order, clipXY,
                            screenEllipse, s.waveCounts, (const int32_t*) nullptr, (uint16_t*) nullptr, (int32_t*) nullptr, 0, s.hitMasks, s.tileRecord,
-                           (int64_t*) nullptr, (int64_t*) nullptr, 0);
+                           (int64_t*) nullptr, (int64_t*) nullptr, 0, (int4*) s.boxRecords);
     }
     if (groups == 0) GS_CHECK(hipMemcpyAsync(s.totalHost, s.total, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
 }

@@ -227,7 +227,9 @@ void gs_renderer_set_tile_rows(GsRenderer* r, int tileRowBegin, int tileRowEnd);
 void gs_renderer_set_band_cull(GsRenderer* r, int mode);
 #define GS_PIPELINE_REFERENCE 0
 #define GS_PIPELINE_TWO_LEVEL 1
-void gs_renderer_set_pipeline(GsRenderer* r, int pipeline);
+/* Returns 0; -1 (nothing changed) for REFERENCE while the renderer holds a scene stored in Morton order (below): that pipeline
+ * breaks depth ties by storage order.  A scene set while REFERENCE is selected is always stored in the caller's order. */
+int gs_renderer_set_pipeline(GsRenderer* r, int pipeline);
 /* 1 when the renderer's frames evaluate SH colours on demand inside the raster kernel instead of running the SH pass over all
  * splats (two-level pipeline, SH degree 1 or 3, two pixels per lane; GS_NO_LAZY_SH=1 in the environment turns it
  * off).  Same colours bit for bit (one shared routine); a frame consumes only the front of its lists -- 88 K distinct splats
@@ -236,11 +238,12 @@ void gs_renderer_set_pipeline(GsRenderer* r, int pipeline);
 int gs_renderer_colours_on_demand(const GsRenderer* r);
 /* Addition: how the renderer STORES the splats of the next gs_renderer_set_scene.  CALLER (default): in the caller's order, like the
  * reference (Demo.cpp:314-331).  MORTON: along a 3-D Morton curve through their positions -- the spatial ordering the reference's
- * author names as the cure for the raster's scattered gathers (README.md:138).  Frames are byte-identical either way: splats of equal
- * depth still blend in the caller's index order (the depth sort's ties are re-ordered by a small extra pass; runs of more than 1024
- * splats at exactly one depth keep the storage order).  What changes is speed (profiles/r03_storage_order.txt: +3.5 % frames/s on one
- * GPU, -15 % per band frame of an 8-way split) and the index space of everything per splat that the renderer hands out:
- * GsRendererBuffers arrays and the `values` of the pair list are in STORAGE order; gs_renderer_storage_order gives the map. */
+ * author names as the cure for the raster's scattered gathers (README.md:138).  Frames are byte-identical either way, for every scene:
+ * the input of the (stable) depth sort is laid out in the caller's order, so splats of equal depth code -- however many -- still blend
+ * in the caller's index order (GaussianRender.cu:446-454: cub's sort is stable over emission order).  What changes is speed
+ * (profiles/r04_storage_order.txt) and the index space of everything per splat that the renderer hands out: GsRendererBuffers arrays
+ * and the `values` of the pair list are in STORAGE order; gs_renderer_storage_order gives the map.  TWO_LEVEL pipeline only: a scene
+ * set while GS_PIPELINE_REFERENCE is selected is stored in the caller's order. */
 #define GS_STORAGE_ORDER_CALLER 0
 #define GS_STORAGE_ORDER_MORTON 1
 void gs_renderer_set_storage_order(GsRenderer* r, int order);
