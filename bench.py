@@ -267,15 +267,26 @@ class Rig:
             torch.cuda.synchronize(self.ctx["device"])
         return (time.perf_counter() - t0) / frames
 
-    def gather_ms(self, chains):
+    def gather_frame_ms(self, chains=4):
+        """What the exchange costs this rank's GPU per FRAME when nothing overlaps it (multigpu.rebalance_bands adds it to the rank's
+        band time: the root's 7 x V receives per chain are invisible to a band timed without the gather).  A collective."""
+        return self.gather_ms(chains, settle=True) / self.V
+
+    def gather_ms(self, chains, settle=False):
         """HIP-event time of the gather alone, chains one at a time on renderer 0 (milliseconds per chain): what the exchange costs
-        this rank when nothing overlaps it."""
+        this rank when nothing overlaps it.  settle: every rank's band is complete before the exchange starts (device synchronise +
+        barrier), so that the interval holds the transfer only, not the wait for the slowest band."""
         import torch
+        import torch.distributed as dist
 
         stream = self.streams[0]
         total = 0.0
         for c in range(chains):
             self.pools[0].submit(self._render, 0, c).result()
+            if settle:
+                torch.cuda.synchronize(self.ctx["device"])
+                if self.ctx["world"] > 1:
+                    dist.barrier()
             start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             start.record(stream)
             self._gather(0)
@@ -345,7 +356,9 @@ class Rig:
 
 
 def make_scene(ctx, args, opacity_mean):
-    """Synthesise a .ply FILE and ingest it through the product's parsePly."""
+    """Synthesise a .ply FILE and ingest it through the product's parsePly.  Returns the scene and what the ingest cost: seconds to
+    synthesise + write the file, seconds inside gs_parse_ply alone (the step SURVEY.md section 8(f2) is about: PlyParser.cpp:132-140
+    reads one value per ifstream::read), the file's size."""
     gs, scenes = ctx["gs"], ctx["scenes"]
     t0 = time.time()
     with tempfile.TemporaryDirectory() as tmp:
@@ -355,9 +368,15 @@ def make_scene(ctx, args, opacity_mean):
             table[:, names.index("opacity")] += np.float32(opacity_mean - 1.0)
         scenes.write_ply(path, names, table)
         del table
+        t1 = time.time()
+        file_bytes = os.path.getsize(path)
         ply = gs.parse_ply(path)
+        t2 = time.time()
     assert ply["vertexCount"] == args.splats
-    return ply, time.time() - t0
+    return ply, {"scene_write_s": round(t1 - t0, 3), "parse_s": round(t2 - t1, 3), "file_MB": round(file_bytes / 1e6, 1),
+                 "parse_MB_per_s": round(file_bytes / 1e6 / max(t2 - t1, 1e-9), 1),
+                 "what": "parse_s = gs_parse_ply on the freshly written (page-cached) file + the copy of its arrays into numpy; the "
+                         "reference's parser on the same files: profiles/r04_ingest.txt"}
 
 
 def stage_report(rig, args, stage_ms, p_mean, pc_mean, nonempty, band_tiles, band_h):
@@ -637,7 +656,7 @@ def main():
                 "colours": "on demand in the raster kernel (no SH pass)" if on_demand else "SH pass over all splats",
                 "footprint": "epanechnikov" if args.epanechnikov else "gaussian",
                 "pipeline": {1: "two_level", 0: "reference"}.get(args.pipeline, str(args.pipeline)),
-                "tile_row_bands": [list(b) for b in bands], "band_ms_measured_by_its_rank": band_times, "ingest_s": round(t_ingest, 2),
+                "tile_row_bands": [list(b) for b in bands], "band_ms_measured_by_its_rank": band_times, "ingest": t_ingest,
                 "dist_backend": backend, "dist_world_size": world, "rehearsal_on_one_gpu": bool(args.rehearse),
                 "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
                 "gather": None if world == 1 else (f"gs_gather_bands: grouped ncclSend/ncclRecv through the C ABI, {len(comms)} communicators (one per frame in flight)" if comms

@@ -7,7 +7,11 @@
 //   gs_camera_from_bounds           <- CameraControls::setBounds/getView/getProjection
 //                                      src/CameraControls.cpp:79-96,132-146 + CameraData fill src/Demo.cpp:377-392
 //   gs_generate_random_gaussians    <- generateRandomGaussians   src/Demo.cpp:119-143
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +21,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gsplat_hip.h"
@@ -28,7 +33,7 @@ inline float clamp01(float x) { return std::min(std::max(x, 0.0f), 1.0f); }
 
 // ---------------------------------------------------------------------------------------------
 // PLY: the reference reads the body with one 4-byte ifstream::read per value (62 M reads for a 1 M
-// splat file); here the body is read in one block and transposed, with identical results.
+// splat file); here the host threads read it in blocks and transpose them, with identical results.
 // ---------------------------------------------------------------------------------------------
 struct Header
 {
@@ -357,12 +362,6 @@ extern "C" int gs_parse_ply(const char* filePath, GsPly* out, char* err, size_t 
                                         " extra spherical harmonics. Found " + std::to_string(extra) + ".");
         const int shCount = extra + 3;
 
-        // Body: [vertex][property] little-endian floats, read in one block. A short file leaves zeros.
-        std::vector<float> body(n * numProps, 0.0f);
-        in.clear();
-        in.seekg(h.bodyOffset);
-        in.read(reinterpret_cast<char*>(body.data()), (std::streamsize) (body.size() * sizeof(float)));
-
         out->vertexCount = h.vertexCount;
         out->sphericalHarmonicsDegree = degree;
         out->sphericalHarmonicsCount = shCount;
@@ -371,57 +370,108 @@ extern "C" int gs_parse_ply(const char* filePath, GsPly* out, char* err, size_t 
         out->color = allocFloats(n * 4);
         if (degree != 0) out->sphericalHarmonics = allocFloats(n * shCount);
 
-        // boundsMax starts at numeric_limits<float>::min() (smallest positive), a reference quirk kept (PlyParser.cpp:290).
-        float bmin[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
-        float bmax[3] = {std::numeric_limits<float>::min(), std::numeric_limits<float>::min(), std::numeric_limits<float>::min()};
+        // Body: [vertex][property] little-endian floats.  The reference reads it with one 4-byte ifstream::read per value
+        // (PlyParser.cpp:132-140); here every host thread reads its slice of the vertices in blocks of a few thousand rows (pread, so
+        // the threads share one descriptor) and converts them while they are in its cache.  A short file leaves zeros, as a block read
+        // into a zeroed buffer would.  Every vertex is converted independently and min/max are exact whatever the order: the arrays are
+        // the same bytes as the serial loop's (and as the reference's, tests/test_host_cpu.py).
         const int perChannel = extra / 3;
-        for (size_t i = 0; i != n; ++i)
+        const int fd = ::open(filePath, O_RDONLY);
+        if (fd < 0) throw std::invalid_argument("Invalid header. Format or vertex count not found."); // (the header was just read: cannot happen)
+        const size_t rowBytes = numProps * sizeof(float);
+        const off_t bodyOffset = (off_t) h.bodyOffset;
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const size_t threads = n < 65536 ? 1 : std::min<size_t>(std::min<unsigned>(hw, 16u), n / 32768);
+        // boundsMax starts at numeric_limits<float>::min() (smallest positive), a reference quirk kept (PlyParser.cpp:290).
+        std::vector<std::array<float, 6>> bounds(threads, {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max(),
+                                                           std::numeric_limits<float>::min(), std::numeric_limits<float>::min(), std::numeric_limits<float>::min()});
+        const auto convertSlice = [&](size_t slice) {
+            const size_t begin = n * slice / threads, end = n * (slice + 1) / threads;
+            constexpr size_t kBlockRows = 4096;
+            std::vector<float> block(kBlockRows * numProps);
+            float* bmin = bounds[slice].data();
+            float* bmax = bmin + 3;
+            for (size_t first = begin; first < end; first += kBlockRows)
+            {
+                const size_t rows = std::min(kBlockRows, end - first);
+                size_t got = 0;
+                const size_t want = rows * rowBytes;
+                while (got < want)
+                {
+                    const ssize_t r = ::pread(fd, reinterpret_cast<char*>(block.data()) + got, want - got, bodyOffset + (off_t) (first * rowBytes + got));
+                    if (r <= 0) break;
+                    got += (size_t) r;
+                }
+                if (got < want) std::memset(reinterpret_cast<char*>(block.data()) + got, 0, want - got);
+                for (size_t i = first; i != first + rows; ++i)
+                {
+                    const float* row = block.data() + (i - first) * numProps;
+                    float* p = out->position + 4 * i;
+                    float* s = out->scaleAndRotation + 4 * i;
+                    float* c = out->color + 4 * i;
+
+                    // sigmoid, evaluated in double and rounded once (the reference's unqualified exp() is ::exp(double))
+                    const float opacity = (float) (1.0 / (1.0 + std::exp(-(double) row[off[13]])));
+                    for (int k = 0; k != 3; ++k)
+                    {
+                        p[k] = row[off[k]];
+                        bmin[k] = std::min(bmin[k], p[k]);
+                        bmax[k] = std::max(bmax[k], p[k]);
+                        s[k] = std::exp(row[off[7 + k]]);
+                        c[k] = row[off[10 + k]] * 0.28209479177387814f + 0.5f; // SH band 0 -> rgb, unclamped
+                    }
+                    p[3] = opacity;
+                    c[3] = opacity;
+
+                    // rot_0 is w. Normalise, map to [0,1], truncating 8-bit pack in (x,y,z,w) order.
+                    float qw = row[off[3]], qx = row[off[4]], qy = row[off[5]], qz = row[off[6]];
+                    const float len = std::sqrt((qw * qw + qx * qx) + (qy * qy + qz * qz));
+                    if (len <= 0.0f)
+                    {
+                        qw = 1.0f;
+                        qx = qy = qz = 0.0f;
+                    }
+                    else
+                    {
+                        const float inv = 1.0f / len;
+                        qw *= inv;
+                        qx *= inv;
+                        qy *= inv;
+                        qz *= inv;
+                    }
+                    const float enc[4] = {(qx + 1.0f) * 0.5f, (qy + 1.0f) * 0.5f, (qz + 1.0f) * 0.5f, (qw + 1.0f) * 0.5f};
+                    const uint32_t packed = gs_encode_vec4(enc);
+                    std::memcpy(&s[3], &packed, sizeof(float));
+
+                    if (degree != 0)
+                    {
+                        // f_dc (rgb) then f_rest, which the file stores channel-major [c][k] -> [k][c] (PlyParser.cpp:269-286).
+                        float* sh = out->sphericalHarmonics + i * (size_t) shCount;
+                        for (int k = 0; k != 3; ++k) sh[k] = row[off[10 + k]];
+                        for (int j = 0; j != perChannel; ++j)
+                            for (int ch = 0; ch != 3; ++ch) sh[3 + j * 3 + ch] = row[rest[ch * perChannel + j]];
+                    }
+                }
+            }
+        };
+        if (threads <= 1) convertSlice(0);
+        else
         {
-            const float* row = body.data() + i * numProps;
-            float* p = out->position + 4 * i;
-            float* s = out->scaleAndRotation + 4 * i;
-            float* c = out->color + 4 * i;
-
-            // sigmoid, evaluated in double and rounded once (the reference's unqualified exp() is ::exp(double))
-            const float opacity = (float) (1.0 / (1.0 + std::exp(-(double) row[off[13]])));
-            for (int k = 0; k != 3; ++k)
+            std::vector<std::thread> pool;
+            for (size_t t = 1; t != threads; ++t) pool.emplace_back(convertSlice, t);
+            convertSlice(0);
+            for (std::thread& t : pool) t.join();
+        }
+        ::close(fd);
+        float bmin[3], bmax[3];
+        for (int k = 0; k != 3; ++k)
+        {
+            bmin[k] = bounds[0][(size_t) k];
+            bmax[k] = bounds[0][(size_t) k + 3];
+            for (size_t t = 1; t < threads; ++t)
             {
-                p[k] = row[off[k]];
-                bmin[k] = std::min(bmin[k], p[k]);
-                bmax[k] = std::max(bmax[k], p[k]);
-                s[k] = std::exp(row[off[7 + k]]);
-                c[k] = row[off[10 + k]] * 0.28209479177387814f + 0.5f; // SH band 0 -> rgb, unclamped
-            }
-            p[3] = opacity;
-            c[3] = opacity;
-
-            // rot_0 is w. Normalise, map to [0,1], truncating 8-bit pack in (x,y,z,w) order.
-            float qw = row[off[3]], qx = row[off[4]], qy = row[off[5]], qz = row[off[6]];
-            const float len = std::sqrt((qw * qw + qx * qx) + (qy * qy + qz * qz));
-            if (len <= 0.0f)
-            {
-                qw = 1.0f;
-                qx = qy = qz = 0.0f;
-            }
-            else
-            {
-                const float inv = 1.0f / len;
-                qw *= inv;
-                qx *= inv;
-                qy *= inv;
-                qz *= inv;
-            }
-            const float enc[4] = {(qx + 1.0f) * 0.5f, (qy + 1.0f) * 0.5f, (qz + 1.0f) * 0.5f, (qw + 1.0f) * 0.5f};
-            const uint32_t packed = gs_encode_vec4(enc);
-            std::memcpy(&s[3], &packed, sizeof(float));
-
-            if (degree != 0)
-            {
-                // f_dc (rgb) then f_rest, which the file stores channel-major [c][k] -> [k][c] (PlyParser.cpp:269-286).
-                float* sh = out->sphericalHarmonics + i * (size_t) shCount;
-                for (int k = 0; k != 3; ++k) sh[k] = row[off[10 + k]];
-                for (int j = 0; j != perChannel; ++j)
-                    for (int ch = 0; ch != 3; ++ch) sh[3 + j * 3 + ch] = row[rest[ch * perChannel + j]];
+                bmin[k] = std::min(bmin[k], bounds[t][(size_t) k]);
+                bmax[k] = std::max(bmax[k], bounds[t][(size_t) k + 3]);
             }
         }
         for (int k = 0; k != 3; ++k)

@@ -138,7 +138,9 @@ _OPS_CACHE = {}
 # ---- the control flow of an N-rank run (used by bench.py with GPU renderers, and by tests/test_multigpu_cpu.py with the CPU oracle) ----
 #
 # A "rig" is whatever renders this rank's band: it offers run_frames(count, gather=True) -> frames rendered, sync_all(),
-# local_frame_ms(frames) -> this rank's own milliseconds per frame without the gather, close().  Every function below is a fixed
+# local_frame_ms(frames) -> this rank's own milliseconds per frame without the gather, close(), and optionally
+# gather_frame_ms() -> what the framebuffer exchange costs this rank's GPU per frame when nothing overlaps it (a collective: every
+# rank calls it, in the same place).  Every function below is a fixed
 # sequence of collectives that all ranks enter in the same order whatever their local results: decisions are taken from all-gathered
 # or all-reduced values only, so no rank can leave a loop that another rank is still in.
 def all_gather_floats(value, world, tensor_device):
@@ -153,19 +155,28 @@ def all_gather_floats(value, world, tensor_device):
     return [float(t.item()) for t in everyone]
 
 
-def rebalance_bands(make_rig, rig, bands, row_cost, world, rounds, tensor_device, frames=256, log=None):
+def rebalance_bands(make_rig, rig, bands, row_cost, world, rounds, tensor_device, frames=256, log=None, gather_weight=1.0):
     """Re-cut cost-balanced bands from what every rank MEASURES for its own band (untimed set-up).  The cost model behind the first
     cut does not know the kernels' fixed costs; here the rows of a band that took longer than the mean get more weight (exponent 2:
     only part of a band's time follows its rows), the cut with the smallest slowest band is kept.  Also absorbs speed differences
-    between the GPUs.  make_rig(bands) builds a rig for a new cut; returns (rig, bands, per-rank milliseconds of the kept cut)."""
+    between the GPUs.  A rank's time is its band rendered WITHOUT the exchange (with it, every rank would measure the lock-step of
+    the slowest) PLUS gather_weight x what the exchange alone costs its GPU per frame (rig.gather_frame_ms, if the rig has it):
+    rank 0 receives world - 1 bands per frame with RCCL kernels that run on the GPU that also renders band 0, so its band must
+    come out smaller by that much.  make_rig(bands) builds a rig for a new cut; returns (rig, bands, per-rank milliseconds of the
+    kept cut -- exchange share included)."""
     from .scenes import balanced_tile_row_bands
 
     cost = [float(c) for c in row_cost]
     best = None
+    sees_exchange = gather_weight > 0 and world > 1 and hasattr(rig, "gather_frame_ms")  # the same on every rank
     for it in range(rounds + 1):
-        times = all_gather_floats(rig.local_frame_ms(frames), world, tensor_device)
+        own = rig.local_frame_ms(frames)
+        exchange = rig.gather_frame_ms() if sees_exchange else 0.0
+        times = all_gather_floats(own + gather_weight * exchange, world, tensor_device)
         if log:
-            log(f"rebalance round {it}: bands {bands} ms {[round(t, 4) for t in times]}")
+            shares = all_gather_floats(exchange, world, tensor_device) if sees_exchange else []
+            log(f"rebalance round {it}: bands {bands} ms {[round(t, 4) for t in times]}" +
+                (f" of which exchange {[round(t, 4) for t in shares]}" if shares else ""))
         if best is None or max(times) < best[0]:
             best = (max(times), bands, times)
         if it == rounds:

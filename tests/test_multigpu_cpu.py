@@ -164,8 +164,18 @@ class _OracleRig:
         t0 = time.perf_counter()
         done = self.run_frames(frames, gather=False)
         # a deterministic "measurement" on top of the real one, so that the re-cut takes the same path in every run of the test:
-        # ranks 0 and world-1 are slow
-        return 1e3 * (time.perf_counter() - t0) / done * 1e-6 + (3.0 if self.rank in (0, self.world - 1) else 1.0)
+        # half of a band's time follows its rows (the rest is fixed cost, as on the GPU), ranks 0 and world-1 are three times slower
+        a, b = self.bands[self.rank]
+        rows_per_rank = self.bands[-1][1] / self.world
+        return 1e3 * (time.perf_counter() - t0) / done * 1e-6 + (3.0 if self.rank in (0, self.world - 1) else 1.0) * (0.5 + 0.5 * (b - a) / rows_per_rank)
+
+    def gather_frame_ms(self):
+        """The exchange's share of a rank's frame (a collective in the real rig: here one barrier).  The root pays a fixed extra cost per
+        frame -- its world - 1 receives --, nobody else does: the re-cut must shrink the root's band for it."""
+        import torch.distributed as dist
+
+        dist.barrier()
+        return 2.5 if self.rank == 0 else 0.0
 
     def close(self):
         self.closed = True
@@ -196,13 +206,22 @@ def _control_flow_worker(rank, world, port, width, height, views, out_path):
             made.append(b)
             return _OracleRig(scene, cams, b, rank, world, width, height, views)
 
+        first_cut = bands
+        # the same re-cut twice: blind to the exchange (round 3), then with the root's share of it (rig.gather_frame_ms) in its time
         rig = make(bands)
-        rig, bands, times = multigpu.rebalance_bands(make, rig, bands, row_cost, world, 2, "cpu", frames=views)
+        rig, blind_bands, _ = multigpu.rebalance_bands(make, rig, bands, row_cost, world, 2, "cpu", frames=views, gather_weight=0.0)
+        rig.close()
+        del made[:]
+        rig = make(first_cut)
+        rig, bands, times = multigpu.rebalance_bands(make, rig, first_cut, row_cost, world, 2, "cpu", frames=views)
         dog.beat("rebalanced")
         assert len(times) == world and len(bands) == world and bands[-1][1] == ty
         # the slow outer ranks must have lost rows to the inner ones
         first_cut = made[0]
         assert (bands[0][1] - bands[0][0]) <= (first_cut[0][1] - first_cut[0][0])
+        # ... and the root, which also pays for the exchange, more than in the cut that does not see the gather (every band is timed
+        # without it either way)
+        assert times[0] >= 2.5 and (bands[0][1] - bands[0][0]) < (blind_bands[0][1] - blind_bands[0][0]), (bands, blind_bands, times)
         assert multigpu.spin_up(rig, 0.05, world, "cpu", chunk=views) >= views
         elapsed, frames, mine = multigpu.timed_frames(rig, 2, views, world, "cpu")
         assert frames == -(-2 // views) * views and elapsed >= mine > 0  # steps round up to whole chains of V frames; MAX over ranks
