@@ -6,6 +6,7 @@ Tolerances (stated once, used below):
   * clip data: centre, depth, conic and extents EQUAL the oracle's values (no contraction, glm's operand order, IEEE
     division and square root on both sides); only the ellipse axis is compared as a line, weighted by the anisotropy: the
     oracle follows the reference's cos(atan2)/sin(atan2) through glibc, the kernel stores the normalised eigenvector;
+  * pair count of a whole frame against the oracle's own frame: PAIR_SLACK (the ellipse axis above; 0-1 of 5.5 M observed);
   * image: per channel |d| <= 1/255 on >= 99.9 % of the channel values and <= IMAGE_MAX_LSB/255 everywhere
     (hardware exp2 vs expf, fma association, and the 8-bit truncation of GaussianRender.cu:1007-1011).
 """
@@ -18,6 +19,14 @@ pytestmark = pytest.mark.gpu
 
 IMAGE_MAX_LSB = 3
 IMAGE_FRAC_GT1 = 1e-3
+
+
+def PAIR_SLACK(pairs):
+    """Pair COUNT of a renderer frame against the oracle's frame of its OWN clip data.  The list builder is bit-exact on given clip data
+    (test_two_level_pipeline_equals_reference_pipeline, test_tile_list_sort_ranges_bit_exact) and centre, depth, conic and extents equal
+    the oracle's; what is left is the ellipse axis (cos/sin(atan2) through glibc in the oracle, the normalised eigenvector in the
+    kernel): a tile whose overlap margin is at the last bit may flip.  Observed 0-1 of 5.5 M; allowed 4 + one per two million."""
+    return 4 + pairs // 2_000_000
 
 
 def _procedural(gs, n, seed=1234, min_scale=0.01, max_scale=0.5):
@@ -202,7 +211,7 @@ def test_end_to_end_config1(gs, gsref):
     cam = gs.camera_from_bounds([-4] * 3, [4] * 3, 256, 256)
     got, want, st, rst = _end_to_end(gs, gsref, {"position": pos, "scaleAndRotation": sr, "color": col}, cam, 256, 256)
     _assert_image_close(got, want)
-    assert abs(st.tileListSize - rst.tileListSize) <= 2  # clip data differs in the last bits -> borderline tiles
+    assert abs(st.tileListSize - rst.tileListSize) <= 2  # the ellipse axis differs in the last bit -> borderline tiles (PAIR_SLACK)
     assert got[..., :3].max() > 0
 
 
@@ -212,7 +221,7 @@ def test_end_to_end_ply(gs, gsref, tmp_path, w, h, degree):
     cam = gs.camera_from_bounds(ply["boundsMin"], ply["boundsMax"], w, h)
     got, want, st, rst = _end_to_end(gs, gsref, ply, cam, w, h)
     _assert_image_close(got, want)
-    assert abs(st.tileListSize - rst.tileListSize) <= max(2, 1e-4 * rst.tileListSize)
+    assert abs(st.tileListSize - rst.tileListSize) <= PAIR_SLACK(rst.tileListSize)
 
 
 def test_edge_cases(gs, gsref):
@@ -632,7 +641,7 @@ def test_epanechnikov_footprint(gs, gsref, tmp_path, degree):
                 r.close()
             for img, size, values in per_pipeline:
                 _assert_image_close(img, want, f"footprint={footprint}")
-                assert abs(size - rst.tileListSize) <= max(4, 2e-5 * rst.tileListSize)
+                assert abs(size - rst.tileListSize) <= PAIR_SLACK(rst.tileListSize)
             captured.render(cam)  # the footprint is part of the captured kernels' arguments: must re-capture
             assert np.array_equal(captured.read_image(), per_pipeline[1][0])
             images[footprint] = (per_pipeline[1][0], ell.copy())
@@ -929,7 +938,7 @@ def test_full_size_parity_with_oracle(gs, gsref, tmp_path_factory, config):
     finally:
         gs.lib().gs_set_collect_raster_stats(0)
     stats = _assert_image_close(got, want, config)
-    assert abs(st.tileListSize - rst.tileListSize) <= max(4, 2e-5 * rst.tileListSize), (st.tileListSize, rst.tileListSize)
+    assert abs(st.tileListSize - rst.tileListSize) <= PAIR_SLACK(rst.tileListSize), (st.tileListSize, rst.tileListSize)
     assert abs(st.consumedPairs - rst.consumedPairs) <= 0.002 * rst.consumedPairs + 64, (st.consumedPairs, rst.consumedPairs)
     assert np.array_equal(got[..., 3], want[..., 3])  # alpha: 255 exactly where the oracle's tiles had work
     # the captured frame (what bench.py times) hands out the same bytes
