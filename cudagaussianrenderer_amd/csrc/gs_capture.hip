@@ -59,12 +59,14 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
     }
     else
     {
-        launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
-                            nullptr, r->clipZ, nullptr, nullptr, nullptr, nullptr, r->bandMask,
-                            r->bandSlotPrefix, r->bandCounts, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord, (float4*) r->rasterRecord,
-                            views);
+        // (Morton storage: in the caller's order, from the caller-ordered copies of the inputs)
+        const bool callerOrder = r->splatToStorage != nullptr;
+        launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) (callerOrder ? r->positionCaller : r->position),
+                            (const float4*) (callerOrder ? r->scaleAndRotationCaller : r->scaleAndRotation), nullptr, r->clipZ, nullptr, nullptr, nullptr,
+                            nullptr, r->bandMask, r->bandSlotPrefix, r->bandCounts, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord,
+                            (float4*) r->rasterRecord, views, r->splatToStorage);
         launchBandCompaction(g.stream, n, views, r->bandMask, r->bandSlotPrefix, r->bandCounts, r->bandOffsets, r->bandTotal, r->clipZ, r->depthKey[0],
-                             (uint32_t*) r->order[0], r->splatToStorage, r->bandMaskCaller);
+                             (uint32_t*) r->order[0], r->splatToStorage);
         countDevice = (const int*) r->bandTotal;
         if (r->shDegree != 0 && !lazy)
             launchSphericalHarmonicsGather(g.stream, n, countDevice, r->shDegree, r->shCount, r->order[0], (const float4*) r->position,

@@ -45,11 +45,8 @@ struct ClipOutputs
     float4* rasterRecord;
 };
 
-// The projection proper for one splat: covariance, eigen decomposition, conic, frustum cull, (band test,) stores under `out`.
-// Returns whether the splat reaches the band (always true without a band test).
-template <bool BAND>
-__device__ __forceinline__ bool projectSplat(const float4 pd, const float4 sr, const ClipCamera& cam, const Screen& scr, int out,
-                                             const ClipOutputs& o)
+// World-space covariance of a splat, Sigma = (R S)(R S)^T (GaussianRender.cu:215-224): the camera-independent half of the projection.
+__device__ __forceinline__ Sym3 splatCovariance(const float4 sr)
 {
     // decodeVec4 (GaussianRender.cu:55-58,220-221): four truncated bytes -> [-1,1], x in the top byte;
     // the quaternion is NOT renormalised.
@@ -78,7 +75,18 @@ __device__ __forceinline__ bool projectSplat(const float4 pd, const float4 sr, c
     S.yy = m01 * m01 + m11 * m11 + m21 * m21;
     S.yz = m01 * m02 + m11 * m12 + m21 * m22;
     S.zz = m02 * m02 + m12 * m12 + m22 * m22;
+    return S;
+}
 
+// The camera-dependent half: projection of the covariance, eigen decomposition, conic, frustum cull, (band test,) stores.
+// `out`: the (virtual) storage slot the records are stored under; `zOut`: where the clip depth goes (= out, except on the band-cull
+// path of a renderer with Morton storage, which walks the splats in the CALLER's order and compacts them in it).
+// Returns whether the splat reaches the band (always true without a band test).  No contraction in this file: the two halves give the
+// same bits whether a kernel runs them back to back for one camera or keeps the covariance for several.
+template <bool BAND>
+__device__ __forceinline__ bool projectCovariance(const float4 pd, const Sym3 S, const ClipCamera& cam, const Screen& scr, int out, int zOut,
+                                                  const ClipOutputs& o)
+{
     const float* v = cam.view;
     const ViewTerms t = viewTerms(pd, cam);
     const float scaleX = t.scaleX, scaleY = t.scaleY, shearX = t.shearX, shearY = t.shearY;
@@ -150,7 +158,7 @@ __device__ __forceinline__ bool projectSplat(const float4 pd, const float4 sr, c
         if (o.splatOrder != nullptr) o.splatOrder[out] = (uint32_t) out;
     }
     if (o.clipXY != nullptr) o.clipXY[out] = make_float2(clipX, clipY);
-    if (o.clipZ != nullptr) o.clipZ[out] = clipDepth;
+    if (o.clipZ != nullptr) o.clipZ[zOut] = clipDepth;
     if (o.screenEllipse != nullptr) o.screenEllipse[out] = make_float4(cosA, sinA, extentX, extentY);
     if (o.tileRecord != nullptr)
     {
@@ -168,6 +176,13 @@ __device__ __forceinline__ bool projectSplat(const float4 pd, const float4 sr, c
         o.rasterRecord[2 * (size_t) out + 1] = make_float4(covA * invDet, clipDepth, 0.0f, 0.0f); // (the depth rides along for gs_renderer_buffers)
     }
     return true;
+}
+
+template <bool BAND>
+__device__ __forceinline__ bool projectSplat(const float4 pd, const float4 sr, const ClipCamera& cam, const Screen& scr, int out, int zOut,
+                                             const ClipOutputs& o)
+{
+    return projectCovariance<BAND>(pd, splatCovariance(sr), cam, scr, out, zOut, o);
 }
 
 constexpr int kBandBlock = 256;                // splats per workgroup of the band-cull kernel; the compaction's scan runs over these blocks
@@ -189,12 +204,17 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
     if (index >= count) return;
     const ClipCamera cam = params ? params[view].camera : camArg; // device-resident when the frame is a captured graph
     // results are stored under the "virtual splat" view * count + index
-    (void) projectSplat<false>(position[index], scaleAndRotation[index], cam, scr, view * count + index, o);
+    (void) projectSplat<false>(position[index], scaleAndRotation[index], cam, scr, view * count + index, view * count + index, o);
 }
 
 // Multi-GPU band cull: the same projection, but a splat whose tile AABB does not reach this GPU's tile rows stores nothing.
 // Leaves, per slot of 64 splats, the 64-bit mask of the kept ones and the number of kept splats in the workgroup's earlier slots;
 // per workgroup, its number of kept splats (the compaction scans these).
+// Morton storage (outSlot != nullptr): the kernel walks the splats in the CALLER's order -- position and scaleAndRotation are then the
+// caller-ordered copies, masks, counts and clip depths are indexed by the caller's index, and only the two 32-byte records of a kept
+// splat go to its storage slot outSlot[index] (whole memory sectors).  The compaction therefore runs in the caller's order without
+// gathering anything, the stable depth sort keeps splats of equal depth code in it, and the frame is the one a renderer with the
+// caller's storage order gives -- for any number of equal codes (round 3 repaired the order after the sort, up to runs of 1024).
 // (Tried and dropped: a cheap conservative bound on the AABB's height first -- trace(Sigma) |J W|_F^2 -- with the candidates of a
 // 256- or 1024-splat workgroup compacted in LDS and only those projected.  24 % of the splats of a centre band of the 8-way split
 // are candidates, the projection work falls to a third -- and the kernel takes as long as before: 48.4 - 58.6 us for a 4-view chain
@@ -204,7 +224,7 @@ __global__ __launch_bounds__(256) void splatClipBandKernel(int count, Screen scr
                                                             const float4* __restrict__ scaleAndRotation, ClipOutputs o,
                                                             unsigned long long* __restrict__ bandMask, int32_t* __restrict__ bandSlotPrefix,
                                                             int32_t* __restrict__ bandBlockCounts, int32_t* __restrict__ rangeTable,
-                                                            int rangeEntries)
+                                                            int rangeEntries, const int32_t* __restrict__ outSlot)
 {
     __shared__ int slotKept[kBandSlots];
     const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
@@ -217,7 +237,9 @@ __global__ __launch_bounds__(256) void splatClipBandKernel(int count, Screen scr
     if (blockBase >= count) return; // whole workgroup
     const ClipCamera cam = params ? params[view].camera : camArg;
     bool kept = false;
-    if (index < count) kept = projectSplat<true>(position[index], scaleAndRotation[index], cam, scr, view * count + index, o);
+    if (index < count)
+        kept = projectSplat<true>(position[index], scaleAndRotation[index], cam, scr, view * count + (outSlot != nullptr ? outSlot[index] : index),
+                                  view * count + index, o);
     const unsigned long long mask = __ballot(kept);
     if (lane == 0) slotKept[wave] = __popcll(mask);
     __syncthreads();
@@ -232,44 +254,70 @@ __global__ __launch_bounds__(256) void splatClipBandKernel(int count, Screen scr
     }
 }
 
-// Morton storage: the keep-masks of the band cull, re-gathered in the CALLER's order (lane = caller index c, one bit fetched from
-// the storage-ordered mask of slot splatToStorage[c]; the 0.5 MB of masks are L2-resident), with the same per-slot prefixes and
-// per-workgroup counts the clip kernel leaves in storage order.  The compaction then runs over the caller's order, the stable depth
-// sort keeps splats of equal depth code in it, and the frame is the one a renderer with the caller's storage order gives -- for any
-// number of equal codes (round 3 repaired the order after the sort, up to runs of 1024).
-__global__ __launch_bounds__(256) void bandCallerMaskKernel(int count, const int32_t* __restrict__ splatToStorage,
-                                                             const unsigned long long* __restrict__ bandMask,
-                                                             unsigned long long* __restrict__ callerMask, int32_t* __restrict__ bandSlotPrefix,
-                                                             int32_t* __restrict__ bandBlockCounts)
+// The band kernel for a chain of several views (gs_renderer_set_views): ONE lane per splat walks all the chain's cameras -- position and
+// scale/rotation are read once and the world-space covariance is computed once, only the camera-dependent half runs per view.  Same
+// outputs as `views` grid rows of the kernel above, bit for bit (no contraction in this file).  Round 3 measured this shape at
+// 45.9 against 50.2 us at V = 4 and had to drop it: with contraction on, the compiler fused the inlined arithmetic differently in
+// the two contexts and half of the conics lost their last bit (profiles/r04_clip_all_views.txt has this round's figures).
+__global__ __launch_bounds__(256) void splatClipBandViewsKernel(int count, int views, Screen scr, const FrameParams* __restrict__ params,
+                                                                 const float4* __restrict__ position,
+                                                                 const float4* __restrict__ scaleAndRotation, ClipOutputs o,
+                                                                 unsigned long long* __restrict__ bandMask, int32_t* __restrict__ bandSlotPrefix,
+                                                                 int32_t* __restrict__ bandBlockCounts, int32_t* __restrict__ rangeTable,
+                                                                 int rangeEntries, const int32_t* __restrict__ outSlot)
 {
-    __shared__ int slotKept[kBandSlots];
+    __shared__ int slotKept[kMaxViews][kBandSlots];
     const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
-    const int index = blockIdx.x * blockDim.x + t; // caller's index
-    const int view = blockIdx.y;
+    const int index = blockIdx.x * blockDim.x + t;
+    if (rangeTable != nullptr)
+        for (int i = index; i < rangeEntries; i += (int) (gridDim.x * blockDim.x)) rangeTable[i] = -1;
     const int blockBase = blockIdx.x * kBandBlock;
-    const int slotsPerView = (count + kWave - 1) / kWave, blocksPerView = (count + kBandBlock - 1) / kBandBlock;
-    bool kept = false;
+    if (blockBase >= count) return; // whole workgroup
+    float4 pd = make_float4(0.f, 0.f, 0.f, 0.f);
+    Sym3 S{};
+    int slot = index;
     if (index < count)
     {
-        const int stored = splatToStorage[index];
-        kept = ((bandMask[view * slotsPerView + (stored >> 6)] >> (stored & (kWave - 1))) & 1ull) != 0ull;
+        pd = position[index];
+        S = splatCovariance(scaleAndRotation[index]);
+        if (outSlot != nullptr) slot = outSlot[index];
     }
-    const unsigned long long mask = __ballot(kept);
-    if (lane == 0) slotKept[wave] = __popcll(mask);
+    unsigned long long masks[kMaxViews];
+#pragma unroll
+    for (int view = 0; view != kMaxViews; ++view)
+    {
+        masks[view] = 0ull;
+        if (view < views) // (uniform)
+        {
+            bool kept = false;
+            if (index < count) kept = projectCovariance<true>(pd, S, params[view].camera, scr, view * count + slot, view * count + index, o);
+            masks[view] = __ballot(kept);
+            if (lane == 0) slotKept[view][wave] = __popcll(masks[view]);
+        }
+    }
     __syncthreads();
     if (lane == 0 && blockBase + wave * kWave < count)
     {
-        int prefix = 0;
-        for (int s = 0; s < wave; ++s) prefix += slotKept[s];
-        callerMask[view * slotsPerView + (blockBase >> 6) + wave] = mask;
-        bandSlotPrefix[view * slotsPerView + (blockBase >> 6) + wave] = prefix;
-        if (wave == 0) bandBlockCounts[view * blocksPerView + blockIdx.x] = slotKept[0] + slotKept[1] + slotKept[2] + slotKept[3];
+        const int slotsPerView = (count + kWave - 1) / kWave, blocksPerView = (count + kBandBlock - 1) / kBandBlock;
+#pragma unroll
+        for (int view = 0; view != kMaxViews; ++view)
+        {
+            if (view < views)
+            {
+                int prefix = 0;
+                for (int s = 0; s < wave; ++s) prefix += slotKept[view][s];
+                bandMask[view * slotsPerView + (blockBase >> 6) + wave] = masks[view];
+                bandSlotPrefix[view * slotsPerView + (blockBase >> 6) + wave] = prefix;
+                if (wave == 0)
+                    bandBlockCounts[view * blocksPerView + blockIdx.x] = slotKept[view][0] + slotKept[view][1] + slotKept[view][2] + slotKept[view][3];
+            }
+        }
     }
 }
 
 // Order-preserving compaction of the splats flagged by the band cull: depth key + (virtual) splat index of every kept splat at
-// blockOffsets[block of 256 splats] + (kept splats of the block's earlier slots) + (kept lanes below it).  With Morton storage the
-// masks are the caller-ordered ones and lane c compacts the splat stored in slot splatToStorage[c].
+// blockOffsets[block of 256 splats] + (kept splats of the block's earlier slots) + (kept lanes below it).  With Morton storage
+// masks and clip depths are the caller-ordered ones (see the band kernel) and lane c compacts the splat stored in slot splatToStorage[c].
 __global__ __launch_bounds__(256) void compactBandKernel(int count, const unsigned long long* __restrict__ bandMask,
                                                           const int32_t* __restrict__ bandSlotPrefix, const int32_t* __restrict__ blockOffsets,
                                                           const float* __restrict__ clipZ, const int32_t* __restrict__ splatToStorage,
@@ -287,7 +335,7 @@ __global__ __launch_bounds__(256) void compactBandKernel(int count, const unsign
         const int out = view * count + (splatToStorage != nullptr ? splatToStorage[index] : index); // virtual splat (see the clip kernel)
         const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
         const int pos = blockOffsets[view * blocksPerView + index / kBandBlock] + bandSlotPrefix[slot] + __popcll(mask & lower);
-        depthKey[pos] = compactDepthKey(clipZ[out]);
+        depthKey[pos] = compactDepthKey(clipZ[view * count + index]);
         splatOrder[pos] = (uint32_t) out;
     }
 }
@@ -326,19 +374,12 @@ void launchUnpackEllipse(hipStream_t stream, int count, const float4* tileRecord
     if (count > 0) hipLaunchKernelGGL(unpackEllipseKernel, dim3((count + 255) / 256), dim3(256), 0, stream, count, tileRecord, screenEllipse);
 }
 
-void launchBandCompaction(hipStream_t stream, int count, int views, const unsigned long long* bandMask, int32_t* bandSlotPrefix,
-                          int32_t* bandBlockCounts, int32_t* bandBlockOffsets, int64_t* bandTotal, const float* clipZ,
-                          uint32_t* depthKey, uint32_t* splatOrder, const int32_t* splatToStorage, unsigned long long* callerMask)
+void launchBandCompaction(hipStream_t stream, int count, int views, const unsigned long long* bandMask, const int32_t* bandSlotPrefix,
+                          const int32_t* bandBlockCounts, int32_t* bandBlockOffsets, int64_t* bandTotal, const float* clipZ,
+                          uint32_t* depthKey, uint32_t* splatOrder, const int32_t* splatToStorage)
 {
     if (count <= 0) return;
     const int blocks = (count + kBandBlock - 1) / kBandBlock;
-    if (splatToStorage != nullptr)
-    {
-        // Morton storage: masks, slot prefixes and block counts once more, in the caller's order
-        hipLaunchKernelGGL(bandCallerMaskKernel, dim3(blocks, views), dim3(256), 0, stream, count, splatToStorage, bandMask, callerMask,
-                           bandSlotPrefix, bandBlockCounts);
-        bandMask = callerMask;
-    }
     launchScanInt32(stream, blocks * views, bandBlockCounts, bandBlockOffsets, bandTotal);
     hipLaunchKernelGGL(compactBandKernel, dim3((count + 255) / 256, views), dim3(256), 0, stream, count, bandMask, bandSlotPrefix,
                        bandBlockOffsets, clipZ, splatToStorage, depthKey, splatOrder);
@@ -348,15 +389,21 @@ void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const
                          const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic,
                          uint32_t* depthKey, uint32_t* splatOrder, unsigned long long* bandMask, int32_t* bandSlotPrefix,
                          int32_t* bandBlockCounts, const FrameParams* paramsDevice, int32_t* rangeTableToClear, int rangeEntries,
-                         float4* tileRecord, float4* rasterRecord, int views)
+                         float4* tileRecord, float4* rasterRecord, int views, const int32_t* bandOutSlot)
 {
     if (count <= 0) return;
     // views > 1: cameras from paramsDevice[view], results under view * count + splat
     const ClipOutputs o{clipXY, clipZ, screenEllipse, conic, depthKey, splatOrder, tileRecord, rasterRecord};
-    if (bandMask != nullptr)
+#ifndef GS_CLIP_ALL_VIEWS
+#define GS_CLIP_ALL_VIEWS 1 // A/B builds: 0 = one grid row per view (round 3)
+#endif
+    if (bandMask != nullptr && views > 1 && paramsDevice != nullptr && GS_CLIP_ALL_VIEWS)
+        hipLaunchKernelGGL(splatClipBandViewsKernel, dim3((count + kBandBlock - 1) / kBandBlock), dim3(256), 0, stream, count, views, scr, paramsDevice,
+                           position, scaleAndRotation, o, bandMask, bandSlotPrefix, bandBlockCounts, rangeTableToClear, rangeEntries, bandOutSlot);
+    else if (bandMask != nullptr)
         hipLaunchKernelGGL(splatClipBandKernel, dim3((count + kBandBlock - 1) / kBandBlock, views), dim3(256), 0, stream, count, scr, cam,
                            paramsDevice, position, scaleAndRotation, o, bandMask, bandSlotPrefix, bandBlockCounts, rangeTableToClear,
-                           rangeEntries);
+                           rangeEntries, bandOutSlot);
     else
         hipLaunchKernelGGL(splatClipDataKernel, dim3((count + 255) / 256, views), dim3(256), 0, stream, count, scr, cam, paramsDevice, position,
                            scaleAndRotation, o, rangeTableToClear, rangeEntries);

@@ -79,7 +79,7 @@ void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const
                          int32_t* bandSlotPrefixOrNull = nullptr, int32_t* bandBlockCountsOrNull = nullptr,
                          const FrameParams* paramsDeviceOrNull = nullptr,
                          int32_t* rangeTableToClearOrNull = nullptr, int rangeEntries = 0, float4* tileRecordOrNull = nullptr,
-                         float4* rasterRecordOrNull = nullptr, int views = 1);
+                         float4* rasterRecordOrNull = nullptr, int views = 1, const int32_t* bandOutSlotOrNull = nullptr);
 // screenEllipse[i] = (cos, sin, extent x, extent y) from the 32-byte tile records the clip kernel can write instead.
 void launchUnpackEllipse(hipStream_t stream, int count, const float4* tileRecord, float4* screenEllipse);
 // positionClipSpaceXY / Z / conic from the 32-byte raster records (cx, cy, conic.x, conic.y | conic.z, depth, 0, 0) the clip kernel can
@@ -87,12 +87,12 @@ void launchUnpackEllipse(hipStream_t stream, int count, const float4* tileRecord
 void launchUnpackRasterRecord(hipStream_t stream, int count, const float4* rasterRecord, float2* clipXY, float* clipZ, float4* conic);
 // Band cull (multi-GPU): the clip kernel flags the splats whose tile AABB reaches this GPU's rows (per 64 splats one 64-bit mask
 // and the kept splats before them in their block of 256, one count per block); this scans the block counts and writes the kept
-// splats' depth keys and (virtual) indices, order preserved, and their number to *bandTotal.  Morton storage: splatToStorage
-// (caller's index -> storage slot) and a second mask array; the compaction then runs in the CALLER's order (gs_clip.hip).
-void launchBandCompaction(hipStream_t stream, int count, int views, const unsigned long long* bandMask, int32_t* bandSlotPrefix,
-                          int32_t* bandBlockCounts, int32_t* bandBlockOffsets, int64_t* bandTotal, const float* clipZ,
-                          uint32_t* depthKey, uint32_t* splatOrder, const int32_t* splatToStorageOrNull = nullptr,
-                          unsigned long long* callerMaskOrNull = nullptr);
+// splats' depth keys and (virtual) indices, order preserved, and their number to *bandTotal.  Morton storage: the band kernel was given
+// the caller-ordered inputs and bandOutSlot = splatToStorage (caller's index -> storage slot); masks and clip depths are then indexed
+// by the caller's index and the compaction runs in the CALLER's order (gs_clip.hip).
+void launchBandCompaction(hipStream_t stream, int count, int views, const unsigned long long* bandMask, const int32_t* bandSlotPrefix,
+                          const int32_t* bandBlockCounts, int32_t* bandBlockOffsets, int64_t* bandTotal, const float* clipZ,
+                          uint32_t* depthKey, uint32_t* splatOrder, const int32_t* splatToStorageOrNull = nullptr);
 // Exclusive scan of n int32 on the device (one workgroup), total as int64.
 void launchScanInt32(hipStream_t stream, int n, const int32_t* in, int32_t* out, int64_t* total);
 // SH colour for the splats of a device-side index list only; coefficients in the [splat][shCount] layout.

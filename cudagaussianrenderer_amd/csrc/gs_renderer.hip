@@ -68,13 +68,14 @@ void freeScene(GsRenderer* r)
         // the read-only inputs are the owner's
         r->position = r->scaleAndRotation = r->sh = r->shPerSplat = nullptr;
         r->splatToStorage = nullptr;
-        r->positionCaller = nullptr;
+        r->positionCaller = r->scaleAndRotationCaller = nullptr;
         r->sceneShared = false;
     }
     gs_device_free(r->splatToStorage);
     gs_device_free(r->positionCaller);
+    gs_device_free(r->scaleAndRotationCaller);
     r->splatToStorage = nullptr;
-    r->positionCaller = nullptr;
+    r->positionCaller = r->scaleAndRotationCaller = nullptr;
     r->storageToSplatHost.clear();
     float** bufs[] = {&r->position, &r->scaleAndRotation, &r->color,   &r->sh,         &r->clipXY,
                       &r->clipZ,    &r->conic,            &r->ellipse, &r->tileRecord, &r->rasterRecord};
@@ -92,13 +93,12 @@ void freeScene(GsRenderer* r)
     }
     gs_device_free(r->shPerSplat);
     gs_device_free(r->bandMask);
-    gs_device_free(r->bandMaskCaller);
     gs_device_free(r->bandCounts);
     gs_device_free(r->bandSlotPrefix);
     gs_device_free(r->bandOffsets);
     gs_device_free(r->bandTotal);
     r->shPerSplat = nullptr;
-    r->bandMask = r->bandMaskCaller = nullptr;
+    r->bandMask = nullptr;
     r->bandCounts = r->bandOffsets = r->bandSlotPrefix = nullptr;
     r->bandTotal = nullptr;
 }
@@ -228,7 +228,6 @@ void allocateSceneIntermediates(GsRenderer* r, int32_t n)
     }
     const size_t waves = (((size_t) n + kWave - 1) / kWave) * (size_t) r->views;
     r->bandMask = (unsigned long long*) gs_device_alloc(sizeof(unsigned long long) * waves);
-    if (r->splatToStorage != nullptr) r->bandMaskCaller = (unsigned long long*) gs_device_alloc(sizeof(unsigned long long) * waves);
     r->bandCounts = (int32_t*) gs_device_alloc(sizeof(int32_t) * waves);
     r->bandSlotPrefix = (int32_t*) gs_device_alloc(sizeof(int32_t) * waves);
     r->bandOffsets = (int32_t*) gs_device_alloc(sizeof(int32_t) * waves);
@@ -282,6 +281,9 @@ extern "C" int gs_renderer_set_scene(GsRenderer* r, int32_t n, const float* posi
         // ... and the positions in the caller's order, from which its first pass makes the keys (gs_radix.hip, KEYGEN)
         r->positionCaller = (float*) gs_device_alloc(f4);
         gs_device_upload(r->positionCaller, position4, f4);
+        // ... and the band-cull kernel of a multi-GPU rank walks the splats in the caller's order (gs_clip.hip)
+        r->scaleAndRotationCaller = (float*) gs_device_alloc(f4);
+        gs_device_upload(r->scaleAndRotationCaller, scaleAndRotation4, f4);
     }
     r->position = (float*) gs_device_alloc(f4);
     r->scaleAndRotation = (float*) gs_device_alloc(f4);
@@ -339,6 +341,7 @@ extern "C" int gs_renderer_share_scene(GsRenderer* r, const GsRenderer* owner)
     if (owner->splatToStorage != nullptr && owner->views != r->views) return -1; // (the order list is laid out per view)
     r->splatToStorage = owner->splatToStorage;
     r->positionCaller = owner->positionCaller;
+    r->scaleAndRotationCaller = owner->scaleAndRotationCaller;
     r->storageToSplatHost = owner->storageToSplatHost;
     r->sceneShared = true;
     if (r->splatToStorage != nullptr) r->pipeline = GS_PIPELINE_TWO_LEVEL; // (see gs_renderer_set_pipeline)
@@ -585,12 +588,14 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         else
         {
             // clip data for every splat + keep-mask, then an order-preserving compaction of (depth key, index)
-            launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation,
-                                nullptr, r->clipZ, nullptr, nullptr, nullptr, nullptr, r->bandMask,
-                                r->bandSlotPrefix, r->bandCounts, nullptr, r->tileRange, 2 * scr.totalTiles, (float4*) r->tileRecord,
-                                (float4*) r->rasterRecord);
+            // (Morton storage: in the caller's order, from the caller-ordered copies of the inputs)
+            const bool callerOrder = r->splatToStorage != nullptr;
+            launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) (callerOrder ? r->positionCaller : r->position),
+                                (const float4*) (callerOrder ? r->scaleAndRotationCaller : r->scaleAndRotation), nullptr, r->clipZ, nullptr, nullptr,
+                                nullptr, nullptr, r->bandMask, r->bandSlotPrefix, r->bandCounts, nullptr, r->tileRange, 2 * scr.totalTiles,
+                                (float4*) r->tileRecord, (float4*) r->rasterRecord, 1, r->splatToStorage);
             launchBandCompaction(g.stream, n, 1, r->bandMask, r->bandSlotPrefix, r->bandCounts, r->bandOffsets, r->bandTotal, r->clipZ, r->depthKey[0],
-                                 (uint32_t*) r->order[0], r->splatToStorage, r->bandMaskCaller);
+                                 (uint32_t*) r->order[0], r->splatToStorage);
             countDevice = (const int*) r->bandTotal; // low 32 bits of the little-endian int64 total
         }
         gs_timer_stop(stageTimers[1]);

@@ -81,15 +81,17 @@ struct GsRenderer
     float lastCameraPosition[3] = {0.f, 0.f, 0.f};
     float* tileRecord = nullptr; // 8 floats per splat: clip x, y, cos, sin, extent x, y, 0, 0 (one memory sector)
     float* rasterRecord = nullptr; // 8 floats per splat: clip x, y, conic x, y, z, 0, 0, 0 (what the raster gathers per list entry)
-    bool sceneShared = false; // position, scaleAndRotation, sh, shPerSplat, splatToStorage, positionCaller belong to another renderer (gs_renderer_share_scene)
+    bool sceneShared = false; // position, scaleAndRotation, sh, shPerSplat, splatToStorage, positionCaller, scaleAndRotationCaller belong to another renderer (gs_renderer_share_scene)
     // gs_renderer_set_storage_order: the splats stored along a Morton curve instead of in the caller's order.  storageToSplat[k] = the
     // caller's index of the splat in slot k (host copy, for gs_renderer_storage_order); splatToStorage its inverse on the device, once
     // per view (entry v * N + c = v * N + slot of caller c): the INPUT ORDER of the depth sort (gs_radix.hip: a stable sort leaves
     // equal depth codes in input order = the caller's) and the order the band cull compacts in; null = the caller's order.
-    // positionCaller: the positions once more in the caller's order -- the depth sort's first pass makes its keys from them.
+    // positionCaller / scaleAndRotationCaller: the projection's inputs once more in the caller's order -- the depth sort's first
+    // pass makes its keys from the positions, the band-cull kernel walks both.
     int storageOrder = GS_STORAGE_ORDER_CALLER;
     int32_t* splatToStorage = nullptr;
     float* positionCaller = nullptr;
+    float* scaleAndRotationCaller = nullptr;
     std::vector<int32_t> storageToSplatHost;
     uint32_t* depthKey[2] = {nullptr, nullptr};
     int32_t* order[2] = {nullptr, nullptr};
@@ -117,7 +119,6 @@ struct GsRenderer
     int capturedRetries = 0; // captured frames rendered again because their pair demand exceeded the list capacity
     gs::FrameState frame;
     unsigned long long* bandMask = nullptr;
-    unsigned long long* bandMaskCaller = nullptr; // Morton storage: the keep-masks re-gathered in the caller's order
     int32_t *bandCounts = nullptr, *bandOffsets = nullptr, *bandSlotPrefix = nullptr;
     int64_t* bandTotal = nullptr;
     int bandCull = GS_BAND_CULL_AUTO;
