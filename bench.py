@@ -55,7 +55,8 @@ def algorithmic_bytes(n, p, pc, tiles, nonempty_tiles, w, h, sh_degree, sort_pas
     }
 
 
-def moved_bytes(n, p, pc, tiles, w, h, sh_degree, tile_key_bytes, colours_on_demand, depth_passes, tile_passes, morton=False):
+def moved_bytes(n, p, pc, tiles, w, h, sh_degree, tile_key_bytes, colours_on_demand, depth_passes, tile_passes, morton=False,
+                fused_first_pass=False):
     """Bytes the kernels of THIS implementation request per frame (one line per kernel): what the
     per-stage GB/s figures are computed from.  Gathers are counted at the size of the record they fetch, not at the
     memory-sector size (the PMC counters show the difference)."""
@@ -68,10 +69,12 @@ def moved_bytes(n, p, pc, tiles, w, h, sh_degree, tile_key_bytes, colours_on_dem
         # the splats are stored in Morton order (the depth sort's first pass then makes the codes itself, in the caller's order)
         "clip": n * (32 + 32 + 32 + (0 if morton else 8)),
         # count: order entry + tile record in, 16-byte box record + 16 hit-mask bytes out; emit: order entry + box record + masks in, pairs out
-        "tile_list": n * ((4 + 32 + 16 + 16) + (4 + 16 + 16)) + p * (kb + 4),
+        # (list fusion: the pairs leave the emit pass already sorted by their low tile digit -- same bytes out, + the digit table of the
+        # count pass, 4 bytes per digit and group of 256 splats, written, scanned and read: 3 x 2 = 6 passes over it at most)
+        "tile_list": n * ((4 + 32 + 16 + 16) + (4 + 16 + 16)) + p * (kb + 4) + (6 * 4 * 256 * (n // 256) if fused_first_pass else 0),
         # LSD passes: histogram reads keys, scatter reads and writes (key, value); Morton: the first depth pass reads the caller-ordered
         # positions and writes the codes before it counts them
-        "sort": depth_passes * n * (4 + 2 * 8) + (n * 16 if morton else 0) + tile_passes * p * (kb + 2 * (kb + 4)),
+        "sort": depth_passes * n * (4 + 2 * 8) + (n * 16 if morton else 0) + (tile_passes - (1 if fused_first_pass else 0)) * p * (kb + 2 * (kb + 4)),
         # the last pass of the tile sort leaves the ranges (two atomics per run of equal keys in a workgroup): no range kernel
         "ranges": 8 * tiles,
         # per consumed entry: value, 32-byte raster record (centre, conic), colour -- or position + coefficient row with colours on demand
@@ -395,7 +398,8 @@ def stage_report(rig, args, stage_ms, p_mean, pc_mean, nonempty, band_tiles, ban
         stage_ms = dict(stage_ms, sh=0.0)  # no SH pass: the colours are evaluated inside the raster kernel (empty timer pair)
     ab = algorithmic_bytes(args.splats, p_mean, pc_mean, band_tiles, nonempty, args.width, band_h, args.sh_degree, (end_bit + 7) // 8)
     mb = moved_bytes(args.splats, p_mean, pc_mean, band_tiles, args.width, band_h, args.sh_degree, tile_key_bytes, on_demand,
-                     depth_passes=DEPTH_SORT_PASSES, tile_passes=(tile_bits + 7) // 8, morton=args.storage_order == "morton")
+                     depth_passes=DEPTH_SORT_PASSES, tile_passes=(tile_bits + 7) // 8, morton=args.storage_order == "morton",
+                     fused_first_pass=bool(gs.lib().gs_get_list_fusion()) and tile_key_bytes == 2 and 11 <= tile_bits <= 16)
 
     def rate(nbytes, ms):
         return round(nbytes / 1e9 / (ms / 1e3), 1) if ms > 0 else None
@@ -459,6 +463,7 @@ def main():
     ap.add_argument("--spin-up", type=float, default=1.0, help="seconds of untimed rendering before the W warm-up frames: a handful of warm-up frames leaves the clocks, the host threads and the streams cold (20 timed frames after 5 warm-up frames: 4 600 frames/s without, 5 200 with 0.25 s or more -- the rate 512 timed frames give either way)")
     ap.add_argument("--watchdog", type=float, default=180.0, help="multi-GPU: seconds without progress after which a rank prints where it was and exits 5 (0 = off)")
     ap.add_argument("--storage-order", choices=["auto", "caller", "morton"], default="auto", help="how the renderers store the splats (gs_renderer_set_storage_order): the file's order, or along a 3-D Morton curve (same frames byte for byte; +2 %% frames/s on one GPU, -10 %% per band frame of an 8-way split: profiles/r04_ab_experiments.txt, r04_band_sim.txt); auto = morton")
+    ap.add_argument("--list-fusion", type=int, default=-1, help="gs_set_list_fusion: 1 the emit pass carries the first pass of the tile sort, 0 plain emit + full tile sort, -1 the library's default")
     ap.add_argument("--inflight", type=int, default=0, help="frames in flight per GPU (renderers on separate HIP streams); 0 = 4 (the measured optimum with 8 hardware queues)")
     args = ap.parse_args()
     if args.storage_order == "auto":
@@ -509,6 +514,8 @@ def main():
         lib.gs_set_raster_pixels_per_lane(args.ppl)
     if args.epanechnikov:
         gs.set_footprint(gs.FOOTPRINT_EPANECHNIKOV)
+    if args.list_fusion >= 0:
+        lib.gs_set_list_fusion(args.list_fusion)
     # The band gather's own communicators (RCCL through the C ABI), ONE PER FRAME IN FLIGHT: slot d's chains are gathered on slot d's
     # stream through slot d's communicator, so RCCL never sees a communicator on two streams.  torch.distributed stays the bootstrap,
     # barrier and timing reduce.  BandComm either succeeds on every rank or raises on every rank (its own agreement collectives), so
@@ -652,6 +659,7 @@ def main():
                 "splats": N, "width": W, "height": H, "sh_degree": args.sh_degree, "views": len(cameras),
                 "pairs_per_frame": round(p_mean), "consumed_pairs_per_frame": round(pc_mean), "nonempty_tiles": round(nonempty),
                 "log_scale_mean": args.log_scale_mean, "opacity_mean_raw": args.opacity_mean, "seed": args.seed, "storage_order": args.storage_order,
+                "list_fusion": int(lib.gs_get_list_fusion()),
                 "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": device_name(lib), "frames_in_flight": depth, "frames_per_chain": rig.V, "frames_ahead": depth * rig.V,
                 "frames_ahead_what": "cameras the caller must hand over before the first image of them is complete (frames per chain x chains in flight); "
                                      "the reference's loop is 1 -- extra.latency has that figure",

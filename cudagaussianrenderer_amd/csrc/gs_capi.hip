@@ -260,6 +260,8 @@ extern "C" void gs_set_sort_backend(int backend)
     cfg.sortBackend = (backend == GS_SORT_BACKEND_ROCPRIM) ? GS_SORT_BACKEND_ROCPRIM : GS_SORT_BACKEND_NATIVE;
 }
 extern "C" int gs_get_sort_backend(void) { return cfg.sortBackend; }
+extern "C" void gs_set_list_fusion(int enabled) { cfg.listFusion = enabled != 0; }
+extern "C" int gs_get_list_fusion(void) { return cfg.listFusion ? 1 : 0; }
 
 extern "C" int gs_radix_sort_pairs(int keyBytes, void* keys0, void* keys1, int32_t* values0, int32_t* values1, int32_t count, int beginBit,
                                    int endBit)

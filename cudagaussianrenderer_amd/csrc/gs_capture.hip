@@ -86,10 +86,14 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
                                                                  kDepthKeyBits, callerOrderedInput ? r->splatToStorage : nullptr,
                                                                  callerOrderedInput ? &keySource : nullptr);
     const uint32_t* order = (const uint32_t*) r->order[orderSel];
-    if (!(g_ablation & 4)) launchTileListFastCount(g.stream, nv, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch);
+    // (gs_set_list_fusion: the emit pass carries the first pass of the tile sort; not under ablation, which leaves passes out one by one)
+    const int sortBits = (cfg.listFusion && g_ablation == 0) ? tileListFusedSortBits(tBits, tileKeyBytes) : 0;
+    if (!(g_ablation & 4))
+        launchTileListFastCount(g.stream, nv, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, sortBits,
+                                views > 1 ? n : 0);
     if (!(g_ablation & 8))
         launchTileListFastEmit(g.stream, nv, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],
-                               tileKeyBytes, r->values[0], r->tileListCapacity, views > 1 ? n : 0);
+                               tileKeyBytes, r->values[0], r->tileListCapacity, views > 1 ? n : 0, sortBits);
     // tile sort + ranges on the device-side pair count (low word of the int64 total), grids sized for the capacity
     const int* pairCount = (const int*) r->scratch.total;
     r->radix.countDevice = pairCount;
@@ -98,7 +102,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
     r->radix.rangeTableForLastPass = (g_ablation & 32) ? nullptr : r->tileRange;
     const int sel = (g_ablation & 16) ? 0
                                       : launchRadixSortPairs(g.stream, r->radix, tileKeyBytes, r->keys[0], r->keys[1], r->values[0], r->values[1],
-                                                             r->tileListCapacity, 0, tBits);
+                                                             r->tileListCapacity, sortBits, tBits);
     r->radix.countDevice = nullptr;
     r->radix.rangeTableForLastPass = nullptr;
     if (!(g_ablation & 64))
@@ -212,7 +216,8 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
     {
         if (r->graphValid && (r->graphCapacity != r->tileListCapacity || r->graphSplats != n || r->graphRowBegin != scr.rowBegin ||
                               r->graphRowEnd != scr.rowEnd || r->graphCull != (int) cull ||
-                              r->graphFootprint != scr.epanechnikov || r->graphLazy != (int) lazy || r->graphAblation != g_ablation))
+                              r->graphFootprint != scr.epanechnikov || r->graphLazy != (int) lazy || r->graphAblation != g_ablation ||
+                              r->graphFusion != (int) cfg.listFusion))
             r->graphValid = false;
         if (!r->graphValid)
         {
@@ -242,6 +247,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
             r->graphFootprint = scr.epanechnikov;
             r->graphLazy = (int) lazy;
             r->graphAblation = g_ablation;
+            r->graphFusion = (int) cfg.listFusion;
         }
         const int slot = r->graphSlot;
         r->graphSlot ^= 1;

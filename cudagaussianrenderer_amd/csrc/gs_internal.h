@@ -118,6 +118,12 @@ struct TileListScratch
     // when set, the renderer's builders read it instead of clipXY + screenEllipse
     const float4* tileRecord = nullptr;
     const int* countDevice = nullptr; // optional device-side splat count (renderer, culled list); nullptr = host count
+    // emit pass that carries the first pass of the tile sort (gs_tiles_fast.hip, sortBits > 0): the count pass's digit histogram per
+    // group of 256 splats as table[digit][group], its scan over the groups, the digit totals
+    int32_t* digitTable = nullptr;
+    int32_t* digitScanned = nullptr;
+    int32_t* digitTotals = nullptr;
+    int digitStride = 0; // groups per digit row (multiple of 4)
 };
 void ensureTileListScratch(TileListScratch& s, int count);
 void freeTileListScratch(TileListScratch& s);
@@ -134,11 +140,19 @@ void ensureTileListFastScratch(TileListScratch& s, int count);
 // Renderer-only builder (gs_tiles_fast.hip): splats visited in `order` (depth-sorted), key = tile index (2 or 4 bytes).
 // Count leaves one pair total per group of 256 splats; Emit sums the totals in front of each group itself and leaves the pair
 // total of the frame in *s.total (+ the host-mapped word): the demand is known to the host only after Emit.
+// sortBits > 0 (tileListFusedSortBits): the emit pass carries the FIRST PASS of the tile sort -- the count pass also counts the low
+// `sortBits` bits of its pairs' tile indices per group (table[digit][group]), a column scan turns that into output positions, and the
+// emit pass stages its pairs in LDS, ranks them stably by that digit and writes them where the first scatter would have put them
+// (no histogram kernel, no scatter kernel, the unsorted list is never written or read).  The caller then sorts on bits
+// [sortBits, tileBits) only.  Both passes must be given the same sortBits and viewSplats.
 void launchTileListFastCount(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
-                             const float4* screenEllipse, TileListScratch& s);
+                             const float4* screenEllipse, TileListScratch& s, int sortBits = 0, int viewSplats = 0);
 void launchTileListFastEmit(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
                             const float4* screenEllipse, const TileListScratch& s, void* tileKeys, int tileKeyBytes, int32_t* values,
-                            int capacity, int viewSplats = 0);
+                            int capacity, int viewSplats = 0, int sortBits = 0);
+// Digit width of that first pass for a tile sort over `tileBitCount` bits of `tileKeyBytes`-byte keys, 0 when the sort is not a
+// two-pass sort of 16-bit keys with a 6..8-bit first digit (then the plain emit pass and the full sort run).
+int tileListFusedSortBits(int tileBitCount, int tileKeyBytes);
 
 // rocPRIM radix sort of (key, int32 value) pairs on key bits [beginBit, endBit); keyBytes in {2, 4, 8}.
 size_t sortTempBytes(int keyBytes, int size, int beginBit, int endBit);
@@ -179,6 +193,10 @@ struct DepthKeySource
 // order, and a stable sort leaves equal keys in input order: ties blend in the caller's index order however the splats are stored.
 int launchRadixSortPairs(hipStream_t stream, RadixScratch& s, int keyBytes, void* keys0, void* keys1, int32_t* values0, int32_t* values1,
                          int n, int beginBit, int endBit, const int32_t* inputValues = nullptr, const DepthKeySource* keySource = nullptr);
+// One pass's column scan by itself: table[digit][tile] (rows `stride` apart, ceil(n / tileElements) live tiles) -> exclusive scan of
+// every digit's row + its total.  Used by the list builder when its emit pass carries the tile sort's first pass (gs_tiles_fast.hip).
+void launchRadixColumnScan(hipStream_t stream, int digits, int nHost, const int* nDevice, int tileElements, int stride, const int32_t* table,
+                           int32_t* scanned, int32_t* totals);
 // The same input sequence materialised from storage-ordered keys (for the rocPRIM backend, which has no such hook):
 // keysOut[i] = keysIn[inputOrder[i]], valuesOut[i] = inputOrder[i].
 void launchGatherSortInput(hipStream_t stream, int n, const uint32_t* keysIn, const int32_t* inputOrder, uint32_t* keysOut, int32_t* valuesOut);

@@ -17,6 +17,7 @@
 
 #include "gs_depth_key.h"
 #include "gs_internal.h"
+#include "gs_wave_match.h"
 
 namespace gs
 {
@@ -32,27 +33,6 @@ constexpr int kItemsSmall = 4;
 constexpr int kSmallLimit = 2 * 1024 * 1024;
 constexpr int kDigits = 256;
 constexpr int kMaxDigitBits = 9; // 512 bins: two per lane in the histogram and scatter kernels
-
-// Lanes of the wave whose (valid) digit equals this lane's digit.  Written on the two 32-bit halves of the mask with
-// xnor/and against the ballot of each digit bit: seven VALU instructions per bit and no scalar temporaries beyond the
-// ballot itself (the obvious `m &= b ? bal : ~bal` makes the compiler keep every ballot alive and spill SGPRs).
-template <int BITS>
-__device__ __forceinline__ unsigned long long matchDigit(int digit, bool valid)
-{
-    const unsigned long long all = __ballot(valid);
-    unsigned lo = (unsigned) all, hi = (unsigned) (all >> 32);
-#pragma unroll
-    for (int bit = 0; bit != BITS; ++bit)
-    {
-        // lanes outside `valid` may vote anything: they were removed from the mask above and stay removed
-        const unsigned long long bal = __ballot(((unsigned) digit & (1u << bit)) != 0u);
-        const unsigned mine = 0u - (((unsigned) digit >> bit) & 1u); // all ones when my bit is set
-        lo &= ~((unsigned) bal ^ mine);
-        hi &= ~((unsigned) (bal >> 32) ^ mine);
-    }
-    const unsigned long long m = ((unsigned long long) hi << 32) | lo;
-    return valid ? m : 0ull;
-}
 
 // Tiles counted by one histogram workgroup: its four counts of a digit are one 16-byte store into the digit's row of
 // table[digit][tile] (a single tile per workgroup would scatter 256 four-byte stores a row apart).
@@ -515,7 +495,8 @@ int sortT(hipStream_t stream, K* keys0, K* keys1, int32_t* values0, int32_t* val
         const int32_t* vin = sel ? values1 : (pass == 0 && inputValues != nullptr ? inputValues : values0);
         int32_t* vout = sel ? values0 : values1;
         // the top digit of a multi-pass sort of tile indices is shared by most neighbours: count it through ballots
-        const bool skewed = sizeof(K) == 2 && passes > 1 && pass == passes - 1 && bits < 8;
+        // (beginBit > 0: the passes below it were done elsewhere -- the emit pass of the list builder carries the first one)
+        const bool skewed = sizeof(K) == 2 && (passes > 1 || beginBit > 0) && pass == passes - 1 && bits < 8;
         runPassBits<K>(stream, bits, kin, vin, pass == 0 ? keySource : nullptr, kout, vout, n, shift, skewed, s,
                        pass == passes - 1 ? s.rangeTableForLastPass : nullptr);
         shift += bits;
@@ -539,6 +520,16 @@ __global__ __launch_bounds__(256) void gatherSortInputKernel(int n, const uint32
 void launchGatherSortInput(hipStream_t stream, int n, const uint32_t* keysIn, const int32_t* inputOrder, uint32_t* keysOut, int32_t* valuesOut)
 {
     if (n > 0) hipLaunchKernelGGL(gatherSortInputKernel, dim3((n + 255) / 256), dim3(256), 0, stream, n, keysIn, inputOrder, keysOut, valuesOut);
+}
+
+void launchRadixColumnScan(hipStream_t stream, int digits, int nHost, const int* nDevice, int tileElements, int stride, const int32_t* table,
+                           int32_t* scanned, int32_t* totals)
+{
+    const int numTiles = (nHost + tileElements - 1) / tileElements;
+    if (numTiles <= GS_SCAN_ROW_LIMIT)
+        hipLaunchKernelGGL(radixColumnScanKernel<256>, dim3(digits), dim3(256), 0, stream, nHost, nDevice, tileElements, stride, table, scanned, totals);
+    else
+        hipLaunchKernelGGL(radixColumnScanKernel<1024>, dim3(digits), dim3(1024), 0, stream, nHost, nDevice, tileElements, stride, table, scanned, totals);
 }
 
 bool radixSortSupported(int keyBytes, int n) { return (keyBytes == 2 || keyBytes == 4) && n >= 0; }

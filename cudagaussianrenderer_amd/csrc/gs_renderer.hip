@@ -650,9 +650,11 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         // (2) pairs in depth order, keyed by tile. The emit pass is launched with the current capacity while the
         // pair count travels to the host, so the readback (GaussianRender.cu:793) costs no GPU idle time.
         gs_timer_start(stageTimers[2]);
-        launchTileListFastCount(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch);
+        // (gs_set_list_fusion: the emit pass carries the first pass of the tile sort, finish() sorts on the remaining bits)
+        f.sortBits = (cfg.listFusion && native) ? tileListFusedSortBits(tileBits(scr.totalTiles), f.tileKeyBytes) : 0;
+        launchTileListFastCount(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, f.sortBits);
         launchTileListFastEmit(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],
-                               f.tileKeyBytes, r->values[0], r->tileListCapacity);
+                               f.tileKeyBytes, r->values[0], r->tileListCapacity, 0, f.sortBits);
         GS_CHECK(hipEventRecord(r->countReady, g.stream)); // the emit pass leaves the pair total
         gs_timer_stop(stageTimers[2]);
     }
@@ -687,7 +689,7 @@ extern "C" int gs_renderer_finish(GsRenderer* r, GsFrameStats* stats)
             // the list did not fit: re-emit into the larger buffers (rare; the first frames of a scene)
             st.grewTileList = 1;
             launchTileListFastEmit(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch,
-                                   r->keys[0], f.tileKeyBytes, r->values[0], r->tileListCapacity);
+                                   r->keys[0], f.tileKeyBytes, r->values[0], r->tileListCapacity, 0, f.sortBits);
         }
         if (blocking) st.msBuildTileList = gs_timer_elapsed_ms(stageTimers[2]);
         r->radix.countDevice = nullptr;
@@ -703,8 +705,8 @@ extern "C" int gs_renderer_finish(GsRenderer* r, GsFrameStats* stats)
             if (native && radixSortSupported(f.tileKeyBytes, size))
             {
                 r->radix.rangeTableForLastPass = r->tileRange; // the last pass leaves the tile ranges: no range kernel (gs_radix.hip)
-                sel = launchRadixSortPairs(g.stream, r->radix, f.tileKeyBytes, r->keys[0], r->keys[1], r->values[0], r->values[1], size, 0,
-                                           tBits);
+                sel = launchRadixSortPairs(g.stream, r->radix, f.tileKeyBytes, r->keys[0], r->keys[1], r->values[0], r->values[1], size,
+                                           f.sortBits, tBits);
             }
             else
             {

@@ -45,6 +45,7 @@ struct Settings
 {
     int sortBackend = GS_SORT_BACKEND_NATIVE;
     bool collectRasterStats = false;
+    bool listFusion = GS_LIST_FUSION_DEFAULT != 0; // the emit pass carries the tile sort's first pass (gs_set_list_fusion)
     unsigned long long* consumedDevice = nullptr; // counter of the staged gs_rasterize_tile
 };
 extern Settings cfg;
@@ -62,6 +63,7 @@ struct FrameState
     bool blocking = false;
     bool listDone = false; // reference pipeline: the sorted list and ranges were produced in begin()
     int orderSel = 0, tileKeyBytes = 2;
+    int sortBits = 0; // low tile bits already sorted by the emit pass (gs_tiles_fast.hip), 0 = none
     bool lazyColours = false; // colours are evaluated by the raster kernel, entry by entry (no SH pass this frame)
     float cameraPosition[3] = {0.f, 0.f, 0.f};
     int32_t size = 0;
@@ -114,7 +116,7 @@ struct GsRenderer
     int views = 1;     // cameras per captured chain (gs_renderer_set_views)
     gs::FrameParams* paramsDevice = nullptr;
     gs::FrameParams* paramsHost = nullptr; // pinned, two slots
-    int graphCapacity = 0, graphSplats = 0, graphRowBegin = -1, graphRowEnd = -1, graphCull = -1, graphFootprint = -1, graphLazy = -1, graphAblation = 0, graphSelector = 0, graphKeyBytes = 2;
+    int graphCapacity = 0, graphSplats = 0, graphRowBegin = -1, graphRowEnd = -1, graphCull = -1, graphFootprint = -1, graphLazy = -1, graphAblation = 0, graphSelector = 0, graphKeyBytes = 2, graphFusion = -1;
     bool pending = false; // begin() issued, finish() not yet
     int capturedRetries = 0; // captured frames rendered again because their pair demand exceeded the list capacity
     gs::FrameState frame;

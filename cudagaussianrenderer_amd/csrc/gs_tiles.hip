@@ -265,6 +265,9 @@ void freeTileListScratch(TileListScratch& s)
     if (s.waveOffsets) (void) hipFree(s.waveOffsets);
     if (s.hitMasks) (void) hipFree(s.hitMasks);
     if (s.boxRecords) (void) hipFree(s.boxRecords);
+    if (s.digitTable) (void) hipFree(s.digitTable);
+    if (s.digitScanned) (void) hipFree(s.digitScanned);
+    if (s.digitTotals) (void) hipFree(s.digitTotals);
     if (s.total) (void) hipFree(s.total);
     if (s.totalHost) (void) hipHostFree(s.totalHost);
     s = TileListScratch{};

@@ -36,6 +36,7 @@
 #include "gs_aabb.h"
 #include "gs_internal.h"
 #include "gs_overlap_exact.h"
+#include "gs_wave_match.h"
 
 namespace gs
 {
@@ -51,19 +52,31 @@ constexpr int kMaskRounds = 16;                // rounds of a workgroup whose hi
 // limit on the host-side group count is wider there.
 constexpr int kSelfSumGroups = 4096;
 constexpr int kSelfSumGroupsCulled = 16384;
+// Emit pass that carries the tile sort's first pass (SORT_BITS > 0): pairs are staged in LDS in emission order and flushed -- ranked
+// stably by their low tile digit, reordered, written as runs -- when another round (up to kGroup * kTilesPerUnit pairs) might not fit.
+#ifndef GS_FUSED_STAGE_ROWS
+#define GS_FUSED_STAGE_ROWS 12
+#endif
+constexpr int kStageRows = GS_FUSED_STAGE_ROWS;         // rows of 64 pairs per wave and flush (register arrays of this length)
+constexpr int kStageCap = kStageRows * kGroup;         // pairs the staging buffer holds
+constexpr int kStageFlushAt = kStageCap - kGroup * kTilesPerUnit;
+static_assert(kStageFlushAt > 0, "a round's pairs must fit the staging buffer");
 
+// OPERANDS = false (the emit pass that carries the tile sort's first pass, whose LDS goes to the staging buffer): without the operands of
+// the overlap tests -- the rare rounds past the recorded ones fetch their unit's splat record again and derive them on the spot.
+template <bool OPERANDS>
 struct GroupStage
 {
     int excl[kGroup];   // exclusive prefix of units
     int area[kGroup];   // AABB tiles
     int origin[kGroup]; // x0 | y0 << 16
     int w[kGroup];
-    int centreLocal[kGroup]; // local index (row-major in the box) of the tile that strictly contains the centre, or -1
-    float4 centreM[kGroup]; // cx, cy, m00, m01
-    float4 mInv[kGroup];    // m10, m11, 1/|u|^2, 1/|v|^2
+    int centreLocal[kGroup]; // local index (row-major in the box) of the tile that strictly contains the centre, or -1 (OPERANDS = false: or -2, see the prologue)
     int splat[kGroup];
-    float guard[kGroup];    // kGuard (1 + A*): the splat-wide filter of the guard band
-    float4 ellipse[kGroup]; // cos, sin, extent x, y as the clip stage stored them: operands of the exact predicate inside the band
+    float4 centreM[OPERANDS ? kGroup : 1]; // cx, cy, m00, m01
+    float4 mInv[OPERANDS ? kGroup : 1];    // m10, m11, 1/|u|^2, 1/|v|^2
+    float guard[OPERANDS ? kGroup : 1];    // kGuard (1 + A*): the splat-wide filter of the guard band
+    float4 ellipse[OPERANDS ? kGroup : 1]; // cos, sin, extent x, y as the clip stage stored them: operands of the exact predicate inside the band
 };
 
 // Guard band of the cheap overlap decision (see the head of the file and tools/guard_band_check.cpp).
@@ -136,22 +149,45 @@ __device__ __forceinline__ int centreTileOnAxis(float c, float size, float tiles
     return count == 1 ? found : (count == 0 ? -1 : -2);
 }
 
-template <bool EMIT, typename TileKey>
+template <bool EMIT, typename TileKey, int SORT_BITS>
 __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, const int* __restrict__ countDevice, Screen scr, const uint32_t* __restrict__ order,
                                                              const float2* __restrict__ clipXY, const float4* __restrict__ screenEllipse,
                                                              int32_t* __restrict__ groupCounts, const int32_t* __restrict__ groupOffsets,
                                                              TileKey* __restrict__ tileKeys, int32_t* __restrict__ values, int capacity,
                                                              uint8_t* __restrict__ hitMasks, const float4* __restrict__ tileRecord,
                                                              int64_t* __restrict__ total, int64_t* __restrict__ totalHostMapped, int viewSplats,
-                                                             int4* __restrict__ boxRecords)
+                                                             int4* __restrict__ boxRecords, int32_t* __restrict__ digitTable,
+                                                             const int32_t* __restrict__ digitTotals, int digitStride)
 {
-    __shared__ GroupStage st;
+    // SORT_BITS > 0: the first pass of the tile sort happens here.  COUNT also counts the pairs' low tile digits (digitTable[digit][group],
+    // raw); EMIT gets the table scanned over the groups + the digit totals and writes every pair where a stable scatter on that digit
+    // would have put it.
+    constexpr bool FUSED = SORT_BITS > 0;
+    constexpr int kBins = FUSED ? (1 << SORT_BITS) : 1;
+    static_assert(kBins <= kGroup, "one digit per lane");
+    constexpr bool LEAN = EMIT && FUSED; // no overlap operands in LDS
+    __shared__ GroupStage<!LEAN> st;
+    __shared__ int digitHist[!EMIT && FUSED ? kBins : 1];
+    __shared__ int sortCnt[EMIT && FUSED ? kWavesPerBlock : 1][kBins];
+    __shared__ int sortLocalBase[EMIT && FUSED ? kBins : 1];
+    __shared__ int sortRunBase[EMIT && FUSED ? kBins : 1];
+    __shared__ int sortWaveSums[kWavesPerBlock];
+    __shared__ TileKey stageKeys[EMIT && FUSED ? kStageCap : 1];
+    __shared__ int32_t stageValues[EMIT && FUSED ? kStageCap : 1];
     __shared__ int waveTotals[kWavesPerBlock];
     __shared__ long long scanTotals[kWavesPerBlock];
     __shared__ int roundHits[2][kWavesPerBlock];
     const int t = threadIdx.x;
     const int wave = t >> 6, lane = t & (kWave - 1);
-    const int group = blockIdx.x;
+#ifndef GS_FUSED_XCD_CHUNK
+#define GS_FUSED_XCD_CHUNK 0
+#endif
+    // Workgroups are dealt to the 8 XCDs round-robin.  The emit pass that carries the sort's first pass writes, per digit, a run
+    // right behind the run of the group before it: runs of GS_FUSED_XCD_CHUNK consecutive groups meet in ONE L2 when the groups are
+    // dealt to the XCDs in chunks (any bijection works: everything is indexed by `group`; the grid is padded to whole chunks).
+    constexpr int kXcdChunk = (EMIT && SORT_BITS > 0) ? GS_FUSED_XCD_CHUNK : 0;
+    const int slotInXcd = (int) blockIdx.x >> 3;
+    const int group = kXcdChunk > 0 ? ((slotInXcd / kXcdChunk) * 8 + ((int) blockIdx.x & 7)) * kXcdChunk + slotInXcd % kXcdChunk : (int) blockIdx.x;
     const int count = countDevice ? min(*countDevice, countHost) : countHost; // device-side count: culled splat list
     if (EMIT && groupOffsets == nullptr && count <= 0 && group == 0 && t == 0)
     {
@@ -162,6 +198,7 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
     }
     if (group * kGroup >= count) return; // whole workgroup
     const int sorted = group * kGroup + t;
+    if (!EMIT && FUSED && t < kBins) digitHist[t] = 0; // (the prefix barrier below comes before the first add)
 
     // What a lane knows about its splat: the tile box (always) and the operands of the overlap tests (when tests will be run).
     int area = 0, x0 = 0, y0 = 0, w = 0, splat = 0, centreLocal = -1;
@@ -241,7 +278,7 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
             w = b.z;
             centreLocal = b.w;
         }
-        if (centreLocal == -2)
+        if (!LEAN && centreLocal == -2) // (LEAN keeps the flag: the guard is not staged, the late rounds look at the flag itself)
         {
             guard = __builtin_inff();
             centreLocal = -1;
@@ -271,6 +308,7 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
     if (totalUnits == 0 && !(EMIT && group == lastGroup)) // nothing on screen (e.g. the culled splats, which sort first): uniform exit
     {
         if (!EMIT && t == 0) groupCounts[group] = 0;
+        if (!EMIT && FUSED && t < kBins) digitTable[(size_t) t * digitStride + group] = 0;
         return;
     }
     // EMIT: where this workgroup's pairs start = the pairs of all groups before it.  Up to kSelfSumGroups groups every workgroup
@@ -279,7 +317,40 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
     // total.  Beyond that (5 M splats: 19.5 K groups, 190 M word loads) the self-summing would be quadratic work: the host launches
     // the scan kernel in between and the offsets (and the total) come from there.
     int outBase = 0;
-    if (EMIT && groupOffsets != nullptr)
+    int digitCursor = 0; // FUSED EMIT, lane d < kBins: where this group's next pair of digit d goes
+    if (EMIT && FUSED)
+    {
+        // first output position of digit d for this group = the pairs of all smaller digits (exclusive scan of the digit totals over
+        // the lanes) + the pairs of digit d in the groups before this one (the scanned table); the last group leaves the pair total.
+        const unsigned myTotal = t < kBins ? (unsigned) digitTotals[t] : 0u;
+        const int myEntry = t < kBins ? digitTable[(size_t) t * digitStride + group] : 0;
+        unsigned long long incl64 = myTotal;
+#pragma unroll
+        for (int delta = 1; delta < kWave; delta <<= 1)
+        {
+            const unsigned long long o = __shfl_up(incl64, delta);
+            if (lane >= delta) incl64 += o;
+        }
+        __syncthreads(); // waveTotals: everybody is past the prologue's reads
+        if (lane == kWave - 1) scanTotals[wave] = (long long) incl64;
+        __syncthreads();
+        long long before = 0, all = 0;
+#pragma unroll
+        for (int wv = 0; wv != kWavesPerBlock; ++wv)
+        {
+            const long long v = scanTotals[wv];
+            before += (wv < wave) ? v : 0;
+            all += v;
+        }
+        digitCursor = (int) (unsigned) ((unsigned long long) before + incl64 - myTotal + (unsigned) myEntry);
+        if (group == lastGroup && t == 0)
+        {
+            *total = all;
+            if (totalHostMapped != nullptr) *totalHostMapped = all;
+        }
+        if (totalUnits == 0) return;
+    }
+    else if (EMIT && groupOffsets != nullptr)
     {
         outBase = groupOffsets[group];
         if (totalUnits == 0) return;
@@ -305,7 +376,7 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
         if (totalUnits == 0) return;
     }
 
-    if (EMIT && totalUnits > kMaskRounds * kGroup && sorted < count)
+    if (EMIT && !LEAN && totalUnits > kMaskRounds * kGroup && sorted < count)
     {
         // rounds past the recorded ones are tested again: only then does the emit pass need the splats themselves
         // (uniform branch; a group of 256 splats with more than 4 096 work units is a handful of near, large splats)
@@ -319,17 +390,121 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
     st.origin[t] = x0 | (y0 << 16);
     st.w[t] = max(w, 1);
     st.centreLocal[t] = centreLocal;
-    st.centreM[t] = make_float4(cx, cy, m00, m01);
-    st.mInv[t] = make_float4(m10, m11, invUU, invVV);
     st.splat[t] = splat;
-    st.guard[t] = guard;
-    st.ellipse[t] = se;
+    if constexpr (!LEAN)
+    {
+        st.centreM[t] = make_float4(cx, cy, m00, m01);
+        st.mInv[t] = make_float4(m10, m11, invUU, invVV);
+        st.guard[t] = guard;
+        st.ellipse[t] = se;
+    }
     __syncthreads();
 
     int running = 0; // COUNT: hits of this wave so far; EMIT: hits of the whole workgroup in the rounds before this one
     const unsigned long long lowerLanes = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
+
+    // FUSED EMIT: the first pass of the tile sort on the `staged` pairs in the staging buffer (emission order), exactly what
+    // radixScatterKernel does with a tile of the unsorted list (gs_radix.hip): stable rank inside each wave's contiguous share
+    // (ballot match + running per-digit counters), prefixes over the waves and over the digits, reorder in LDS, runs of consecutive
+    // addresses out.  Pairs of one tile keep their (depth) order; the group's digit cursors move on by what was written.
+    const auto flushStaged = [&](int staged) {
+        (void) staged;
+        if constexpr (EMIT && FUSED)
+        {
+            constexpr int kDigitMask = kBins - 1;
+            const int rows = (staged + kGroup - 1) / kGroup; // rows of 64 per wave, <= kStageRows
+            const int waveBase = wave * rows * kWave;
+            if (t < kBins)
+#pragma unroll
+                for (int wv = 0; wv != kWavesPerBlock; ++wv) sortCnt[wv][t] = 0;
+            __syncthreads(); // the staged pairs and the zeroed counters are visible
+            TileKey key[kStageRows];
+            int32_t val[kStageRows];
+            int rank[kStageRows];
+#pragma unroll
+            for (int r = 0; r != kStageRows; ++r)
+            {
+                rank[r] = -1;
+                if (r < rows) // uniform
+                {
+                    const int idx = waveBase + r * kWave + lane;
+                    const bool valid = idx < staged;
+                    key[r] = valid ? stageKeys[idx] : TileKey(0);
+                    val[r] = valid ? stageValues[idx] : 0;
+                    const int digit = (int) key[r] & kDigitMask;
+                    const unsigned long long m = matchDigit<SORT_BITS>(digit, valid);
+                    const int leader = valid ? (__ffsll((long long) m) - 1) : lane;
+                    // every lane of a digit group reads the running count (one broadcast read), then the group's first lane bumps it:
+                    // LDS instructions of a wave execute in order, so the next row sees the bumped value
+                    const int old = valid ? sortCnt[wave][digit] : 0;
+                    if (valid && lane == leader) sortCnt[wave][digit] = old + __popcll(m);
+                    if (valid) rank[r] = old + __popcll(m & lowerLanes);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            __syncthreads();
+            // per digit (lane d): exclusive prefixes over the waves, the digit's first slot in the buffer, its first output position
+            int sum = 0;
+            if (t < kBins)
+            {
+#pragma unroll
+                for (int wv = 0; wv != kWavesPerBlock; ++wv)
+                {
+                    const int c = sortCnt[wv][t];
+                    sortCnt[wv][t] = sum;
+                    sum += c;
+                }
+            }
+            int incl = sum;
+#pragma unroll
+            for (int delta = 1; delta < kWave; delta <<= 1)
+            {
+                const int o = __shfl_up(incl, delta);
+                if (lane >= delta) incl += o;
+            }
+            if (lane == kWave - 1) sortWaveSums[wave] = incl;
+            __syncthreads();
+            int beforeWaves = 0;
+#pragma unroll
+            for (int wv = 0; wv != kWavesPerBlock; ++wv) beforeWaves += (wv < wave) ? sortWaveSums[wv] : 0;
+            if (t < kBins)
+            {
+                const int localBase = beforeWaves + incl - sum;
+                sortLocalBase[t] = localBase;
+                sortRunBase[t] = digitCursor - localBase; // output position of buffer slot j of this digit = sortRunBase + j
+                digitCursor += sum;
+            }
+            __syncthreads();
+            // reorder by digit, in place (every pair of the buffer is in a register by now)
+#pragma unroll
+            for (int r = 0; r != kStageRows; ++r)
+            {
+                if (r < rows && rank[r] >= 0)
+                {
+                    const int digit = (int) key[r] & kDigitMask;
+                    const int slot = sortLocalBase[digit] + sortCnt[wave][digit] + rank[r];
+                    stageKeys[slot] = key[r];
+                    stageValues[slot] = val[r];
+                }
+            }
+            __syncthreads();
+            // runs out (unsigned compare: a demand beyond the capacity -- or beyond 2^31 -- is dropped, the frame is rendered again)
+            for (int j = t; j < staged; j += kGroup)
+            {
+                const TileKey k = stageKeys[j];
+                const unsigned pos = (unsigned) (sortRunBase[(int) k & kDigitMask] + j);
+                if (pos < (unsigned) capacity)
+                {
+                    tileKeys[pos] = k;
+                    values[pos] = stageValues[j];
+                }
+            }
+        }
+    };
     const float sx = scr.tileClipSizeX, sy = scr.tileClipSizeY;
 
+    unsigned nextMask = 0;
+    if (EMIT) nextMask = hitMasks[(size_t) group * kMaskRounds * kGroup + t]; // round 0 (totalUnits > 0 here)
     for (int base = 0, round = 0; base < totalUnits; base += kGroup, ++round)
     {
         const int unit = base + t;
@@ -348,7 +523,9 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
         // local0 / wk through the (approximate, 1 ulp) reciprocal: the quotient's fractional part is at least 0.5/wk away from an
         // integer, far above the float error for local0 < 2^16.
         const float rcpW = __builtin_amdgcn_rcpf((float) wk);
-        const int centreK = st.centreLocal[k];
+        int centreK = st.centreLocal[k];
+        const bool centreAmbiguous = LEAN && centreK == -2; // (two candidate centre tiles an ulp apart: every tile of the splat is decided exactly)
+        if (centreAmbiguous) centreK = -1;
         const int ly0 = (int) (((float) local0 + 0.5f) * rcpW);
         const int lx0 = local0 - ly0 * wk;
 
@@ -357,11 +534,34 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
         const bool recorded = round < kMaskRounds;
         uint8_t* maskSlot = hitMasks + ((size_t) group * kMaskRounds + (size_t) (recorded ? round : 0)) * kGroup + t;
         unsigned hitMask = 0;
-        if (EMIT && recorded) hitMask = *maskSlot;
+        if (EMIT && recorded)
+        {
+            // (the next round's masks are fetched one round early: their address depends on nothing the round computes)
+            hitMask = nextMask;
+            if (round + 1 < kMaskRounds && base + kGroup < totalUnits) nextMask = maskSlot[kGroup];
+        }
         else
         {
-            const float4 cm = st.centreM[k];
-            const float4 mi = st.mInv[k];
+            float4 cm, mi, seK;
+            float guardK;
+            if constexpr (LEAN)
+            {
+                // the unit's splat once more (a round past the recorded ones: a group of near, large splats)
+                splat = st.splat[k];
+                loadSplat();
+                overlapOperands();
+                cm = make_float4(cx, cy, m00, m01);
+                mi = make_float4(m10, m11, invUU, invVV);
+                seK = se;
+                guardK = centreAmbiguous ? __builtin_inff() : guard;
+            }
+            else
+            {
+                cm = st.centreM[k];
+                mi = st.mInv[k];
+                seK = st.ellipse[k];
+                guardK = st.guard[k];
+            }
             const float ux = cm.z * sx, uy = mi.x * sx; // u = M (sx, 0)
             const float vx = cm.w * sy, vy = mi.y * sy; // v = M (0, sy)
             const float uv = fmaf(ux, vx, uy * vy);
@@ -411,10 +611,10 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
             // Every comparison is written so that a NaN (degenerate extents) lands on the exact side.
 #ifdef GS_AB_GUARD_COUNT
             if (!EMIT && valid) atomicAdd(&g_guardStats[0], 1ull);
-            if (!EMIT && !(fminf(fminf(dev[0], dev[1]), fminf(dev[2], dev[3])) > st.guard[k])) atomicAdd(&g_guardStats[1], 1ull);
+            if (!EMIT && !(fminf(fminf(dev[0], dev[1]), fminf(dev[2], dev[3])) > guardK)) atomicAdd(&g_guardStats[1], 1ull);
 #endif
-            if (!(fminf(fminf(dev[0], dev[1]), fminf(dev[2], dev[3])) > st.guard[k]))
-                hitMask = decideInsideGuardBand(hitMask, make_float4(dev[0], dev[1], dev[2], dev[3]), st.ellipse[k], local0, areaK, wk, rcpW, origin, cm,
+            if (!(fminf(fminf(dev[0], dev[1]), fminf(dev[2], dev[3])) > guardK))
+                hitMask = decideInsideGuardBand(hitMask, make_float4(dev[0], dev[1], dev[2], dev[3]), seK, local0, areaK, wk, rcpW, origin, cm,
                                                 mi, sx, sy);
             if (!EMIT && recorded) *maskSlot = (uint8_t) hitMask;
         }
@@ -427,7 +627,37 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
             waveHits += __popcll(ballots[e]);
         }
 
-        if (!EMIT) running += waveHits;
+        if (!EMIT)
+        {
+            running += waveHits;
+            if (FUSED && hitMask != 0u)
+            {
+                // digit histogram of this group's pairs (the emit pass will rank them by it): the tile index as the emit pass writes it
+                int wx = lx0, wy = ly0;
+                int viewTileBase = 0;
+                if (viewSplats > 0)
+                {
+                    const int splatK = st.splat[k];
+#pragma unroll
+                    for (int v = 1; v != kMaxViews; ++v) viewTileBase += (splatK >= v * viewSplats) ? scr.totalTiles : 0;
+                }
+#pragma unroll
+                for (int e = 0; e != kTilesPerUnit; ++e)
+                {
+                    if (hitMask & (1u << e))
+                    {
+                        const int gx = (origin & 0xFFFF) + wx, gy = (origin >> 16) + wy;
+                        atomicAdd(&digitHist[(gy * scr.tilesX + gx + viewTileBase) & (kBins - 1)], 1);
+                    }
+                    ++wx;
+                    if (wx == wk)
+                    {
+                        wx = 0;
+                        ++wy;
+                    }
+                }
+            }
+        }
         else
         {
             // this round's hits of the waves before this one (order = unit order: round, wave, lane, tile)
@@ -442,7 +672,8 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                 all += v;
             }
             // (unsigned: a demand beyond 2^31 pairs wraps past every capacity instead of into negative positions)
-            unsigned pos = (unsigned) outBase + (unsigned) running + (unsigned) before;
+            // (FUSED: position in the staging buffer -- `running` counts the pairs staged since the last flush)
+            unsigned pos = (FUSED ? 0u : (unsigned) outBase) + (unsigned) running + (unsigned) before;
 #pragma unroll
             for (int e = 0; e != kTilesPerUnit; ++e) pos += (unsigned) __popcll(ballots[e] & lowerLanes);
             // re-walk the unit's tiles to write the hits, unit-major
@@ -459,9 +690,14 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
             {
                 if (hitMask & (1u << e))
                 {
-                    if (pos < (unsigned) capacity)
+                    const int gx = (origin & 0xFFFF) + wx, gy = (origin >> 16) + wy;
+                    if (FUSED)
                     {
-                        const int gx = (origin & 0xFFFF) + wx, gy = (origin >> 16) + wy;
+                        stageKeys[pos] = (TileKey) (gy * scr.tilesX + gx + viewTileBase);
+                        stageValues[pos] = splatK;
+                    }
+                    else if (pos < (unsigned) capacity)
+                    {
                         tileKeys[pos] = (TileKey) (gy * scr.tilesX + gx + viewTileBase);
                         values[pos] = splatK;
                     }
@@ -475,12 +711,18 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                 }
             }
             running += all;
+            if (FUSED && (running > kStageFlushAt || base + kGroup >= totalUnits))
+            {
+                flushStaged(running); // (uniform; its last reads of the staging buffer are behind the next round's barrier)
+                running = 0;
+            }
         }
     }
 
     if (!EMIT)
     {
         __syncthreads(); // waveTotals: everybody is past the prologue's reads
+        if (FUSED && t < kBins) digitTable[(size_t) t * digitStride + group] = digitHist[t];
         if (lane == 0) waveTotals[wave] = running;
         __syncthreads();
         if (t == 0) groupCounts[group] = waveTotals[0] + waveTotals[1] + waveTotals[2] + waveTotals[3];
@@ -581,14 +823,23 @@ __global__ __launch_bounds__(kScanThreads) void scanFastKernel(int nHost, const 
     }
 }
 
-template <typename TileKey>
+template <typename TileKey, int SORT_BITS>
 void launchEmit(hipStream_t stream, dim3 grid, dim3 block, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
                 const float4* screenEllipse, const TileListScratch& s, const int32_t* groupOffsets, void* tileKeys, int32_t* values, int capacity,
                 int viewSplats)
 {
-    hipLaunchKernelGGL((tileListFastKernel<true, TileKey>), grid, block, 0, stream, count, s.countDevice, scr, order, clipXY, screenEllipse,
+    hipLaunchKernelGGL((tileListFastKernel<true, TileKey, SORT_BITS>), grid, block, 0, stream, count, s.countDevice, scr, order, clipXY, screenEllipse,
                        s.waveCounts, groupOffsets, (TileKey*) tileKeys, values, capacity, s.hitMasks, s.tileRecord, s.total,
-                       s.totalHostMapped, viewSplats, (int4*) s.boxRecords);
+                       s.totalHostMapped, viewSplats, (int4*) s.boxRecords, s.digitScanned, s.digitTotals, s.digitStride);
+}
+
+template <int SORT_BITS>
+void launchCount(hipStream_t stream, int groups, int count, const Screen& scr, const uint32_t* order, const float2* clipXY, const float4* screenEllipse,
+                 TileListScratch& s, int viewSplats)
+{
+    hipLaunchKernelGGL((tileListFastKernel<false, uint16_t, SORT_BITS>), dim3(groups), dim3(kGroup), 0, stream, count, s.countDevice, scr, order, clipXY,
+                       screenEllipse, s.waveCounts, (const int32_t*) nullptr, (uint16_t*) nullptr, (int32_t*) nullptr, 0, s.hitMasks, s.tileRecord,
+                       (int64_t*) nullptr, (int64_t*) nullptr, viewSplats, (int4*) s.boxRecords, s.digitTable, (const int32_t*) nullptr, s.digitStride);
 }
 
 } // namespace
@@ -621,12 +872,26 @@ void ensureTileListFastScratch(TileListScratch& s, int count)
         if (s.boxRecords) GS_CHECK(hipFree(s.boxRecords));
         GS_CHECK(hipMalloc((void**) &s.hitMasks, (size_t) groups * kMaskRounds * kGroup));
         GS_CHECK(hipMalloc(&s.boxRecords, (size_t) groups * kGroup * 16)); // (area, origin, width, centre tile) per sorted splat
+        // (emit pass with the tile sort's first pass: up to 256 digit rows of `groups` counters, raw and scanned)
+        if (s.digitTable) GS_CHECK(hipFree(s.digitTable));
+        if (s.digitScanned) GS_CHECK(hipFree(s.digitScanned));
+        s.digitStride = (groups + 3) & ~3;
+        GS_CHECK(hipMalloc((void**) &s.digitTable, sizeof(int32_t) * 256 * (size_t) s.digitStride));
+        GS_CHECK(hipMalloc((void**) &s.digitScanned, sizeof(int32_t) * 256 * (size_t) s.digitStride));
+        if (s.digitTotals == nullptr) GS_CHECK(hipMalloc((void**) &s.digitTotals, sizeof(int32_t) * 256));
         s.capacityMaskGroups = groups;
     }
 }
 
+int tileListFusedSortBits(int tileBitCount, int tileKeyBytes)
+{
+    if (tileKeyBytes != 2 || tileBitCount <= 9 || tileBitCount > 18) return 0; // one-pass sorts keep their pass (it fills the range table)
+    const int bits = (tileBitCount + 1) / 2;                                    // the first digit of gs_radix.hip's two-pass split
+    return (bits >= 6 && bits <= 8) ? bits : 0;
+}
+
 void launchTileListFastCount(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
-                             const float4* screenEllipse, TileListScratch& s)
+                             const float4* screenEllipse, TileListScratch& s, int sortBits, int viewSplats)
 {
     ensureTileListFastScratch(s, count);
     const int groups = (count + kGroup - 1) / kGroup;
@@ -636,24 +901,44 @@ void launchTileListFastCount(hipStream_t stream, int count, const Screen& scr, c
     }
     else
     {
-        // per-group totals and their scan live in the first ceil(N/256) entries of the per-wave arrays
         // per-group totals live in the first ceil(N/256) entries of the per-wave array; the emit pass sums them itself and
         // leaves the pair total (no scan kernel in between)
-        hipLaunchKernelGGL((tileListFastKernel<false, uint16_t>), dim3(groups), dim3(kGroup), 0, stream, count, s.countDevice, scr, order, clipXY,
-                           screenEllipse, s.waveCounts, (const int32_t*) nullptr, (uint16_t*) nullptr, (int32_t*) nullptr, 0, s.hitMasks, s.tileRecord,
-                           (int64_t*) nullptr, (int64_t*) nullptr, 0, (int4*) s.boxRecords);
+        switch (sortBits)
+        {
+        case 6: launchCount<6>(stream, groups, count, scr, order, clipXY, screenEllipse, s, viewSplats); break;
+        case 7: launchCount<7>(stream, groups, count, scr, order, clipXY, screenEllipse, s, viewSplats); break;
+        case 8: launchCount<8>(stream, groups, count, scr, order, clipXY, screenEllipse, s, viewSplats); break;
+        default: launchCount<0>(stream, groups, count, scr, order, clipXY, screenEllipse, s, 0); break;
+        }
     }
     if (groups == 0) GS_CHECK(hipMemcpyAsync(s.totalHost, s.total, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
 }
 
 void launchTileListFastEmit(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
                             const float4* screenEllipse, const TileListScratch& s, void* tileKeys, int tileKeyBytes, int32_t* values,
-                            int capacity, int viewSplats)
+                            int capacity, int viewSplats, int sortBits)
 {
     const int groups = (count + kGroup - 1) / kGroup;
     if (groups == 0) return;
     // (capacity 0 still runs: the pass is also what produces the pair total; nothing is written past `capacity`)
     const dim3 grid(groups), block(kGroup);
+    if (sortBits > 0 && tileKeyBytes == 2)
+    {
+        // the count pass left table[digit][group]: scanned over the groups (and summed per digit) it is where every group's pairs of
+        // every digit go; the emit pass then IS the first scatter of the tile sort
+        launchRadixColumnScan(stream, 1 << sortBits, count, s.countDevice, kGroup, s.digitStride, s.digitTable, s.digitScanned, s.digitTotals);
+#if GS_FUSED_XCD_CHUNK > 0
+        const dim3 grid((groups + 8 * GS_FUSED_XCD_CHUNK - 1) / (8 * GS_FUSED_XCD_CHUNK) * (8 * GS_FUSED_XCD_CHUNK)); // whole chunks on every XCD
+#endif
+        switch (sortBits)
+        {
+        case 6: launchEmit<uint16_t, 6>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, nullptr, tileKeys, values, capacity, viewSplats); break;
+        case 7: launchEmit<uint16_t, 7>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, nullptr, tileKeys, values, capacity, viewSplats); break;
+        default: launchEmit<uint16_t, 8>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, nullptr, tileKeys, values, capacity, viewSplats); break;
+        }
+        if (s.totalHostMapped == nullptr) GS_CHECK(hipMemcpyAsync(s.totalHost, s.total, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+        return;
+    }
     const int32_t* groupOffsets = nullptr;
     if (groups > (s.countDevice != nullptr ? kSelfSumGroupsCulled : kSelfSumGroups))
     {
@@ -662,8 +947,8 @@ void launchTileListFastEmit(hipStream_t stream, int count, const Screen& scr, co
                            s.totalHostMapped);
         groupOffsets = s.waveOffsets;
     }
-    if (tileKeyBytes == 2) launchEmit<uint16_t>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, groupOffsets, tileKeys, values, capacity, viewSplats);
-    else launchEmit<uint32_t>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, groupOffsets, tileKeys, values, capacity, viewSplats);
+    if (tileKeyBytes == 2) launchEmit<uint16_t, 0>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, groupOffsets, tileKeys, values, capacity, viewSplats);
+    else launchEmit<uint32_t, 0>(stream, grid, block, count, scr, order, clipXY, screenEllipse, s, groupOffsets, tileKeys, values, capacity, viewSplats);
     if (s.totalHostMapped == nullptr) GS_CHECK(hipMemcpyAsync(s.totalHost, s.total, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
 }
 

@@ -132,6 +132,16 @@ int64_t gs_last_raster_consumed_pairs(void);
 #define GS_SORT_BACKEND_ROCPRIM 0
 #define GS_SORT_BACKEND_NATIVE 1
 void gs_set_sort_backend(int backend);
+/* Addition: the renderer's emit pass may carry the FIRST PASS of its tile sort (native backend, two-pass sorts of 16-bit tile
+ * indices): the count pass also counts the pairs' low tile digits per group of 256 splats, a column scan turns the table into output
+ * positions, and the emit pass ranks its pairs in LDS and writes them where the first scatter would have put them -- one histogram
+ * kernel and one scatter kernel less per frame, the unsorted list is never written.  Same sorted list, same image, bit for bit
+ * (replaces cub::DeviceRadixSort::SortPairs at GaussianRender.cu:806-855 together with the emission at :684-712).  Process-wide. */
+#ifndef GS_LIST_FUSION_DEFAULT
+#define GS_LIST_FUSION_DEFAULT 1
+#endif
+void gs_set_list_fusion(int enabled);
+int gs_get_list_fusion(void);
 /* The reference's compile-time option `#define EPANECHNIKOV_KERNEL` (GaussianRender.cu:8-9, README.md:133-136) as a
  * run-time switch: footprint extent sqrt(7) sigma instead of 3 sigma (.cu:298-302), density 1 - q/7 instead of exp(-q/2)
  * (.cu:977-981).  Process-wide, like the reference's #define; applies to the staged calls and to every renderer. */

@@ -430,6 +430,79 @@ def test_sort_backends_give_identical_frames(gs):
         assert np.array_equal(out[0][1], other[1]) and np.array_equal(out[0][0], other[0])
 
 
+def _sorted_list_ranges_image(gs, r, tiles):
+    b = r.buffers()
+    kd = {2: np.uint16, 4: np.uint32}[b.keyBytes]
+    return (r.download(b.keys, b.tileListSize, kd).astype(np.int64), r.download(b.values, b.tileListSize, np.int32),
+            r.download(b.tileRange, 2 * tiles, np.int32), r.read_image())
+
+
+@pytest.mark.parametrize("w,h,n,scales,first_digit", [(1024, 1024, 60_000, (0.01, 0.5), 6), (1920, 1080, 200_000, (0.005, 0.08), 7),
+                                                      (1920, 1080, 30_000, (0.05, 1.5), 7), (3840, 2160, 150_000, (0.005, 0.2), 8),
+                                                      (640, 360, 50_000, (0.01, 0.3), 0), (256, 256, 10_000, (0.01, 0.5), 0)])
+def test_list_fusion_is_invisible(gs, w, h, n, scales, first_digit):
+    """gs_set_list_fusion: the emit pass that carries the first pass of the tile sort (digit histogram in the count pass, column
+    scan, LDS-staged stable rank + runs in the emit pass; GaussianRender.cu:684-712 + :806-855) leaves the SAME sorted pair list,
+    the same tile ranges and the same image bytes as the plain emit pass followed by the full tile sort -- plain and captured frames,
+    first digits of 6, 7 and 8 bits, groups of near splats that flush their staging buffer many times, and the sizes where the sort is
+    not a two-pass one and the fusion stands aside (first_digit 0)."""
+    tx, ty = (w + 15) // 16, (h + 15) // 16
+    tbits = max(1, int(np.ceil(np.log2(tx * ty))))
+    assert ((tbits + 1) // 2 if 9 < tbits <= 16 and 6 <= (tbits + 1) // 2 <= 8 else 0) == first_digit
+    pos, sr, col = _procedural(gs, n, seed=31, min_scale=scales[0], max_scale=scales[1])
+    cam = gs.camera_from_bounds([-4] * 3, [4] * 3, w, h)
+    out = {}
+    try:
+        for fusion in (0, 1):
+            gs.lib().gs_set_list_fusion(fusion)
+            for graph in (False, True):
+                r = gs.Renderer(w, h)
+                r.set_graph(graph)
+                r.set_scene(pos, sr, col)
+                r.render(cam)
+                r.render(cam)  # (captured: the second graph instance)
+                out[(fusion, graph)] = _sorted_list_ranges_image(gs, r, tx * ty)
+                r.close()
+    finally:
+        gs.lib().gs_set_list_fusion(1)
+    want = out[(0, False)]
+    assert len(want[0]) > n // 4 and want[3].any()
+    for key, got in out.items():
+        for a, b_, what in zip(want, got, ("keys", "values", "ranges", "image")):
+            assert np.array_equal(a, b_), (key, what)
+
+
+def test_list_fusion_with_views_and_band_cull(gs, tmp_path):
+    """The same through what a multi-GPU rank runs: four views per captured chain (virtual tiles: a 7-bit first digit at 1280x720)
+    on a band-culled sub-band and on the full frame, Morton storage, SH 3 colours on demand."""
+    from cudagaussianrenderer_amd import scenes
+
+    w, h, views = 1280, 720, 4
+    ply = _ply_scene(gs, tmp_path, 80_003, 3, log_scale_mean=-3.0)
+    scene = (ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+    cams = [gs.camera_from_pose(p, q, w, h) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 8)]
+    images = {}
+    try:
+        for fusion in (0, 1):
+            gs.lib().gs_set_list_fusion(fusion)
+            for rows in (None, (14, 31)):
+                r = gs.Renderer(w, h, tile_rows=rows, views=views, storage_order=gs.STORAGE_ORDER_MORTON)
+                r.set_graph(True)
+                r.set_scene(*scene)
+                got = []
+                for first in (0, 4):
+                    r.render_views(cams[first:first + views])
+                    got += [r.read_image(view=v) for v in range(views)]
+                images[(fusion, rows)] = got
+                r.close()
+    finally:
+        gs.lib().gs_set_list_fusion(1)
+    for rows in (None, (14, 31)):
+        assert any(img.any() for img in images[(0, rows)])
+        for a, b_ in zip(images[(0, rows)], images[(1, rows)]):
+            assert np.array_equal(a, b_), rows
+
+
 @pytest.mark.parametrize("degree", [0, 3])
 def test_band_cull_is_invisible(gs, tmp_path, degree):
     """Band cull (compacted splat list, gathered SH, device-side counts) on/off: same pair list, same image; and a
