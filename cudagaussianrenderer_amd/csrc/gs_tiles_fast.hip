@@ -57,6 +57,9 @@ constexpr int kSelfSumGroupsCulled = 16384;
 #ifndef GS_FUSED_STAGE_ROWS
 #define GS_FUSED_STAGE_ROWS 12
 #endif
+#ifndef GS_FUSED_XCD_CHUNK
+#define GS_FUSED_XCD_CHUNK 16 // consecutive groups per XCD in the fused emit pass (0: round-robin, as dispatched); 8..64 measure alike, profiles/r04_list_fusion.txt
+#endif
 constexpr int kStageRows = GS_FUSED_STAGE_ROWS;         // rows of 64 pairs per wave and flush (register arrays of this length)
 constexpr int kStageCap = kStageRows * kGroup;         // pairs the staging buffer holds
 constexpr int kStageFlushAt = kStageCap - kGroup * kTilesPerUnit;
@@ -179,9 +182,6 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
     __shared__ int roundHits[2][kWavesPerBlock];
     const int t = threadIdx.x;
     const int wave = t >> 6, lane = t & (kWave - 1);
-#ifndef GS_FUSED_XCD_CHUNK
-#define GS_FUSED_XCD_CHUNK 0
-#endif
     // Workgroups are dealt to the 8 XCDs round-robin.  The emit pass that carries the sort's first pass writes, per digit, a run
     // right behind the run of the group before it: runs of GS_FUSED_XCD_CHUNK consecutive groups meet in ONE L2 when the groups are
     // dealt to the XCDs in chunks (any bijection works: everything is indexed by `group`; the grid is padded to whole chunks).
