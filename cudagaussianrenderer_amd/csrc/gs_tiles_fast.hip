@@ -60,6 +60,9 @@ constexpr int kSelfSumGroupsCulled = 16384;
 #ifndef GS_FUSED_XCD_CHUNK
 #define GS_FUSED_XCD_CHUNK 16 // consecutive groups per XCD in the fused emit pass (0: round-robin, as dispatched); 8..64 measure alike, profiles/r04_list_fusion.txt
 #endif
+#ifndef GS_FUSED_COUNT_CHUNKED
+#define GS_FUSED_COUNT_CHUNKED 1 // the count pass of a fused frame deals its groups the same way: a line of its digit table (16 groups) is written through one L2
+#endif
 constexpr int kStageRows = GS_FUSED_STAGE_ROWS;         // rows of 64 pairs per wave and flush (register arrays of this length)
 constexpr int kStageCap = kStageRows * kGroup;         // pairs the staging buffer holds
 constexpr int kStageFlushAt = kStageCap - kGroup * kTilesPerUnit;
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
     // Workgroups are dealt to the 8 XCDs round-robin.  The emit pass that carries the sort's first pass writes, per digit, a run
     // right behind the run of the group before it: runs of GS_FUSED_XCD_CHUNK consecutive groups meet in ONE L2 when the groups are
     // dealt to the XCDs in chunks (any bijection works: everything is indexed by `group`; the grid is padded to whole chunks).
-    constexpr int kXcdChunk = (EMIT && SORT_BITS > 0) ? GS_FUSED_XCD_CHUNK : 0;
+    constexpr int kXcdChunk = (SORT_BITS > 0 && (EMIT || GS_FUSED_COUNT_CHUNKED)) ? GS_FUSED_XCD_CHUNK : 0;
     const int slotInXcd = (int) blockIdx.x >> 3;
     const int group = kXcdChunk > 0 ? ((slotInXcd / kXcdChunk) * 8 + ((int) blockIdx.x & 7)) * kXcdChunk + slotInXcd % kXcdChunk : (int) blockIdx.x;
     const int count = countDevice ? min(*countDevice, countHost) : countHost; // device-side count: culled splat list
@@ -837,6 +840,8 @@ template <int SORT_BITS>
 void launchCount(hipStream_t stream, int groups, int count, const Screen& scr, const uint32_t* order, const float2* clipXY, const float4* screenEllipse,
                  TileListScratch& s, int viewSplats)
 {
+    if (SORT_BITS > 0 && GS_FUSED_COUNT_CHUNKED && GS_FUSED_XCD_CHUNK > 0)
+        groups = (groups + 8 * GS_FUSED_XCD_CHUNK - 1) / (8 * GS_FUSED_XCD_CHUNK) * (8 * GS_FUSED_XCD_CHUNK); // whole chunks on every XCD
     hipLaunchKernelGGL((tileListFastKernel<false, uint16_t, SORT_BITS>), dim3(groups), dim3(kGroup), 0, stream, count, s.countDevice, scr, order, clipXY,
                        screenEllipse, s.waveCounts, (const int32_t*) nullptr, (uint16_t*) nullptr, (int32_t*) nullptr, 0, s.hitMasks, s.tileRecord,
                        (int64_t*) nullptr, (int64_t*) nullptr, viewSplats, (int4*) s.boxRecords, s.digitTable, (const int32_t*) nullptr, s.digitStride);
