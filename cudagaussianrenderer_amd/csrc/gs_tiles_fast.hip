@@ -891,7 +891,10 @@ void ensureTileListFastScratch(TileListScratch& s, int count)
 int tileListFusedSortBits(int tileBitCount, int tileKeyBytes)
 {
     if (tileKeyBytes != 2 || tileBitCount <= 9 || tileBitCount > 18) return 0; // one-pass sorts keep their pass (it fills the range table)
-    const int bits = (tileBitCount + 1) / 2;                                    // the first digit of gs_radix.hip's two-pass split
+#ifndef GS_FUSED_FIRST_DIGIT_BIAS
+#define GS_FUSED_FIRST_DIGIT_BIAS 0 // A/B builds: a wider (+1) or narrower (-1) first digit than the even split
+#endif
+    const int bits = (tileBitCount + 1) / 2 + GS_FUSED_FIRST_DIGIT_BIAS;        // the first digit of gs_radix.hip's two-pass split
     return (bits >= 6 && bits <= 8) ? bits : 0;
 }
 
