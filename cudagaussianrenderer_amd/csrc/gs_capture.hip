@@ -86,8 +86,9 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
                                                                  kDepthKeyBits, callerOrderedInput ? r->splatToStorage : nullptr,
                                                                  callerOrderedInput ? &keySource : nullptr);
     const uint32_t* order = (const uint32_t*) r->order[orderSel];
-    // (gs_set_list_fusion: the emit pass carries the first pass of the tile sort; not under ablation, which leaves passes out one by one)
-    const int sortBits = (cfg.listFusion && g_ablation == 0) ? tileListFusedSortBits(tBits, tileKeyBytes) : 0;
+    // (gs_set_list_fusion: the emit pass carries the first pass of the tile sort.  Under ablation -- cumulative from the back -- the
+    // stages in front of a missing one still run as in the product; every position the emit pass writes is checked against the capacity)
+    const int sortBits = cfg.listFusion ? tileListFusedSortBits(tBits, tileKeyBytes) : 0;
     if (!(g_ablation & 4))
         launchTileListFastCount(g.stream, nv, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, sortBits,
                                 views > 1 ? n : 0);
