@@ -45,7 +45,7 @@ constexpr int kHistTiles = 4;
 // codes in input order: ties blend in the caller's index order however the splats are stored.
 // A plain histogram workgroup (256 lanes) walks its kHistTiles tiles in turn.  Counting them side by side, one 256-lane quarter each,
 // was measured in round 4: the kernel is at its floor either way (5.6 against 5.7 us at 1 M keys) and the 1024-lane workgroups cost
-// the pipelined frame loop 3 % (profiles/r04_ab_histogram.txt) -- kept only for the key-generating variant, whose per-element
+// the pipelined frame loop 3 % (profiles/r04_ab_experiments.txt) -- kept only for the key-generating variant, whose per-element
 // arithmetic (a projection and an IEEE division) would otherwise run four tiles deep on a wave that has its SIMD to itself.
 struct NoKeySource
 {
@@ -526,7 +526,8 @@ void launchRadixColumnScan(hipStream_t stream, int digits, int nHost, const int*
                            int32_t* scanned, int32_t* totals)
 {
     const int numTiles = (nHost + tileElements - 1) / tileElements;
-    if (numTiles <= GS_SCAN_ROW_LIMIT)
+    // (a device-side count is a culled list: a fraction of the rows the host-side bound would make -- 256 lanes walk it in a few rounds)
+    if (numTiles <= GS_SCAN_ROW_LIMIT || nDevice != nullptr)
         hipLaunchKernelGGL(radixColumnScanKernel<256>, dim3(digits), dim3(256), 0, stream, nHost, nDevice, tileElements, stride, table, scanned, totals);
     else
         hipLaunchKernelGGL(radixColumnScanKernel<1024>, dim3(digits), dim3(1024), 0, stream, nHost, nDevice, tileElements, stride, table, scanned, totals);
