@@ -47,11 +47,14 @@ constexpr int kHistTiles = 4;
 // was measured in round 4: the kernel is at its floor either way (5.6 against 5.7 us at 1 M keys) and the 1024-lane workgroups cost
 // the pipelined frame loop 3 % (profiles/r04_ab_experiments.txt) -- kept only for the key-generating variant, whose per-element
 // arithmetic (a projection and an IEEE division) would otherwise run four tiles deep on a wave that has its SIMD to itself.
+#ifndef GS_KEYGEN_PARALLEL_TILES
+#define GS_KEYGEN_PARALLEL_TILES 1 // A/B builds: 0 = the key-generating histogram on 256-lane workgroups too
+#endif
 struct NoKeySource
 {
 };
 template <bool KEYGEN>
-constexpr int kHistThreadsFor = KEYGEN ? kThreads * 4 : kThreads;
+constexpr int kHistThreadsFor = (KEYGEN && GS_KEYGEN_PARALLEL_TILES) ? kThreads * 4 : kThreads;
 template <typename SOURCE>
 constexpr bool kIsKeySource = !std::is_same<SOURCE, NoKeySource>::value;
 
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(kHistThreadsFor<kIsKeySource<SOURCE>>) void radixHi
 {
     constexpr bool KEYGEN = kIsKeySource<SOURCE>;
     constexpr int kHistThreads = kHistThreadsFor<KEYGEN>;
-    constexpr bool kParallelTiles = KEYGEN;
+    constexpr bool kParallelTiles = KEYGEN && GS_KEYGEN_PARALLEL_TILES;
     constexpr int kTile = kThreads * ITEMS;
     constexpr int DIGITS = BITS > 8 ? 2 * kDigits : kDigits; // 9-bit digits: every lane owns two bins
     static_assert(kHistTiles == 4, "four tiles per workgroup: one 16-byte table store per digit");
