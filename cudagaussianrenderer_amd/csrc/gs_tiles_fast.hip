@@ -597,6 +597,13 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
             const float vx = cm.w * sy, vy = mi.y * sy; // v = M (0, sy)
             const float uv = fmaf(ux, vx, uy * vy);
             int lx = lx0, ly = ly0;
+            int histTileBase = 0; // several views per chain: the virtual tile of view v is v * totalTiles + tile, as the emit pass writes it
+            if (!EMIT && FUSED && viewSplats > 0)
+            {
+                const int splatK = st.splat[k];
+#pragma unroll
+                for (int v = 1; v != kMaxViews; ++v) histTileBase += (splatK >= v * viewSplats) ? scr.totalTiles : 0;
+            }
             float dev[kTilesPerUnit]; // |decision value - 1| of the unit's tiles (tiles past the box: certain)
 #pragma unroll
             for (int e = 0; e != kTilesPerUnit; ++e)
@@ -626,6 +633,9 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                     const float decision = fminf(fminf(fminf(bottom2, right2), fminf(top2, left2)), centre2);
                     hit |= decision < 1.0f;
                     dev[e] = fabsf(decision - 1.0f);
+                    // digit histogram of this group's pairs (the emit pass will rank them by it), by the cheap decision: a decision the
+                    // guard band turns over is put right below
+                    if (!EMIT && FUSED && hit) atomicAdd(&digitHist[(gy * scr.tilesX + gx + histTileBase) & (kBins - 1)], 1);
                 }
                 hitMask |= hit ? (1u << e) : 0u;
                 // next local tile
@@ -645,8 +655,31 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
             if (!EMIT && !(fminf(fminf(dev[0], dev[1]), fminf(dev[2], dev[3])) > guardK)) atomicAdd(&g_guardStats[1], 1ull);
 #endif
             if (!(fminf(fminf(dev[0], dev[1]), fminf(dev[2], dev[3])) > guardK))
+            {
+                const unsigned cheapMask = hitMask;
                 hitMask = decideInsideGuardBand(hitMask, make_float4(dev[0], dev[1], dev[2], dev[3]), seK, local0, areaK, wk, rcpW, origin, cm,
                                                 mi, sx, sy);
+                if (!EMIT && FUSED && hitMask != cheapMask)
+                {
+                    // (a handful of tiles per frame) the histogram follows the exact decision
+                    int wx = lx0, wy = ly0;
+#pragma unroll 1
+                    for (int e = 0; e != kTilesPerUnit; ++e)
+                    {
+                        if ((hitMask ^ cheapMask) & (1u << e))
+                        {
+                            const int gx = (origin & 0xFFFF) + wx, gy = (origin >> 16) + wy;
+                            atomicAdd(&digitHist[(gy * scr.tilesX + gx + histTileBase) & (kBins - 1)], (hitMask & (1u << e)) ? 1 : -1);
+                        }
+                        ++wx;
+                        if (wx == wk)
+                        {
+                            wx = 0;
+                            ++wy;
+                        }
+                    }
+                }
+            }
             if (!EMIT && recorded) *maskSlot = (uint8_t) hitMask;
         }
         unsigned long long ballots[kTilesPerUnit];
@@ -661,33 +694,6 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
         if (!EMIT)
         {
             running += waveHits;
-            if (FUSED && hitMask != 0u)
-            {
-                // digit histogram of this group's pairs (the emit pass will rank them by it): the tile index as the emit pass writes it
-                int wx = lx0, wy = ly0;
-                int viewTileBase = 0;
-                if (viewSplats > 0)
-                {
-                    const int splatK = st.splat[k];
-#pragma unroll
-                    for (int v = 1; v != kMaxViews; ++v) viewTileBase += (splatK >= v * viewSplats) ? scr.totalTiles : 0;
-                }
-#pragma unroll
-                for (int e = 0; e != kTilesPerUnit; ++e)
-                {
-                    if (hitMask & (1u << e))
-                    {
-                        const int gx = (origin & 0xFFFF) + wx, gy = (origin >> 16) + wy;
-                        atomicAdd(&digitHist[(gy * scr.tilesX + gx + viewTileBase) & (kBins - 1)], 1);
-                    }
-                    ++wx;
-                    if (wx == wk)
-                    {
-                        wx = 0;
-                        ++wy;
-                    }
-                }
-            }
         }
         else
         {
