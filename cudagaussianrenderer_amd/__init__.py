@@ -212,6 +212,52 @@ def camera_from_pose(position, rotation_xyzw, width, height):
     return cam
 
 
+MOUSE_LEFT, MOUSE_MIDDLE, MOUSE_RIGHT = 1, 2, 4
+KEY_W, KEY_A, KEY_S, KEY_D, KEY_Q, KEY_E = 1, 2, 4, 8, 16, 32
+
+
+class CameraControls:
+    """The reference's interactive camera (CameraControls.h:7-76) without a window: `update` takes the frame's input state
+    (mouse buttons, cursor, keys) instead of polling GLFW.  Left button = look around, middle = orbit the anchor, right = pan,
+    W A S D Q E = move (CameraControls.cpp:148-253); same poses as the reference, bit for bit (csrc/gs_camera.cpp)."""
+
+    def __init__(self, width, height):
+        self._h = lib().gs_camera_controls_create(float(width), float(height))
+        if not self._h:
+            raise MemoryError("gs_camera_controls_create")
+
+    def close(self):
+        if self._h:
+            lib().gs_camera_controls_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_bounds(self, bounds_min, bounds_max):
+        lib().gs_camera_controls_set_bounds(self._h, _fp(_f32(bounds_min)), _fp(_f32(bounds_max)))
+
+    def set_pose(self, position, rotation_xyzw):
+        lib().gs_camera_controls_set_pose(self._h, _fp(_f32(position)), _fp(_f32(rotation_xyzw)))
+
+    def update(self, dt, mouse_buttons=0, keys=0, cursor=(0.0, 0.0)):
+        inp = _capi.CameraInput(int(mouse_buttons), int(keys), float(cursor[0]), float(cursor[1]))
+        lib().gs_camera_controls_update(self._h, C.byref(inp), float(dt))
+
+    def state(self):
+        st = _capi.CameraControlsState()
+        lib().gs_camera_controls_get_state(self._h, C.byref(st))
+        return st
+
+    def camera_data(self):
+        cam = CameraData()
+        lib().gs_camera_controls_camera_data(self._h, C.byref(cam))
+        return cam
+
+
 def morton_order(position):
     """gs_morton_order: storage_to_splat for (N, 4) positions."""
     pos = _f32(position)

@@ -54,6 +54,17 @@ class GlobalArgs(C.Structure):
     ]
 
 
+class CameraInput(C.Structure):
+    """GsCameraInput: what CameraControls::update polls from GLFW, handed in by the caller."""
+
+    _fields_ = [("mouseButtons", C.c_uint32), ("keys", C.c_uint32), ("cursorX", C.c_double), ("cursorY", C.c_double)]
+
+
+class CameraControlsState(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("rotationXYZW", C.c_float * 4), ("anchorPosition", C.c_float * 3), ("speed", C.c_float),
+                ("mode", C.c_int32)]
+
+
 class TileListArgs(C.Structure):
     _fields_ = [("keys", C.c_void_p), ("values", C.c_void_p), ("size", C.c_int32), ("capacity", C.c_int32)]
 
@@ -163,6 +174,13 @@ SIGNATURES = {
     "gs_realign_spherical_harmonics": (None, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int]),
     "gs_camera_from_bounds": (None, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(CameraData)]),
     "gs_camera_from_pose": (None, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, C.POINTER(CameraData)]),
+    "gs_camera_controls_create": (C.c_void_p, [C.c_float, C.c_float]),
+    "gs_camera_controls_destroy": (None, [C.c_void_p]),
+    "gs_camera_controls_set_bounds": (None, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "gs_camera_controls_update": (None, [C.c_void_p, C.POINTER(CameraInput), C.c_float]),
+    "gs_camera_controls_camera_data": (None, [C.c_void_p, C.POINTER(CameraData)]),
+    "gs_camera_controls_get_state": (None, [C.c_void_p, C.POINTER(CameraControlsState)]),
+    "gs_camera_controls_set_pose": (None, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "gs_generate_random_gaussians": (None, [C.c_int32, C.c_uint64, C.c_float, C.c_float, C.POINTER(C.c_float),
                                             C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                             C.POINTER(C.c_float)]),

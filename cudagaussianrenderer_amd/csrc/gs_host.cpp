@@ -4,8 +4,7 @@
 //   gs_parse_ply                    <- parsePly            src/PlyParser.cpp:15-339
 //   gs_encode_vec4                  <- encodeVec4          src/PlyParser.cpp:155-165
 //   gs_realign_spherical_harmonics  <- realignSphericalHarmonics  src/Demo.cpp:160-194
-//   gs_camera_from_bounds           <- CameraControls::setBounds/getView/getProjection
-//                                      src/CameraControls.cpp:79-96,132-146 + CameraData fill src/Demo.cpp:377-392
+//   (gs_camera_from_bounds / gs_camera_from_pose live in gs_camera.cpp, on top of the windowless CameraControls)
 //   gs_generate_random_gaussians    <- generateRandomGaussians   src/Demo.cpp:119-143
 #include <fcntl.h>
 #include <unistd.h>
@@ -110,53 +109,6 @@ struct SplitMix64
     float uniform(float lo, float hi) { return lo + (hi - lo) * uniform(); }
 };
 
-void fillCamera(const float position[3], const float q[4], int width, int height, GsCameraData* out)
-{
-    // CameraControls.h:35-37
-    const float nearZ = 0.1f, farZ = 100.0f, fov = 60.0f * 0.01745329251994329576923690768489f;
-    const float aspect = (float) width / (float) height;
-    std::memset(out, 0, sizeof(*out));
-
-    // Rotation matrix of the unit quaternion (x,y,z,w), columns c0..c2.
-    const float x = q[0], y = q[1], z = q[2], w = q[3];
-    const float R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y)},
-                           {2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x)},
-                           {2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)}}; // R[col][row]
-    // view = inverse(T * R) = [R^T | -R^T p]  (CameraControls.cpp:79-86)
-    float view[4][4] = {};
-    for (int c = 0; c != 3; ++c)
-        for (int r = 0; r != 3; ++r) view[c][r] = R[r][c];
-    for (int r = 0; r != 3; ++r) view[3][r] = -(R[r][0] * position[0] + R[r][1] * position[1] + R[r][2] * position[2]);
-    view[3][3] = 1.0f;
-
-    // glm::perspective (RH, depth -1..1)
-    const float tanHalf = std::tan(fov / 2.0f);
-    float proj[4][4] = {};
-    proj[0][0] = 1.0f / (aspect * tanHalf);
-    proj[1][1] = 1.0f / tanHalf;
-    proj[2][2] = -(farZ + nearZ) / (farZ - nearZ);
-    proj[2][3] = -1.0f;
-    proj[3][2] = -(2.0f * farZ * nearZ) / (farZ - nearZ);
-
-    for (int c = 0; c != 4; ++c)
-        for (int r = 0; r != 4; ++r)
-        {
-            out->view[c * 4 + r] = view[c][r];
-            out->projection[c * 4 + r] = proj[c][r];
-            float s = 0.0f;
-            for (int k = 0; k != 4; ++k) s += proj[k][r] * view[c][k];
-            out->viewProjection[c * 4 + r] = s;
-        }
-    // Demo.cpp:383-392
-    const float cotY = 1.0f / std::tan(fov * 0.5f);
-    out->fovCotangent[0] = cotY / aspect;
-    out->fovCotangent[1] = cotY;
-    out->depthScaleBias[0] = -2.0f / (farZ - nearZ);
-    out->depthScaleBias[1] = -(farZ + nearZ) / (farZ - nearZ);
-    for (int k = 0; k != 3; ++k) out->position[k] = position[k];
-    out->aspect = aspect;
-}
-
 } // namespace
 
 extern "C" uint32_t gs_encode_vec4(const float v[4])
@@ -225,76 +177,6 @@ extern "C" void gs_morton_order(const float* position4, int32_t count, int32_t* 
     }
     std::stable_sort(keyed.begin(), keyed.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
     for (int32_t k = 0; k != count; ++k) storageToSplat[k] = keyed[(size_t) k].second;
-}
-
-extern "C" void gs_camera_from_pose(const float position[3], const float rotationXYZW[4], int width, int height, GsCameraData* out)
-{
-    fillCamera(position, rotationXYZW, width, height, out);
-}
-
-extern "C" void gs_camera_from_bounds(const float bmin[3], const float bmax[3], int width, int height, GsCameraData* out)
-{
-    // CameraControls.cpp:132-146: look at the box centre from the (0,1,1) diagonal at a distance that fits it.
-    const float fov = 60.0f * 0.01745329251994329576923690768489f;
-    float size[3], center[3];
-    for (int k = 0; k != 3; ++k)
-    {
-        size[k] = bmax[k] - bmin[k];
-        center[k] = bmin[k] + size[k] * 0.5f;
-    }
-    const float maxSize = std::max(size[0], std::max(size[1], size[2]));
-    const float half = maxSize * 0.5f;
-    const float invLen = 1.0f / std::sqrt(half * half + half * half);
-    const float offset[3] = {0.0f, half * invLen, half * invLen};
-    const float dist = std::sqrt(2.0f) * maxSize * 0.5f / std::tan(fov * 0.5f);
-    const float position[3] = {center[0] + offset[0] * dist, center[1] + offset[1] * dist, center[2] + offset[2] * dist};
-
-    // quatLookAt(-offset, +Y): camera -Z looks along -offset. Basis columns: right, up, back(= offset).
-    const float back[3] = {offset[0], offset[1], offset[2]};
-    float right[3] = {1.0f * back[2] - back[1] * 0.0f, 0.0f * back[0] - back[2] * 0.0f, 0.0f * back[1] - back[0] * 1.0f}; // cross(up, back)
-    const float rl = 1.0f / std::sqrt(std::max(0.00001f, right[0] * right[0] + right[1] * right[1] + right[2] * right[2]));
-    for (float& v : right) v *= rl;
-    const float up[3] = {back[1] * right[2] - right[1] * back[2], back[2] * right[0] - right[2] * back[0],
-                         back[0] * right[1] - right[0] * back[1]}; // cross(back, right)
-    // rotation matrix -> quaternion (w largest is guaranteed for this pose family, but handle all branches)
-    const float m00 = right[0], m01 = right[1], m02 = right[2];
-    const float m10 = up[0], m11 = up[1], m12 = up[2];
-    const float m20 = back[0], m21 = back[1], m22 = back[2];
-    float q[4];
-    const float trace = m00 + m11 + m22;
-    if (trace > 0.0f)
-    {
-        const float s = std::sqrt(trace + 1.0f) * 2.0f;
-        q[3] = 0.25f * s;
-        q[0] = (m12 - m21) / s;
-        q[1] = (m20 - m02) / s;
-        q[2] = (m01 - m10) / s;
-    }
-    else if (m00 > m11 && m00 > m22)
-    {
-        const float s = std::sqrt(1.0f + m00 - m11 - m22) * 2.0f;
-        q[3] = (m12 - m21) / s;
-        q[0] = 0.25f * s;
-        q[1] = (m01 + m10) / s;
-        q[2] = (m20 + m02) / s;
-    }
-    else if (m11 > m22)
-    {
-        const float s = std::sqrt(1.0f + m11 - m00 - m22) * 2.0f;
-        q[3] = (m20 - m02) / s;
-        q[0] = (m01 + m10) / s;
-        q[1] = 0.25f * s;
-        q[2] = (m12 + m21) / s;
-    }
-    else
-    {
-        const float s = std::sqrt(1.0f + m22 - m00 - m11) * 2.0f;
-        q[3] = (m01 - m10) / s;
-        q[0] = (m20 + m02) / s;
-        q[1] = (m12 + m21) / s;
-        q[2] = 0.25f * s;
-    }
-    fillCamera(position, q, width, height, out);
 }
 
 extern "C" void gs_generate_random_gaussians(int32_t count, uint64_t seed, float minScale, float maxScale, const float minPosition[3],

@@ -11,6 +11,7 @@
 //   setGlobalArgs ... rasterizeTile (8 functions)       .cuh:118-143               same names in namespace gs
 //   parsePly / encodeVec4                               PlyParser.h:11-21          gs::parsePly / gs::encodeVec4
 //   realignSphericalHarmonics / generateRandomGaussians Demo.cpp:119-143,160-194   same names in namespace gs
+//   CameraControls (interactive camera)                 CameraControls.h:7-76      gs::CameraControls (input handed in, not polled from GLFW)
 //
 // No glm dependency: vectors are plain structs with the same memory layout as float4 / glm::vec3.
 #pragma once
@@ -18,6 +19,7 @@
 #include <cassert>
 #include <cstdint>
 #include <cstring>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -188,5 +190,46 @@ inline void generateRandomGaussians(std::vector<float4_t>& position, std::vector
     gs_generate_random_gaussians((int32_t) position.size(), seed, minScale, maxScale, minPosition, maxPosition, &position[0].x,
                                  &scaleAndRotation[0].x, &color[0].x);
 }
+
+// CameraControls.h:7-76 without the window.  The reference's update() polls GLFW for the mouse button, the cursor and the W A S D Q E
+// keys; here the host sets them (setInput) before update(dt) -- from a recorded session, or from whatever toolkit owns its window.
+// Left button: look around; middle: orbit the anchor under the pointer; right: pan; keys: move.  Same poses as the reference's class,
+// bit for bit (csrc/gs_camera.cpp).
+class CameraControls
+{
+    GsCameraControls* m_Handle{nullptr};
+    GsCameraInput m_Input{};
+
+  public:
+    CameraControls(float screenWidth, float screenHeight) : m_Handle(gs_camera_controls_create(screenWidth, screenHeight))
+    {
+        if (m_Handle == nullptr) throw std::bad_alloc();
+    }
+    ~CameraControls() { gs_camera_controls_destroy(m_Handle); }
+    CameraControls(const CameraControls&) = delete;
+    CameraControls& operator=(const CameraControls&) = delete;
+    void setInput(const GsCameraInput& input) { m_Input = input; }
+    void setBounds(const vec3_t& min, const vec3_t& max) { gs_camera_controls_set_bounds(m_Handle, &min.x, &max.x); }
+    void update(float dt) { gs_camera_controls_update(m_Handle, &m_Input, dt); }
+    vec3_t getPosition() const
+    {
+        GsCameraControlsState s;
+        gs_camera_controls_get_state(m_Handle, &s);
+        return vec3_t{s.position[0], s.position[1], s.position[2]};
+    }
+    GsCameraControlsState getState() const
+    {
+        GsCameraControlsState s;
+        gs_camera_controls_get_state(m_Handle, &s);
+        return s;
+    }
+    // getView / getProjection / getViewProjection + the CameraData fill of the frame loop (Demo.cpp:377-392) in one call
+    CameraData getCameraData() const
+    {
+        CameraData c;
+        gs_camera_controls_camera_data(m_Handle, &c);
+        return c;
+    }
+};
 
 } // namespace gs

@@ -187,6 +187,39 @@ void gs_realign_spherical_harmonics(const float* src, float* dst, int groupSize,
 /* CameraControls.cpp:132-146 default pose + Demo.cpp:377-392 CameraData fill (near .1, far 100, fov 60 deg). */
 void gs_camera_from_bounds(const float boundsMin[3], const float boundsMax[3], int width, int height, GsCameraData* out);
 void gs_camera_from_pose(const float position[3], const float rotationXYZW[4], int width, int height, GsCameraData* out);
+
+/* ---- interactive camera without a window: class CameraControls, CameraControls.h:7-76 ------------------
+ * The reference polls GLFW inside CameraControls::update (glfwGetMouseButton / glfwGetCursorPos / glfwGetKey,
+ * CameraControls.cpp:44-72,116-130,176-177); here the caller hands the same three things in per frame, so a headless host can
+ * replay a recorded session and a windowed one can fill them from its toolkit.  Same state machine, same arithmetic in glm's
+ * operand order: a session gives the reference's poses bit for bit (csrc/gs_camera.cpp).  Host code, no GPU involved. */
+enum { GS_MOUSE_LEFT = 1, GS_MOUSE_MIDDLE = 2, GS_MOUSE_RIGHT = 4 };                              /* GLFW_MOUSE_BUTTON_LEFT/MIDDLE/RIGHT pressed */
+enum { GS_KEY_W = 1, GS_KEY_A = 2, GS_KEY_S = 4, GS_KEY_D = 8, GS_KEY_Q = 16, GS_KEY_E = 32 };    /* GLFW_KEY_* pressed, CameraControls.cpp:44-72 */
+typedef struct GsCameraInput
+{
+    uint32_t mouseButtons; /* GS_MOUSE_* bits; left wins over middle wins over right (CameraControls.cpp:116-130): drag / orbit / pan */
+    uint32_t keys;         /* GS_KEY_* bits */
+    double cursorX;        /* glfwGetCursorPos: pixels from the window's top-left corner */
+    double cursorY;
+} GsCameraInput;
+typedef struct GsCameraControlsState
+{
+    float position[3];       /* m_Position */
+    float rotationXYZW[4];   /* m_Rotation */
+    float anchorPosition[3]; /* m_AnchorPosition: what orbit turns about; follows the pointer over the floor plane while no button is down */
+    float speed;             /* m_Speed (set by setBounds; unused by update, as in the reference) */
+    int32_t mode;            /* 0 none, 1 pan, 2 orbit, 3 drag (CameraControls.h:10-16) */
+} GsCameraControlsState;
+typedef struct GsCameraControls GsCameraControls;
+GsCameraControls* gs_camera_controls_create(float screenWidth, float screenHeight);                /* CameraControls.h:46-49 */
+void gs_camera_controls_destroy(GsCameraControls* controls);
+void gs_camera_controls_set_bounds(GsCameraControls* controls, const float boundsMin[3], const float boundsMax[3]); /* CameraControls.cpp:132-146 */
+void gs_camera_controls_update(GsCameraControls* controls, const GsCameraInput* input, float dt); /* CameraControls.cpp:148-253 */
+void gs_camera_controls_camera_data(const GsCameraControls* controls, GsCameraData* out);         /* getters + Demo.cpp:377-392 */
+void gs_camera_controls_get_state(const GsCameraControls* controls, GsCameraControlsState* out);
+/* Addition (the reference only places the camera through setBounds): start a session from a saved pose. */
+void gs_camera_controls_set_pose(GsCameraControls* controls, const float position[3], const float rotationXYZW[4]);
+
 /* Demo.cpp:119-143 generateRandomGaussians with a seeded PRNG (splitmix64) instead of std::rand. */
 void gs_generate_random_gaussians(int32_t count, uint64_t seed, float minScale, float maxScale, const float minPosition[3],
                                   const float maxPosition[3], float* position4, float* scaleAndRotation4, float* color4);

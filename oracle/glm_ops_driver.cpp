@@ -99,4 +99,50 @@ float glmops_cos(float x) { return glm::cos(x); }
 float glmops_sin(float x) { return glm::sin(x); }
 float glmops_floor(float x) { return glm::floor(x); }
 float glmops_ceil(float x) { return glm::ceil(x); }
+
+// ---- the glm calls CameraControls::update() adds (CameraControls.cpp:29-42,79-114,195-251); quaternions travel as (x, y, z, w)
+// glm::angleAxis(angle, axis) (CameraControls.cpp:208-209,218-219)
+void glmops_angle_axis(float angle, const float axis[3], float out[4])
+{
+    const glm::quat q = glm::angleAxis(angle, glm::vec3(axis[0], axis[1], axis[2]));
+    out[0] = q.x, out[1] = q.y, out[2] = q.z, out[3] = q.w;
+}
+// quat * quat (CameraControls.cpp:210,220-221)
+void glmops_quat_mul(const float p[4], const float q[4], float out[4])
+{
+    const glm::quat r = glm::quat::wxyz(p[3], p[0], p[1], p[2]) * glm::quat::wxyz(q[3], q[0], q[1], q[2]);
+    out[0] = r.x, out[1] = r.y, out[2] = r.z, out[3] = r.w;
+}
+// quat * vec3 (CameraControls.cpp:217,223,231,251)
+void glmops_quat_rotate(const float q[4], const float v[3], float out[3])
+{
+    const glm::vec3 r = glm::quat::wxyz(q[3], q[0], q[1], q[2]) * glm::vec3(v[0], v[1], v[2]);
+    out[0] = r.x, out[1] = r.y, out[2] = r.z;
+}
+// glm::quat(mat3) (CameraControls.cpp:41)
+void glmops_quat_cast(const float m[9], float out[4])
+{
+    const glm::quat q = glm::quat(load3(m));
+    out[0] = q.x, out[1] = q.y, out[2] = q.z, out[3] = q.w;
+}
+// glm::cross, glm::dot on vec3 (CameraControls.cpp:5,11,17,22,39)
+void glmops_cross(const float a[3], const float b[3], float out[3])
+{
+    const glm::vec3 r = glm::cross(glm::vec3(a[0], a[1], a[2]), glm::vec3(b[0], b[1], b[2]));
+    out[0] = r.x, out[1] = r.y, out[2] = r.z;
+}
+float glmops_dot3(const float a[3], const float b[3]) { return glm::dot(glm::vec3(a[0], a[1], a[2]), glm::vec3(b[0], b[1], b[2])); }
+// mat4 * mat4, glm::inverse(mat4) (CameraControls.cpp:85,95,102)
+void glmops_mat4_mul(const float a[16], const float b[16], float out[16])
+{
+    const glm::mat4 r = load4(a) * load4(b);
+    for (int c = 0; c != 4; ++c)
+        for (int k = 0; k != 4; ++k) out[c * 4 + k] = r[c][k];
+}
+void glmops_mat4_inverse(const float a[16], float out[16])
+{
+    const glm::mat4 r = glm::inverse(load4(a));
+    for (int c = 0; c != 4; ++c)
+        for (int k = 0; k != 4; ++k) out[c * 4 + k] = r[c][k];
+}
 }

@@ -968,90 +968,7 @@ extern "C" int gsref_render_threads(int32_t count, const float* position4, const
     return 0;
 }
 
-// ----------------------------------------------------------------------------------------------
-// Camera (CameraControls.cpp:79-96,132-146; CameraControls.h:35-37; Demo.cpp:377-392)
-// ----------------------------------------------------------------------------------------------
-namespace
-{
-void fillCamera(V3 position, V4 q, int width, int height, GsRefCameraData* out)
-{
-    const float nearZ = 0.1f, farZ = 100.0f, fov = 60.0f * 0.01745329251994329576923690768489f; // glm::radians
-    const float aspect = (float) width / (float) height;                                          // CameraControls.h:54-57
-    std::memset(out, 0, sizeof(*out));
-
-    // view = inverse(translate(position) * mat4_cast(rotation)) (CameraControls.cpp:79-86); rigid -> [R^T | -R^T p]
-    M3 R = mat3Cast(q.x, q.y, q.z, q.w);
-    M4 view{};
-    for (int c = 0; c != 3; ++c)
-        for (int r = 0; r != 3; ++r) view.m[c][r] = R.m[r][c];
-    for (int r = 0; r != 3; ++r)
-        view.m[3][r] = -(R.m[r][0] * position.x + R.m[r][1] * position.y + R.m[r][2] * position.z);
-    view.m[3][3] = 1.0f;
-
-    // glm::perspective == perspectiveRH_NO (glm/ext/matrix_clip_space.inl:249-262)
-    const float tanHalfFovy = std::tan(fov / 2.0f);
-    M4 proj{};
-    proj.m[0][0] = 1.0f / (aspect * tanHalfFovy);
-    proj.m[1][1] = 1.0f / tanHalfFovy;
-    proj.m[2][2] = -(farZ + nearZ) / (farZ - nearZ);
-    proj.m[2][3] = -1.0f;
-    proj.m[3][2] = -(2.0f * farZ * nearZ) / (farZ - nearZ);
-
-    for (int c = 0; c != 4; ++c)
-        for (int r = 0; r != 4; ++r)
-        {
-            out->view[c * 4 + r] = view.m[c][r];
-            out->projection[c * 4 + r] = proj.m[c][r];
-            float s = 0.0f;
-            for (int k = 0; k != 4; ++k) s += proj.m[k][r] * view.m[c][k];
-            out->viewProjection[c * 4 + r] = s; // unused by the kernels
-        }
-    // Demo.cpp:383-392
-    float cotangentY = 1.0f / std::tan(fov * 0.5f);
-    float cotangentX = cotangentY / aspect;
-    out->fovCotangent[0] = cotangentX;
-    out->fovCotangent[1] = cotangentY;
-    out->depthScaleBias[0] = -2.0f / (farZ - nearZ);
-    out->depthScaleBias[1] = -(farZ + nearZ) / (farZ - nearZ);
-    out->position[0] = position.x;
-    out->position[1] = position.y;
-    out->position[2] = position.z;
-    out->aspect = aspect;
-}
-} // namespace
-
-extern "C" void gsref_camera_from_pose(const float position[3], const float rotationXYZW[4], int width, int height,
-                                       GsRefCameraData* out)
-{
-    fillCamera(V3{position[0], position[1], position[2]}, V4{rotationXYZW[0], rotationXYZW[1], rotationXYZW[2], rotationXYZW[3]},
-               width, height, out);
-}
-
-extern "C" void gsref_camera_from_bounds(const float bmin[3], const float bmax[3], int width, int height, GsRefCameraData* out)
-{
-    // CameraControls.cpp:132-146
-    const float fov = 60.0f * 0.01745329251994329576923690768489f;
-    V3 size{bmax[0] - bmin[0], bmax[1] - bmin[1], bmax[2] - bmin[2]};
-    V3 center{bmin[0] + size.x * 0.5f, bmin[1] + size.y * 0.5f, bmin[2] + size.z * 0.5f};
-    float maxSize = gmax(size.x, gmax(size.y, size.z));
-    V3 offset = normalize3(V3{0.0f, maxSize * 0.5f, maxSize * 0.5f});
-    float dist = std::sqrt(2.0f) * maxSize * 0.5f / std::tan(fov * 0.5f);
-    V3 position{center.x + offset.x * dist, center.y + offset.y * dist, center.z + offset.z * dist};
-    // glm::quatLookAtRH(-offset, up) (glm/gtc/quaternion.inl:179-189)
-    V3 direction{-offset.x, -offset.y, -offset.z};
-    V3 up{0.0f, 1.0f, 0.0f};
-    M3 basis;
-    V3 col2{-direction.x, -direction.y, -direction.z};
-    V3 right = cross(up, col2);
-    float invLen = 1.0f / std::sqrt(gmax(0.00001f, dot3(right, right)));
-    V3 col0{right.x * invLen, right.y * invLen, right.z * invLen};
-    V3 col1 = cross(col2, col0);
-    basis.m[0][0] = col0.x; basis.m[0][1] = col0.y; basis.m[0][2] = col0.z;
-    basis.m[1][0] = col1.x; basis.m[1][1] = col1.y; basis.m[1][2] = col1.z;
-    basis.m[2][0] = col2.x; basis.m[2][1] = col2.y; basis.m[2][2] = col2.z;
-    V4 q = quatCast(basis);
-    fillCamera(position, q, width, height, out);
-}
+// (Camera: gsref_camera_from_pose / gsref_camera_from_bounds are at the end of the file, on top of the CameraControls restatement.)
 
 // ----------------------------------------------------------------------------------------------
 // PLY ingest (PlyParser.cpp)
@@ -1313,5 +1230,486 @@ extern "C" float gsref_glm_cos(float x) { return std::cos(x); }
 extern "C" float gsref_glm_sin(float x) { return std::sin(x); }
 extern "C" float gsref_glm_floor(float x) { return std::floor(x); }
 extern "C" float gsref_glm_ceil(float x) { return std::ceil(x); }
+
+// ----------------------------------------------------------------------------------------------
+// Interactive camera: CameraControls.cpp / CameraControls.h restated without the window.
+//
+// Pinning status: update() polls GLFW, which this image lacks, so the reference's update() cannot run here and a session as a
+// whole is PARITY UNPINNED.  Everything update() is made of IS pinned, bit for bit (tests/golden/camera_controls.json):
+//   * against the REFERENCE's own code, compiled where it lies (oracle/upstream_driver.cpp up_cc_*): getView / getProjection /
+//     getViewProjection at arbitrary poses, the private getWorldSpaceRay, removeRoll, rayIntersectsPlane, getPlane, projectOnPlane,
+//     the whole state setBounds leaves;
+//   * against glm 1.0.1 itself (oracle/glm_ops_driver.cpp): angleAxis, quat * quat, quat * vec3, quat_cast, cross, dot,
+//     mat4 * mat4, inverse(mat4).
+// What remains hand-restated is the statement order of update() (CameraControls.cpp:148-253), cited line by line below.
+// ----------------------------------------------------------------------------------------------
+namespace
+{
+// tanf at RUN time, as the reference's binary calls it for its member m_FieldOfView (CameraControls.cpp:88-91,142; Demo.cpp:383): a
+// compile-time fold of tan(30 deg) is correctly rounded and differs from glibc's tanf in the last bit.
+float runtimeTan(float x)
+{
+    volatile float v = x;
+    return std::tan(v);
+}
+// glm/ext/quaternion_trigonometric.inl:30-36; quaternions are V4 (x, y, z, w) here
+V4 angleAxis(float angle, V3 v)
+{
+    float a = angle;
+    float s = std::sin(a * 0.5f);
+    return V4{v.x * s, v.y * s, v.z * s, std::cos(a * 0.5f)};
+}
+// glm/detail/type_quat.inl:298-308 (operator*= with p = left operand)
+V4 quatMul(V4 p, V4 q)
+{
+    V4 r;
+    r.w = p.w * q.w - p.x * q.x - p.y * q.y - p.z * q.z;
+    r.x = p.w * q.x + p.x * q.w + p.y * q.z - p.z * q.y;
+    r.y = p.w * q.y + p.y * q.w + p.z * q.x - p.x * q.z;
+    r.z = p.w * q.z + p.z * q.w + p.x * q.y - p.y * q.x;
+    return r;
+}
+// glm/detail/type_quat.inl:359-366: v + ((uv * q.w) + uuv) * 2
+V3 quatRotate(V4 q, V3 v)
+{
+    V3 quatVector{q.x, q.y, q.z};
+    V3 uv = cross(quatVector, v);
+    V3 uuv = cross(quatVector, uv);
+    return V3{v.x + ((uv.x * q.w) + uuv.x) * 2.0f, v.y + ((uv.y * q.w) + uuv.y) * 2.0f, v.z + ((uv.z * q.w) + uuv.z) * 2.0f};
+}
+// glm/detail/type_mat4x4.inl:630-648
+M4 mul(const M4& a, const M4& b)
+{
+    M4 r;
+    for (int c = 0; c != 4; ++c)
+        for (int row = 0; row != 4; ++row)
+        {
+            float acc = a.m[0][row] * b.m[c][0];
+            acc = acc + a.m[1][row] * b.m[c][1];
+            acc = acc + a.m[2][row] * b.m[c][2];
+            acc = acc + a.m[3][row] * b.m[c][3];
+            r.m[c][row] = acc;
+        }
+    return r;
+}
+// glm/detail/func_matrix.inl, compute_inverse<4, 4, T, Q, Aligned>::call
+M4 inverse(const M4& in)
+{
+    const float(*m)[4] = in.m;
+    float Coef00 = m[2][2] * m[3][3] - m[3][2] * m[2][3];
+    float Coef02 = m[1][2] * m[3][3] - m[3][2] * m[1][3];
+    float Coef03 = m[1][2] * m[2][3] - m[2][2] * m[1][3];
+    float Coef04 = m[2][1] * m[3][3] - m[3][1] * m[2][3];
+    float Coef06 = m[1][1] * m[3][3] - m[3][1] * m[1][3];
+    float Coef07 = m[1][1] * m[2][3] - m[2][1] * m[1][3];
+    float Coef08 = m[2][1] * m[3][2] - m[3][1] * m[2][2];
+    float Coef10 = m[1][1] * m[3][2] - m[3][1] * m[1][2];
+    float Coef11 = m[1][1] * m[2][2] - m[2][1] * m[1][2];
+    float Coef12 = m[2][0] * m[3][3] - m[3][0] * m[2][3];
+    float Coef14 = m[1][0] * m[3][3] - m[3][0] * m[1][3];
+    float Coef15 = m[1][0] * m[2][3] - m[2][0] * m[1][3];
+    float Coef16 = m[2][0] * m[3][2] - m[3][0] * m[2][2];
+    float Coef18 = m[1][0] * m[3][2] - m[3][0] * m[1][2];
+    float Coef19 = m[1][0] * m[2][2] - m[2][0] * m[1][2];
+    float Coef20 = m[2][0] * m[3][1] - m[3][0] * m[2][1];
+    float Coef22 = m[1][0] * m[3][1] - m[3][0] * m[1][1];
+    float Coef23 = m[1][0] * m[2][1] - m[2][0] * m[1][1];
+    V4 Fac0{Coef00, Coef00, Coef02, Coef03}, Fac1{Coef04, Coef04, Coef06, Coef07}, Fac2{Coef08, Coef08, Coef10, Coef11};
+    V4 Fac3{Coef12, Coef12, Coef14, Coef15}, Fac4{Coef16, Coef16, Coef18, Coef19}, Fac5{Coef20, Coef20, Coef22, Coef23};
+    V4 Vec0{m[1][0], m[0][0], m[0][0], m[0][0]}, Vec1{m[1][1], m[0][1], m[0][1], m[0][1]};
+    V4 Vec2{m[1][2], m[0][2], m[0][2], m[0][2]}, Vec3{m[1][3], m[0][3], m[0][3], m[0][3]};
+    auto mulv = [](V4 a, V4 b) { return V4{a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w}; };
+    auto subv = [](V4 a, V4 b) { return V4{a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w}; };
+    auto addv = [](V4 a, V4 b) { return V4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; };
+    V4 Inv0 = addv(subv(mulv(Vec1, Fac0), mulv(Vec2, Fac1)), mulv(Vec3, Fac2));
+    V4 Inv1 = addv(subv(mulv(Vec0, Fac0), mulv(Vec2, Fac3)), mulv(Vec3, Fac4));
+    V4 Inv2 = addv(subv(mulv(Vec0, Fac1), mulv(Vec1, Fac3)), mulv(Vec3, Fac5));
+    V4 Inv3 = addv(subv(mulv(Vec0, Fac2), mulv(Vec1, Fac4)), mulv(Vec2, Fac5));
+    V4 SignA{+1.0f, -1.0f, +1.0f, -1.0f}, SignB{-1.0f, +1.0f, -1.0f, +1.0f};
+    V4 col[4] = {mulv(Inv0, SignA), mulv(Inv1, SignB), mulv(Inv2, SignA), mulv(Inv3, SignB)};
+    V4 Row0{col[0].x, col[1].x, col[2].x, col[3].x};
+    V4 Dot0 = mulv(V4{m[0][0], m[0][1], m[0][2], m[0][3]}, Row0);
+    float Dot1 = (Dot0.x + Dot0.y) + (Dot0.z + Dot0.w);
+    float OneOverDeterminant = 1.0f / Dot1;
+    M4 r;
+    for (int c = 0; c != 4; ++c)
+    {
+        r.m[c][0] = col[c].x * OneOverDeterminant;
+        r.m[c][1] = col[c].y * OneOverDeterminant;
+        r.m[c][2] = col[c].z * OneOverDeterminant;
+        r.m[c][3] = col[c].w * OneOverDeterminant;
+    }
+    return r;
+}
+void storeM4(const M4& a, float* p)
+{
+    for (int c = 0; c != 4; ++c)
+        for (int row = 0; row != 4; ++row) p[c * 4 + row] = a.m[c][row];
+}
+
+// CameraControls.cpp:3-13
+bool rayIntersectsPlane(V3 rayOrigin, V3 rayDirection, V4 plane, float& t)
+{
+    float denom = dot3(rayDirection, V3{plane.x, plane.y, plane.z});
+    if (denom == 0.0f) return false;
+    t = -(dot3(rayOrigin, V3{plane.x, plane.y, plane.z}) + plane.w) / denom;
+    return true;
+}
+// CameraControls.cpp:15-18
+V4 getPlane(V3 normal, V3 point) { return V4{normal.x, normal.y, normal.z, -dot3(normal, point)}; }
+// CameraControls.cpp:20-23 (vec - scalar: glm subtracts the scalar from every component)
+V3 projectOnPlane(V3 vec, V3 planeNormal)
+{
+    float d = dot3(planeNormal, vec);
+    return V3{vec.x - d, vec.y - d, vec.z - d};
+}
+const V3 k_Up{0.0f, 1.0f, 0.0f}, k_Right{1.0f, 0.0f, 0.0f}, k_Back{0.0f, 0.0f, 1.0f}; // CameraControls.cpp:25-27
+// CameraControls.cpp:29-42
+V4 removeRoll(V4 rotation)
+{
+    M3 rot = mat3Cast(rotation.x, rotation.y, rotation.z, rotation.w);
+    V3 right{rot.m[0][0], rot.m[0][1], rot.m[0][2]};
+    V3 up{rot.m[1][0], rot.m[1][1], rot.m[1][2]};
+    right = normalize3(projectOnPlane(right, k_Up));
+    up = normalize3(projectOnPlane(up, right));
+    V3 forward = cross(right, up);
+    M3 basis;
+    basis.m[0][0] = right.x; basis.m[0][1] = right.y; basis.m[0][2] = right.z;
+    basis.m[1][0] = up.x; basis.m[1][1] = up.y; basis.m[1][2] = up.z;
+    basis.m[2][0] = forward.x; basis.m[2][1] = forward.y; basis.m[2][2] = forward.z;
+    return quatCast(basis);
+}
+
+enum class CcMode { None, Pan, Orbit, Drag };                 // CameraControls.h:10-16
+enum class CcMouseButton { None, Left, Middle, Right };       // CameraControls.h:18-24
+} // namespace
+
+struct GsRefCameraControls
+{
+    CcMode m_Mode = CcMode::None;
+    bool m_MousePositionIsValid = false;
+    CcMouseButton m_MouseButton = CcMouseButton::None;
+    V2 m_PointerPosition{0.0f, 0.0f};
+    V3 m_StartPanPosition{0.0f, 0.0f, 0.0f};
+    bool m_StartPanPositionIsValid = false;
+    V2 m_ScreenSize{1.0f, 1.0f};
+    float m_Near = 0.1f, m_Far = 100.0f, m_FieldOfView = 60.0f * 0.01745329251994329576923690768489f; // CameraControls.h:35-37
+    float m_Speed = 0.0f;                          // (these five are uninitialised in the reference until setBounds)
+    V3 m_AnchorPosition{0.0f, 0.0f, 0.0f};
+    V4 m_FloorPlane{0.0f, 1.0f, 0.0f, 0.0f};
+    V4 m_Rotation{0.0f, 0.0f, 0.0f, 1.0f};
+    V3 m_Position{0.0f, 0.0f, 0.0f};
+
+    float getAspect() const { return m_ScreenSize.x / m_ScreenSize.y; }
+    // CameraControls.cpp:79-86
+    M4 getView() const
+    {
+        M3 r3 = mat3Cast(m_Rotation.x, m_Rotation.y, m_Rotation.z, m_Rotation.w);
+        M4 rotation{}; // glm::mat4_cast = mat4(mat3_cast(q))
+        for (int c = 0; c != 3; ++c)
+            for (int row = 0; row != 3; ++row) rotation.m[c][row] = r3.m[c][row];
+        rotation.m[3][3] = 1.0f;
+        M4 identity{};
+        for (int k = 0; k != 4; ++k) identity.m[k][k] = 1.0f;
+        M4 translation = identity; // glm::translate, glm/ext/matrix_transform.inl:10-15
+        for (int row = 0; row != 4; ++row)
+            translation.m[3][row] = identity.m[0][row] * m_Position.x + identity.m[1][row] * m_Position.y + identity.m[2][row] * m_Position.z + identity.m[3][row];
+        return inverse(mul(translation, rotation));
+    }
+    // CameraControls.cpp:88-91, glm/ext/matrix_clip_space.inl:249-262
+    M4 getProjection() const
+    {
+        float tanHalfFovy = runtimeTan(m_FieldOfView / 2.0f);
+        M4 r{};
+        r.m[0][0] = 1.0f / (getAspect() * tanHalfFovy);
+        r.m[1][1] = 1.0f / tanHalfFovy;
+        r.m[2][2] = -(m_Far + m_Near) / (m_Far - m_Near);
+        r.m[2][3] = -1.0f;
+        r.m[3][2] = -(2.0f * m_Far * m_Near) / (m_Far - m_Near);
+        return r;
+    }
+    M4 getViewProjection() const { return mul(getProjection(), getView()); } // CameraControls.cpp:93-96
+    // CameraControls.cpp:98-114
+    void getWorldSpaceRay(V2 pointerPosition, V3& rayOrigin, V3& rayDirection) const
+    {
+        M4 viewProjectionInverse = inverse(getViewProjection());
+        V2 pointerPositionClip{(pointerPosition.x / m_ScreenSize.x) * 2.0f - 1.0f, (pointerPosition.y / m_ScreenSize.y) * 2.0f - 1.0f};
+        pointerPositionClip.y *= -1.0f;
+        V4 from = mul(viewProjectionInverse, V4{pointerPositionClip.x, pointerPositionClip.y, -1.0f, 1.0f});
+        V4 to = mul(viewProjectionInverse, V4{pointerPositionClip.x, pointerPositionClip.y, 1.0f, 1.0f});
+        from = V4{from.x / from.w, from.y / from.w, from.z / from.w, from.w / from.w};
+        to = V4{to.x / to.w, to.y / to.w, to.z / to.w, to.w / to.w};
+        rayOrigin = V3{from.x, from.y, from.z};
+        V4 d{to.x - from.x, to.y - from.y, to.z - from.z, to.w - from.w};
+        // glm::normalize(vec4) = v * inversesqrt(dot(v, v)), dot of vec4 = (x + y) + (z + w) (glm/detail/func_geometric.inl:58-65)
+        float inv = 1.0f / std::sqrt((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w));
+        rayDirection = V3{d.x * inv, d.y * inv, d.z * inv};
+    }
+    // CameraControls.cpp:132-146
+    void setBounds(V3 min, V3 max)
+    {
+        V3 size{max.x - min.x, max.y - min.y, max.z - min.z};
+        V3 center{min.x + size.x * 0.5f, min.y + size.y * 0.5f, min.z + size.z * 0.5f};
+        float maxSize = gmax(size.x, gmax(size.y, size.z));
+        m_Speed = maxSize * 0.02f;
+        V3 offset = normalize3(V3{0.0f, maxSize * 0.5f, maxSize * 0.5f});
+        float dist = std::sqrt(2.0f) * maxSize * 0.5f / runtimeTan(m_FieldOfView * 0.5f);
+        m_Position = V3{center.x + offset.x * dist, center.y + offset.y * dist, center.z + offset.z * dist};
+        // glm::quatLookAtRH(-offset, k_Up), glm/gtc/quaternion.inl:179-189
+        V3 direction{-offset.x, -offset.y, -offset.z};
+        V3 col2{-direction.x, -direction.y, -direction.z};
+        V3 right = cross(k_Up, col2);
+        float invLen = 1.0f / std::sqrt(gmax(0.00001f, dot3(right, right)));
+        V3 col0{right.x * invLen, right.y * invLen, right.z * invLen};
+        V3 col1 = cross(col2, col0);
+        M3 basis;
+        basis.m[0][0] = col0.x; basis.m[0][1] = col0.y; basis.m[0][2] = col0.z;
+        basis.m[1][0] = col1.x; basis.m[1][1] = col1.y; basis.m[1][2] = col1.z;
+        basis.m[2][0] = col2.x; basis.m[2][1] = col2.y; basis.m[2][2] = col2.z;
+        m_Rotation = quatCast(basis);
+        m_FloorPlane = getPlane(k_Up, center);
+        m_AnchorPosition = center;
+    }
+    // CameraControls.cpp:148-253; the three glfw polls are the arguments
+    void update(float dt, CcMouseButton mouseButton, double xpos, double ypos, V3 movement)
+    {
+        if (mouseButton != m_MouseButton) // :152-173
+        {
+            switch (mouseButton)
+            {
+            case CcMouseButton::None: m_Mode = CcMode::None; break;
+            case CcMouseButton::Left: m_Mode = CcMode::Drag; break;
+            case CcMouseButton::Middle: m_Mode = CcMode::Orbit; break;
+            case CcMouseButton::Right:
+                m_Mode = CcMode::Pan;
+                m_StartPanPositionIsValid = false;
+                break;
+            }
+            m_MouseButton = mouseButton;
+        }
+        bool pointerIsInside = xpos >= 0 || xpos < m_ScreenSize.x || ypos >= 0 || ypos < m_ScreenSize.y; // :178 (always true)
+        V2 pointerPosition{(float) xpos, (float) ypos};
+        V3 rayOrigin{0.0f, 0.0f, 0.0f}, rayDirection{0.0f, 0.0f, 0.0f};
+        getWorldSpaceRay(pointerPosition, rayOrigin, rayDirection);
+        V2 pointerDelta = m_MousePositionIsValid ? V2{pointerPosition.x - m_PointerPosition.x, pointerPosition.y - m_PointerPosition.y} : V2{0.0f, 0.0f};
+        m_MousePositionIsValid = true;
+        switch (m_Mode)
+        {
+        case CcMode::None: { // :195-202
+            float t = 0.0f;
+            if (rayIntersectsPlane(rayOrigin, rayDirection, m_FloorPlane, t))
+                m_AnchorPosition = V3{rayOrigin.x + rayDirection.x * t, rayOrigin.y + rayDirection.y * t, rayOrigin.z + rayDirection.z * t};
+        }
+        break;
+        case CcMode::Drag: { // :206-211
+            V2 yawAndPitch{m_FieldOfView * getAspect() * pointerDelta.x / m_ScreenSize.x, m_FieldOfView * pointerDelta.y / m_ScreenSize.y};
+            V4 yaw = angleAxis(yawAndPitch.x, k_Up);
+            V4 pitch = angleAxis(yawAndPitch.y, k_Right);
+            m_Rotation = removeRoll(quatMul(quatMul(m_Rotation, yaw), pitch));
+        }
+        break;
+        case CcMode::Orbit: { // :215-227
+            V2 yawAndPitch{m_FieldOfView * getAspect() * pointerDelta.x / m_ScreenSize.x, m_FieldOfView * pointerDelta.y / m_ScreenSize.y};
+            V3 right = quatRotate(m_Rotation, k_Right);
+            V4 pitchRot = angleAxis(-yawAndPitch.y, right);
+            V4 yawRot = angleAxis(-yawAndPitch.x, k_Up);
+            V4 deltaRotation = quatMul(yawRot, pitchRot);
+            V4 rotation = removeRoll(quatMul(deltaRotation, m_Rotation));
+            V3 anchorToCamera = quatRotate(deltaRotation, V3{m_Position.x - m_AnchorPosition.x, m_Position.y - m_AnchorPosition.y, m_Position.z - m_AnchorPosition.z});
+            m_Rotation = rotation;
+            m_Position = V3{m_AnchorPosition.x + anchorToCamera.x, m_AnchorPosition.y + anchorToCamera.y, m_AnchorPosition.z + anchorToCamera.z};
+        }
+        break;
+        case CcMode::Pan: { // :230-248
+            V4 plane = getPlane(quatRotate(m_Rotation, k_Back), m_AnchorPosition);
+            float t = 0.0f;
+            if (rayIntersectsPlane(rayOrigin, rayDirection, plane, t))
+            {
+                V3 hit{rayOrigin.x + rayDirection.x * t, rayOrigin.y + rayDirection.y * t, rayOrigin.z + rayDirection.z * t};
+                if (m_StartPanPositionIsValid)
+                {
+                    V3 delta{hit.x - m_StartPanPosition.x, hit.y - m_StartPanPosition.y, hit.z - m_StartPanPosition.z};
+                    m_Position = V3{m_Position.x - delta.x, m_Position.y - delta.y, m_Position.z - delta.z};
+                }
+                else if (pointerIsInside)
+                {
+                    m_StartPanPosition = hit;
+                    m_StartPanPositionIsValid = true;
+                }
+            }
+        }
+        break;
+        }
+        V3 step = quatRotate(m_Rotation, V3{movement.x * dt, movement.y * dt, movement.z * dt}); // :251
+        m_Position = V3{m_Position.x + step.x, m_Position.y + step.y, m_Position.z + step.z};
+        m_PointerPosition = pointerPosition;
+    }
+};
+
+extern "C" GsRefCameraControls* gsref_cc_create(float screenWidth, float screenHeight)
+{
+    GsRefCameraControls* c = new GsRefCameraControls();
+    c->m_ScreenSize = V2{screenWidth, screenHeight};
+    return c;
+}
+extern "C" void gsref_cc_destroy(GsRefCameraControls* c) { delete c; }
+extern "C" void gsref_cc_set_bounds(GsRefCameraControls* c, const float bmin[3], const float bmax[3])
+{
+    c->setBounds(V3{bmin[0], bmin[1], bmin[2]}, V3{bmax[0], bmax[1], bmax[2]});
+}
+extern "C" void gsref_cc_set_pose(GsRefCameraControls* c, const float position[3], const float rotationXYZW[4])
+{
+    c->m_Position = V3{position[0], position[1], position[2]};
+    c->m_Rotation = V4{rotationXYZW[0], rotationXYZW[1], rotationXYZW[2], rotationXYZW[3]};
+}
+// mouseButtons: bit 0 left, 1 middle, 2 right (getMouseButton's priority, CameraControls.cpp:116-130); keys: bit 0 W, 1 A, 2 S, 3 D, 4 Q, 5 E (:44-72)
+extern "C" void gsref_cc_update(GsRefCameraControls* c, float dt, uint32_t mouseButtons, uint32_t keys, double cursorX, double cursorY)
+{
+    CcMouseButton b = CcMouseButton::None;
+    if (mouseButtons & 1u) b = CcMouseButton::Left;
+    else if (mouseButtons & 2u) b = CcMouseButton::Middle;
+    else if (mouseButtons & 4u) b = CcMouseButton::Right;
+    V3 result{0.0f, 0.0f, 0.0f};
+    if (keys & 1u) result.z -= 1.0f;
+    if (keys & 2u) result.x -= 1.0f;
+    if (keys & 4u) result.z += 1.0f;
+    if (keys & 8u) result.x += 1.0f;
+    if (keys & 16u) result.y += 1.0f;
+    if (keys & 32u) result.y -= 1.0f;
+    c->update(dt, b, cursorX, cursorY, result);
+}
+// state[16]: position 3, rotation xyzw 4, anchor 3, floor plane 4, speed, mode
+extern "C" void gsref_cc_state(const GsRefCameraControls* c, float state[16])
+{
+    const float s[16] = {c->m_Position.x, c->m_Position.y, c->m_Position.z, c->m_Rotation.x, c->m_Rotation.y, c->m_Rotation.z, c->m_Rotation.w,
+                         c->m_AnchorPosition.x, c->m_AnchorPosition.y, c->m_AnchorPosition.z, c->m_FloorPlane.x, c->m_FloorPlane.y, c->m_FloorPlane.z,
+                         c->m_FloorPlane.w, c->m_Speed, (float) (int) c->m_Mode};
+    std::memcpy(state, s, sizeof(s));
+}
+extern "C" void gsref_cc_camera_data(const GsRefCameraControls* c, GsRefCameraData* out)
+{
+    // Demo.cpp:377-392
+    std::memset(out, 0, sizeof(*out));
+    storeM4(c->getView(), out->view);
+    storeM4(c->getProjection(), out->projection);
+    storeM4(c->getViewProjection(), out->viewProjection);
+    float cotangentY = 1.0f / runtimeTan(c->m_FieldOfView * 0.5f);
+    float cotangentX = cotangentY / c->getAspect();
+    out->fovCotangent[0] = cotangentX;
+    out->fovCotangent[1] = cotangentY;
+    out->depthScaleBias[0] = -2.0f / (c->m_Far - c->m_Near);
+    out->depthScaleBias[1] = -(c->m_Far + c->m_Near) / (c->m_Far - c->m_Near);
+    out->position[0] = c->m_Position.x, out->position[1] = c->m_Position.y, out->position[2] = c->m_Position.z;
+    out->aspect = c->getAspect();
+}
+
+// Default pose and CameraData of a given pose (CameraControls.cpp:79-96,132-146; CameraControls.h:35-37; Demo.cpp:377-392): the
+// restatement above, so that view (through glm's general inverse), projection and the cotangents (run-time tanf) carry the bits the
+// reference's binary produces (tests/golden/camera_default_pose.json: equal, not close).
+extern "C" void gsref_camera_from_pose(const float position[3], const float rotationXYZW[4], int width, int height, GsRefCameraData* out)
+{
+    GsRefCameraControls c;
+    c.m_ScreenSize = V2{(float) width, (float) height};
+    c.m_Position = V3{position[0], position[1], position[2]};
+    c.m_Rotation = V4{rotationXYZW[0], rotationXYZW[1], rotationXYZW[2], rotationXYZW[3]};
+    gsref_cc_camera_data(&c, out);
+}
+extern "C" void gsref_camera_from_bounds(const float bmin[3], const float bmax[3], int width, int height, GsRefCameraData* out)
+{
+    GsRefCameraControls c;
+    c.m_ScreenSize = V2{(float) width, (float) height};
+    c.setBounds(V3{bmin[0], bmin[1], bmin[2]}, V3{bmax[0], bmax[1], bmax[2]});
+    gsref_cc_camera_data(&c, out);
+}
+
+// ---- hooks with the signatures of oracle/upstream_driver.cpp's up_cc_* (held to the REFERENCE's results, tests/golden/camera_controls.json)
+namespace
+{
+GsRefCameraControls posed(const float position[3], const float rotationXYZW[4], const float screen[2])
+{
+    GsRefCameraControls c;
+    c.m_ScreenSize = V2{screen[0], screen[1]};
+    c.m_Position = V3{position[0], position[1], position[2]};
+    c.m_Rotation = V4{rotationXYZW[0], rotationXYZW[1], rotationXYZW[2], rotationXYZW[3]};
+    return c;
+}
+} // namespace
+extern "C" void gsref_cc_matrices(const float position[3], const float rotationXYZW[4], const float screen[2], float view[16],
+                                  float projection[16], float viewProjection[16])
+{
+    GsRefCameraControls c = posed(position, rotationXYZW, screen);
+    storeM4(c.getView(), view);
+    storeM4(c.getProjection(), projection);
+    storeM4(c.getViewProjection(), viewProjection);
+}
+extern "C" void gsref_cc_world_ray(const float position[3], const float rotationXYZW[4], const float screen[2], const float pointer[2],
+                                   float origin[3], float direction[3])
+{
+    GsRefCameraControls c = posed(position, rotationXYZW, screen);
+    V3 o, d;
+    c.getWorldSpaceRay(V2{pointer[0], pointer[1]}, o, d);
+    origin[0] = o.x, origin[1] = o.y, origin[2] = o.z;
+    direction[0] = d.x, direction[1] = d.y, direction[2] = d.z;
+}
+extern "C" void gsref_cc_remove_roll(const float rotationXYZW[4], float out[4])
+{
+    V4 q = removeRoll(V4{rotationXYZW[0], rotationXYZW[1], rotationXYZW[2], rotationXYZW[3]});
+    out[0] = q.x, out[1] = q.y, out[2] = q.z, out[3] = q.w;
+}
+extern "C" int gsref_cc_ray_plane(const float origin[3], const float direction[3], const float plane[4], float* t)
+{
+    return rayIntersectsPlane(V3{origin[0], origin[1], origin[2]}, V3{direction[0], direction[1], direction[2]}, V4{plane[0], plane[1], plane[2], plane[3]}, *t) ? 1 : 0;
+}
+extern "C" void gsref_cc_get_plane(const float normal[3], const float point[3], float out[4])
+{
+    V4 p = getPlane(V3{normal[0], normal[1], normal[2]}, V3{point[0], point[1], point[2]});
+    out[0] = p.x, out[1] = p.y, out[2] = p.z, out[3] = p.w;
+}
+extern "C" void gsref_cc_project_on_plane(const float vec[3], const float normal[3], float out[3])
+{
+    V3 r = projectOnPlane(V3{vec[0], vec[1], vec[2]}, V3{normal[0], normal[1], normal[2]});
+    out[0] = r.x, out[1] = r.y, out[2] = r.z;
+}
+extern "C" void gsref_cc_set_bounds_state(const float bmin[3], const float bmax[3], const float screen[2], float position[3], float rotationXYZW[4],
+                                          float anchor[3], float floorPlane[4], float* speed)
+{
+    GsRefCameraControls c;
+    c.m_ScreenSize = V2{screen[0], screen[1]};
+    c.setBounds(V3{bmin[0], bmin[1], bmin[2]}, V3{bmax[0], bmax[1], bmax[2]});
+    position[0] = c.m_Position.x, position[1] = c.m_Position.y, position[2] = c.m_Position.z;
+    rotationXYZW[0] = c.m_Rotation.x, rotationXYZW[1] = c.m_Rotation.y, rotationXYZW[2] = c.m_Rotation.z, rotationXYZW[3] = c.m_Rotation.w;
+    anchor[0] = c.m_AnchorPosition.x, anchor[1] = c.m_AnchorPosition.y, anchor[2] = c.m_AnchorPosition.z;
+    floorPlane[0] = c.m_FloorPlane.x, floorPlane[1] = c.m_FloorPlane.y, floorPlane[2] = c.m_FloorPlane.z, floorPlane[3] = c.m_FloorPlane.w;
+    *speed = c.m_Speed;
+}
+// ---- the glm primitives update() adds to the pinned set (tests/golden/glm_ops.json)
+extern "C" void gsref_glm_angle_axis(float angle, const float axis[3], float out[4])
+{
+    V4 q = angleAxis(angle, V3{axis[0], axis[1], axis[2]});
+    out[0] = q.x, out[1] = q.y, out[2] = q.z, out[3] = q.w;
+}
+extern "C" void gsref_glm_quat_mul(const float p[4], const float q[4], float out[4])
+{
+    V4 r = quatMul(V4{p[0], p[1], p[2], p[3]}, V4{q[0], q[1], q[2], q[3]});
+    out[0] = r.x, out[1] = r.y, out[2] = r.z, out[3] = r.w;
+}
+extern "C" void gsref_glm_quat_rotate(const float q[4], const float v[3], float out[3])
+{
+    V3 r = quatRotate(V4{q[0], q[1], q[2], q[3]}, V3{v[0], v[1], v[2]});
+    out[0] = r.x, out[1] = r.y, out[2] = r.z;
+}
+extern "C" void gsref_glm_quat_cast(const float m[9], float out[4])
+{
+    V4 q = quatCast(loadM3(m));
+    out[0] = q.x, out[1] = q.y, out[2] = q.z, out[3] = q.w;
+}
+extern "C" void gsref_glm_cross(const float a[3], const float b[3], float out[3])
+{
+    V3 r = cross(V3{a[0], a[1], a[2]}, V3{b[0], b[1], b[2]});
+    out[0] = r.x, out[1] = r.y, out[2] = r.z;
+}
+extern "C" float gsref_glm_dot3(const float a[3], const float b[3]) { return dot3(V3{a[0], a[1], a[2]}, V3{b[0], b[1], b[2]}); }
+extern "C" void gsref_glm_mat4_mul(const float a[16], const float b[16], float out[16]) { storeM4(mul(loadM4(a), loadM4(b)), out); }
+extern "C" void gsref_glm_mat4_inverse(const float a[16], float out[16]) { storeM4(inverse(loadM4(a)), out); }
 
 extern "C" int gsref_hardware_concurrency(void) { return (int) std::thread::hardware_concurrency(); }

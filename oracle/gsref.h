@@ -11,6 +11,11 @@
  *   - PLY ingest / encodeVec4 / default camera pose: PINNED against the reference's own
  *     PlyParser.cpp and CameraControls.cpp compiled from /root/reference (oracle/_ref,
  *     tests/golden/ply_*.json, camera_default_pose.json).
+ *   - Interactive camera (CameraControls::update): its building blocks (view / projection at arbitrary poses,
+ *     getWorldSpaceRay, removeRoll, rayIntersectsPlane, getPlane, projectOnPlane, setBounds' state) are PINNED against the
+ *     reference's own CameraControls.cpp (tests/golden/camera_controls.json) and the glm calls it adds against glm itself;
+ *     update() polls GLFW and cannot run here, so the ~60 statements that string the blocks together are restated by hand:
+ *     a session as a whole is PARITY UNPINNED.
  *   - SH basis: PINNED against the closed forms printed by the reference's sh_gen.py
  *     (tests/golden/sh_basis.json).
  *   - Kernel stages (clip data, tile list, sort, ranges, raster): the reference ships no

@@ -235,6 +235,41 @@ def camera_from_pose(position, rotation_xyzw, width, height):
     return cam
 
 
+def camera_controls_session(width, height, bounds_min, bounds_max, frames, with_camera_data=False):
+    """The oracle's CameraControls restatement (gsref_cc_*, CameraControls.cpp:132-253) over a recorded session:
+    frames = [(dt, mouseButtons, keys, cursorX, cursorY), ...] -> (len(frames) + 1, 16) float32 states (the state setBounds
+    leaves, then the state after every update): position 3, rotation xyzw 4, anchor 3, floor plane 4, speed, mode."""
+    L = lib()
+    L.gsref_cc_create.restype = C.c_void_p
+    L.gsref_cc_create.argtypes = [C.c_float, C.c_float]
+    L.gsref_cc_destroy.argtypes = [C.c_void_p]
+    L.gsref_cc_set_bounds.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.gsref_cc_update.argtypes = [C.c_void_p, C.c_float, C.c_uint32, C.c_uint32, C.c_double, C.c_double]
+    L.gsref_cc_state.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.gsref_cc_camera_data.argtypes = [C.c_void_p, C.POINTER(CameraData)]
+    c = L.gsref_cc_create(float(width), float(height))
+    try:
+        a, ap = _f(bounds_min)
+        b, bp = _f(bounds_max)
+        L.gsref_cc_set_bounds(c, ap, bp)
+        states = np.zeros((len(frames) + 1, 16), np.float32)
+        cams = []
+
+        def snap(i):
+            L.gsref_cc_state(c, _p(states[i], C.c_float))
+            if with_camera_data:
+                cam = CameraData()
+                L.gsref_cc_camera_data(c, C.byref(cam))
+                cams.append(cam)
+        snap(0)
+        for i, (dt, buttons, keys, x, y) in enumerate(frames):
+            L.gsref_cc_update(c, float(dt), int(buttons), int(keys), float(x), float(y))
+            snap(i + 1)
+    finally:
+        L.gsref_cc_destroy(c)
+    return (states, cams) if with_camera_data else states
+
+
 class PlyError(ValueError):
     pass
 

@@ -18,7 +18,14 @@ Outputs (data only -- inputs and expected outputs):
   tests/golden/sh_basis.json                            Y_lm, l<=4, at sample directions
   tests/golden/glm_ops.json                             the glm 1.0.1 primitives the clip / tile-list / key code calls (GaussianRender.cu:215-320,
                                                         351-436,452,537-551), evaluated by glm itself (oracle/_ref/libglmops.so = oracle/glm_ops_driver.cpp
-                                                        against the reference's vendored headers) on seeded inputs; float bit patterns in and out
+                                                        against the reference's vendored headers) on seeded inputs; float bit patterns in and out;
+                                                        plus the glm calls CameraControls::update() adds (angleAxis, quat*quat, quat*vec3, quat(mat3), cross,
+                                                        dot, mat4*mat4, inverse(mat4))
+  tests/golden/camera_controls.json                     SURVEY.md 8(f4): what CameraControls::update() is made of, evaluated by the REFERENCE's own code
+                                                        (up_cc_* of oracle/upstream_driver.cpp: view/projection at arbitrary poses, getWorldSpaceRay, removeRoll,
+                                                        rayIntersectsPlane, getPlane, projectOnPlane, the state setBounds leaves), float bit patterns; and
+                                                        recorded input sessions with the poses the ORACLE's restatement of update() gives for them (update()
+                                                        itself polls GLFW and cannot run here: sessions are a regression record, not a reference output)
 
 Run:  make -C oracle && python tests/golden/make_golden.py
 """
@@ -208,6 +215,9 @@ GLM_OPS = {
     "atan2": (["f", "f"], "f"), "max": (["f", "f"], "f"), "min": (["f", "f"], "f"), "step": (["f", "f"], "f"),
     "mix": (["f", "f", "f"], "f"), "clamp01": (["f"], "f"), "clampi": (["i", "i", "i"], "i"), "length2": ([2], "f"),
     "dot2": ([2, 2], "f"), "sqrt": (["f"], "f"), "cos": (["f"], "f"), "sin": (["f"], "f"), "floor": (["f"], "f"), "ceil": (["f"], "f"),
+    # CameraControls::update(); quaternions as (x, y, z, w)
+    "angle_axis": (["f", 3], 4), "quat_mul": ([4, 4], 4), "quat_rotate": ([4, 3], 3), "quat_cast": ([9], 4), "cross": ([3, 3], 3),
+    "dot3": ([3, 3], "f"), "mat4_mul": ([16, 16], 16), "mat4_inverse": ([16], 16),
 }
 
 
@@ -266,7 +276,7 @@ def glm_op_inputs():
     pairs = [(a, b) for a in scal[:17] for b in scal[:17]][::3] + list(zip(scal[17:], scal[:17:-1]))
     angles = [f32(v) for v in (0, -0.0, np.pi, -np.pi, np.pi / 2, -np.pi / 2, 3.1415927, 1e-8, 100.0, -1e4)] + list(rng.uniform(-np.pi, np.pi, 60).astype(f32))
     unit = [np.array([np.cos(t), np.sin(t)], f32) for t in rng.uniform(-np.pi, np.pi, 60)]
-    return {
+    ops = {
         "mat3_cast": [[q] for q in quats(120)],
         "mat3_mul": [[a, b] for a, b in zip(mats(60, 9), mats(60, 9))] + [[a, d] for a, d in zip(mats(30, 9), diag)],
         "mat3_transpose": [[a] for a in mats(20, 9)],
@@ -286,6 +296,47 @@ def glm_op_inputs():
         "floor": [[f32(v)] for v in rng.uniform(-3, 130, 50)] + [[f32(-0.0)], [f32(63.999996)], [f32(np.nan)], [f32(64.0)]],
         "ceil": [[f32(v)] for v in rng.uniform(-3, 130, 50)] + [[f32(-0.5)], [f32(64.000004)], [f32(np.nan)], [f32(64.0)]],
     }
+    # ---- CameraControls::update(): drawn AFTER everything above, so the cases above keep their values
+    def unit_quats(n):
+        q = rng.standard_normal((n, 4))
+        return list((q / np.linalg.norm(q, axis=1, keepdims=True)).astype(f32))
+
+    def rotations(n):  # rotation matrices (columns), as floats: what removeRoll hands to quat(mat3), all four branches of quat_cast
+        out = []
+        for q in unit_quats(n):
+            x, y, z, w = [float(v) for v in q]
+            out.append(np.array([1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y), 2 * (x * y - w * z), 1 - 2 * (x * x + z * z),
+                                 2 * (y * z + w * x), 2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)], f32))
+        return out
+    axes = [np.array(v, f32) for v in ([0, 1, 0], [1, 0, 0], [0, 0, 1])] + [(v / np.linalg.norm(v)).astype(f32) for v in rng.standard_normal((40, 3))]
+    small = [f32(v) for v in (0, -0.0, 1e-8, 0.5, -0.5, np.pi, -np.pi)] + list((rng.standard_normal(50) * 0.05).astype(f32))
+    rigid = []
+    for q, t in zip(unit_quats(40), rng.standard_normal((40, 3)) * 8):
+        x, y, z, w = [float(v) for v in q]
+        m = np.eye(4)
+        m[:3, 0] = [1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y)]
+        m[:3, 1] = [2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x)]
+        m[:3, 2] = [2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)]
+        m[:3, 3] = t
+        rigid.append(m.T.astype(f32).reshape(16))  # column-major
+    persp = []
+    for aspect in (1.0, 16 / 9, 4 / 3, 0.5):
+        t = np.tan(np.radians(60.0) / 2)
+        m = np.zeros((4, 4))
+        m[0, 0], m[1, 1], m[2, 2], m[3, 2], m[2, 3] = 1 / (aspect * t), 1 / t, -(100 + 0.1) / (100 - 0.1), -1.0, -(2 * 100 * 0.1) / (100 - 0.1)
+        persp.append(m.T.astype(f32).reshape(16))
+    vp = [(p.reshape(4, 4).T.astype(np.float64) @ np.linalg.inv(r.reshape(4, 4).T.astype(np.float64))).T.astype(f32).reshape(16) for r in rigid[:20] for p in persp[:2]]
+    ops.update({
+        "angle_axis": [[a, ax] for a, ax in zip(small, axes + axes)][:50],
+        "quat_mul": [[a, b] for a, b in zip(unit_quats(50), unit_quats(50))] + [[a, b] for a, b in zip(mats(10, 4), mats(10, 4))],
+        "quat_rotate": [[q, v] for q, v in zip(unit_quats(50), mats(50, 3, 6.0))] + [[q, np.array(v, f32)] for q in unit_quats(6) for v in ([1, 0, 0], [0, 0, 1])],
+        "quat_cast": [[m] for m in rotations(80)] + [[np.array(v, f32)] for v in ([1, 0, 0, 0, 1, 0, 0, 0, 1], [1, 0, 0, 0, -1, 0, 0, 0, -1], [-1, 0, 0, 0, 1, 0, 0, 0, -1], [-1, 0, 0, 0, -1, 0, 0, 0, 1])],
+        "cross": [[a, b] for a, b in zip(mats(40, 3, 3.0), mats(40, 3, 3.0))] + [[axes[0], axes[1]], [axes[1], axes[1]]],
+        "dot3": [[a, b] for a, b in zip(mats(40, 3, 3.0), mats(40, 3, 3.0))] + [[axes[0], m] for m in mats(10, 3)],
+        "mat4_mul": [[a, b] for a, b in zip(mats(20, 16), mats(20, 16))] + [[p, r] for p, r in zip(persp * 5, rigid[:20])] + [[r, q] for r, q in zip(rigid[:10], rigid[10:20])],
+        "mat4_inverse": [[m] for m in rigid] + [[m] for m in vp] + [[m] for m in mats(20, 16)],
+    })
+    return ops
 
 
 def make_glm_ops_fixture():
@@ -310,7 +361,112 @@ def make_glm_ops_fixture():
     print(f"glm_ops.json: {total} cases over {len(out['cases'])} primitives")
 
 
+def _bits(v):
+    if isinstance(v, (int, np.integer)) and not isinstance(v, np.floating):
+        return int(v)
+    return [int(b) for b in np.atleast_1d(np.asarray(v, np.float32)).view(np.uint32)]
+
+
+def camera_sessions():
+    """Recorded inputs: (dt, mouseButtons, keys, cursorX, cursorY) per frame; every mode, button changes, keys, the first-frame delta."""
+    rng = np.random.default_rng(424242)
+    sessions = []
+    for (w, h, bmin, bmax) in [(1920, 1080, [-4, -4, -4], [4, 4, 4]), (1024, 1024, [-1.5, 0.25, -3.0], [2.5, 1.75, 6.0]), (640, 480, [10, 10, 10], [11, 12, 10.5])]:
+        frames = []
+        x, y = w * 0.5, h * 0.5
+        for seg in range(14):
+            buttons = [0, 1, 2, 4, 0, 4, 2, 1, 3, 6, 0, 2, 4, 1][seg]
+            keys = [0, 0, 1, 0, 8 | 16, 0, 2, 4 | 32, 0, 0, 63, 0, 1 | 8, 0][seg]
+            vx, vy = rng.uniform(-14, 14, 2)
+            for _ in range(int(rng.integers(3, 9))):
+                x, y = x + vx + rng.uniform(-2, 2), y + vy + rng.uniform(-2, 2)
+                frames.append([float(np.float32(rng.uniform(0.004, 0.03))), buttons, keys, float(np.round(x * 4) / 4), float(np.round(y * 4) / 4)])
+        sessions.append({"width": w, "height": h, "boundsMin": bmin, "boundsMax": bmax, "frames": frames})
+    return sessions
+
+
+def make_camera_controls_fixture(up):
+    sys.path.insert(0, ROOT)
+    fp = C.POINTER(C.c_float)
+    rng = np.random.default_rng(777)
+    f32 = np.float32
+    P = lambda a: a.ctypes.data_as(fp)  # noqa: E731
+
+    def unit_quat():
+        q = rng.standard_normal(4)
+        return (q / np.linalg.norm(q)).astype(f32)
+    screens = [np.array(v, f32) for v in ([1920, 1080], [1024, 1024], [640, 480], [3840, 2160])]
+    out = {"what": "what CameraControls::update() is made of, evaluated by the reference's own code (oracle/upstream_driver.cpp up_cc_*, "
+                   "CameraControls.cpp compiled where it lies); float bit patterns (uint32). 'sessions' are input recordings with the poses the "
+                   "ORACLE's restatement of update() gives (oracle/gsref.cpp gsref_cc_update): a regression record, not a reference output"}
+    rows = []
+    for i in range(60):
+        pos, q, scr = (rng.standard_normal(3) * 9).astype(f32), unit_quat() if i % 5 else rng.standard_normal(4).astype(f32), screens[i % 4]
+        v, p, vp = np.zeros(16, f32), np.zeros(16, f32), np.zeros(16, f32)
+        up.up_cc_matrices(P(pos), P(q), P(scr), P(v), P(p), P(vp))
+        rows.append({"in": [_bits(pos), _bits(q), _bits(scr)], "out": [_bits(v), _bits(p), _bits(vp)]})
+    out["matrices"] = rows
+    rows = []
+    for i in range(80):
+        pos, q, scr = (rng.standard_normal(3) * 9).astype(f32), unit_quat(), screens[i % 4]
+        ptr = (rng.uniform(-0.2, 1.2, 2) * scr).astype(f32)
+        o, d = np.zeros(3, f32), np.zeros(3, f32)
+        up.up_cc_world_ray(P(pos), P(q), P(scr), P(ptr), P(o), P(d))
+        rows.append({"in": [_bits(pos), _bits(q), _bits(scr), _bits(ptr)], "out": [_bits(o), _bits(d)]})
+    out["world_ray"] = rows
+    rows = []
+    for i in range(80):
+        q = unit_quat() if i % 4 else rng.standard_normal(4).astype(f32)
+        r = np.zeros(4, f32)
+        up.up_cc_remove_roll(P(q), P(r))
+        rows.append({"in": [_bits(q)], "out": [_bits(r)]})
+    out["remove_roll"] = rows
+    rows = []
+    up.up_cc_ray_plane.restype = C.c_int
+    for i in range(60):
+        o, d = (rng.standard_normal(3) * 5).astype(f32), rng.standard_normal(3).astype(f32)
+        d = (d / np.linalg.norm(d)).astype(f32)
+        plane = np.append(rng.standard_normal(3), rng.standard_normal() * 4).astype(f32)
+        if i % 10 == 0:  # a ray inside the plane: denominator exactly 0
+            plane = np.array([0, 1, 0, -1.5], f32)
+            d = np.array([1, 0, 0], f32)
+        t = C.c_float(-123.0)
+        hit = up.up_cc_ray_plane(P(o), P(d), P(plane), C.byref(t))
+        rows.append({"in": [_bits(o), _bits(d), _bits(plane)], "out": [int(hit), _bits(f32(t.value))]})
+    out["ray_plane"] = rows
+    rows, rows2 = [], []
+    for i in range(40):
+        a, b = rng.standard_normal(3).astype(f32), (rng.standard_normal(3) * 4).astype(f32)
+        r4, r3 = np.zeros(4, f32), np.zeros(3, f32)
+        up.up_cc_get_plane(P(a), P(b), P(r4))
+        up.up_cc_project_on_plane(P(b), P(a), P(r3))
+        rows.append({"in": [_bits(a), _bits(b)], "out": [_bits(r4)]})
+        rows2.append({"in": [_bits(b), _bits(a)], "out": [_bits(r3)]})
+    out["get_plane"], out["project_on_plane"] = rows, rows2
+    rows = []
+    for (bmin, bmax) in [([-4, -4, -4], [4, 4, 4]), ([-1.5, 0.25, -3.0], [2.5, 1.75, 6.0]), ([10, 10, 10], [11, 12, 10.5]), ([-30, -2, -7], [15, 3, 8])]:
+        for scr in screens[:2]:
+            a, b = np.array(bmin, f32), np.array(bmax, f32)
+            pos, q, anchor, floor, speed = np.zeros(3, f32), np.zeros(4, f32), np.zeros(3, f32), np.zeros(4, f32), C.c_float(0)
+            up.up_cc_set_bounds(P(a), P(b), P(scr), P(pos), P(q), P(anchor), P(floor), C.byref(speed))
+            rows.append({"in": [_bits(a), _bits(b), _bits(scr)], "out": [_bits(pos), _bits(q), _bits(anchor), _bits(floor), _bits(f32(speed.value))]})
+    out["set_bounds_state"] = rows
+
+    # sessions through the oracle's restatement of update()
+    from oracle import gsref
+    sessions = camera_sessions()
+    for sess in sessions:
+        sess["states"] = [_bits(st) for st in gsref.camera_controls_session(sess["width"], sess["height"], sess["boundsMin"], sess["boundsMax"], sess["frames"])]
+    out["sessions"] = sessions
+    with open(os.path.join(HERE, "camera_controls.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("camera_controls.json:", {k: len(v) for k, v in out.items() if isinstance(v, list)})
+
+
 def main():
+    if "--only-camera-controls" in sys.argv:
+        make_camera_controls_fixture(load_upstream())
+        return
     if "--only-glm" in sys.argv:
         make_glm_ops_fixture()
         return
@@ -318,6 +474,7 @@ def main():
     make_ply_fixtures(up)
     make_encode_fixture(up)
     make_camera_fixture(up)
+    make_camera_controls_fixture(up)
     make_sh_fixture()
     make_glm_ops_fixture()
     print("golden fixtures written to", HERE)

@@ -109,3 +109,35 @@ def test_cpp_host_ply_frame_equals_python_reference_pipeline(gs, demo_binary, tm
     r.close()
     assert st.tileListSize > 8 * 20000  # the C++ loop had to double its buffers to get the complete frame
     assert np.array_equal(_read_ppm(out)[::-1], want[..., :3])
+
+
+def test_cpp_host_replays_a_recorded_camera_session(gs, gsref, demo_binary, tmp_path, golden_dir):
+    """SURVEY.md 8(f4), the interactive viewer without its window: the C++ frame loop moves gs::CameraControls with one recorded input
+    line per frame (drag, orbit, pan, keys -- the first session of tests/golden/camera_controls.json) and renders every frame.  The pose
+    it ends in is the oracle's pose for that session and the image it leaves is the frame the Python Renderer draws from the oracle's
+    CameraData for that pose, byte for byte; the oracle's (view, projection, rays, roll removal ...) are held to the reference's own
+    CameraControls.cpp in tests/test_oracle_golden.py."""
+    sess = json.load(open(os.path.join(golden_dir, "camera_controls.json")))["sessions"][1]
+    w, h, frames = sess["width"] // 4, sess["height"] // 4, sess["frames"][:48]  # 256 x 256 window: scale the recorded cursor
+    frames = [(dt, b, k, x / 4.0, y / 4.0) for (dt, b, k, x, y) in frames]
+    events = tmp_path / "events.txt"
+    events.write_text("".join("%.9g %d %d %.9g %.9g\n" % tuple(f) for f in frames))
+    out = str(tmp_path / "session.ppm")
+    log = subprocess.run([demo_binary, "--procedural", "10000", str(w), str(h), str(len(frames)), out, "--events", str(events)],
+                         stdout=subprocess.PIPE, text=True, check=True).stdout
+    line = [ln for ln in log.splitlines() if ln.startswith("camera after")]
+    assert len(line) == 1
+    nums = [float(v) for v in line[0].replace("camera after %d frames:" % len(frames), "").replace("position", "").replace("rotation", "")
+            .replace("anchor", "").replace("mode", "").split()]
+    states, cams = gsref.camera_controls_session(w, h, [-4] * 3, [4] * 3, frames, with_camera_data=True)
+    assert np.array_equal(np.array(nums[:10], np.float32), states[-1, :10]) and int(nums[10]) == int(states[-1, 15])
+    assert not np.array_equal(states[-1, :7], states[0, :7])  # the camera did move
+    pos, sr, col = gs.generate_random_gaussians(10000, seed=1234, min_scale=0.01, max_scale=0.5)
+    cam = gs.CameraData.from_buffer_copy(bytes(cams[-1]))
+    r = gs.Renderer(w, h, pipeline=gs.PIPELINE_REFERENCE)
+    r.set_scene(pos, sr, col)
+    r.render(cam)
+    want = r.read_image()
+    r.close()
+    got = _read_ppm(out)[::-1]
+    assert np.array_equal(got, want[..., :3]) and got.max() > 0

@@ -8,7 +8,14 @@
 //                                                            with the library's RCCL exchange (gs_gather_bands) every frame; the
 //                                                            128-byte RCCL id travels through PATH.  Rank 0 writes the image.
 //
+//   ... --events FILE                                        the interactive viewer without the window (Demo.cpp:371-392): one line per
+//                                                            frame, "dt mouseButtons keys cursorX cursorY" (GS_MOUSE_* / GS_KEY_* bit masks,
+//                                                            cursor in pixels from the top-left corner), fed to gs::CameraControls::update before
+//                                                            the frame is rendered; frames beyond the file repeat its last line with dt = 0.
+//                                                            The pose after the last frame is printed.
+//
 // Build: make -C cudagaussianrenderer_amd/csrc demo
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -29,12 +36,14 @@ int main(int argc, char** argv)
     // multi-GPU options (anywhere on the command line)
     int world = 1, rank = 0;
     const char* idFile = nullptr;
+    const char* eventsFile = nullptr;
     std::vector<char*> positional;
     for (int i = 0; i < argc; ++i)
     {
         if (std::strcmp(argv[i], "--world") == 0 && i + 1 < argc) world = std::atoi(argv[++i]);
         else if (std::strcmp(argv[i], "--rank") == 0 && i + 1 < argc) rank = std::atoi(argv[++i]);
         else if (std::strcmp(argv[i], "--id-file") == 0 && i + 1 < argc) idFile = argv[++i];
+        else if (std::strcmp(argv[i], "--events") == 0 && i + 1 < argc) eventsFile = argv[++i];
         else positional.push_back(argv[i]);
     }
     argc = (int) positional.size();
@@ -123,8 +132,30 @@ int main(int argc, char** argv)
     void* sortTemp = nullptr;
     size_t sortTempBytes = 0;
 
-    gs::CameraData camera;
-    gs_camera_from_bounds(&boundsMin.x, &boundsMax.x, width, height, &camera);
+    // Camera: CameraControls placed by the scene's bounds (Demo.cpp:336-337), moved by the recorded input when there is any.
+    gs::CameraControls cameraControls((float) width, (float) height);
+    cameraControls.setBounds(boundsMin, boundsMax);
+    struct Event { float dt; GsCameraInput input; };
+    std::vector<Event> events;
+    if (eventsFile != nullptr)
+    {
+        std::FILE* f = std::fopen(eventsFile, "r");
+        if (f == nullptr)
+        {
+            std::fprintf(stderr, "cannot open %s\n", eventsFile);
+            return 2;
+        }
+        Event e{};
+        unsigned buttons = 0, keys = 0;
+        while (std::fscanf(f, "%f %u %u %lf %lf", &e.dt, &buttons, &keys, &e.input.cursorX, &e.input.cursorY) == 5)
+        {
+            e.input.mouseButtons = buttons;
+            e.input.keys = keys;
+            events.push_back(e);
+        }
+        std::fclose(f);
+    }
+    gs::CameraData camera = cameraControls.getCameraData();
 
     gs::GpuTimer timer;
     double msSh = 0, msClip = 0, msBuild = 0, msSort = 0, msRanges = 0, msRaster = 0;
@@ -138,6 +169,14 @@ int main(int argc, char** argv)
             keysB.resizeIfNeeded(capacity);
             valuesA.resizeIfNeeded(capacity);
             valuesB.resizeIfNeeded(capacity);
+        }
+        if (!events.empty()) // Demo.cpp:371-392: update input & camera controls, build the camera data
+        {
+            Event e = events[std::min((size_t) frame, events.size() - 1)];
+            if ((size_t) frame >= events.size()) e.dt = 0.0f;
+            cameraControls.setInput(e.input);
+            cameraControls.update(e.dt);
+            camera = cameraControls.getCameraData();
         }
         backBuffer.clearMemory(0);
         tileRangeBuffer.clearMemory(255);
@@ -207,6 +246,13 @@ int main(int argc, char** argv)
                 msSh / f, msClip / f, msBuild / f, msSort / f, msRanges / f, msRaster / f,
                 (msSh + msClip + msBuild + msSort + msRanges + msRaster) / f);
 
+    if (!events.empty())
+    {
+        const GsCameraControlsState st = cameraControls.getState();
+        std::printf("camera after %d frames: position %.9g %.9g %.9g rotation %.9g %.9g %.9g %.9g anchor %.9g %.9g %.9g mode %d\n", frames,
+                    st.position[0], st.position[1], st.position[2], st.rotationXYZW[0], st.rotationXYZW[1], st.rotationXYZW[2], st.rotationXYZW[3],
+                    st.anchorPosition[0], st.anchorPosition[1], st.anchorPosition[2], st.mode);
+    }
     gs_comm_destroy(comm);
     if (outPath != nullptr && rank == 0)
     {
