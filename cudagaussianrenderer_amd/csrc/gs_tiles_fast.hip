@@ -18,8 +18,9 @@
 //   * the ellipse/rectangle predicate is evaluated in the ellipse's unit-circle space with the affine map
 //     hoisted per splat (reciprocals instead of the reference's 14 divisions per test).  It is the same
 //     predicate -- centre-in-rect OR rect-centre-in-ellipse OR an edge within the unit circle
-//     (GaussianRender.cu:375-405) -- evaluated in a different floating-point order, so its decision value (the
-//     smallest of the five squared distances, compared with 1) differs from the reference's by rounding.  A GUARD
+//     (GaussianRender.cu:375-405) -- evaluated in a different floating-point order, and (round 4) on the two edges nearest to the
+//     ellipse's centre only, which is where the smallest of the reference's five squared distances lies (see the hot loop), so
+//     its decision value (that smallest squared distance, compared with 1) differs from the reference's by rounding.  A GUARD
 //     BAND makes the decisions the reference's all the same: a tile whose value lies within kGuard (1 + A) of 1 is
 //     decided again by the reference's own arithmetic (gs_overlap_exact.h, shared with gs_tiles.hip).  A is what the
 //     rounding errors of BOTH formulations scale with: the absolute terms of the two dot products that map the tile's
@@ -141,6 +142,9 @@ __device__ __forceinline__ unsigned decideInsideGuardBand(unsigned hitMask, floa
 // floor / ceil keep every tile the inflated box touches.  A NaN ellipse keeps the reference's box (it emits no pairs anyway).
 #ifndef GS_TIGHT_BOX
 #define GS_TIGHT_BOX 1
+#endif
+#ifndef GS_VISIBLE_EDGES
+#define GS_VISIBLE_EDGES 1 // A/B builds: 0 = all four edges and the centre term of every tile (round 3's hot loop)
 #endif
 __device__ __forceinline__ void tightenToEllipse(TileAabb& box, float cx, float cy, float4 se, const Screen& scr)
 {
@@ -596,6 +600,7 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
             const float ux = cm.z * sx, uy = mi.x * sx; // u = M (sx, 0)
             const float vx = cm.w * sy, vy = mi.y * sy; // v = M (0, sy)
             const float uv = fmaf(ux, vx, uy * vy);
+            const float negHalfSx = -0.5f * sx, negHalfSy = -0.5f * sy;
             int lx = lx0, ly = ly0;
             int histTileBase = 0; // several views per chain: the virtual tile of view v is v * totalTiles + tile, as the emit pass writes it
             if (!EMIT && FUSED && viewSplats > 0)
@@ -621,11 +626,30 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                     // corner q0 = M (min - c); the other corners are q0 + u, q0 + v, q0 + u + v
                     const float dx = minX - cm.x, dy = minY - cm.y;
                     const float q0x = fmaf(cm.z, dx, cm.w * dy), q0y = fmaf(mi.x, dx, mi.y * dy);
+                    const float q0u = fmaf(q0x, ux, q0y * uy), q0v = fmaf(q0x, vx, q0y * vy);
+#if GS_VISIBLE_EDGES
+                    // Rectangle centre inside the ellipse (:389), or an edge within the unit circle (:392-402): the smallest of five
+                    // squared distances decides -- and for a rectangle that does not hold the ellipse's centre that smallest value lies
+                    // on an edge the centre can SEE (the quadratic form grows along every ray from the centre): the left edge when the
+                    // centre is left of the tile, the right one when it is right of it; likewise bottom / top; the rectangle's own
+                    // centre is never closer than where the segment towards it enters the rectangle.  Inside the tile's column (row)
+                    // neither vertical (horizontal) edge is visible and either may be taken; the NEARER one (one compare against the
+                    // tile's midline, which outside the column is the visible edge) also covers a centre within rounding of a tile
+                    // boundary: the tile it grazes gets a distance of ~0 whichever side the arithmetic puts it on.  Two edge distances
+                    // instead of four and the centre term, the same bits as those (fma(1, u, q) = q + u); a dropped term that would
+                    // have won by rounding moves the value by at most 3e-7 (1 + A), inside the guard band's margin
+                    // (tools/guard_band_check.cpp, 9 x 10^8 tiles: no differing decision outside the band).
+                    const float fx = dx < negHalfSx ? 1.0f : 0.0f, fy = dy < negHalfSy ? 1.0f : 0.0f;
+                    const float xEdge2 = edgeDistanceSquared(fmaf(fx, ux, q0x), fmaf(fx, uy, q0y), vx, vy, fmaf(fx, uv, q0v), mi.w);
+                    const float yEdge2 = edgeDistanceSquared(fmaf(fy, vx, q0x), fmaf(fy, vy, q0y), ux, uy, fmaf(fy, uv, q0u), mi.z);
+                    const float decision = fminf(xEdge2, yEdge2);
+                    hit |= decision < 1.0f;
+                    dev[e] = fabsf(decision - 1.0f);
+#else
                     const float qcx = fmaf(0.5f, ux + vx, q0x), qcy = fmaf(0.5f, uy + vy, q0y);
                     // rectangle centre inside the ellipse (:389), or an edge within the unit circle (:392-402): the smallest of
                     // the five squared distances decides
                     const float centre2 = fmaf(qcx, qcx, qcy * qcy);
-                    const float q0u = fmaf(q0x, ux, q0y * uy), q0v = fmaf(q0x, vx, q0y * vy);
                     const float bottom2 = edgeDistanceSquared(q0x, q0y, ux, uy, q0u, mi.z);
                     const float right2 = edgeDistanceSquared(q0x + ux, q0y + uy, vx, vy, q0v + uv, mi.w);
                     const float top2 = edgeDistanceSquared(q0x + vx, q0y + vy, ux, uy, q0u + uv, mi.z);
@@ -633,6 +657,7 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                     const float decision = fminf(fminf(fminf(bottom2, right2), fminf(top2, left2)), centre2);
                     hit |= decision < 1.0f;
                     dev[e] = fabsf(decision - 1.0f);
+#endif
                     // digit histogram of this group's pairs (the emit pass will rank them by it), by the cheap decision: a decision the
                     // guard band turns over is put right below
                     if (!EMIT && FUSED && hit) atomicAdd(&digitHist[(gy * scr.tilesX + gx + histTileBase) & (kBins - 1)], 1);

@@ -7,9 +7,14 @@
 namespace gs
 {
 
-// Lanes of the wave whose (valid) digit equals this lane's digit.  Written on the two 32-bit halves of the mask with
-// xnor/and against the ballot of each digit bit: seven VALU instructions per bit and no scalar temporaries beyond the
-// ballot itself (the obvious `m &= b ? bal : ~bal` makes the compiler keep every ballot alive and spill SGPRs).
+// Lanes of the wave whose (valid) digit equals this lane's digit.  Four VALU instructions per digit bit on the two 32-bit halves of
+// the mask: the bit as 0 / -1 (v_bfe_i32), its ballot (v_cmp_ne), and per half ONE three-input boolean, mask & ~(ballot ^ mine)
+// (v_bitop3_b32, truth table 0x90 in the a = 0xF0, b = 0xCC, c = 0xAA convention: 0xF0 & ~(0xCC ^ 0xAA)).  Round 3's form (`lo &=
+// ~(bal ^ mine)` with the bit taken by shift-and-subtract) compiled to seven per bit: the compiler re-made every ballot from a 0/1
+// select and spent two xors before its own v_bitop3 (GS_MATCH_BITOP3 = 0 keeps it for A/B builds).
+#ifndef GS_MATCH_BITOP3
+#define GS_MATCH_BITOP3 1
+#endif
 template <int BITS>
 __device__ __forceinline__ unsigned long long matchDigit(int digit, bool valid)
 {
@@ -19,10 +24,17 @@ __device__ __forceinline__ unsigned long long matchDigit(int digit, bool valid)
     for (int bit = 0; bit != BITS; ++bit)
     {
         // lanes outside `valid` may vote anything: they were removed from the mask above and stay removed
+#if GS_MATCH_BITOP3
+        const unsigned mine = (unsigned) __builtin_amdgcn_sbfe(digit, bit, 1); // all ones when my bit is set
+        const unsigned long long bal = __ballot(mine != 0u);
+        lo = __builtin_amdgcn_bitop3_b32(lo, (unsigned) bal, mine, 0x90);
+        hi = __builtin_amdgcn_bitop3_b32(hi, (unsigned) (bal >> 32), mine, 0x90);
+#else
         const unsigned long long bal = __ballot(((unsigned) digit & (1u << bit)) != 0u);
         const unsigned mine = 0u - (((unsigned) digit >> bit) & 1u); // all ones when my bit is set
         lo &= ~((unsigned) bal ^ mine);
         hi &= ~((unsigned) (bal >> 32) ^ mine);
+#endif
     }
     const unsigned long long m = ((unsigned long long) hi << 32) | lo;
     return valid ? m : 0ull;

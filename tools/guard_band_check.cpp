@@ -102,6 +102,27 @@ inline float fastMin(const Ell& e, const Hoisted& h, float minX, float minY, flo
     cond = (std::fabs(h.m00 * dx) + std::fabs(h.m01 * dy)) + (std::fabs(h.m10 * dx) + std::fabs(h.m11 * dy)) + std::fabs(ux) + std::fabs(uy) + std::fabs(vx) + std::fabs(vy);
     return std::fmin(std::fmin(std::fmin(bottom2, right2), std::fmin(top2, left2)), centre2);
 }
+// ---- round 4, second formulation: only the two edges NEAREST to the ellipse's centre ---------------------------------------
+// The smallest value of the quadratic form over a rectangle that does not hold the centre lies on an edge the centre can see (the
+// form grows along every ray from the centre): the left edge when the centre is left of the tile, the right one when it is right of
+// it -- likewise bottom / top -- and the rectangle's own centre is never closer than the point where the segment towards it enters
+// the rectangle.  For a centre inside the tile's column (row) neither vertical (horizontal) edge is visible and either may be
+// taken -- no point of the rectangle is closer than the visible edge's closest one; taking the NEARER one (one compare against the
+// tile's midline, which outside the column IS the visible edge) also covers a centre within rounding of a tile boundary: the tile
+// it grazes gets a distance of ~0 whichever side of the boundary the arithmetic puts it on.  Two edge distances instead of four plus
+// the centre term; the values that are computed are the SAME bits as fastMin's (fma(1, u, q) == q + u).
+inline float fastMinVisible(const Ell& e, const Hoisted& h, float minX, float minY, float sx, float sy)
+{
+    const float ux = h.m00 * sx, uy = h.m10 * sx, vx = h.m01 * sy, vy = h.m11 * sy;
+    const float uv = fmaf(ux, vx, uy * vy);
+    const float dx = minX - e.cx, dy = minY - e.cy;
+    const float q0x = fmaf(h.m00, dx, h.m01 * dy), q0y = fmaf(h.m10, dx, h.m11 * dy);
+    const float q0u = fmaf(q0x, ux, q0y * uy), q0v = fmaf(q0x, vx, q0y * vy);
+    const float fx = dx < -0.5f * sx ? 1.0f : 0.0f, fy = dy < -0.5f * sy ? 1.0f : 0.0f; // the centre is right of / above the tile's midline
+    const float xEdge = edgeFast(fmaf(fx, ux, q0x), fmaf(fx, uy, q0y), vx, vy, fmaf(fx, uv, q0v), h.invVV); // left or right
+    const float yEdge = edgeFast(fmaf(fy, vx, q0x), fmaf(fy, vy, q0y), ux, uy, fmaf(fy, uv, q0u), h.invUU); // bottom or top
+    return std::fmin(xEdge, yEdge);
+}
 } // namespace
 
 int main(int argc, char** argv)
@@ -122,6 +143,9 @@ int main(int argc, char** argv)
     // whose decision value is near 1 lies within 1.05 x the larger extent + one tile of the centre on either axis), then per tile
     const double kGuard = 1.0e-5;
     long long insideSplatGuard = 0, insideBothGuards = 0, straddleOutside = 0;
+    // the visible-edges formulation under the same guard
+    long long visStraddleOutside = 0, visDiffersFromFast = 0, visInsideBoth = 0;
+    double visWorstVsFastRel = 0, visWorstVsExactRelA = 0;
     constexpr int kBins = 9;
     double binWorst[kBins] = {}, binWorstA[kBins] = {};
     long long binCount[kBins] = {}, binCountA[kBins] = {};
@@ -191,6 +215,21 @@ int main(int argc, char** argv)
                 insideSplatGuard += inSplat;
                 insideBothGuards += inSplat && inTile;
                 if ((me < 1.0f) != (mf < 1.0f) && !inside && !(inSplat && inTile)) ++straddleOutside;
+                const float mv = fastMinVisible(e, h, minX, minY, sx, sy);
+                if (!inside)
+                {
+                    // (a tile that holds the centre by the reference's arithmetic is a hit whatever the value: decided per splat)
+                    const double devV = std::fabs((double) mv - 1.0);
+                    const bool inSplatV = !(devV > guardSplat), inTileV = !(devV > kGuard * aTile);
+                    visInsideBoth += inSplatV && inTileV;
+                    if ((me < 1.0f) != (mv < 1.0f) && !(inSplatV && inTileV)) ++visStraddleOutside;
+                    if (mv != mf) ++visDiffersFromFast;
+                    if (std::min(me, mv) < 4.0f && std::isfinite(mv))
+                    {
+                        visWorstVsFastRel = std::max(visWorstVsFastRel, std::fabs((double) mv - (double) mf) / aTile);
+                        visWorstVsExactRelA = std::max(visWorstVsExactRelA, std::fabs((double) mv - (double) me) / aTile);
+                    }
+                }
             }
             for (int k = 0; k != 3; ++k)
             {
@@ -231,6 +270,9 @@ int main(int argc, char** argv)
            100.0 * guardHits[0] / tests, 100.0 * guardHits[1] / tests, 100.0 * guardHits[2] / tests, 100.0 * guardHits[3] / tests);
     printf("kernel's guard (%.1e (1 + A)): tests inside the per-splat filter %.4f %%, inside both (decided exactly) %.4f %%; differing decisions OUTSIDE the guard: %lld\n",
            kGuard, 100.0 * insideSplatGuard / tests, 100.0 * insideBothGuards / tests, straddleOutside);
+    printf("nearest-two-edges formulation: value differs from the five-term value in %lld tests, worst |two-edge - five-term| %.3e (1 + A), worst "
+           "|two-edge - exact| near the decision %.3e (1 + A); inside both guards %.4f %%; differing decisions OUTSIDE the guard: %lld\n",
+           visDiffersFromFast, visWorstVsFastRel, visWorstVsExactRelA, 100.0 * visInsideBoth / tests, visStraddleOutside);
     printf("decision values within 5 %% of 1, by S = |q0|_1 + |u|_1 + |v|_1:\n");
     for (int b = 0; b != kBins; ++b)
     {
