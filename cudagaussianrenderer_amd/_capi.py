@@ -206,6 +206,8 @@ SIGNATURES = {
     "gs_renderer_read_back_buffer_view": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "gs_renderer_captured_retries": (C.c_int, [C.c_void_p]),
     "gs_debug_set_ablation": (None, [C.c_int]),
+    "gs_debug_set_clip_scan_fusion": (None, [C.c_int]),
+    "gs_debug_get_clip_scan_fusion": (C.c_int, []),
     "gs_debug_set_await_timeout": (None, [C.c_double]),
     "gs_debug_host_times": (C.c_longlong, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
     "gs_renderer_set_stream": (None, [C.c_void_p, C.c_void_p]),

@@ -49,13 +49,35 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
         launchSphericalHarmonics(g.stream, n, r->shDegree, r->shCount, (const float4*) r->position, r->sh, unused, (float4*) r->color,
                                  r->paramsDevice);
     const int* countDevice = nullptr;
+    // Morton storage: the depth sort makes its own keys, so the clip kernel and the sort do not depend on each other -- the clip kernel
+    // is handed to the sort and shares the launch of its first column scan (gs_internal.h RadixScanCompanion): 17 kernels per frame.
+    ClipWithScan deferredClip;
+    const auto launchClip = [&]() {
+        launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation, nullptr, nullptr, nullptr,
+                            nullptr, r->splatToStorage != nullptr ? nullptr : r->depthKey[0],
+                            r->splatToStorage != nullptr ? nullptr : (uint32_t*) r->order[0], nullptr, nullptr, nullptr, r->paramsDevice, clearTable,
+                            clearEntries, (float4*) r->tileRecord, (float4*) r->rasterRecord, views);
+    };
     if (!cull)
     {
         if (!(g_ablation & 1))
-            launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation,
-                                nullptr, nullptr, nullptr, nullptr, r->splatToStorage != nullptr ? nullptr : r->depthKey[0],
-                                r->splatToStorage != nullptr ? nullptr : (uint32_t*) r->order[0], nullptr, nullptr, nullptr, r->paramsDevice, clearTable,
-                                clearEntries, (float4*) r->tileRecord, (float4*) r->rasterRecord, views);
+        {
+            if (cfg.clipScanFusion && r->splatToStorage != nullptr && !(g_ablation & 2))
+            {
+                deferredClip.count = n;
+                deferredClip.scr = scr;
+                deferredClip.params = r->paramsDevice;
+                deferredClip.position = (const float4*) r->position;
+                deferredClip.scaleAndRotation = (const float4*) r->scaleAndRotation;
+                deferredClip.rangeTableToClear = clearTable;
+                deferredClip.rangeEntries = clearEntries;
+                deferredClip.tileRecord = (float4*) r->tileRecord;
+                deferredClip.rasterRecord = (float4*) r->rasterRecord;
+                deferredClip.views = views;
+                r->radix.firstScanCompanion = RadixScanCompanion{&clipWithScanCompanion, &deferredClip};
+            }
+            else launchClip();
+        }
     }
     else
     {
@@ -85,6 +107,12 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
                                           : launchRadixSortPairs(g.stream, r->radix, 4, r->depthKey[0], r->depthKey[1], r->order[0], r->order[1], nv, 0,
                                                                  kDepthKeyBits, callerOrderedInput ? r->splatToStorage : nullptr,
                                                                  callerOrderedInput ? &keySource : nullptr);
+    if (r->radix.firstScanCompanion.launch != nullptr)
+    {
+        // the sort could not take the clip kernel along (rows of more than 4096 tiles): by itself, then
+        r->radix.firstScanCompanion = RadixScanCompanion{};
+        launchClip();
+    }
     const uint32_t* order = (const uint32_t*) r->order[orderSel];
     // (gs_set_list_fusion: the emit pass carries the first pass of the tile sort.  Under ablation -- cumulative from the back -- the
     // stages in front of a missing one still run as in the product; every position the emit pass writes is checked against the capacity)
@@ -218,7 +246,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
         if (r->graphValid && (r->graphCapacity != r->tileListCapacity || r->graphSplats != n || r->graphRowBegin != scr.rowBegin ||
                               r->graphRowEnd != scr.rowEnd || r->graphCull != (int) cull ||
                               r->graphFootprint != scr.epanechnikov || r->graphLazy != (int) lazy || r->graphAblation != g_ablation ||
-                              r->graphFusion != (int) cfg.listFusion))
+                              r->graphFusion != ((int) cfg.listFusion | ((int) cfg.clipScanFusion << 1))))
             r->graphValid = false;
         if (!r->graphValid)
         {
@@ -248,7 +276,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
             r->graphFootprint = scr.epanechnikov;
             r->graphLazy = (int) lazy;
             r->graphAblation = g_ablation;
-            r->graphFusion = (int) cfg.listFusion;
+            r->graphFusion = (int) cfg.listFusion | ((int) cfg.clipScanFusion << 1);
         }
         const int slot = r->graphSlot;
         r->graphSlot ^= 1;
@@ -288,6 +316,8 @@ extern "C" void gs_renderer_set_graph(GsRenderer* r, int enabled)
 
 extern "C" int gs_renderer_captured_retries(const GsRenderer* r) { return r->capturedRetries; }
 extern "C" void gs_debug_set_ablation(int mask) { g_ablation = mask; }
+extern "C" void gs_debug_set_clip_scan_fusion(int enabled) { cfg.clipScanFusion = enabled != 0; }
+extern "C" int gs_debug_get_clip_scan_fusion(void) { return cfg.clipScanFusion ? 1 : 0; }
 extern "C" void gs_debug_set_await_timeout(double seconds) { g_awaitTimeoutSeconds = seconds > 0.0 ? seconds : 30.0; }
 extern "C" long long gs_debug_host_times(double* launchMicroseconds, double* awaitMicroseconds, int reset)
 {

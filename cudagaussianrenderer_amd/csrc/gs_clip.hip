@@ -19,6 +19,7 @@
 #include "gs_aabb.h"
 #include "gs_depth_key.h"
 #include "gs_internal.h"
+#include "gs_radix_scan.h"
 
 #pragma clang fp contract(off)
 
@@ -188,23 +189,51 @@ __device__ __forceinline__ bool projectSplat(const float4 pd, const float4 sr, c
 constexpr int kBandBlock = 256;                // splats per workgroup of the band-cull kernel; the compaction's scan runs over these blocks
 constexpr int kBandSlots = kBandBlock / kWave; // 64-splat slots (one kept mask each) per workgroup
 
-// Every splat projected and stored, one per lane (the single-GPU frame, the staged API).
+// Every splat projected and stored, one per lane (the single-GPU frame, the staged API): workgroup `block` of `blocks`, grid row `view`
+// of `views`.
+__device__ __forceinline__ void clipDataBlock(int block, int blocks, int view, int views, int count, const Screen& scr, const ClipCamera& camArg,
+                                              const FrameParams* __restrict__ params, const float4* __restrict__ position,
+                                              const float4* __restrict__ scaleAndRotation, const ClipOutputs& o, int32_t* __restrict__ rangeTable,
+                                              int rangeEntries)
+{
+    const int index = block * 256 + (int) threadIdx.x; // splat of the scene
+    // The renderer has this kernel reset the tile range table to -1 (Demo.cpp:403) on the side: nothing reads the table before the
+    // range search (the last scatter of the tile sort), so the frame needs no separate clear.
+    if (rangeTable != nullptr)
+        for (int i = view * (blocks * 256) + index; i < rangeEntries; i += blocks * views * 256) rangeTable[i] = -1;
+    if (index >= count) return;
+    const ClipCamera cam = params ? params[view].camera : camArg; // device-resident when the frame is a captured graph
+    // results are stored under the "virtual splat" view * count + index
+    (void) projectSplat<false>(position[index], scaleAndRotation[index], cam, scr, view * count + index, view * count + index, o);
+}
+
 __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr, ClipCamera camArg, const FrameParams* __restrict__ params,
                                                             const float4* __restrict__ position,
                                                             const float4* __restrict__ scaleAndRotation, ClipOutputs o,
                                                             int32_t* __restrict__ rangeTable, int rangeEntries)
 {
-    const int index = blockIdx.x * blockDim.x + threadIdx.x; // splat of the scene
-    const int view = blockIdx.y;                              // gs_renderer_set_views: one grid row per camera
-    // The renderer has this kernel reset the tile range table to -1 (Demo.cpp:403) on the side: it is the first kernel
-    // of the frame and nothing reads the table before the range search, so the frame needs no separate clear.
-    if (rangeTable != nullptr)
-        for (int i = view * (int) (gridDim.x * blockDim.x) + index; i < rangeEntries; i += (int) (gridDim.x * gridDim.y * blockDim.x))
-            rangeTable[i] = -1;
-    if (index >= count) return;
-    const ClipCamera cam = params ? params[view].camera : camArg; // device-resident when the frame is a captured graph
-    // results are stored under the "virtual splat" view * count + index
-    (void) projectSplat<false>(position[index], scaleAndRotation[index], cam, scr, view * count + index, view * count + index, o);
+    // gs_renderer_set_views: one grid row per camera
+    clipDataBlock((int) blockIdx.x, (int) gridDim.x, (int) blockIdx.y, (int) gridDim.y, count, scr, camArg, params, position, scaleAndRotation, o, rangeTable,
+                  rangeEntries);
+}
+
+// The same, sharing its launch with the FIRST column scan of the depth sort (gs_internal.h RadixScanCompanion).  A renderer with Morton
+// storage has the depth sort make its own keys, so nothing of the sort waits for the clip data and the clip kernel needs nothing of the
+// sort: the scan -- 512 workgroups that each add up one row of a 2 MB table, 5 us of pure latency -- rides in front of the clip kernel's
+// grid (its workgroups start first and are gone long before the clip stage's 22 us of streaming end).  One kernel, one dependent launch
+// and one chip-wide kernel boundary less per frame; the results are the two kernels' results (same routines, same order of operations).
+__global__ __launch_bounds__(256) void splatClipDataScanKernel(RadixScanArgs scan, int count, Screen scr, ClipCamera camArg,
+                                                                const FrameParams* __restrict__ params, const float4* __restrict__ position,
+                                                                const float4* __restrict__ scaleAndRotation, ClipOutputs o,
+                                                                int32_t* __restrict__ rangeTable, int rangeEntries)
+{
+    if ((int) blockIdx.x < scan.rows) // (uniform per workgroup)
+    {
+        if (blockIdx.y == 0) radixColumnScanRow<256>((int) blockIdx.x, scan.nHost, scan.nDevice, scan.tileElements, scan.stride, scan.table, scan.scanned, scan.totals);
+        return;
+    }
+    clipDataBlock((int) blockIdx.x - scan.rows, (int) gridDim.x - scan.rows, (int) blockIdx.y, (int) gridDim.y, count, scr, camArg, params, position,
+                  scaleAndRotation, o, rangeTable, rangeEntries);
 }
 
 // Multi-GPU band cull: the same projection, but a splat whose tile AABB does not reach this GPU's tile rows stores nothing.
@@ -407,6 +436,14 @@ void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const
     else
         hipLaunchKernelGGL(splatClipDataKernel, dim3((count + 255) / 256, views), dim3(256), 0, stream, count, scr, cam, paramsDevice, position,
                            scaleAndRotation, o, rangeTableToClear, rangeEntries);
+}
+
+void launchSplatClipDataWithScan(hipStream_t stream, const ClipWithScan& c, const RadixScanArgs& scan)
+{
+    const ClipOutputs o{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c.tileRecord, c.rasterRecord};
+    const int clipBlocks = (c.count + 255) / 256;
+    hipLaunchKernelGGL(splatClipDataScanKernel, dim3(scan.rows + clipBlocks, c.views), dim3(256), 0, stream, scan, c.count, c.scr, c.camera, c.params, c.position,
+                       c.scaleAndRotation, o, c.rangeTableToClear, c.rangeEntries);
 }
 
 } // namespace gs

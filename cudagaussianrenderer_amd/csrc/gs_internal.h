@@ -160,6 +160,27 @@ size_t sortTempBytes(int keyBytes, int size, int beginBit, int endBit);
 int launchSortPairs(hipStream_t stream, void* temp, size_t tempBytes, int keyBytes, void* keys0, void* keys1, int32_t* values0,
                     int32_t* values1, int selector, int size, int beginBit, int endBit);
 
+// A column scan of the renderer's radix sort is a latency-bound kernel of 256-512 small workgroups between a histogram and a scatter.
+// A kernel of the caller's that does not depend on the sort may SHARE THE LAUNCH of the sort's first scan (one kernel, one dependent
+// launch and one chip-wide kernel boundary less per frame): the caller leaves a companion in RadixScratch, and the next
+// launchRadixSortPairs hands it the arguments of its first scan instead of launching the scan kernel; the companion must launch ONE
+// kernel of 256-lane workgroups whose first `rows` workgroups (of grid row 0) call radixColumnScanRow<256> (gs_radix_scan.h).  One shot:
+// the sort clears it when it takes it; a sort that cannot (rows of more than 4096 tiles) leaves it, and the caller launches its kernel itself.
+struct RadixScanArgs
+{
+    int rows; // digit rows = workgroups of the scan
+    int nHost;
+    const int* nDevice;
+    int tileElements, stride;
+    const int32_t* table;
+    int32_t* scanned;
+    int32_t* totals;
+};
+struct RadixScanCompanion
+{
+    void (*launch)(hipStream_t stream, const RadixScanArgs& scan, void* user) = nullptr;
+    void* user = nullptr;
+};
 // The renderer's own radix sort (gs_radix.hip): 2- or 4-byte keys, int32 values, stable, bits [beginBit, endBit).
 struct RadixScratch
 {
@@ -173,7 +194,30 @@ struct RadixScratch
     // Tile range table (int32[2 * tiles], preset to -1) that the LAST pass of the next sort fills from its scatter -- the key is then the
     // tile index and no range kernel is needed (GaussianRender.cu:857-888); set per call by the renderer, null otherwise.
     int32_t* rangeTableForLastPass = nullptr;
+    RadixScanCompanion firstScanCompanion; // see above; set per call by the renderer
 };
+// The clip stage of a frame whose depth sort makes its own keys (Morton storage, no band cull), deferred: launched by the sort as the
+// companion of its first column scan (gs_clip.hip splatClipDataScanKernel).  Writes the two 32-byte records per (virtual) splat and
+// resets the range table, exactly as launchSplatClipData does with the same arguments.
+struct ClipWithScan
+{
+    int count = 0;
+    Screen scr{};
+    ClipCamera camera{};
+    const FrameParams* params = nullptr; // captured frames: cameras on the device, one per view
+    const float4* position = nullptr;
+    const float4* scaleAndRotation = nullptr;
+    int32_t* rangeTableToClear = nullptr;
+    int rangeEntries = 0;
+    float4* tileRecord = nullptr;
+    float4* rasterRecord = nullptr;
+    int views = 1;
+};
+void launchSplatClipDataWithScan(hipStream_t stream, const ClipWithScan& clip, const RadixScanArgs& scan);
+inline void clipWithScanCompanion(hipStream_t stream, const RadixScanArgs& scan, void* user)
+{
+    launchSplatClipDataWithScan(stream, *static_cast<const ClipWithScan*>(user), scan);
+}
 bool radixSortSupported(int keyBytes, int n);
 void ensureRadixScratch(RadixScratch& s, int n);
 void freeRadixScratch(RadixScratch& s);

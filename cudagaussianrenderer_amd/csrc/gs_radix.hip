@@ -17,6 +17,7 @@
 
 #include "gs_depth_key.h"
 #include "gs_internal.h"
+#include "gs_radix_scan.h"
 #include "gs_wave_match.h"
 
 namespace gs
@@ -194,55 +195,13 @@ __global__ __launch_bounds__(kHistThreadsFor<kIsKeySource<SOURCE>>) void radixHi
         *reinterpret_cast<int4*>(table + (size_t) d * stride + firstTile) = make_int4(hist[0][d], hist[1][d], hist[2][d], hist[3][d]);
 }
 
-// One workgroup per digit: exclusive scan of that digit's row of table[digit][tile] over the tiles (contiguous: 16 bytes per
-// lane and round), row total to totals[digit].  256 lanes for rows of up to 4096 tiles (one to four rounds), 1024 lanes beyond:
-// the kernel is pure latency, and with 1024 lanes per digit its 256-512 workgroups took every wave slot of the chip, so that in
-// the pipelined frame loop nothing of the other frames could run beside it (17 us per launch there against 5 us alone).
+// One workgroup per digit: exclusive scan of that digit's row of table[digit][tile] over the tiles (gs_radix_scan.h).
 template <int kScanThreads>
 __global__ __launch_bounds__(kScanThreads) void radixColumnScanKernel(int nHost, const int* __restrict__ nDevice, int tileElements, int stride,
                                                                       const int32_t* __restrict__ table, int32_t* __restrict__ scanned,
                                                                       int32_t* __restrict__ totals)
 {
-    constexpr int kScanWaves = kScanThreads / kWave;
-    __shared__ int waveSums[2][kScanWaves];
-    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
-    const int digit = blockIdx.x;
-    const int n = nDevice ? min(*nDevice, nHost) : nHost;
-    const int numTiles = (n + tileElements - 1) / tileElements;
-    const int32_t* in = table + (size_t) digit * stride;
-    int32_t* out = scanned + (size_t) digit * stride;
-    int carry = 0, flip = 0;
-    for (int base = 0; base < numTiles; base += kScanThreads * 4, flip ^= 1)
-    {
-        const int tile = base + t * 4; // stride is a multiple of 4: a quad never leaves the row
-        int4 v = make_int4(0, 0, 0, 0);
-        if (tile < numTiles) v = *reinterpret_cast<const int4*>(in + tile);
-        if (tile + 1 >= numTiles) v.y = 0; // entries past the live tiles hold stale counts
-        if (tile + 2 >= numTiles) v.z = 0;
-        if (tile + 3 >= numTiles) v.w = 0;
-        const int own = v.x + v.y + v.z + v.w;
-        int incl = own;
-#pragma unroll
-        for (int delta = 1; delta < kWave; delta <<= 1)
-        {
-            const int o = __shfl_up(incl, delta);
-            if (lane >= delta) incl += o;
-        }
-        if (lane == kWave - 1) waveSums[flip][wave] = incl;
-        __syncthreads(); // the other half of waveSums is free for the next round: one barrier per round
-        int before = 0, all = 0;
-#pragma unroll
-        for (int w = 0; w != kScanWaves; ++w)
-        {
-            const int ws = waveSums[flip][w];
-            before += (w < wave) ? ws : 0;
-            all += ws;
-        }
-        const int p0 = carry + before + incl - own;
-        if (tile < numTiles) *reinterpret_cast<int4*>(out + tile) = make_int4(p0, p0 + v.x, p0 + v.x + v.y, p0 + v.x + v.y + v.z);
-        carry += all;
-    }
-    if (t == 0) totals[digit] = carry;
+    radixColumnScanRow<kScanThreads>((int) blockIdx.x, nHost, nDevice, tileElements, stride, table, scanned, totals);
 }
 
 template <typename K, int BITS, int ITEMS>
@@ -444,7 +403,15 @@ void runPassItems(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, 
 #ifndef GS_SCAN_ROW_LIMIT
 #define GS_SCAN_ROW_LIMIT 4096 // A/B builds: 0 = always 1024 lanes
 #endif
-    if (numTiles <= GS_SCAN_ROW_LIMIT)
+    if (s.firstScanCompanion.launch != nullptr && numTiles <= GS_SCAN_ROW_LIMIT)
+    {
+        // the caller has a kernel that does not depend on this sort and shares the launch of its first column scan (gs_internal.h)
+        const RadixScanArgs scan{BITS > 8 ? 2 * kDigits : kDigits, n, s.countDevice, kTile, stride, s.table, s.scanned, s.chunkTotals};
+        const RadixScanCompanion companion = s.firstScanCompanion;
+        s.firstScanCompanion = RadixScanCompanion{};
+        companion.launch(stream, scan, companion.user);
+    }
+    else if (numTiles <= GS_SCAN_ROW_LIMIT)
         hipLaunchKernelGGL(radixColumnScanKernel<256>, dim3(BITS > 8 ? 2 * kDigits : kDigits), dim3(256), 0, stream, n, s.countDevice, kTile, stride, s.table, s.scanned, s.chunkTotals);
     else
         hipLaunchKernelGGL(radixColumnScanKernel<1024>, dim3(BITS > 8 ? 2 * kDigits : kDigits), dim3(1024), 0, stream, n, s.countDevice, kTile, stride, s.table, s.scanned, s.chunkTotals);

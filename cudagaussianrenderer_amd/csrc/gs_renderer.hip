@@ -9,6 +9,7 @@
 //                          splat index) while the radix-sort traffic drops from ~152 B to ~30 B per pair;
 // The latter leaves the SH pass out when the raster kernel can evaluate colours on demand (useLazyColours below),
 // keeps centre + ellipse in one 32-byte record per splat, and resets the range table from inside the clip kernel.
+#include <functional>
 #include <algorithm>
 #include <cstring>
 
@@ -576,14 +577,34 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
 
         gs_timer_start(stageTimers[1]);
         const int* countDevice = nullptr;
+        ClipWithScan deferredClip;
+        std::function<void()> launchClip;
         if (!cull)
         {
             // (Morton storage on the native sort: no keys from here -- the depth sort's first pass makes them in the caller's order)
             const bool keysFromSort = r->splatToStorage != nullptr && cfg.sortBackend == GS_SORT_BACKEND_NATIVE && radixSortSupported(4, n);
-            launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation,
-                                nullptr, nullptr, nullptr, nullptr, keysFromSort ? nullptr : r->depthKey[0],
-                                r->splatToStorage != nullptr ? nullptr : (uint32_t*) r->order[0], nullptr, nullptr, nullptr, nullptr, r->tileRange,
-                                2 * scr.totalTiles, (float4*) r->tileRecord, (float4*) r->rasterRecord);
+            launchClip = [=]() {
+                launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation, nullptr, nullptr,
+                                    nullptr, nullptr, keysFromSort ? nullptr : r->depthKey[0],
+                                    r->splatToStorage != nullptr ? nullptr : (uint32_t*) r->order[0], nullptr, nullptr, nullptr, nullptr, r->tileRange,
+                                    2 * scr.totalTiles, (float4*) r->tileRecord, (float4*) r->rasterRecord);
+            };
+            // The sort makes its own keys: the clip kernel shares the launch of the sort's first column scan (gs_internal.h
+            // RadixScanCompanion) -- unless the stages are timed one by one (the clip stage then runs, and is timed, by itself).
+            if (keysFromSort && cfg.clipScanFusion && !timed && n > 0)
+            {
+                deferredClip.count = n;
+                deferredClip.scr = scr;
+                deferredClip.camera = currentCamera();
+                deferredClip.position = (const float4*) r->position;
+                deferredClip.scaleAndRotation = (const float4*) r->scaleAndRotation;
+                deferredClip.rangeTableToClear = r->tileRange;
+                deferredClip.rangeEntries = 2 * scr.totalTiles;
+                deferredClip.tileRecord = (float4*) r->tileRecord;
+                deferredClip.rasterRecord = (float4*) r->rasterRecord;
+                r->radix.firstScanCompanion = RadixScanCompanion{&clipWithScanCompanion, &deferredClip};
+            }
+            else launchClip();
         }
         else
         {
@@ -642,6 +663,12 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
                 orderSel = launchSortPairs(g.stream, r->sortTemp, r->sortTempBytes, 4, r->depthKey[0], r->depthKey[1], r->order[0],
                                            r->order[1], inputSel, n, 0, kDepthKeyBits);
             }
+        }
+        if (r->radix.firstScanCompanion.launch != nullptr)
+        {
+            // the sort could not take the clip kernel along (rows of more than 4096 tiles): by itself, then
+            r->radix.firstScanCompanion = RadixScanCompanion{};
+            launchClip();
         }
         gs_timer_stop(stageTimers[6]);
         f.orderSel = orderSel;

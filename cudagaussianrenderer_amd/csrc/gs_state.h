@@ -40,12 +40,16 @@ struct State
 // its own renderer / staged sequence on its own stream (bench.py runs one thread per frame in flight).
 extern thread_local State g;
 
+#ifndef GS_CLIP_SCAN_FUSION_DEFAULT
+#define GS_CLIP_SCAN_FUSION_DEFAULT 0 // off: +3 % for one frame at a time, -1 % with four frames in flight (profiles/r04_ab_experiments.txt); A/B builds: 1
+#endif
 // Process-wide settings.
 struct Settings
 {
     int sortBackend = GS_SORT_BACKEND_NATIVE;
     bool collectRasterStats = false;
     bool listFusion = GS_LIST_FUSION_DEFAULT != 0; // the emit pass carries the tile sort's first pass (gs_set_list_fusion)
+    bool clipScanFusion = GS_CLIP_SCAN_FUSION_DEFAULT != 0; // Morton storage, no band cull: the clip kernel shares the launch of the depth sort's first column scan (gs_debug_set_clip_scan_fusion)
     unsigned long long* consumedDevice = nullptr; // counter of the staged gs_rasterize_tile
 };
 extern Settings cfg;

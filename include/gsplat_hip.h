@@ -336,6 +336,14 @@ int gs_renderer_read_back_buffer_view(GsRenderer* r, int view, uint8_t* hostRgba
 /* Diagnostics (bench.py --ablate): leave stages out of the captured frames -- bit 0 clip, 1 depth sort, 2 pair count, 3 pair emit,
  * 4 tile sort, 5 ranges, 6 raster -- to measure what each stage costs the pipelined frame rate.  The images are garbage. */
 void gs_debug_set_ablation(int mask);
+/* A renderer with Morton storage (no band cull) has the depth sort make its own keys, so its clip kernel and the sort are independent:
+ * the clip kernel may share the LAUNCH of the sort's first column scan (one kernel with both workloads: 17 instead of 18 kernels per
+ * frame; same results, same routines).  Measured (profiles/r04_ab_experiments.txt): one frame at a time -- the reference's loop,
+ * Demo.cpp:394-479 -- gains 3 % (0.275 -> 0.266 ms), four frames in flight lose 1 %; OFF by default, for hosts that render one frame
+ * at a time to switch on.  Process-wide.  Frames whose stages are timed one by one (timed != 0) always launch the two separately, so
+ * that the clip stage's time is its own. */
+void gs_debug_set_clip_scan_fusion(int enabled);
+int gs_debug_get_clip_scan_fusion(void);
 /* A captured frame hands its pair total to the host in the middle of the frame; the host waits for it at most this long (default
  * 30 s) and gives up at once when the stream reports anything but "not ready" -- print + exit, the reference's convention for a
  * failed runtime call (CudaErrorCheck.cpp:2-11), so that a faulted GPU ends the process instead of hanging it. */

@@ -472,6 +472,49 @@ def test_list_fusion_is_invisible(gs, w, h, n, scales, first_digit):
             assert np.array_equal(a, b_), (key, what)
 
 
+@pytest.mark.parametrize("w,h,n,views", [(1920, 1080, 200_003, 1), (640, 368, 30_000, 1), (1280, 720, 60_001, 4)])
+def test_clip_kernel_sharing_the_scan_launch_is_invisible(gs, tmp_path, w, h, n, views):
+    """Morton storage, no band cull: the depth sort makes its own keys, so the clip kernel shares the launch of the sort's first column scan
+    (gs_debug_set_clip_scan_fusion, one kernel per frame less; evaluateSplatClipDataKernel GaussianRender.cu:204-329 beside the first
+    pass of the sort that replaces cub::DeviceRadixSort :806-855).  Same sorted pair list, tile ranges, clip-stage buffers and image bytes as
+    with the two kernels launched by themselves -- plain frames, captured frames (both graph instances) and four views per chain."""
+    from cudagaussianrenderer_amd import scenes
+
+    ply = _ply_scene(gs, tmp_path, n, 3, log_scale_mean=-3.2)
+    scene = (ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+    cams = [gs.camera_from_pose(p, q, w, h) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 8)]
+    tx, ty = (w + 15) // 16, (h + 15) // 16
+    out = {}
+    default = gs.lib().gs_debug_get_clip_scan_fusion()
+    try:
+        for fusion in (0, 1):
+            gs.lib().gs_debug_set_clip_scan_fusion(fusion)
+            for graph in ((True,) if views > 1 else (False, True)):
+                r = gs.Renderer(w, h, views=views, storage_order=gs.STORAGE_ORDER_MORTON)
+                r.set_graph(graph)
+                r.set_scene(*scene)
+                if views > 1:
+                    got = []
+                    for first in (0, 4, 0):
+                        r.render_views(cams[first:first + views])
+                        got += [r.read_image(view=v) for v in range(views)]
+                    out[(fusion, graph)] = got
+                else:
+                    r.render(cams[1])
+                    r.render(cams[2])  # (captured: the second graph instance)
+                    out[(fusion, graph)] = list(_sorted_list_ranges_image(gs, r, tx * ty))
+                r.close()
+    finally:
+        gs.lib().gs_debug_set_clip_scan_fusion(default)
+    keys = list(out)
+    want = out[keys[0]]
+    assert any(np.asarray(a).any() for a in want)
+    for key in keys[1:]:
+        assert len(out[key]) == len(want)
+        for i, (a, b_) in enumerate(zip(want, out[key])):
+            assert np.array_equal(a, b_), (key, i)
+
+
 def test_list_fusion_with_views_and_band_cull(gs, tmp_path):
     """The same through what a multi-GPU rank runs: four views per captured chain (virtual tiles: a 7-bit first digit at 1280x720)
     on a band-culled sub-band and on the full frame, Morton storage, SH 3 colours on demand."""
