@@ -426,6 +426,9 @@ def offline_counters(args, world):
     if d.get("source_hash") != source_hash():
         return dict(empty, counters_note=f"profiles/r04_pmc_raster.json was collected with other kernel sources ({d.get('source_hash')})")
     out = {"traffic": round(d["traffic_bytes_per_launch"]), "traffic_unit": "bytes per launch", "traffic_source": d["traffic_source"],
+           "traffic_low": round(d.get("traffic_bytes_per_launch_low", d["traffic_bytes_per_launch"])),
+           "traffic_high": round(d.get("traffic_bytes_per_launch_high", d["traffic_bytes_per_launch"])),
+           "fetch_requests_per_launch": d.get("fetch_requests_per_launch"),
            "valu_issue_frac": d.get("valu_issue_frac"), "waves_per_simd": d.get("waves_per_simd"), "counters_source": d.get("sq_source"),
            "counters": "OFFLINE: traffic, valu_issue_frac and waves_per_simd are read from profiles/r04_pmc_raster.json (separate rocprofv3 --pmc "
                        "passes of this workload with one frame in flight and plain launches, same kernel sources by hash), not measured in this run"}

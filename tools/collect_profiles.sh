@@ -44,12 +44,18 @@ out = {
     "kernel": "rasterizeTilesKernel<2, gaussian, SH 3>", "source_hash": bench.source_hash(),
     "workload": "bench.py default scene (1 M splats, SH 3, 1920x1080, seed 1234), --steps 16 --warmup 4 --inflight 1 --no-graph",
     "fetch_size_kb_raw": f["FETCH_SIZE"], "write_size_kb": w["WRITE_SIZE"], "dispatches": n,
-    "traffic_bytes_per_launch": (f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024,
+    # FETCH_SIZE tallies 64 bytes per memory-side read request whatever the request's size (profiles/r04_fetch_calibration.txt: 4-, 16-, 32- and
+    # 64-byte gathers 64 B each, a 128-byte line 64 B, a 192-byte coefficient row 128 B, a 16-byte-per-lane stream half its bytes).
+    "fetch_requests_per_launch": round(f["FETCH_SIZE"] * 1024 / 64),
+    "traffic_bytes_per_launch_low": (f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024,
     "traffic_bytes_per_launch_high": (2 * f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024,
+    "traffic_bytes_per_launch": (1.25 * f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024,
     "traffic_source": f"profiles/{tag}_pmc_fetch_size_kb.txt + {tag}_pmc_write_size_kb.txt: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, "
-                      "kernel trace only, mean per dispatch; FETCH_SIZE raw (the kernel's reads are 4-byte list entries and 8/16-byte gathers: "
-                      "MI355X_MICROARCH.md calibrates the 2x under-count only for wide coalesced streams, so raw is the lower bound and "
-                      "traffic_bytes_per_launch_high the upper)",
+                      "kernel trace only, mean per dispatch; FETCH_SIZE corrected by the calibration MI355X_MICROARCH.md prescribes for non-streaming reads "
+                      "(tools/fetch_calibration.sh -> profiles/r04_fetch_calibration.txt): the counter tallies 64 B per read request, a request moves 64 B (a "
+                      "gather of up to 64 B) or 128 B (a whole line); the kernel's misses are one 32-byte record, one 16-byte position (64 B each) and one "
+                      "192-byte coefficient row (192 B, tallied 128) per entry = 320 B moved per 256 B tallied: x 1.25.  _low is the raw tally (every request "
+                      "64 B), _high counts every request as a full 128-byte line",
     "sq": sq,
     "sq_source": f"profiles/{tag}_pmc_sq_counters.txt; SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md:488), SQ_BUSY_CYCLES per shader engine",
     "busy_cycles_per_se": busy,
