@@ -9,7 +9,6 @@
 //                          splat index) while the radix-sort traffic drops from ~152 B to ~30 B per pair;
 // The latter leaves the SH pass out when the raster kernel can evaluate colours on demand (useLazyColours below),
 // keeps centre + ellipse in one 32-byte record per splat, and resets the range table from inside the clip kernel.
-#include <functional>
 #include <algorithm>
 #include <cstring>
 
@@ -578,17 +577,15 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         gs_timer_start(stageTimers[1]);
         const int* countDevice = nullptr;
         ClipWithScan deferredClip;
-        std::function<void()> launchClip;
+        // (Morton storage on the native sort: no keys from the clip kernel -- the depth sort's first pass makes them in the caller's order)
+        const bool keysFromSort = !cull && r->splatToStorage != nullptr && cfg.sortBackend == GS_SORT_BACKEND_NATIVE && radixSortSupported(4, n);
+        const auto launchClip = [&]() { // the clip kernel of a frame without band cull, by itself
+            launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation, nullptr, nullptr, nullptr,
+                                nullptr, keysFromSort ? nullptr : r->depthKey[0], r->splatToStorage != nullptr ? nullptr : (uint32_t*) r->order[0], nullptr,
+                                nullptr, nullptr, nullptr, r->tileRange, 2 * scr.totalTiles, (float4*) r->tileRecord, (float4*) r->rasterRecord);
+        };
         if (!cull)
         {
-            // (Morton storage on the native sort: no keys from here -- the depth sort's first pass makes them in the caller's order)
-            const bool keysFromSort = r->splatToStorage != nullptr && cfg.sortBackend == GS_SORT_BACKEND_NATIVE && radixSortSupported(4, n);
-            launchClip = [=]() {
-                launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation, nullptr, nullptr,
-                                    nullptr, nullptr, keysFromSort ? nullptr : r->depthKey[0],
-                                    r->splatToStorage != nullptr ? nullptr : (uint32_t*) r->order[0], nullptr, nullptr, nullptr, nullptr, r->tileRange,
-                                    2 * scr.totalTiles, (float4*) r->tileRecord, (float4*) r->rasterRecord);
-            };
             // The sort makes its own keys: the clip kernel shares the launch of the sort's first column scan (gs_internal.h
             // RadixScanCompanion) -- unless the stages are timed one by one (the clip stage then runs, and is timed, by itself).
             if (keysFromSort && cfg.clipScanFusion && !timed && n > 0)

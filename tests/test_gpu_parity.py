@@ -260,12 +260,15 @@ def test_edge_cases(gs, gsref):
 
 
 @pytest.mark.parametrize("w,h,n,scales", [(640, 360, 50000, (0.01, 0.3)), (1920, 1080, 200000, (0.005, 0.08)), (333, 177, 20000, (0.01, 1.0)),
-                                          (1920, 1080, 5_000_000, (0.002, 0.03))])
+                                          (1920, 1080, 5_000_000, (0.002, 0.03)), (1280, 720, 40_000, (0.0004, 0.9)), (3840, 2160, 60_000, (0.0002, 0.4)),
+                                          (256, 256, 30_000, (0.001, 2.5))])
 def test_two_level_pipeline_equals_reference_pipeline(gs, w, h, n, scales):
     """The default two-level sort (depth-sort splats, emit, stable tile sort) gives the SAME sorted pair list as the
     reference-shaped pipeline (bit-exact staged builder + 64-bit tile|depth radix sort), entry for entry: the fast builder decides
     every tile whose cheap decision value lies in its guard band with the reference's own arithmetic (gs_tiles_fast.hip,
-    gs_overlap_exact.h; GaussianRender.cu:375-405, 645-679).  No set-difference slack.  Same image bytes."""
+    gs_overlap_exact.h; GaussianRender.cu:375-405, 645-679).  No set-difference slack.  Same image bytes.  The last three cases are
+    needles and slabs (axis ratios up to 2 000 : 1 next to sub-pixel splats and splats larger than the screen): the harsh end of what
+    tools/guard_band_check.cpp models on the host for the two-edge decision."""
     pos, sr, col = _procedural(gs, n, seed=11, min_scale=scales[0], max_scale=scales[1])
     cam = gs.camera_from_bounds([-4] * 3, [4] * 3, w, h)
     lists, images = [], []
