@@ -23,7 +23,12 @@ std::atomic<long long> g_hostLaunchNs{0}, g_hostAwaitNs{0}, g_hostFrames{0};
 
 int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool lazy, int slot)
 {
-    const RasterColourSource lazySource = colourSource(r, nullptr, r->paramsDevice);
+#ifndef GS_PARAMS_FROM_HOST
+#define GS_PARAMS_FROM_HOST 0 // A/B builds: 1 = the kernels read the cameras from the pinned host slot itself (no copy node in the graph)
+#endif
+    // The cameras of the frame: a memcpy node at the head of the graph refreshes them in device memory from this instance's pinned slot.
+    FrameParams* const params = GS_PARAMS_FROM_HOST ? r->paramsHost + slot * kMaxViews : r->paramsDevice;
+    const RasterColourSource lazySource = colourSource(r, nullptr, params);
     const RasterColourSource* lazyColours = lazy ? &lazySource : nullptr;
     const int n = r->splatCount;
     // Several views per chain: V grid rows in the clip, compaction and raster kernels; everything in between works on the
@@ -36,7 +41,8 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
     const float3 unused = make_float3(0.f, 0.f, 0.f);
     ClipCamera unusedCamera{};
 
-    GS_CHECK(hipMemcpyAsync(r->paramsDevice, r->paramsHost + slot * kMaxViews, sizeof(FrameParams) * views, hipMemcpyHostToDevice, g.stream));
+    if (!GS_PARAMS_FROM_HOST)
+        GS_CHECK(hipMemcpyAsync(r->paramsDevice, r->paramsHost + slot * kMaxViews, sizeof(FrameParams) * views, hipMemcpyHostToDevice, g.stream));
     // the range table is reset to -1 by the clip kernel (one node less than a memset; see gs_ranges.hip)
     int32_t* clearTable = r->tileRange;
     const int clearEntries = 2 * virtualTiles;
@@ -47,7 +53,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
 #endif
     if (r->shDegree != 0 && !cull && !lazy)
         launchSphericalHarmonics(g.stream, n, r->shDegree, r->shCount, (const float4*) r->position, r->sh, unused, (float4*) r->color,
-                                 r->paramsDevice);
+                                 params);
     const int* countDevice = nullptr;
     // Morton storage: the depth sort makes its own keys, so the clip kernel and the sort do not depend on each other -- the clip kernel
     // is handed to the sort and shares the launch of its first column scan (gs_internal.h RadixScanCompanion): 17 kernels per frame.
@@ -55,7 +61,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
     const auto launchClip = [&]() {
         launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation, nullptr, nullptr, nullptr,
                             nullptr, r->splatToStorage != nullptr ? nullptr : r->depthKey[0],
-                            r->splatToStorage != nullptr ? nullptr : (uint32_t*) r->order[0], nullptr, nullptr, nullptr, r->paramsDevice, clearTable,
+                            r->splatToStorage != nullptr ? nullptr : (uint32_t*) r->order[0], nullptr, nullptr, nullptr, params, clearTable,
                             clearEntries, (float4*) r->tileRecord, (float4*) r->rasterRecord, views);
     };
     if (!cull)
@@ -66,7 +72,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
             {
                 deferredClip.count = n;
                 deferredClip.scr = scr;
-                deferredClip.params = r->paramsDevice;
+                deferredClip.params = params;
                 deferredClip.position = (const float4*) r->position;
                 deferredClip.scaleAndRotation = (const float4*) r->scaleAndRotation;
                 deferredClip.rangeTableToClear = clearTable;
@@ -85,14 +91,14 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
         const bool callerOrder = r->splatToStorage != nullptr;
         launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) (callerOrder ? r->positionCaller : r->position),
                             (const float4*) (callerOrder ? r->scaleAndRotationCaller : r->scaleAndRotation), nullptr, r->clipZ, nullptr, nullptr, nullptr,
-                            nullptr, r->bandMask, r->bandSlotPrefix, r->bandCounts, r->paramsDevice, clearTable, clearEntries, (float4*) r->tileRecord,
+                            nullptr, r->bandMask, r->bandSlotPrefix, r->bandCounts, params, clearTable, clearEntries, (float4*) r->tileRecord,
                             (float4*) r->rasterRecord, views, r->splatToStorage);
         launchBandCompaction(g.stream, n, views, r->bandMask, r->bandSlotPrefix, r->bandCounts, r->bandOffsets, r->bandTotal, r->clipZ, r->depthKey[0],
                              (uint32_t*) r->order[0], r->splatToStorage);
         countDevice = (const int*) r->bandTotal;
         if (r->shDegree != 0 && !lazy)
             launchSphericalHarmonicsGather(g.stream, n, countDevice, r->shDegree, r->shCount, r->order[0], (const float4*) r->position,
-                                           r->shPerSplat, unused, (float4*) r->color, r->paramsDevice);
+                                           r->shPerSplat, unused, (float4*) r->color, params);
     }
     r->radix.countDevice = countDevice;
     r->scratch.countDevice = countDevice;
@@ -100,7 +106,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
     // positions and the cameras on the device; the culled list was compacted in that order already)
     DepthKeySource keySource;
     keySource.positionCaller = (const float4*) r->positionCaller;
-    keySource.params = r->paramsDevice;
+    keySource.params = params;
     keySource.splatsPerView = n;
     const bool callerOrderedInput = !cull && r->splatToStorage != nullptr;
     const int orderSel = (g_ablation & 2) ? 0
