@@ -123,7 +123,7 @@ def test_cpp_host_replays_a_recorded_camera_session(gs, gsref, demo_binary, tmp_
     events = tmp_path / "events.txt"
     events.write_text("".join("%.9g %d %d %.9g %.9g\n" % tuple(f) for f in frames))
     out = str(tmp_path / "session.ppm")
-    log = subprocess.run([demo_binary, "--procedural", "10000", str(w), str(h), str(len(frames)), out, "--events", str(events)],
+    log = subprocess.run([demo_binary, "--procedural", "10000", str(w), str(h), str(len(frames)), out, "--events", str(events), "--dump-every", "16"],
                          stdout=subprocess.PIPE, text=True, check=True).stdout
     line = [ln for ln in log.splitlines() if ln.startswith("camera after")]
     assert len(line) == 1
@@ -141,3 +141,7 @@ def test_cpp_host_replays_a_recorded_camera_session(gs, gsref, demo_binary, tmp_
     r.close()
     got = _read_ppm(out)[::-1]
     assert np.array_equal(got, want[..., :3]) and got.max() > 0
+    # --dump-every 16: the session as an image sequence; its last image is the final frame, an earlier one is another view
+    dumps = [out + ".%05d.ppm" % k for k in (16, 32, 48)]
+    assert all(os.path.exists(d) for d in dumps)
+    assert np.array_equal(_read_ppm(dumps[-1]), _read_ppm(out)) and not np.array_equal(_read_ppm(dumps[0]), _read_ppm(out))

@@ -13,6 +13,7 @@
 //                                                            cursor in pixels from the top-left corner), fed to gs::CameraControls::update before
 //                                                            the frame is rendered; frames beyond the file repeat its last line with dt = 0.
 //                                                            The pose after the last frame is printed.
+//   ... --dump-every K                                       every K-th frame as <out.ppm>.<frame>.ppm (the session as an image sequence)
 //
 // Build: make -C cudagaussianrenderer_amd/csrc demo
 #include <algorithm>
@@ -37,6 +38,7 @@ int main(int argc, char** argv)
     int world = 1, rank = 0;
     const char* idFile = nullptr;
     const char* eventsFile = nullptr;
+    int dumpEvery = 0;
     std::vector<char*> positional;
     for (int i = 0; i < argc; ++i)
     {
@@ -44,6 +46,7 @@ int main(int argc, char** argv)
         else if (std::strcmp(argv[i], "--rank") == 0 && i + 1 < argc) rank = std::atoi(argv[++i]);
         else if (std::strcmp(argv[i], "--id-file") == 0 && i + 1 < argc) idFile = argv[++i];
         else if (std::strcmp(argv[i], "--events") == 0 && i + 1 < argc) eventsFile = argv[++i];
+        else if (std::strcmp(argv[i], "--dump-every") == 0 && i + 1 < argc) dumpEvery = std::atoi(argv[++i]);
         else positional.push_back(argv[i]);
     }
     argc = (int) positional.size();
@@ -157,6 +160,27 @@ int main(int argc, char** argv)
     }
     gs::CameraData camera = cameraControls.getCameraData();
 
+    // PPM writer (Demo.cpp:146-147 convention: row 0 of the buffer is the bottom of the image)
+    const auto writePpm = [&](const char* path) {
+        std::vector<gs::uchar4_t> image;
+        backBuffer.copyTo(image, (size_t) width * height);
+        std::FILE* fp = std::fopen(path, "wb");
+        if (fp == nullptr) return false;
+        std::fprintf(fp, "P6\n%d %d\n255\n", width, height);
+        std::vector<unsigned char> row((size_t) width * 3);
+        for (int y = height - 1; y >= 0; --y)
+        {
+            for (int x = 0; x != width; ++x)
+            {
+                const gs::uchar4_t p = image[(size_t) y * width + x];
+                row[3 * (size_t) x] = p.x, row[3 * (size_t) x + 1] = p.y, row[3 * (size_t) x + 2] = p.z;
+            }
+            std::fwrite(row.data(), 1, row.size(), fp);
+        }
+        std::fclose(fp);
+        return true;
+    };
+
     gs::GpuTimer timer;
     double msSh = 0, msClip = 0, msBuild = 0, msSort = 0, msRanges = 0, msRaster = 0;
     bool saturated = false;
@@ -236,6 +260,13 @@ int main(int argc, char** argv)
         // the one exchange of the frame: every band's pixel rows -> rank 0's back buffer (no-op in a world of one)
         if (gs_gather_bands(comm, &backBuffer.getPtr()->x, width, height, bands.data(), 0, gs_get_stream()) != 0) return 1;
         gs_synchronize();
+        if (dumpEvery > 0 && rank == 0 && outPath != nullptr && (frame + 1) % dumpEvery == 0)
+        {
+            // the viewer's "screen", headless: every dumpEvery-th frame next to the final image as <out>.<frame>.ppm
+            char path[1024];
+            std::snprintf(path, sizeof(path), "%s.%05d.ppm", outPath, frame + 1);
+            if (!writePpm(path)) return 1;
+        }
     }
     gs_device_free(sortTemp);
 
@@ -254,21 +285,6 @@ int main(int argc, char** argv)
                     st.anchorPosition[0], st.anchorPosition[1], st.anchorPosition[2], st.mode);
     }
     gs_comm_destroy(comm);
-    if (outPath != nullptr && rank == 0)
-    {
-        std::vector<gs::uchar4_t> image;
-        backBuffer.copyTo(image, (size_t) width * height);
-        std::FILE* fp = std::fopen(outPath, "wb");
-        if (fp == nullptr) return 1;
-        std::fprintf(fp, "P6\n%d %d\n255\n", width, height);
-        for (int y = height - 1; y >= 0; --y) // row 0 of the buffer is the bottom of the image
-            for (int x = 0; x != width; ++x)
-            {
-                const gs::uchar4_t p = image[(size_t) y * width + x];
-                const unsigned char rgb[3] = {p.x, p.y, p.z};
-                std::fwrite(rgb, 1, 3, fp);
-            }
-        std::fclose(fp);
-    }
+    if (outPath != nullptr && rank == 0 && !writePpm(outPath)) return 1;
     return 0;
 }
