@@ -180,10 +180,8 @@ __global__ __launch_bounds__(kHistThreadsFor<kIsKeySource<SOURCE>>) void radixHi
                 else
                 {
                     // skewed digit, ragged tile: one add per distinct digit per wave
-                    const int lane = t & (kWave - 1);
-                    const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
                     const unsigned long long m = matchDigit<BITS>(digit, valid);
-                    if (valid && (m & lower) == 0ull) atomicAdd(&h[digit], __popcll(m));
+                    if (valid && lanesBelow(m) == 0) atomicAdd(&h[digit], __popcll(m));
                 }
             }
         }
@@ -259,7 +257,6 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
     __syncthreads();
 
     // ---- stable rank inside the wave: ballot match, then running per-digit counters ----------------------
-    const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
     unsigned long long match[ITEMS];
 #pragma unroll
     for (int r = 0; r != ITEMS; ++r) // independent of each other: issued back to back
@@ -274,12 +271,12 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
         const unsigned long long m = match[r];
         const int digit = (int) ((key[r] >> shift) & kDigitMask);
         const bool valid = m != 0ull;
-        const int leader = valid ? (__ffsll((long long) m) - 1) : lane;
-        // every lane of a digit group reads the running count (one broadcast read), then the group's first lane
-        // bumps it: LDS instructions of a wave execute in order, so the next row sees the bumped value
+        // every lane of a digit group reads the running count (one broadcast read), then the group's first lane -- the one with no
+        // lane of the group below it -- bumps it: LDS instructions of a wave execute in order, so the next row sees the bumped value
+        const int below = lanesBelow(m);
         const int old = valid ? cnt[wave][digit] : 0;
-        if (valid && lane == leader) cnt[wave][digit] = old + __popcll(m);
-        rank[r] = old + __popcll(m & lower);
+        if (valid && below == 0) cnt[wave][digit] = old + __popcll(m);
+        rank[r] = old + below;
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();

@@ -436,7 +436,6 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
     __syncthreads();
 
     int running = 0; // COUNT: hits of this wave so far; EMIT: hits of the whole workgroup in the rounds before this one
-    const unsigned long long lowerLanes = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
 
     // FUSED EMIT: the first pass of the tile sort on the `staged` pairs in the staging buffer (emission order), exactly what
     // radixScatterKernel does with a tile of the unsorted list (gs_radix.hip): stable rank inside each wave's contiguous share
@@ -468,12 +467,13 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                     val[r] = valid ? stageValues[idx] : 0;
                     const int digit = (int) key[r] & kDigitMask;
                     const unsigned long long m = matchDigit<SORT_BITS>(digit, valid);
-                    const int leader = valid ? (__ffsll((long long) m) - 1) : lane;
-                    // every lane of a digit group reads the running count (one broadcast read), then the group's first lane bumps it:
-                    // LDS instructions of a wave execute in order, so the next row sees the bumped value
+                    // every lane of a digit group reads the running count (one broadcast read), then the group's first lane -- the one
+                    // with no lane of the group below it -- bumps it: LDS instructions of a wave execute in order, so the next row sees
+                    // the bumped value
+                    const int below = lanesBelow(m);
                     const int old = valid ? sortCnt[wave][digit] : 0;
-                    if (valid && lane == leader) sortCnt[wave][digit] = old + __popcll(m);
-                    if (valid) rank[r] = old + __popcll(m & lowerLanes);
+                    if (valid && below == 0) sortCnt[wave][digit] = old + __popcll(m);
+                    if (valid) rank[r] = old + below;
                     __builtin_amdgcn_wave_barrier();
                 }
             }
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
             // (FUSED: position in the staging buffer -- `running` counts the pairs staged since the last flush)
             unsigned pos = (FUSED ? 0u : (unsigned) outBase) + (unsigned) running + (unsigned) before;
 #pragma unroll
-            for (int e = 0; e != kTilesPerUnit; ++e) pos += (unsigned) __popcll(ballots[e] & lowerLanes);
+            for (int e = 0; e != kTilesPerUnit; ++e) pos = (unsigned) lanesBelow(ballots[e], (int) pos);
             // re-walk the unit's tiles to write the hits, unit-major
             int wx = lx0, wy = ly0;
             const int splatK = st.splat[k];

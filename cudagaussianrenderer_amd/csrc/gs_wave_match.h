@@ -7,6 +7,14 @@
 namespace gs
 {
 
+// add + the number of set bits of `mask` that belong to lanes BELOW this one: v_mbcnt_lo / v_mbcnt_hi (two instructions, the addend rides
+// along; popcount(mask & lowerLanes) is two ANDs and two popcounts and needs the lane's own mask in registers).  `mask` may differ
+// from lane to lane.
+__device__ __forceinline__ int lanesBelow(unsigned long long mask, int add = 0)
+{
+    return (int) __builtin_amdgcn_mbcnt_hi((unsigned) (mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) mask, (unsigned) add));
+}
+
 // Lanes of the wave whose (valid) digit equals this lane's digit.  Four VALU instructions per digit bit on the two 32-bit halves of
 // the mask: the bit as 0 / -1 (v_bfe_i32), its ballot (v_cmp_ne), and per half ONE three-input boolean, mask & ~(ballot ^ mine)
 // (v_bitop3_b32, truth table 0x90 in the a = 0xF0, b = 0xCC, c = 0xAA convention: 0xF0 & ~(0xCC ^ 0xAA)).  Round 3's form (`lo &=
@@ -25,7 +33,9 @@ __device__ __forceinline__ unsigned long long matchDigit(int digit, bool valid)
     {
         // lanes outside `valid` may vote anything: they were removed from the mask above and stay removed
 #if GS_MATCH_BITOP3
-        const unsigned mine = (unsigned) __builtin_amdgcn_sbfe(digit, bit, 1); // all ones when my bit is set
+        // all ones when my bit is set: v_bfe_i32 (written as such: the builtin is expanded into a shift pair and not matched back)
+        unsigned mine;
+        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(mine) : "v"(digit), "n"(bit));
         const unsigned long long bal = __ballot(mine != 0u);
         lo = __builtin_amdgcn_bitop3_b32(lo, (unsigned) bal, mine, 0x90);
         hi = __builtin_amdgcn_bitop3_b32(hi, (unsigned) (bal >> 32), mine, 0x90);
