@@ -43,6 +43,9 @@ constexpr int kBatch = 64; // entries staged per LDS fill; two vote chunks
 #else
 #define GS_PHASE(k)
 #endif
+#ifndef GS_RASTER_PK_OPSEL
+#define GS_RASTER_PK_OPSEL 1 // A/B builds: 0 = the colour accumulation as the compiler writes it
+#endif
 // blockIdx -> tile mapping: block shape dealt to one XCD (A/B builds may override)
 #ifndef GS_RASTER_BLOCK_W
 #define GS_RASTER_BLOCK_W 8
@@ -291,9 +294,23 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
                 {
                     // GaussianRender.cu:983-984
                     const V w = tr * alpha[e];
-                    cr = __builtin_elementwise_fma(V(b[e].y), w, cr);
-                    cg = __builtin_elementwise_fma(V(b[e].z), w, cg);
-                    cb = __builtin_elementwise_fma(V(b[e].w), w, cb);
+                    if constexpr (PPL == 2 && GS_RASTER_PK_OPSEL)
+                    {
+                        // colour += component * w for both pixels, the component broadcast from where it lies in the staged record
+                        // ((C', r) and (g, b) are the two register pairs of the 16-byte LDS read) through the packed instruction's operand
+                        // select: the compiler copies b into a pair of its own first (one v_mov per entry and wave)
+                        typedef float Pair __attribute__((ext_vector_type(2)));
+                        const Pair cR = {b[e].x, b[e].y}, gB = {b[e].z, b[e].w};
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(cr) : "v"(cR), "v"(w));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(cg) : "v"(gB), "v"(w));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(cb) : "v"(gB), "v"(w));
+                    }
+                    else
+                    {
+                        cr = __builtin_elementwise_fma(V(b[e].y), w, cr);
+                        cg = __builtin_elementwise_fma(V(b[e].z), w, cg);
+                        cb = __builtin_elementwise_fma(V(b[e].w), w, cb);
+                    }
                     tr = __builtin_elementwise_fma(-tr, alpha[e], tr);
                 }
             }
