@@ -300,18 +300,7 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
             sumAll += acc;
             totalAll += digitTotal[o];
         }
-        int inclLocal = sumAll, inclGlobal = totalAll;
-#pragma unroll
-        for (int delta = 1; delta < kWave; delta <<= 1)
-        {
-            const int a = __shfl_up(inclLocal, delta);
-            const int b = __shfl_up(inclGlobal, delta);
-            if (lane >= delta)
-            {
-                inclLocal += a;
-                inclGlobal += b;
-            }
-        }
+        const int inclLocal = waveInclusiveSum(sumAll), inclGlobal = waveInclusiveSum(totalAll);
         if (lane == kWave - 1)
         {
             waveSums[0][wave] = inclLocal;

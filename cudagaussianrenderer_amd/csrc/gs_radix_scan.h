@@ -3,6 +3,7 @@
 #pragma once
 
 #include "gs_internal.h"
+#include "gs_wave_match.h"
 
 namespace gs
 {
@@ -32,13 +33,7 @@ __device__ __forceinline__ void radixColumnScanRow(int digit, int nHost, const i
         if (tile + 2 >= numTiles) v.z = 0;
         if (tile + 3 >= numTiles) v.w = 0;
         const int own = v.x + v.y + v.z + v.w;
-        int incl = own;
-#pragma unroll
-        for (int delta = 1; delta < kWave; delta <<= 1)
-        {
-            const int o = __shfl_up(incl, delta);
-            if (lane >= delta) incl += o;
-        }
+        const int incl = waveInclusiveSum(own);
         if (lane == kWave - 1) waveSums[flip][wave] = incl;
         __syncthreads(); // the other half of waveSums is free for the next round: one barrier per round
         int before = 0, all = 0;

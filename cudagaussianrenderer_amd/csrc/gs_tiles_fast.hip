@@ -322,13 +322,7 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
     const int units = (area + kTilesPerUnit - 1) / kTilesPerUnit;
 
     // exclusive prefix of the units over the workgroup's 256 splats
-    int incl = units;
-#pragma unroll
-    for (int delta = 1; delta < kWave; delta <<= 1)
-    {
-        const int n = __shfl_up(incl, delta);
-        if (lane >= delta) incl += n;
-    }
+    const int incl = waveInclusiveSum(units);
     if (lane == kWave - 1) waveTotals[wave] = incl;
     __syncthreads();
     int unitsBefore = 0, totalUnits = 0;
@@ -490,13 +484,7 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                     sum += c;
                 }
             }
-            int incl = sum;
-#pragma unroll
-            for (int delta = 1; delta < kWave; delta <<= 1)
-            {
-                const int o = __shfl_up(incl, delta);
-                if (lane >= delta) incl += o;
-            }
+            const int incl = waveInclusiveSum(sum);
             if (lane == kWave - 1) sortWaveSums[wave] = incl;
             __syncthreads();
             int beforeWaves = 0;

@@ -15,6 +15,21 @@ __device__ __forceinline__ int lanesBelow(unsigned long long mask, int add = 0)
     return (int) __builtin_amdgcn_mbcnt_hi((unsigned) (mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned) mask, (unsigned) add));
 }
 
+// Inclusive prefix sum over the 64 lanes of the wave in six DPP adds: shifts by 1, 2, 4, 8 inside each row of 16 lanes (a lane with no
+// source keeps the 0 it was given), then lane 15 of every row broadcast to the row above it (rows 1 and 3), then lane 31 to the upper
+// half.  No LDS: __shfl_up compiles to ds_bpermute_b32 plus five instructions of index arithmetic per step.
+__device__ __forceinline__ int waveInclusiveSum(int x)
+{
+    int v = x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // Lanes of the wave whose (valid) digit equals this lane's digit.  Four VALU instructions per digit bit on the two 32-bit halves of
 // the mask: the bit as 0 / -1 (v_bfe_i32), its ballot (v_cmp_ne), and per half ONE three-input boolean, mask & ~(ballot ^ mine)
 // (v_bitop3_b32, truth table 0x90 in the a = 0xF0, b = 0xCC, c = 0xAA convention: 0xF0 & ~(0xCC ^ 0xAA)).  Round 3's form (`lo &=
