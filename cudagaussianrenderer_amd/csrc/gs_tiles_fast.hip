@@ -353,13 +353,7 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
         // the lanes) + the pairs of digit d in the groups before this one (the scanned table); the last group leaves the pair total.
         const unsigned myTotal = t < kBins ? (unsigned) digitTotals[t] : 0u;
         const int myEntry = t < kBins ? digitTable[(size_t) t * digitStride + group] : 0;
-        unsigned long long incl64 = myTotal;
-#pragma unroll
-        for (int delta = 1; delta < kWave; delta <<= 1)
-        {
-            const unsigned long long o = __shfl_up(incl64, delta);
-            if (lane >= delta) incl64 += o;
-        }
+        const unsigned long long incl64 = waveInclusiveSumWide(myTotal);
         __syncthreads(); // waveTotals: everybody is past the prologue's reads
         if (lane == kWave - 1) scanTotals[wave] = (long long) incl64;
         __syncthreads();

@@ -30,6 +30,14 @@ __device__ __forceinline__ int waveInclusiveSum(int x)
     return v;
 }
 
+// The same for 64 values below 2^32 each whose sum needs more than 32 bits (pair totals of the digits: a demand beyond 2^31 must show as
+// such): the low 20 and the upper 12 bits are summed apart -- 64 x 2^20 and 64 x 2^12 fit 32 bits -- and put together again.
+__device__ __forceinline__ unsigned long long waveInclusiveSumWide(unsigned x)
+{
+    const unsigned lo = (unsigned) waveInclusiveSum((int) (x & 0xFFFFFu)), hi = (unsigned) waveInclusiveSum((int) (x >> 20));
+    return ((unsigned long long) hi << 20) + lo;
+}
+
 // Lanes of the wave whose (valid) digit equals this lane's digit.  Four VALU instructions per digit bit on the two 32-bit halves of
 // the mask: the bit as 0 / -1 (v_bfe_i32), its ballot (v_cmp_ne), and per half ONE three-input boolean, mask & ~(ballot ^ mine)
 // (v_bitop3_b32, truth table 0x90 in the a = 0xF0, b = 0xCC, c = 0xAA convention: 0xF0 & ~(0xCC ^ 0xAA)).  Round 3's form (`lo &=
