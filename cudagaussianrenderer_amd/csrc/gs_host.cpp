@@ -11,15 +11,18 @@
 
 #include <algorithm>
 #include <array>
+#include <cerrno>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <limits>
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -258,8 +261,13 @@ extern "C" int gs_parse_ply(const char* filePath, GsPly* out, char* err, size_t 
         // into a zeroed buffer would.  Every vertex is converted independently and min/max are exact whatever the order: the arrays are
         // the same bytes as the serial loop's (and as the reference's, tests/test_host_cpu.py).
         const int perChannel = extra / 3;
-        const int fd = ::open(filePath, O_RDONLY);
-        if (fd < 0) throw std::invalid_argument("Invalid header. Format or vertex count not found."); // (the header was just read: cannot happen)
+        struct Descriptor // closed on every way out of this function, exceptions included
+        {
+            int fd;
+            ~Descriptor() { if (fd >= 0) ::close(fd); }
+        } file{::open(filePath, O_RDONLY)};
+        const int fd = file.fd;
+        if (fd < 0) throw std::runtime_error(std::string("Cannot open '") + filePath + "' for its vertex data: " + std::strerror(errno) + ".");
         const size_t rowBytes = numProps * sizeof(float);
         const off_t bodyOffset = (off_t) h.bodyOffset;
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -336,15 +344,31 @@ extern "C" int gs_parse_ply(const char* filePath, GsPly* out, char* err, size_t 
                 }
             }
         };
-        if (threads <= 1) convertSlice(0);
-        else
+        // A slice that cannot get a thread of its own (EAGAIN under a process or thread limit) is converted by this thread; an exception
+        // inside a slice (bad_alloc for its block) is carried out of its thread and rethrown after every thread has been joined, so
+        // the caller gets the error text and return code of this function's contract and never std::terminate.
+        std::vector<std::exception_ptr> failed(threads);
+        const auto guardedSlice = [&](size_t slice) noexcept {
+            try { convertSlice(slice); }
+            catch (...) { failed[slice] = std::current_exception(); }
+        };
         {
-            std::vector<std::thread> pool;
-            for (size_t t = 1; t != threads; ++t) pool.emplace_back(convertSlice, t);
-            convertSlice(0);
-            for (std::thread& t : pool) t.join();
-        }
-        ::close(fd);
+            struct Pool
+            {
+                std::vector<std::thread> threads;
+                ~Pool() { for (std::thread& t : threads) if (t.joinable()) t.join(); }
+            } pool;
+            pool.threads.reserve(threads);
+            std::vector<size_t> inlineSlices{0};
+            for (size_t t = 1; t < threads; ++t)
+            {
+                try { pool.threads.emplace_back(guardedSlice, t); }
+                catch (const std::system_error&) { inlineSlices.push_back(t); }
+            }
+            for (size_t slice : inlineSlices) guardedSlice(slice);
+        } // joined
+        for (const std::exception_ptr& e : failed)
+            if (e) std::rethrow_exception(e);
         float bmin[3], bmax[3];
         for (int k = 0; k != 3; ++k)
         {

@@ -325,6 +325,9 @@ extern "C" int32_t gs_renderer_storage_order(const GsRenderer* r, int32_t* stora
 extern "C" int gs_renderer_share_scene(GsRenderer* r, const GsRenderer* owner)
 {
     if (r == nullptr || owner == nullptr || r == owner || owner->sceneShared) return -1;
+    // Every refusal comes before anything of r is touched: a sharer that fails keeps the scene it had (the order list of a
+    // Morton-stored scene is laid out per view, so the two renderers must agree on the views of a chain).
+    if (owner->splatToStorage != nullptr && owner->views != r->views) return -1;
     StreamScope scope(r);
     GS_CHECK(hipStreamSynchronize(g.stream));
     freeScene(r);
@@ -338,7 +341,6 @@ extern "C" int gs_renderer_share_scene(GsRenderer* r, const GsRenderer* owner)
     r->sh = owner->sh;
     r->shPerSplat = owner->shPerSplat;
     r->storageOrder = owner->storageOrder;
-    if (owner->splatToStorage != nullptr && owner->views != r->views) return -1; // (the order list is laid out per view)
     r->splatToStorage = owner->splatToStorage;
     r->positionCaller = owner->positionCaller;
     r->scaleAndRotationCaller = owner->scaleAndRotationCaller;

@@ -88,9 +88,17 @@ struct GroupStage
 
 // Guard band of the cheap overlap decision (see the head of the file and tools/guard_band_check.cpp).
 constexpr float kGuard = 1.0e-5f;
+#if defined(GS_AUDIT_OVERLAP) && !defined(GS_AB_GUARD_COUNT)
+#define GS_AB_GUARD_COUNT 1
+#endif
 #ifdef GS_AB_GUARD_COUNT
-// diagnostics build: [0] units tested, [1] units that entered the band's slow side, [2] tiles decided exactly, [3] decisions changed
-__device__ unsigned long long g_guardStats[4];
+// diagnostics builds: [0] units tested, [1] units that entered the band's slow side, [2] tiles decided exactly, [3] decisions changed.
+// -DGS_AUDIT_OVERLAP (libgsplat_hip_audit.so, `make audit`; tests/test_gpu_parity.py::test_overlap_audit_build_finds_no_differing_decision)
+// additionally sends EVERY tile of the count pass through the reference's predicate and compares: [4] tiles audited, [5] tiles whose
+// final decision differs from the reference's predicate (must stay 0: the guard band's claim, checked at run time instead of by
+// the host model alone), [6] tiles of the reference's box that the ellipse's own bounding box left out, [7] of those, tiles the
+// reference's predicate would have listed (must stay 0: the tight box's claim).
+__device__ unsigned long long g_guardStats[8];
 #endif
 
 // Squared distance of the origin to the segment q + t e, t in [0,1]: the edge comes within the unit circle when it is
@@ -288,8 +296,30 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
             loadSplat();
             // AABB in tiles, exactly as gs_tiles.hip / GaussianRender.cu:408-436,537-551 (shared with the band cull).
             TileAabb box = splatTileAabb(cx, cy, se.x, se.y, se.z, se.w, scr);
+#ifdef GS_AUDIT_OVERLAP
+            const TileAabb referenceBox = box;
+#endif
 #if GS_TIGHT_BOX
             tightenToEllipse(box, cx, cy, se, scr);
+#endif
+#ifdef GS_AUDIT_OVERLAP
+            if (referenceBox.x1 > referenceBox.x0 && referenceBox.y1 > referenceBox.y0)
+            {
+                // every tile the tight box dropped from the reference's box must be a tile the reference's predicate rejects
+                const EllipseD ell{cx, cy, se.z, se.w, se.x, se.y};
+                const bool kept = box.x1 > box.x0 && box.y1 > box.y0;
+#pragma unroll 1
+                for (int gy = referenceBox.y0; gy < referenceBox.y1; ++gy)
+#pragma unroll 1
+                    for (int gx = referenceBox.x0; gx < referenceBox.x1; ++gx)
+                    {
+                        if (kept && gx >= box.x0 && gx < box.x1 && gy >= box.y0 && gy < box.y1) continue;
+                        const float minX = tileClipMin(gx, scr.tileClipSizeX), minY = tileClipMin(gy, scr.tileClipSizeY);
+                        atomicAdd(&g_guardStats[6], 1ull);
+                        if (ellipseRectOverlapExactRolled(ell, minX, minY, minX + scr.tileClipSizeX, minY + scr.tileClipSizeY))
+                            atomicAdd(&g_guardStats[7], 1ull);
+                    }
+            }
 #endif
             x0 = box.x0;
             y0 = box.y0;
@@ -687,6 +717,31 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                     }
                 }
             }
+#ifdef GS_AUDIT_OVERLAP
+            if (!EMIT)
+            {
+                const EllipseD ell{cm.x, cm.y, seK.z, seK.w, seK.x, seK.y};
+                int ax = lx0, ay = ly0;
+#pragma unroll 1
+                for (int e = 0; e != kTilesPerUnit; ++e)
+                {
+                    if (local0 + e < areaK)
+                    {
+                        const int gx = (origin & 0xFFFF) + ax, gy = (origin >> 16) + ay;
+                        const float minX = tileClipMin(gx, sx), minY = tileClipMin(gy, sy);
+                        const bool exact = ellipseRectOverlapExactRolled(ell, minX, minY, minX + sx, minY + sy);
+                        atomicAdd(&g_guardStats[4], 1ull);
+                        if (exact != ((hitMask >> e) & 1u)) atomicAdd(&g_guardStats[5], 1ull);
+                    }
+                    ++ax;
+                    if (ax == wk)
+                    {
+                        ax = 0;
+                        ++ay;
+                    }
+                }
+            }
+#endif
             if (!EMIT && recorded) *maskSlot = (uint8_t) hitMask;
         }
         unsigned long long ballots[kTilesPerUnit];
@@ -897,7 +952,18 @@ extern "C" void gs_debug_guard_stats(unsigned long long out[4], int reset)
     GS_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_guardStats), sizeof(unsigned long long) * 4));
     if (reset)
     {
-        const unsigned long long zero[4] = {0, 0, 0, 0};
+        const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        GS_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_guardStats), zero, sizeof(zero)));
+    }
+}
+// all eight counters (the audit build's four after the guard band's four, see g_guardStats)
+extern "C" void gs_debug_overlap_audit(unsigned long long out[8], int reset)
+{
+    GS_CHECK(hipDeviceSynchronize());
+    GS_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_guardStats), sizeof(unsigned long long) * 8));
+    if (reset)
+    {
+        const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         GS_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_guardStats), zero, sizeof(zero)));
     }
 }

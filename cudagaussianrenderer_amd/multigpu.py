@@ -144,15 +144,19 @@ _OPS_CACHE = {}
 # sequence of collectives that all ranks enter in the same order whatever their local results: decisions are taken from all-gathered
 # or all-reduced values only, so no rank can leave a loop that another rank is still in.
 def all_gather_floats(value, world, tensor_device):
-    """[value of rank 0, ..., value of rank world-1], the same list on every rank."""
+    """[value of rank 0, ..., value of rank world-1], the same list on every rank.  `value` may be a tuple of floats (the same
+    length on every rank): the result is then a list of tuples -- ONE collective whatever the length."""
     import torch
 
+    scalar = not isinstance(value, (tuple, list))
+    mine_host = [float(value)] if scalar else [float(v) for v in value]
     if world == 1:
-        return [float(value)]
-    mine = torch.tensor([float(value)], dtype=torch.float64, device=tensor_device)
+        return [mine_host[0] if scalar else tuple(mine_host)]
+    mine = torch.tensor(mine_host, dtype=torch.float64, device=tensor_device)
     everyone = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(everyone, mine)
-    return [float(t.item()) for t in everyone]
+    rows = [t.cpu().tolist() for t in everyone]
+    return [row[0] if scalar else tuple(row) for row in rows]
 
 
 def rebalance_bands(make_rig, rig, bands, row_cost, world, rounds, tensor_device, frames=256, log=None, gather_weight=1.0):
@@ -172,9 +176,11 @@ def rebalance_bands(make_rig, rig, bands, row_cost, world, rounds, tensor_device
     for it in range(rounds + 1):
         own = rig.local_frame_ms(frames)
         exchange = rig.gather_frame_ms() if sees_exchange else 0.0
-        times = all_gather_floats(own + gather_weight * exchange, world, tensor_device)
+        # one collective per round whoever prints: `log` may be set on some ranks only
+        both = all_gather_floats((own + gather_weight * exchange, exchange), world, tensor_device)
+        times = [b[0] for b in both]
         if log:
-            shares = all_gather_floats(exchange, world, tensor_device) if sees_exchange else []
+            shares = [b[1] for b in both] if sees_exchange else []
             log(f"rebalance round {it}: bands {bands} ms {[round(t, 4) for t in times]}" +
                 (f" of which exchange {[round(t, 4) for t in shares]}" if shares else ""))
         if best is None or max(times) < best[0]:

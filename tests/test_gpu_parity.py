@@ -1258,3 +1258,109 @@ def test_renderers_sharing_one_scene(gs, tmp_path):
     owner.render(cam)
     assert np.array_equal(owner.read_image(), want)
     owner.close()
+
+
+def test_refused_scene_share_leaves_both_renderers_intact(gs, tmp_path):
+    """gs_renderer_share_scene refuses a Morton-stored owner whose chains have another number of views (the order list is laid out
+    per view) BEFORE it touches the sharer: the sharer keeps the scene it had and renders it, destroying it afterwards frees nothing
+    of the owner's, and the owner renders the same bytes as before (the refusal used to leave the sharer holding the
+    owner's pointers as if it owned them)."""
+    w, h = 640, 368
+    ply = _ply_scene(gs, tmp_path, 20000, 3, log_scale_mean=-3.0)
+    scene = (ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+    cam = gs.camera_from_bounds(ply["boundsMin"], ply["boundsMax"], w, h)
+    owner = gs.Renderer(w, h, storage_order="morton")
+    owner.set_scene(*scene)
+    owner.render(cam)
+    want = owner.read_image()
+    sharer = gs.Renderer(w, h, views=2, storage_order="morton")
+    pos, sr, col = _procedural(gs, 4000, seed=5)
+    sharer.set_scene(pos, sr, col)
+    own_cam = gs.camera_from_bounds([-4] * 3, [4] * 3, w, h)
+    sharer.set_graph(True)
+    sharer.render_views([own_cam, own_cam])
+    before = sharer.read_image(0)
+    with pytest.raises(ValueError):
+        sharer.share_scene(owner)
+    assert sharer.splat_count == 4000
+    sharer.render_views([own_cam, own_cam])  # still its own scene, untouched
+    assert np.array_equal(sharer.read_image(0), before) and before[..., :3].max() > 0
+    sharer.close()
+    owner.render(cam)
+    assert np.array_equal(owner.read_image(), want)
+    # a renderer with matching views may share, also after a refusal elsewhere
+    ok = gs.Renderer(w, h, storage_order="morton")
+    ok.share_scene(owner)
+    ok.render(cam)
+    assert np.array_equal(ok.read_image(), want)
+    ok.close()
+    owner.close()
+
+
+def test_overlap_audit_build_finds_no_differing_decision(tmp_path):
+    """the renderer's list builder rests on three claims the host model (tools/guard_band_check.cpp) makes -- outside its
+    guard band the cheap two-edge decision IS the reference's decision (GaussianRender.cu:375-405); the tile that holds the centre is
+    the one the reference finds; the ellipse's own bounding box drops no tile the reference would list.  libgsplat_hip_audit.so
+    (`make audit`: gs_tiles_fast.hip with -DGS_AUDIT_OVERLAP, otherwise the same objects) checks them at RUN time: every tile the
+    count pass decides also goes through gs_overlap_exact.h, every tile of the reference's box outside the tight box too, and
+    differing decisions are counted.  The harsh scenes of test_two_level_pipeline_equals_reference_pipeline and an orbit of the
+    clustered .ply scene run through it in a child process (the product library stays the one this process has loaded)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    audit = os.path.join(root, "cudagaussianrenderer_amd", "libgsplat_hip_audit.so")
+    assert os.path.exists(audit), "libgsplat_hip_audit.so missing: run `make -C cudagaussianrenderer_amd/csrc` (or __graft_entry__.build())"
+    code = r"""
+import ctypes as C, json, sys
+sys.path.insert(0, %r)
+import numpy as np
+import cudagaussianrenderer_amd as gs
+from cudagaussianrenderer_amd import scenes
+lib = gs.lib()
+fn = lib.gs_debug_overlap_audit
+fn.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+fn.restype = None
+out = (C.c_ulonglong * 8)()
+fn(out, 1)
+report = []
+def run(name, w, h, scene, cams, **kw):
+    r = gs.Renderer(w, h, **kw)
+    r.set_scene(*scene)
+    pairs = 0
+    for cam in cams:
+        pairs += r.render(cam, stats=True).tileListSize
+    r.close()
+    fn(out, 1)
+    report.append({"scene": name, "pairs": int(pairs), "stats": [int(v) for v in out]})
+cases = [(640, 360, 50000, (0.01, 0.3)), (1920, 1080, 200000, (0.005, 0.08)), (333, 177, 20000, (0.01, 1.0)),
+         (1280, 720, 40000, (0.0004, 0.9)), (3840, 2160, 60000, (0.0002, 0.4)), (256, 256, 30000, (0.001, 2.5)),
+         (7680, 4320, 2000, (0.00005, 1.5))]
+for w, h, n, (lo, hi) in cases:
+    scene = gs.generate_random_gaussians(n, seed=11, min_scale=lo, max_scale=hi)
+    run(f"procedural {n} @ {w}x{h} scales {lo}..{hi}", w, h, scene, [gs.camera_from_bounds([-4] * 3, [4] * 3, w, h)])
+path = %r
+scenes.write_synthetic_ply(path, 200000, sh_degree=0, seed=1234)
+ply = gs.parse_ply(path)
+w, h = 1920, 1080
+cams = [gs.camera_from_pose(p, q, w, h) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 8)]
+for order in ("caller", "morton"):
+    run(f"clustered ply 200000 @ 1080p, 8-view orbit, {order}", w, h, (ply["position"], ply["scaleAndRotation"], ply["color"]), cams, storage_order=order)
+print("AUDIT " + json.dumps(report))
+""" % (root, str(tmp_path / "audit_scene.ply"))
+    env = dict(os.environ, GSPLAT_HIP_LIBRARY=audit)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("AUDIT ")][-1]
+    report = json.loads(line[6:])
+    assert len(report) == 9
+    for entry in report:
+        units, slow, exact, changed, audited, differing, dropped, dropped_hits = entry["stats"]
+        assert audited > entry["pairs"] > 0, entry  # every listed pair is a tile that was decided, and audited
+        assert differing == 0, entry  # cheap decision + guard band + per-splat centre tile == the reference's predicate, tile for tile
+        assert dropped_hits == 0, entry  # the ellipse's own bounding box dropped nothing the reference lists
+        assert exact <= audited and slow <= units, entry
+    # the audit saw the machinery at work: the band was entered, and the tight box did drop tiles
+    assert sum(e["stats"][2] for e in report) > 0 and sum(e["stats"][6] for e in report) > 0

@@ -213,8 +213,12 @@ def _control_flow_worker(rank, world, port, width, height, views, out_path):
         rig.close()
         del made[:]
         rig = make(first_cut)
-        rig, bands, times = multigpu.rebalance_bands(make, rig, first_cut, row_cost, world, 2, "cpu", frames=views)
+        # `log` on rank 0 only: printing must not add a collective that the silent ranks never enter (this would hang)
+        lines = []
+        rig, bands, times = multigpu.rebalance_bands(make, rig, first_cut, row_cost, world, 2, "cpu", frames=views,
+                                                     log=lines.append if rank == 0 else None)
         dog.beat("rebalanced")
+        assert (len(lines) >= 1 and "of which exchange" in lines[0]) if rank == 0 else not lines
         assert len(times) == world and len(bands) == world and bands[-1][1] == ty
         # the slow outer ranks must have lost rows to the inner ones
         first_cut = made[0]
@@ -227,6 +231,7 @@ def _control_flow_worker(rank, world, port, width, height, views, out_path):
         assert frames == -(-2 // views) * views and elapsed >= mine > 0  # steps round up to whole chains of V frames; MAX over ranks
         everyone = multigpu.all_gather_floats(float(rank), world, "cpu")
         assert everyone == [float(r) for r in range(world)]
+        assert multigpu.all_gather_floats((float(rank), 0.5), world, "cpu") == [(float(r), 0.5) for r in range(world)]
         # one more chain through the same path: rank 0 must hold all V complete frames
         rig.next_chain = 0
         rig.run_frames(views)
