@@ -284,7 +284,7 @@ int gs_renderer_colours_on_demand(const GsRenderer* r);
  * author names as the cure for the raster's scattered gathers (README.md:138).  Frames are byte-identical either way, for every scene:
  * the input of the (stable) depth sort is laid out in the caller's order, so splats of equal depth code -- however many -- still blend
  * in the caller's index order (GaussianRender.cu:446-454: cub's sort is stable over emission order).  What changes is speed
- * (profiles/r04_storage_order.txt) and the index space of everything per splat that the renderer hands out: GsRendererBuffers arrays
+ * (profiles/r04_ab_experiments.txt, "Morton storage"; round 3's tie-fix variant: profiles/r03_storage_order.txt) and the index space of everything per splat that the renderer hands out: GsRendererBuffers arrays
  * and the `values` of the pair list are in STORAGE order; gs_renderer_storage_order gives the map.  TWO_LEVEL pipeline only: a scene
  * set while GS_PIPELINE_REFERENCE is selected is stored in the caller's order. */
 #define GS_STORAGE_ORDER_CALLER 0
