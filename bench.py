@@ -361,14 +361,15 @@ class Rig:
             r.close()
 
 
-def make_scene(ctx, args, opacity_mean):
+def make_scene(ctx, args, opacity_mean, keep_path=None):
     """Synthesise a .ply FILE and ingest it through the product's parsePly.  Returns the scene and what the ingest cost: seconds to
     synthesise + write the file, seconds inside gs_parse_ply alone (the step SURVEY.md section 8(f2) is about: PlyParser.cpp:132-140
-    reads one value per ifstream::read), the file's size."""
+    reads one value per ifstream::read), the file's size.  keep_path: write the file there and leave it (the C++ host of
+    extra.staged_api reads it again)."""
     gs, scenes = ctx["gs"], ctx["scenes"]
     t0 = time.time()
     with tempfile.TemporaryDirectory() as tmp:
-        path = os.path.join(tmp, f"scene_rank{ctx['rank']}.ply")
+        path = keep_path or os.path.join(tmp, f"scene_rank{ctx['rank']}.ply")
         names, table = scenes.synthetic_vertex_table(args.splats, sh_degree=args.sh_degree, seed=args.seed, log_scale_mean=args.log_scale_mean)
         if opacity_mean != 1.0:
             table[:, names.index("opacity")] += np.float32(opacity_mean - 1.0)
@@ -383,6 +384,40 @@ def make_scene(ctx, args, opacity_mean):
                  "parse_MB_per_s": round(file_bytes / 1e6 / max(t2 - t1, 1e-9), 1),
                  "what": "parse_s = gs_parse_ply on the freshly written (page-cached) file + the copy of its arrays into numpy; the "
                          "reference's parser on the same files: profiles/r04_ingest.txt"}
+
+
+def staged_api_table(ply_path, width, height, frames, warm_up=16):
+    """The reference's OWN frame loop -- the eight staged calls of GaussianRender.cuh:118-143 with a blocking timer after every stage,
+    Demo.cpp:394-479 -- compiled against the C++ facade (tools/gsplat_demo.cpp over include/GaussianRender.hpp) and run as a child
+    process on the same .ply, default camera.  Returns the reference's Stats table (Demo.cpp:541-562; README.md:144-153 is this table on
+    an RTX 3050 laptop) for both staged builders.  This is what a host that keeps the reference's loop gets; `value` is the one-call
+    renderer with frames in flight."""
+    demo = os.path.join(ROOT, "tools", "gsplat_demo")
+    if not os.path.exists(demo):
+        return {"note": "tools/gsplat_demo is not built (make -C cudagaussianrenderer_amd/csrc demo)"}
+    names = {"Evaluate Spherical Harmonics": "msSphericalHarmonics", "Evaluate Clip Data": "msClipData", "Build Tile List": "msBuildTileList",
+             "Sort Tile List": "msSortTileList", "Evaluate Tile Ranges": "msTileRanges", "Rasterize": "msRasterize", "Total": "msTotal",
+             "Frame loop wall clock": "msWallClockPerFrame"}
+    out = {"what": "the reference's frame loop (eight staged calls, blocking per-stage timers, Demo.cpp:394-479) through the C++ facade, "
+                   f"{frames} frames of the default camera after {warm_up} warm-up frames; msTotal = sum of the stage timers as Demo.cpp:541-562 prints it"}
+    for builder in ("sorted", "reference-order"):
+        try:
+            proc = subprocess.run([demo, ply_path, str(width), str(height), str(frames), "--warm-up", str(warm_up), "--builder", builder],
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        except (OSError, subprocess.TimeoutExpired) as exc:
+            out[builder] = {"note": f"{type(exc).__name__}: {exc}"}
+            continue
+        table = {}
+        for ln in proc.stdout.splitlines():
+            for label, key in names.items():
+                if ln.startswith(label + " "):
+                    table[key] = round(float(ln[len(label):].split()[0]), 4)
+        if proc.returncode != 0 or "msTotal" not in table:
+            out[builder] = {"note": f"rc {proc.returncode}: {proc.stderr[-300:]}"}
+            continue
+        table["frames_per_s_by_stage_timers"] = round(1e3 / table["msTotal"], 1) if table["msTotal"] > 0 else None
+        out[builder] = table
+    return out
 
 
 def stage_report(rig, args, stage_ms, p_mean, pc_mean, nonempty, band_tiles, band_h):
@@ -539,7 +574,9 @@ def main():
            "device": device, "rehearse": args.rehearse, "comms": comms, "beat": beat, "tensor_device": tensor_device}
 
     W, H, N = args.width, args.height, args.splats
-    ply, t_ingest = make_scene(ctx, args, args.opacity_mean)
+    keep_dir = tempfile.TemporaryDirectory() if (world == 1 and not args.no_extra) else None  # the scene file, for extra.staged_api
+    ply_path = os.path.join(keep_dir.name, "scene.ply") if keep_dir else None
+    ply, t_ingest = make_scene(ctx, args, args.opacity_mean, keep_path=ply_path)
     beat("scene ingested")
     tiles_x, tiles_y = gs.tile_counts(W, H)
     cameras = [gs.camera_from_pose(p, q, W, H) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], args.views)]
@@ -707,6 +744,12 @@ def main():
                                                                               args.epanechnikov)
             parity_failed = not result["parity"]["ok"]
     rig.close()
+
+    # ---- the literal drop-in (N = 1): the reference's frame loop over the eight staged calls, C++ host, same scene file ----
+    if world == 1 and ply_path is not None and result is not None:
+        result["extra"]["staged_api"] = staged_api_table(ply_path, W, H, frames=min(max(args.steps, 50), 200))
+    if keep_dir is not None:
+        keep_dir.cleanup()
 
     # ---- second workload (N = 1): the same scene with low opacities -- tiles saturate late, the raster dominates --------
     if world == 1 and not args.no_extra and args.opacity_mean == 1.0:

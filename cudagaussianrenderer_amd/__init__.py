@@ -19,6 +19,8 @@ FOOTPRINT_EPANECHNIKOV = 1  # the reference's EPANECHNIKOV_KERNEL option: 1 - q/
 PIPELINE_REFERENCE = 0  # the reference's stage order: one 64-bit tile|depth radix sort of all pairs
 PIPELINE_TWO_LEVEL = 1  # default: depth-sort the splats, emit, stable-sort the pairs on the tile bits
 STORAGE_ORDER_CALLER = 0  # splats stored in the caller's order (the reference's behaviour)
+STAGED_BUILDER_REFERENCE_ORDER = 0  # gs_set_staged_builder: (splat, local tile) emission order + unconditional sort
+STAGED_BUILDER_SORTED = 1  # default: buildTileList emits in the order the sort leaves, sortTileList looks before it sorts
 STORAGE_ORDER_MORTON = 1  # splats stored along a Morton curve: same frames, faster (include/gsplat_hip.h)
 
 

@@ -187,6 +187,8 @@ extern "C" int32_t gs_build_tile_list(GsTimer* timer, int32_t /*numBlocks*/, int
 {
     const Screen scr = currentScreen();
     const int count = g.global.splatCount;
+    // Default: the pairs are emitted in the order the sort would leave them (gs_staged.hip); sortTileList then finds nothing to do.
+    if (cfg.stagedBuilder == GS_STAGED_BUILDER_SORTED && radixSortSupported(4, count)) return stagedBuildTileListSorted(timer, tileListCapacity);
     gs_timer_start(timer);
     launchTileListCount(g.stream, count, scr, (const float2*) g.global.positionClipSpaceXY, (const float4*) g.global.screenEllipse,
                         g.scratch);
@@ -205,7 +207,22 @@ extern "C" int64_t gs_last_tile_list_demand(void) { return g.lastDemand; }
 extern "C" void gs_sort_tile_list(GsTimer* timer, int32_t size, void** deviceTempStorage, size_t* tempStorageSizeInBytes,
                                   GsDoubleBufferU64* keys, GsDoubleBufferI32* values)
 {
+    sortTileListImpl(timer, size, deviceTempStorage, tempStorageSizeInBytes, keys, values, cfg.stagedBuilder == GS_STAGED_BUILDER_SORTED);
+}
+
+void gs::sortTileListImpl(GsTimer* timer, int32_t size, void** deviceTempStorage, size_t* tempStorageSizeInBytes, GsDoubleBufferU64* keys,
+                          GsDoubleBufferI32* values, bool lookFirst)
+{
     gs_timer_start(timer);
+    // A stable sort of a list that is already in order on the compared bits is the identity: look first (one read of the keys).  The
+    // default staged builder emits exactly such a list; any other list goes through the sort as before.
+    if (size > 0 && lookFirst && keys->selector == values->selector &&
+        stagedListIsSorted(size, keys->buffers[keys->selector], sortEndBit(currentScreen().totalTiles)))
+    {
+        gs_timer_stop(timer);
+        if (hipGetLastError() != hipSuccess) printf("error sortTileList\n");
+        return;
+    }
     if (size > 0)
     {
         const int endBit = sortEndBit(currentScreen().totalTiles);

@@ -24,6 +24,21 @@ __device__ __forceinline__ uint32_t compactDepthKey(float clipDepth)
     return ((uint32_t) (top - 22) << 23) | ((q >> (top - 23)) & 0x7FFFFFu);
 }
 
+// The low word of getKey() itself (GaussianRender.cu:446-454): (uint32) of clamp((z + 1) / 2, 0, 1) * 2^32, the 2^32 of depth == far
+// saturated to 0xFFFFFFFF explicitly, NaN -> 0 (glm::clamp lets a NaN through; the conversion of a NaN gives 0).  compactDepthKey above
+// is a lossless, order-preserving re-coding of exactly this value.
+__device__ __forceinline__ uint32_t quantizeDepth(float clipDepth)
+{
+#pragma clang fp contract(off)
+    const float n = (clipDepth + 1.0f) * 0.5f;
+    const float lo = (n < 0.0f) ? 0.0f : n; // glm::max(n, 0): (x < y) ? y : x
+    const float c = (1.0f < lo) ? 1.0f : lo; // glm::min(lo, 1): (y < x) ? y : x
+    const float scaled = c * 4294967296.0f;
+    if (scaled != scaled) return 0u;
+    if (scaled >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t) scaled;
+}
+
 // View-space centre and the para-perspective terms every later step needs (GaussianRender.cu:227-259,265).  ONE routine for the
 // band cull's early test, the projection proper and the depth sort's key generation, so that all see the same clip position bit for bit.
 struct ViewTerms

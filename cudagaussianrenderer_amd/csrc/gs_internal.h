@@ -219,6 +219,8 @@ inline void clipWithScanCompanion(hipStream_t stream, const RadixScanArgs& scan,
     launchSplatClipDataWithScan(stream, *static_cast<const ClipWithScan*>(user), scan);
 }
 bool radixSortSupported(int keyBytes, int n);
+// Passes launchRadixSortPairs makes over bits [beginBit, endBit) (digits of up to 9 bits); the sorted data ends in buffer pair passes % 2.
+int radixSortPasses(int beginBit, int endBit);
 void ensureRadixScratch(RadixScratch& s, int n);
 void freeRadixScratch(RadixScratch& s);
 // First pass of the depth sort of a renderer with Morton storage: where the keys come from when they are made by the sort itself

@@ -438,8 +438,7 @@ int sortT(hipStream_t stream, K* keys0, K* keys1, int32_t* values0, int32_t* val
     // As few passes as 9-bit digits allow (512 bins, two per lane: the 27-bit compact depth keys sort in three passes), the bits
     // spread evenly over them (13 tile bits -> 7 + 6, not 8 + 5): fewer digits per pass means longer runs of consecutive
     // output addresses per workgroup in BOTH passes.  9 bits are only used where they save a pass (32 bits stay 4 x 8).
-    const int totalBits = endBit - beginBit;
-    const int passes = (totalBits + kMaxDigitBits - 1) / kMaxDigitBits;
+    const int passes = radixSortPasses(beginBit, endBit);
     int sel = 0, shift = beginBit;
     for (int pass = 0; pass != passes; ++pass)
     {
@@ -488,6 +487,8 @@ void launchRadixColumnScan(hipStream_t stream, int digits, int nHost, const int*
     else
         hipLaunchKernelGGL(radixColumnScanKernel<1024>, dim3(digits), dim3(1024), 0, stream, nHost, nDevice, tileElements, stride, table, scanned, totals);
 }
+
+int radixSortPasses(int beginBit, int endBit) { return endBit > beginBit ? (endBit - beginBit + kMaxDigitBits - 1) / kMaxDigitBits : 0; }
 
 bool radixSortSupported(int keyBytes, int n) { return (keyBytes == 2 || keyBytes == 4) && n >= 0; }
 

@@ -556,7 +556,7 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
 
         GsDoubleBufferU64 keys{{r->keys[0], r->keys[1]}, 0};
         GsDoubleBufferI32 values{{r->values[0], r->values[1]}, 0};
-        gs_sort_tile_list(stageTimers[3], size, &r->sortTemp, &r->sortTempBytes, &keys, &values); // Demo.cpp:458
+        sortTileListImpl(stageTimers[3], size, &r->sortTemp, &r->sortTempBytes, &keys, &values, false); // Demo.cpp:458 (the list above is in emission order: no look first)
         if (blocking) st.msSortTileList = gs_timer_elapsed_ms(stageTimers[3]);
         r->selector = keys.selector;
         r->keyBytes = 8;

@@ -1,0 +1,197 @@
+// gs_staged.hip -- the staged buildTileList / sortTileList pair (GaussianRender.cu:776-855) on the renderer's machinery.
+//
+// The reference's list has set semantics: buildTileListKernel appends its hits through atomics (GaussianRender.cu:674,689), so the
+// order in which the pairs reach the list is not defined, and the only consumer of the unsorted list is cub's sort (Demo.cpp:442-458).
+// A host that keeps the reference's eight calls therefore cannot tell in which order buildTileList emitted -- and this builder emits
+// the pairs ALREADY IN THE ORDER THE SORT WOULD LEAVE THEM:
+//   1. the splats' depth codes from the caller's positionClipSpaceZ (compactDepthKey, the lossless 27-bit re-coding of getKey's low
+//      word) and a stable three-pass radix sort of the splats by it (gs_radix.hip);
+//   2. count / emit over the depth-sorted splats (gs_tiles_fast.hip: the reference's overlap predicate bit for bit, guard band +
+//      gs_overlap_exact.h), the emit pass carrying the first pass of the tile sort;
+//   3. the remaining pass(es) of the stable tile sort, ending in the CALLER's value buffer;
+//   4. the 64-bit keys (tile << 32 | getKey's quantised depth of the entry's splat) written beside them into the caller's key buffer.
+// That is the renderer's two-level sort: N splats through three passes and P pairs of 6 bytes through two,
+// instead of P pairs of 12 bytes through six.  Equal keys (same tile, same depth code) are in splat-index order: the depth sort is
+// stable over the index order and so is the tile sort -- the tie-break the oracle uses.
+// sortTileList then LOOKS before it sorts: one pass over the keys finds out whether they are already in order on the bits it
+// compares; a stable sort of such a list is the identity, so it returns with the selectors untouched.  Any other list (a caller's
+// own, or one from the reference-order builder) is sorted by rocPRIM as before -- the check costs it one read of the keys.
+// gs_set_staged_builder(GS_STAGED_BUILDER_REFERENCE_ORDER) brings back gs_tiles.hip's (splat, local tile) emission order and the
+// unconditional sort.
+#include "gs_depth_key.h"
+#include "gs_state.h"
+
+namespace gs
+{
+namespace
+{
+
+__global__ __launch_bounds__(256) void stagedDepthKeysKernel(int n, const float* __restrict__ clipZ, uint32_t* __restrict__ keys,
+                                                             int32_t* __restrict__ order)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = compactDepthKey(clipZ[i]);
+    order[i] = i;
+}
+
+// keys[i] = getKey(tile of entry i, clip depth of its splat) (GaussianRender.cu:446-454); the list length lives on the device (the low
+// word of the emit pass's 64-bit pair total), bounded by the capacity the grid covers.
+template <typename TileKey>
+__global__ __launch_bounds__(256) void stagedExpandKeysKernel(int capacity, const int* __restrict__ sizeDevice, const TileKey* __restrict__ tiles,
+                                                              const int32_t* __restrict__ values, const float* __restrict__ clipZ,
+                                                              uint64_t* __restrict__ keys)
+{
+    const int size = min(*sizeDevice, capacity);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= size) return;
+    keys[i] = ((uint64_t) tiles[i] << 32) | (uint64_t) quantizeDepth(clipZ[values[i]]);
+}
+
+// One lane = two consecutive keys (16 bytes) + the key in front of them; a wave that sees a descent on the compared bits stores the
+// epoch of this check (plain store: every writer writes the same value).
+__global__ __launch_bounds__(256) void stagedSortedCheckKernel(int size, const uint64_t* __restrict__ keys, uint64_t mask, int epoch,
+                                                               int* __restrict__ unsortedEpoch)
+{
+    const int first = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    bool descent = false;
+    if (first < size)
+    {
+        // (8-byte loads: the caller's key buffer need not be 16-byte aligned)
+        const uint64_t a = keys[first] & mask;
+        const uint64_t b = (first + 1 < size ? keys[first + 1] : keys[first]) & mask;
+        const uint64_t before = first > 0 ? (keys[first - 1] & mask) : 0ull;
+        descent = before > a || a > b;
+    }
+    if (__any(descent) && (threadIdx.x & (kWave - 1)) == 0) *unsortedEpoch = epoch;
+}
+
+void ensureStagedScratch(StagedScratch& s, int splats, int capacityPairs, int tileKeyBytes)
+{
+    if (splats > s.capacitySplats)
+    {
+        for (int i = 0; i != 2; ++i)
+        {
+            if (s.depthKey[i]) GS_CHECK(hipFree(s.depthKey[i]));
+            if (s.order[i]) GS_CHECK(hipFree(s.order[i]));
+            GS_CHECK(hipMalloc((void**) &s.depthKey[i], sizeof(uint32_t) * (size_t) splats));
+            GS_CHECK(hipMalloc((void**) &s.order[i], sizeof(int32_t) * (size_t) splats));
+        }
+        s.capacitySplats = splats;
+    }
+    const int64_t keyBytes = (int64_t) std::max(capacityPairs, 1) * tileKeyBytes;
+    if (keyBytes > s.capacityPairBytes)
+    {
+        for (int i = 0; i != 2; ++i)
+        {
+            if (s.tileKeys[i]) GS_CHECK(hipFree(s.tileKeys[i]));
+            GS_CHECK(hipMalloc(&s.tileKeys[i], (size_t) keyBytes));
+        }
+        s.capacityPairBytes = keyBytes;
+    }
+    if (capacityPairs > s.capacityPairs)
+    {
+        if (s.values) GS_CHECK(hipFree(s.values));
+        GS_CHECK(hipMalloc((void**) &s.values, sizeof(int32_t) * (size_t) capacityPairs));
+        s.capacityPairs = capacityPairs;
+    }
+}
+
+void ensureSortedCheck(StagedScratch& s)
+{
+    if (s.unsortedEpoch != nullptr) return;
+    GS_CHECK(hipMalloc((void**) &s.unsortedEpoch, sizeof(int)));
+    GS_CHECK(hipMemset(s.unsortedEpoch, 0, sizeof(int)));
+    GS_CHECK(hipHostMalloc((void**) &s.unsortedEpochHost, sizeof(int)));
+    *s.unsortedEpochHost = 0;
+}
+
+} // namespace
+
+int32_t stagedBuildTileListSorted(GsTimer* timer, int32_t tileListCapacity)
+{
+    const Screen scr = currentScreen();
+    const int n = g.global.splatCount;
+    const int capacity = std::max(tileListCapacity, 0);
+    StagedScratch& st = g.staged;
+    const int tBits = tileBits(scr.totalTiles);
+    const int tileKeyBytes = scr.totalTiles > 65536 ? 4 : 2;
+    if (n > 0) ensureStagedScratch(st, n, capacity, tileKeyBytes); // (before the timed interval: allocation is not the stage's work)
+    gs_timer_start(timer);
+    if (n <= 0)
+    {
+        ensureTileListScratch(g.scratch, 0);
+        *g.scratch.totalHost = 0;
+    }
+    else
+    {
+        const float* clipZ = g.global.positionClipSpaceZ;
+        const float2* clipXY = (const float2*) g.global.positionClipSpaceXY;
+        const float4* ellipse = (const float4*) g.global.screenEllipse;
+        // (1) splats by depth
+        hipLaunchKernelGGL(stagedDepthKeysKernel, dim3((n + 255) / 256), dim3(256), 0, g.stream, n, clipZ, st.depthKey[0], st.order[0]);
+        g.radix.countDevice = nullptr;
+        g.radix.rangeTableForLastPass = nullptr;
+        const int orderSel = launchRadixSortPairs(g.stream, g.radix, 4, st.depthKey[0], st.depthKey[1], st.order[0], st.order[1], n, 0, kDepthKeyBits);
+        const uint32_t* order = (const uint32_t*) st.order[orderSel];
+        // (2) count / emit in depth order; the emit pass carries the tile sort's first pass when that sort is a two-pass one
+        const int sortBits = cfg.listFusion ? tileListFusedSortBits(tBits, tileKeyBytes) : 0;
+        g.scratch.tileRecord = nullptr;
+        g.scratch.countDevice = nullptr;
+        launchTileListFastCount(g.stream, n, scr, order, clipXY, ellipse, g.scratch, sortBits);
+        // The passes that are left flip between two buffer pairs; the value half they END in is the caller's list.
+        const int passes = radixSortPasses(sortBits, tBits);
+        int32_t* caller = g.tileList.values;
+        int32_t* v0 = (passes % 2 == 0) ? caller : st.values;
+        int32_t* v1 = (passes % 2 == 0) ? st.values : caller;
+        launchTileListFastEmit(g.stream, n, scr, order, clipXY, ellipse, g.scratch, st.tileKeys[0], tileKeyBytes, v0, capacity, 0, sortBits);
+        if (capacity > 0)
+        {
+            // (3) the rest of the stable tile sort; the list length stays on the device (the pair total the emit pass left, low word of
+            // the little-endian int64), bounded by the capacity
+            const int* sizeDevice = (const int*) g.scratch.total;
+            st.radixPairs.countDevice = sizeDevice;
+            st.radixPairs.rangeTableForLastPass = nullptr;
+            const int sel = launchRadixSortPairs(g.stream, st.radixPairs, tileKeyBytes, st.tileKeys[0], st.tileKeys[1], v0, v1, capacity, sortBits, tBits);
+            st.radixPairs.countDevice = nullptr;
+            // (4) the reference's keys beside the values
+            const dim3 grid((capacity + 255) / 256), block(256);
+            if (tileKeyBytes == 2)
+                hipLaunchKernelGGL(stagedExpandKeysKernel<uint16_t>, grid, block, 0, g.stream, capacity, sizeDevice, (const uint16_t*) st.tileKeys[sel], caller,
+                                   clipZ, g.tileList.keys);
+            else
+                hipLaunchKernelGGL(stagedExpandKeysKernel<uint32_t>, grid, block, 0, g.stream, capacity, sizeDevice, (const uint32_t*) st.tileKeys[sel], caller,
+                                   clipZ, g.tileList.keys);
+        }
+    }
+    gs_timer_stop(timer);
+    // The reference reads the pair counter back here too (GaussianRender.cu:793), a host sync point.
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    reportLaunch("buildTileList");
+    g.lastDemand = *g.scratch.totalHost;
+    return (int32_t) std::min<int64_t>(g.lastDemand, (int64_t) capacity); // GaussianRender.cu:800-801
+}
+
+bool stagedListIsSorted(int32_t size, const uint64_t* keys, int endBit)
+{
+    if (size <= 1) return true;
+    StagedScratch& st = g.staged;
+    ensureSortedCheck(st);
+    st.epoch = st.epoch == 0x7FFFFFFF ? 1 : st.epoch + 1;
+    const uint64_t mask = endBit >= 64 ? ~0ull : ((1ull << endBit) - 1ull);
+    const int lanes = (size + 1) / 2;
+    hipLaunchKernelGGL(stagedSortedCheckKernel, dim3((lanes + 255) / 256), dim3(256), 0, g.stream, size, keys, mask, st.epoch, st.unsortedEpoch);
+    GS_CHECK(hipMemcpyAsync(st.unsortedEpochHost, st.unsortedEpoch, sizeof(int), hipMemcpyDeviceToHost, g.stream));
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    return *st.unsortedEpochHost != st.epoch;
+}
+
+} // namespace gs
+
+using namespace gs;
+
+extern "C" void gs_set_staged_builder(int mode)
+{
+    cfg.stagedBuilder = mode == GS_STAGED_BUILDER_REFERENCE_ORDER ? GS_STAGED_BUILDER_REFERENCE_ORDER : GS_STAGED_BUILDER_SORTED;
+}
+extern "C" int gs_get_staged_builder(void) { return cfg.stagedBuilder; }

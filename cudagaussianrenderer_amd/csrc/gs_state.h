@@ -27,6 +27,24 @@ extern int g_ablation;  // diagnostics: stages left out of captured frames (gs_d
 
 // The reference keeps these in __constant__ symbols (GaussianRender.cu:42-43); here they are a host
 // copy and every launch passes what its kernel needs by value.
+// Scratch of the staged buildTileList that emits its pairs already sorted (gs_staged.hip): depth codes and order of the splats, the
+// library's halves of the (tile index, value) ping-pong of the tile sort -- the other value half is the caller's list --, the sort's
+// tables for the pairs, and the flag of sortTileList's is-it-sorted-already check.
+struct StagedScratch
+{
+    uint32_t* depthKey[2] = {nullptr, nullptr};
+    int32_t* order[2] = {nullptr, nullptr};
+    int capacitySplats = 0;
+    void* tileKeys[2] = {nullptr, nullptr};
+    int32_t* values = nullptr;
+    int64_t capacityPairBytes = 0; // bytes of each tileKeys half; values holds capacityPairs entries
+    int capacityPairs = 0;
+    gs::RadixScratch radixPairs;
+    int* unsortedEpoch = nullptr;     // device word: the epoch of the last check that found a descent
+    int* unsortedEpochHost = nullptr; // pinned mirror
+    int epoch = 0;
+};
+
 struct State
 {
     GsGlobalArgs global{};
@@ -34,6 +52,7 @@ struct State
     hipStream_t stream = nullptr;
     gs::TileListScratch scratch;
     gs::RadixScratch radix;
+    StagedScratch staged;
     int64_t lastDemand = 0;
 };
 // One state per host thread: like the reference, the staged calls are not re-entrant, but each host thread may drive
@@ -48,6 +67,7 @@ struct Settings
 {
     int sortBackend = GS_SORT_BACKEND_NATIVE;
     bool collectRasterStats = false;
+    int stagedBuilder = GS_STAGED_BUILDER_SORTED; // gs_set_staged_builder: how the staged buildTileList emits (and whether sortTileList looks before it sorts)
     bool listFusion = GS_LIST_FUSION_DEFAULT != 0; // the emit pass carries the tile sort's first pass (gs_set_list_fusion)
     bool clipScanFusion = GS_CLIP_SCAN_FUSION_DEFAULT != 0; // Morton storage, no band cull: the clip kernel shares the launch of the depth sort's first column scan (gs_debug_set_clip_scan_fusion)
     unsigned long long* consumedDevice = nullptr; // counter of the staged gs_rasterize_tile
@@ -57,6 +77,12 @@ extern Settings cfg;
 Screen currentScreen();
 ClipCamera currentCamera();
 void reportLaunch(const char* stage);
+// gs_staged.hip: the staged buildTileList / sortTileList on the renderer's machinery (see there)
+int32_t stagedBuildTileListSorted(GsTimer* timer, int32_t tileListCapacity);
+bool stagedListIsSorted(int32_t size, const uint64_t* keys, int endBit);
+// sortTileList proper; lookFirst: skip the sort when the list is already in order (a stable sort of a sorted list is the identity)
+void sortTileListImpl(GsTimer* timer, int32_t size, void** deviceTempStorage, size_t* tempStorageSizeInBytes, GsDoubleBufferU64* keys,
+                      GsDoubleBufferI32* values, bool lookFirst);
 
 constexpr int kStageTimers = 7; // sh, clip, tile list, pair sort, ranges, raster, depth sort (added to the sort total)
 // What begin() leaves for finish().

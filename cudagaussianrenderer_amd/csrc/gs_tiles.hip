@@ -16,6 +16,7 @@
 //
 // Floating-point contraction is OFF in this file: the overlap predicate is compared bit-for-bit with
 // the CPU oracle, so every operation must round exactly as written.
+#include "gs_depth_key.h"
 #include "gs_internal.h"
 #include "gs_overlap_exact.h"
 
@@ -43,16 +44,7 @@ __device__ __forceinline__ int f2iSat(float v)
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
-// GaussianRender.cu:446-454 with the explicit saturation of the 2^32 case.
-__device__ __forceinline__ uint32_t quantizeDepth(float clipDepth)
-{
-    const float n = (clipDepth + 1.0f) * 0.5f;
-    const float c = gmin(gmax(n, 0.0f), 1.0f);
-    const float scaled = c * 4294967296.0f;
-    if (scaled != scaled) return 0u;
-    if (scaled >= 4294967296.0f) return 0xFFFFFFFFu;
-    return (uint32_t) scaled;
-}
+// quantizeDepth (the low word of getKey, GaussianRender.cu:446-454): gs_depth_key.h
 
 // Per-wave staging of the 64 splats the wave owns.
 struct WaveStage

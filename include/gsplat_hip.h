@@ -113,12 +113,30 @@ void gs_set_tile_list_args(const GsTileListArgs* tileListArgs);     /* setTileLi
 void gs_evaluate_spherical_harmonics(GsTimer* timer, int32_t count); /* .cu:184-201                    */
 void gs_evaluate_splat_clip_data(GsTimer* timer, int32_t count);    /* .cu:331-348                    */
 /* buildTileList .cu:776-802: returns min(pairs emitted, capacity). numBlocks is accepted for
- * signature compatibility and ignored (the grid is sized from the splat count). */
+ * signature compatibility and ignored (the grid is sized from the splat count).  The list is the reference's SET of
+ * (getKey(tile, depth), splat) pairs; the order in which the reference's kernel appends them is undefined (atomics, .cu:674,689) and
+ * this one emits them in the order the sort leaves them -- see gs_set_staged_builder.  Needs library-owned scratch (grown on demand,
+ * per host thread). */
 int32_t gs_build_tile_list(GsTimer* timer, int32_t numBlocks, int32_t tileListCapacity);
+/* Addition: how gs_build_tile_list emits.
+ * SORTED (default): the renderer's two-level sort behind the reference's two calls -- the splats are sorted by getKey's depth first
+ * (three radix passes over N elements), the pairs are emitted in that order with the first pass of the tile sort inside the emit pass,
+ * the second pass ends in the caller's value buffer and the 64-bit keys are written beside it: the list leaves buildTileList in
+ * (tile, depth, splat index) order.  gs_sort_tile_list then looks before it sorts (one pass over the keys): a stable sort of a
+ * list that is already in order on the compared bits is the identity, so it returns with the selectors untouched; any other list is
+ * sorted as before.  Same sorted list as REFERENCE_ORDER + sort, bit for bit (keys and values), at 0.2 instead of 0.65 ms for the two
+ * calls at BASELINE.json configs[2] (profiles/r05_staged_path.txt).  A list cut off by the capacity is a sorted subset of the full
+ * list (the reference's is an arbitrary subset, .cu:700-703).
+ * REFERENCE_ORDER: (splat, local tile) emission order (gs_tiles.hip, the order the oracle emits in) and an unconditional sort. */
+#define GS_STAGED_BUILDER_REFERENCE_ORDER 0
+#define GS_STAGED_BUILDER_SORTED 1
+void gs_set_staged_builder(int mode);
+int gs_get_staged_builder(void);
 /* Addition: pairs the last gs_build_tile_list would have emitted with unlimited capacity. */
 int64_t gs_last_tile_list_demand(void);
-/* sortTileList .cu:806-855: rocPRIM radix sort on key bits [0, 32+ceil(log2(tiles))). May free and
- * re-allocate *deviceTempStorage (hipFree/hipMalloc), as the reference does with cudaFree/cudaMalloc. */
+/* sortTileList .cu:806-855: stable sort on key bits [0, 32+ceil(log2(tiles))) (rocPRIM radix sort; skipped when the list is
+ * already in order on those bits, see gs_set_staged_builder). May free and re-allocate *deviceTempStorage (hipFree/hipMalloc), as
+ * the reference does with cudaFree/cudaMalloc. */
 void gs_sort_tile_list(GsTimer* timer, int32_t tileListSize, void** deviceTempStorage, size_t* tempStorageSizeInBytes,
                        GsDoubleBufferU64* keys, GsDoubleBufferI32* values);
 void gs_evaluate_tile_range(GsTimer* timer, int32_t tileListSize);  /* .cu:891-906                    */

@@ -98,11 +98,27 @@ def test_clip_stage(gs, gsref, w, h):
     _check_clip(gs, gsref, pos, sr, cam, w, h)
 
 
+@pytest.fixture
+def staged_builder(gs, request):
+    """gs_set_staged_builder for one test: STAGED_BUILDER_SORTED (the default) or STAGED_BUILDER_REFERENCE_ORDER."""
+    gs.lib().gs_set_staged_builder(request.param)
+    yield request.param
+    gs.lib().gs_set_staged_builder(gs.STAGED_BUILDER_SORTED)
+
+
+_BUILDERS = pytest.mark.parametrize("staged_builder", [1, 0], indirect=True, ids=["sorted", "reference_order"])
+
+
+@_BUILDERS
 @pytest.mark.parametrize("w,h,scales", [(1024, 1024, (0.01, 0.5)), (256, 256, (0.01, 0.5)), (1920, 1080, (0.005, 0.05)),
-                                        (333, 177, (0.01, 2.0))])
-def test_tile_list_sort_ranges_bit_exact(gs, gsref, w, h, scales):
-    """Pair list (set AND emission order), sorted list and ranges are bit-exact against the oracle fed with the
-    GPU's own clip data (the overlap predicate uses no contraction and only IEEE-exact operations)."""
+                                        (333, 177, (0.01, 2.0)), (4800, 2700, (0.01, 0.3))])
+def test_tile_list_sort_ranges_bit_exact(gs, gsref, staged_builder, w, h, scales):
+    """Pair list, sorted list and ranges are bit-exact against the oracle fed with the GPU's own clip data (the overlap predicate
+    uses no contraction and only IEEE-exact operations).  The reference's buildTileList defines a SET of pairs (its kernel appends
+    through atomics, GaussianRender.cu:674,689).  REFERENCE_ORDER builder: the list leaves buildTileList in the oracle's own emission
+    order, entry for entry.  SORTED builder (default): it leaves buildTileList already in the order sortTileList would give -- keys
+    AND values equal the oracle's sorted list, equal keys in splat-index order -- and sortTileList leaves it where it is (same
+    buffers, selector untouched).  (4800x2700: 50 869 tiles -- 16 key bits, 8 + 8; 333x177: 264 tiles -- one pass, no fusion.)"""
     pos, sr, col = _procedural(gs, 6000, seed=7, min_scale=scales[0], max_scale=scales[1])
     cam = gs.camera_from_bounds([-4] * 3, [4] * 3, w, h)
     f, (xy, z, ell, con) = _check_clip(gs, gsref, pos, sr, cam, w, h)
@@ -111,36 +127,78 @@ def test_tile_list_sort_ranges_bit_exact(gs, gsref, w, h, scales):
         f = StagedFrame(pos, sr, np.zeros_like(pos), cam, w, h, capacity=total + 5)
         f.begin()
         f.run_clip()
+    end_bit = gs.sort_end_bit(w, h)
+    rsk, rsv = gsref.sort_tile_list(rk, rv, end_bit)
     keys, values, size = f.run_build()
     assert size == total == gs.lib().gs_last_tile_list_demand()
-    assert np.array_equal(keys, rk) and np.array_equal(values, rv)
+    if staged_builder == gs.STAGED_BUILDER_SORTED:
+        assert np.array_equal(keys, rsk) and np.array_equal(values, rsv)
+    else:
+        assert np.array_equal(keys, rk) and np.array_equal(values, rv)
 
-    end_bit = gs.sort_end_bit(w, h)
     sk, sv = f.run_sort()
-    rsk, rsv = gsref.sort_tile_list(rk, rv, end_bit)
     assert np.array_equal(sk, rsk) and np.array_equal(sv, rsv)
     assert np.all(np.diff(sk.astype(np.uint64)) >= 0) or size < 2
+    if staged_builder == gs.STAGED_BUILDER_SORTED:
+        assert f.sorted_sel == 0  # nothing moved: the sorted list is the buffer buildTileList wrote
 
     rng = f.run_ranges()
     assert np.array_equal(rng, gsref.evaluate_tile_ranges(rsk, f.total_tiles))
     f.free_sort_temp()
 
 
-def test_tile_list_capacity_truncation(gs, gsref):
-    """buildTileList returns min(count, capacity) (GaussianRender.cu:800-801); here the first `capacity` pairs of
-    the deterministic emission order are kept, nothing is written past the capacity."""
+@_BUILDERS
+def test_tile_list_capacity_truncation(gs, gsref, staged_builder):
+    """buildTileList returns min(count, capacity) (GaussianRender.cu:800-801) and nothing is written past the capacity.  The reference
+    keeps an arbitrary subset (a block that finds the list full aborts, :700-703); REFERENCE_ORDER keeps the first `capacity` pairs of
+    its deterministic emission order, SORTED a subset that is itself in sorted order."""
     pos, sr, col = _procedural(gs, 4000, seed=3)
     cam = gs.camera_from_bounds([-4] * 3, [4] * 3, 512, 512)
     f = StagedFrame(pos, sr, col, cam, 512, 512, capacity=1000)
     f.begin()
     xy, z, ell, con = f.run_clip()
-    sentinel = np.full(f.capacity, 0xDEADBEEFDEADBEEF, np.uint64)
-    f.upload(f.keys[0], sentinel)
+    sentinel = np.full(f.capacity + 24, 0xDEADBEEFDEADBEEF, np.uint64)
+    guarded = gs.DeviceBuffer(nbytes=8 * (f.capacity + 24), dtype=np.uint64)  # the list buffer with 24 guard words behind it
+    f.upload(guarded, sentinel)
+    f.keys[0] = guarded
+    f._set_list(f.keys[0], f.values[0], 0)
     keys, values, size = f.run_build()
     rk, rv, total = gsref.build_tile_list(xy, z, ell, 512, 512)
     assert total > 1000 and size == 1000
     assert gs.lib().gs_last_tile_list_demand() == total
-    assert np.array_equal(keys, rk[:1000]) and np.array_equal(values, rv[:1000])
+    assert np.all(guarded.copy_to(dtype=np.uint64)[f.capacity:] == 0xDEADBEEFDEADBEEF)
+    if staged_builder == gs.STAGED_BUILDER_SORTED:
+        assert np.all(np.diff(keys) >= 0)
+        full = set(zip(rk.tolist(), rv.tolist()))
+        got = list(zip(keys.tolist(), values.tolist()))
+        assert len(set(got)) == 1000 and all(pair in full for pair in got)
+    else:
+        assert np.array_equal(keys, rk[:1000]) and np.array_equal(values, rv[:1000])
+
+
+def test_sort_of_a_foreign_list_still_sorts(gs, gsref):
+    """sortTileList looks before it sorts only to skip lists that are ALREADY in order; a caller's own unsorted list, a list with one
+    descent at its very end, and a sorted list with garbage above the compared bits all come out as the oracle's stable sort."""
+    rng = np.random.default_rng(5)
+    w, h = 1920, 1080
+    end_bit = gs.sort_end_bit(w, h)
+    n = 100_001
+    base = np.sort((rng.integers(0, 8160, n).astype(np.uint64) << np.uint64(32)) | rng.integers(0, 2 ** 32, n).astype(np.uint64))
+    cases = {"sorted": base.copy(), "last_pair_swapped": base.copy(), "first_pair_swapped": base.copy(),
+             "sorted_but_for_high_garbage": base | (rng.integers(0, 2 ** 12, n).astype(np.uint64) << np.uint64(end_bit + 3))}
+    cases["last_pair_swapped"][[-1, -2]] = cases["last_pair_swapped"][[-2, -1]]
+    cases["first_pair_swapped"][[0, 1]] = cases["first_pair_swapped"][[1, 0]]
+    pos = np.zeros((4, 4), np.float32)
+    cam = gs.camera_from_bounds([-4] * 3, [4] * 3, w, h)
+    for name, keys in cases.items():
+        values = np.arange(n, dtype=np.int32)
+        f = StagedFrame(pos, pos, pos, cam, w, h, capacity=n)
+        f.begin()
+        f.upload_list(keys, values)
+        sk, sv = f.run_sort()
+        rk, rv = gsref.sort_tile_list(keys, values, end_bit)
+        assert np.array_equal(sk, rk) and np.array_equal(sv, rv), name
+        f.free_sort_temp()
 
 
 def test_sort_random_keys_bit_exact(gs, gsref):
@@ -1081,12 +1139,20 @@ def _staged_lists(gs, gsref, pos, sr, col, cam, w, h):
     f.begin()
     xy, z, ell, con = f.run_clip()
     rk, rv, total = gsref.build_tile_list(xy, z, ell, w, h)
-    keys, values, size = f.run_build()
-    assert size == total and np.array_equal(keys, rk) and np.array_equal(values, rv)
-    sk, sv = f.run_sort()
     rsk, rsv = gsref.sort_tile_list(rk, rv, gs.sort_end_bit(w, h))
-    assert np.array_equal(sk, rsk) and np.array_equal(sv, rsv)
-    assert np.array_equal(f.run_ranges(), gsref.evaluate_tile_ranges(rsk, f.total_tiles))
+    try:
+        # both staged builders (gs_set_staged_builder): the oracle's emission order, and the list emitted already sorted (default)
+        for builder in (gs.STAGED_BUILDER_REFERENCE_ORDER, gs.STAGED_BUILDER_SORTED):
+            gs.lib().gs_set_staged_builder(builder)
+            f.begin()
+            keys, values, size = f.run_build()
+            want = (rk, rv) if builder == gs.STAGED_BUILDER_REFERENCE_ORDER else (rsk, rsv)
+            assert size == total and np.array_equal(keys, want[0]) and np.array_equal(values, want[1]), builder
+            sk, sv = f.run_sort()
+            assert np.array_equal(sk, rsk) and np.array_equal(sv, rsv), builder
+            assert np.array_equal(f.run_ranges(), gsref.evaluate_tile_ranges(rsk, f.total_tiles)), builder
+    finally:
+        gs.lib().gs_set_staged_builder(gs.STAGED_BUILDER_SORTED)
     f.free_sort_temp()
     return (xy, z, ell, con), (sk, sv)
 

@@ -13,6 +13,9 @@
 //                                                            cursor in pixels from the top-left corner), fed to gs::CameraControls::update before
 //                                                            the frame is rendered; frames beyond the file repeat its last line with dt = 0.
 //                                                            The pose after the last frame is printed.
+//   ... --builder sorted|reference-order                     gs_set_staged_builder (default sorted: buildTileList emits in the order the
+//                                                            sort leaves, sortTileList looks before it sorts)
+//   ... --warm-up W                                          W more frames first that the printed averages leave out
 //   ... --dump-every K                                       every K-th frame as <out.ppm>.<frame>.ppm (the session as an image sequence)
 //
 // Build: make -C cudagaussianrenderer_amd/csrc demo
@@ -39,6 +42,7 @@ int main(int argc, char** argv)
     const char* idFile = nullptr;
     const char* eventsFile = nullptr;
     int dumpEvery = 0;
+    int warmUp = 0; // frames rendered before the statistics start (first frames allocate scratch and meet cold clocks)
     std::vector<char*> positional;
     for (int i = 0; i < argc; ++i)
     {
@@ -47,6 +51,9 @@ int main(int argc, char** argv)
         else if (std::strcmp(argv[i], "--id-file") == 0 && i + 1 < argc) idFile = argv[++i];
         else if (std::strcmp(argv[i], "--events") == 0 && i + 1 < argc) eventsFile = argv[++i];
         else if (std::strcmp(argv[i], "--dump-every") == 0 && i + 1 < argc) dumpEvery = std::atoi(argv[++i]);
+        else if (std::strcmp(argv[i], "--builder") == 0 && i + 1 < argc)
+            gs_set_staged_builder(std::strcmp(argv[++i], "reference-order") == 0 ? GS_STAGED_BUILDER_REFERENCE_ORDER : GS_STAGED_BUILDER_SORTED);
+        else if (std::strcmp(argv[i], "--warm-up") == 0 && i + 1 < argc) warmUp = std::atoi(argv[++i]);
         else positional.push_back(argv[i]);
     }
     argc = (int) positional.size();
@@ -184,8 +191,14 @@ int main(int argc, char** argv)
     gs::GpuTimer timer;
     double msSh = 0, msClip = 0, msBuild = 0, msSort = 0, msRanges = 0, msRaster = 0;
     bool saturated = false;
-    for (int frame = 0; frame != frames; ++frame)
+    std::chrono::steady_clock::time_point loopStart = std::chrono::steady_clock::now();
+    for (int frame = -warmUp; frame != frames; ++frame)
     {
+        if (frame == 0)
+        {
+            msSh = msClip = msBuild = msSort = msRanges = msRaster = 0;
+            loopStart = std::chrono::steady_clock::now();
+        }
         if (saturated) // grow the list when the previous frame filled it
         {
             capacity <<= 1;
@@ -194,7 +207,7 @@ int main(int argc, char** argv)
             valuesA.resizeIfNeeded(capacity);
             valuesB.resizeIfNeeded(capacity);
         }
-        if (!events.empty()) // Demo.cpp:371-392: update input & camera controls, build the camera data
+        if (!events.empty() && frame >= 0) // Demo.cpp:371-392: update input & camera controls, build the camera data
         {
             Event e = events[std::min((size_t) frame, events.size() - 1)];
             if ((size_t) frame >= events.size()) e.dt = 0.0f;
@@ -260,7 +273,7 @@ int main(int argc, char** argv)
         // the one exchange of the frame: every band's pixel rows -> rank 0's back buffer (no-op in a world of one)
         if (gs_gather_bands(comm, &backBuffer.getPtr()->x, width, height, bands.data(), 0, gs_get_stream()) != 0) return 1;
         gs_synchronize();
-        if (dumpEvery > 0 && rank == 0 && outPath != nullptr && (frame + 1) % dumpEvery == 0)
+        if (dumpEvery > 0 && frame >= 0 && rank == 0 && outPath != nullptr && (frame + 1) % dumpEvery == 0)
         {
             // the viewer's "screen", headless: every dumpEvery-th frame next to the final image as <out>.<frame>.ppm
             char path[1024];
@@ -268,6 +281,7 @@ int main(int argc, char** argv)
             if (!writePpm(path)) return 1;
         }
     }
+    const double wallMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - loopStart).count();
     gs_device_free(sortTemp);
 
     const double f = frames > 0 ? frames : 1;
@@ -276,6 +290,8 @@ int main(int argc, char** argv)
                 "Evaluate Tile Ranges %.6f ms\nRasterize %.6f ms\nTotal %.6f ms\n",
                 msSh / f, msClip / f, msBuild / f, msSort / f, msRanges / f, msRaster / f,
                 (msSh + msClip + msBuild + msSort + msRanges + msRaster) / f);
+    std::printf("Frame loop wall clock %.6f ms per frame (%s builder)\n", wallMs / f,
+                gs_get_staged_builder() == GS_STAGED_BUILDER_SORTED ? "sorted" : "reference-order");
 
     if (!events.empty())
     {
