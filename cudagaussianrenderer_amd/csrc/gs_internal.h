@@ -194,6 +194,12 @@ struct RadixScratch
     // Tile range table (int32[2 * tiles], preset to -1) that the LAST pass of the next sort fills from its scatter -- the key is then the
     // tile index and no range kernel is needed (GaussianRender.cu:857-888); set per call by the renderer, null otherwise.
     int32_t* rangeTableForLastPass = nullptr;
+    // The staged buildTileList (gs_staged.hip) wants the reference's 64-bit keys beside the sorted values: the LAST pass of the next
+    // sort of tile indices then writes keys64[pos] = tile << 32 | quantizeDepth(clipZ[value]) (GaussianRender.cu:446-454) instead of the
+    // tile index itself.  Set per call, null otherwise.
+    uint64_t* lastPassKeys64 = nullptr;
+    const float* lastPassClipZ = nullptr;
+    bool lastPassIsNow = false; // (set by the sort around its last pass)
     RadixScanCompanion firstScanCompanion; // see above; set per call by the renderer
 };
 // The clip stage of a frame whose depth sort makes its own keys (Morton storage, no band cull), deferred: launched by the sort as the

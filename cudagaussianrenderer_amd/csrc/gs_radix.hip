@@ -206,7 +206,8 @@ template <typename K, int BITS, int ITEMS>
 __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restrict__ keysIn, const int32_t* __restrict__ valuesIn,
                                                                 K* __restrict__ keysOut, int32_t* __restrict__ valuesOut, int nHost, const int* __restrict__ nDevice,
                                                                 int shift, const int32_t* __restrict__ scanned,
-                                                                const int32_t* __restrict__ totals, int stride, int32_t* __restrict__ rangeTable)
+                                                                const int32_t* __restrict__ totals, int stride, int32_t* __restrict__ rangeTable,
+                                                                uint64_t* __restrict__ keys64Out, const float* __restrict__ clipZ)
 {
     constexpr int kTile = kThreads * ITEMS;
     constexpr int kDigitMask = (1 << BITS) - 1;
@@ -350,8 +351,11 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
             const K k = sKeys[j];
             const int digit = (int) ((k >> shift) & kDigitMask);
             const int pos = globalBase[digit] + (j - localBase[digit]);
-            keysOut[pos] = k;
-            valuesOut[pos] = sVals[j];
+            const int32_t v = sVals[j];
+            // (the staged buildTileList: the reference's key -- tile | quantised depth of the entry's splat -- instead of the tile index)
+            if (keys64Out != nullptr) keys64Out[pos] = ((uint64_t) k << 32) | (uint64_t) quantizeDepth(clipZ[v]);
+            else keysOut[pos] = k;
+            valuesOut[pos] = v;
             if (rangeTable != nullptr)
             {
                 // The last pass of the renderer's tile sort finds the tile ranges itself (GaussianRender.cu:857-888; no range kernel):
@@ -371,6 +375,8 @@ template <typename K, int BITS, int ITEMS>
 void runPassItems(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, const DepthKeySource* keySource, K* keysOut, int32_t* valuesOut, int n,
                   int shift, bool skewed, RadixScratch& s, int32_t* lastPassRanges)
 {
+    // (lastPassRanges != nullptr marks the last pass of a sort: the 64-bit keys of the staged builder are written there, if asked for)
+    uint64_t* keys64 = (lastPassRanges != nullptr || s.lastPassIsNow) ? s.lastPassKeys64 : nullptr;
     constexpr int kTile = kThreads * ITEMS;
     const int numTiles = (n + kTile - 1) / kTile;
     const int stride = (numTiles + 3) & ~3; // tiles per digit row of the tables
@@ -402,7 +408,7 @@ void runPassItems(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, 
     else
         hipLaunchKernelGGL(radixColumnScanKernel<1024>, dim3(BITS > 8 ? 2 * kDigits : kDigits), dim3(1024), 0, stream, n, s.countDevice, kTile, stride, s.table, s.scanned, s.chunkTotals);
     hipLaunchKernelGGL((radixScatterKernel<K, BITS, ITEMS>), dim3(8 * ((numTiles + 7) / 8)), dim3(kThreads), 0, stream, keysIn, valuesIn, keysOut,
-                       valuesOut, n, s.countDevice, shift, s.scanned, s.chunkTotals, stride, lastPassRanges);
+                       valuesOut, n, s.countDevice, shift, s.scanned, s.chunkTotals, stride, lastPassRanges, keys64, s.lastPassClipZ);
 }
 
 template <typename K, int BITS>
@@ -452,8 +458,10 @@ int sortT(hipStream_t stream, K* keys0, K* keys1, int32_t* values0, int32_t* val
         // the top digit of a multi-pass sort of tile indices is shared by most neighbours: count it through ballots
         // (beginBit > 0: the passes below it were done elsewhere -- the emit pass of the list builder carries the first one)
         const bool skewed = sizeof(K) == 2 && (passes > 1 || beginBit > 0) && pass == passes - 1 && bits < 8;
+        s.lastPassIsNow = pass == passes - 1;
         runPassBits<K>(stream, bits, kin, vin, pass == 0 ? keySource : nullptr, kout, vout, n, shift, skewed, s,
                        pass == passes - 1 ? s.rangeTableForLastPass : nullptr);
+        s.lastPassIsNow = false;
         shift += bits;
         sel ^= 1;
     }

@@ -8,8 +8,9 @@
 //      word) and a stable three-pass radix sort of the splats by it (gs_radix.hip);
 //   2. count / emit over the depth-sorted splats (gs_tiles_fast.hip: the reference's overlap predicate bit for bit, guard band +
 //      gs_overlap_exact.h), the emit pass carrying the first pass of the tile sort;
-//   3. the remaining pass(es) of the stable tile sort, ending in the CALLER's value buffer;
-//   4. the 64-bit keys (tile << 32 | getKey's quantised depth of the entry's splat) written beside them into the caller's key buffer.
+//   3. the remaining pass(es) of the stable tile sort, ending in the CALLER's value buffer,
+//   4. the last scatter writing the 64-bit keys (tile << 32 | getKey's quantised depth of the entry's splat) beside them into the
+//      caller's key buffer instead of the tile indices (gs_radix.hip, RadixScratch::lastPassKeys64).
 // That is the renderer's two-level sort: N splats through three passes and P pairs of 6 bytes through two,
 // instead of P pairs of 12 bytes through six.  Equal keys (same tile, same depth code) are in splat-index order: the depth sort is
 // stable over the index order and so is the tile sort -- the tie-break the oracle uses.
@@ -33,19 +34,6 @@ __global__ __launch_bounds__(256) void stagedDepthKeysKernel(int n, const float*
     if (i >= n) return;
     keys[i] = compactDepthKey(clipZ[i]);
     order[i] = i;
-}
-
-// keys[i] = getKey(tile of entry i, clip depth of its splat) (GaussianRender.cu:446-454); the list length lives on the device (the low
-// word of the emit pass's 64-bit pair total), bounded by the capacity the grid covers.
-template <typename TileKey>
-__global__ __launch_bounds__(256) void stagedExpandKeysKernel(int capacity, const int* __restrict__ sizeDevice, const TileKey* __restrict__ tiles,
-                                                              const int32_t* __restrict__ values, const float* __restrict__ clipZ,
-                                                              uint64_t* __restrict__ keys)
-{
-    const int size = min(*sizeDevice, capacity);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= size) return;
-    keys[i] = ((uint64_t) tiles[i] << 32) | (uint64_t) quantizeDepth(clipZ[values[i]]);
 }
 
 // One lane = two consecutive keys (16 bytes) + the key in front of them; a wave that sees a descent on the compared bits stores the
@@ -150,18 +138,16 @@ int32_t stagedBuildTileListSorted(GsTimer* timer, int32_t tileListCapacity)
             // (3) the rest of the stable tile sort; the list length stays on the device (the pair total the emit pass left, low word of
             // the little-endian int64), bounded by the capacity
             const int* sizeDevice = (const int*) g.scratch.total;
+            // (4) ... whose last scatter writes the reference's 64-bit keys (tile | quantised depth of the entry's splat) into the caller's
+            // key buffer instead of the tile indices
             st.radixPairs.countDevice = sizeDevice;
             st.radixPairs.rangeTableForLastPass = nullptr;
-            const int sel = launchRadixSortPairs(g.stream, st.radixPairs, tileKeyBytes, st.tileKeys[0], st.tileKeys[1], v0, v1, capacity, sortBits, tBits);
+            st.radixPairs.lastPassKeys64 = g.tileList.keys;
+            st.radixPairs.lastPassClipZ = clipZ;
+            launchRadixSortPairs(g.stream, st.radixPairs, tileKeyBytes, st.tileKeys[0], st.tileKeys[1], v0, v1, capacity, sortBits, tBits);
             st.radixPairs.countDevice = nullptr;
-            // (4) the reference's keys beside the values
-            const dim3 grid((capacity + 255) / 256), block(256);
-            if (tileKeyBytes == 2)
-                hipLaunchKernelGGL(stagedExpandKeysKernel<uint16_t>, grid, block, 0, g.stream, capacity, sizeDevice, (const uint16_t*) st.tileKeys[sel], caller,
-                                   clipZ, g.tileList.keys);
-            else
-                hipLaunchKernelGGL(stagedExpandKeysKernel<uint32_t>, grid, block, 0, g.stream, capacity, sizeDevice, (const uint32_t*) st.tileKeys[sel], caller,
-                                   clipZ, g.tileList.keys);
+            st.radixPairs.lastPassKeys64 = nullptr;
+            st.radixPairs.lastPassClipZ = nullptr;
         }
     }
     gs_timer_stop(timer);
