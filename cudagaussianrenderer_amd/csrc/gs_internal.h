@@ -124,6 +124,10 @@ struct TileListScratch
     int32_t* digitScanned = nullptr;
     int32_t* digitTotals = nullptr;
     int digitStride = 0; // groups per digit row (multiple of 4)
+    // the staged buildTileList (gs_staged.hip), set per call: the depth-SORTED 27-bit codes of the splats (parallel to `order`) and where
+    // the emit pass leaves every pair's 32-bit quantised depth (gs_tiles_fast.hip CARRY); null otherwise
+    const uint32_t* depthSorted = nullptr;
+    uint32_t* carryOut = nullptr;
 };
 void ensureTileListScratch(TileListScratch& s, int count);
 void freeTileListScratch(TileListScratch& s);
@@ -195,10 +199,13 @@ struct RadixScratch
     // tile index and no range kernel is needed (GaussianRender.cu:857-888); set per call by the renderer, null otherwise.
     int32_t* rangeTableForLastPass = nullptr;
     // The staged buildTileList (gs_staged.hip) wants the reference's 64-bit keys beside the sorted values: the LAST pass of the next
-    // sort of tile indices then writes keys64[pos] = tile << 32 | quantizeDepth(clipZ[value]) (GaussianRender.cu:446-454) instead of the
+    // sort of tile indices then writes keys64[pos] = tile << 32 | the pair's quantised depth (GaussianRender.cu:446-454) instead of the
     // tile index itself.  Set per call, null otherwise.
     uint64_t* lastPassKeys64 = nullptr;
-    const float* lastPassClipZ = nullptr;
+    // ... and every pass carries a second 32-bit payload along with the values -- the pairs' quantised depths, from the emit pass --
+    // between these two buffers (carry[0] = the input of the first pass); the last pass puts it into the key's low word.
+    uint32_t* carry[2] = {nullptr, nullptr};
+    int carrySel = 0; // which of the two holds the next pass's input (the sort flips it)
     bool lastPassIsNow = false; // (set by the sort around its last pass)
     RadixScanCompanion firstScanCompanion; // see above; set per call by the renderer
 };

@@ -202,12 +202,16 @@ __global__ __launch_bounds__(kScanThreads) void radixColumnScanKernel(int nHost,
     radixColumnScanRow<kScanThreads>((int) blockIdx.x, nHost, nDevice, tileElements, stride, table, scanned, totals);
 }
 
-template <typename K, int BITS, int ITEMS>
+// CARRY (the staged buildTileList, gs_staged.hip): a second 32-bit payload -- the pair's quantised depth -- travels with the value;
+// the last pass writes it as the low word of the reference's 64-bit key (tile << 32 | depth, GaussianRender.cu:446-454) into keys64Out
+// instead of writing the tile index.
+template <typename K, int BITS, int ITEMS, bool CARRY = false>
 __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restrict__ keysIn, const int32_t* __restrict__ valuesIn,
                                                                 K* __restrict__ keysOut, int32_t* __restrict__ valuesOut, int nHost, const int* __restrict__ nDevice,
                                                                 int shift, const int32_t* __restrict__ scanned,
                                                                 const int32_t* __restrict__ totals, int stride, int32_t* __restrict__ rangeTable,
-                                                                uint64_t* __restrict__ keys64Out, const float* __restrict__ clipZ)
+                                                                const uint32_t* __restrict__ carryIn, uint32_t* __restrict__ carryOut,
+                                                                uint64_t* __restrict__ keys64Out)
 {
     constexpr int kTile = kThreads * ITEMS;
     constexpr int kDigitMask = (1 << BITS) - 1;
@@ -219,6 +223,7 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
     __shared__ int waveSums[2][kWaves];
     __shared__ K sKeys[kTile];
     __shared__ int32_t sVals[kTile];
+    __shared__ uint32_t sCarry[CARRY ? kTile : 1];
 
     const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
     const int n = nDevice ? min(*nDevice, nHost) : nHost;
@@ -236,6 +241,7 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
     // ---- load the tile: element (wave, row, lane) is tile index wave*64*ITEMS + row*64 + lane ---------
     K key[ITEMS];
     int32_t val[ITEMS];
+    uint32_t carried[CARRY ? ITEMS : 1];
 #pragma unroll
     for (int r = 0; r != ITEMS; ++r)
     {
@@ -243,6 +249,7 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
         const bool valid = i < n;
         key[r] = valid ? keysIn[i] : K(0);
         val[r] = valid ? valuesIn[i] : 0;
+        if constexpr (CARRY) carried[r] = valid ? carryIn[i] : 0u;
     }
     int digitTotal[OWN], tileEntry[OWN];
 #pragma unroll
@@ -337,6 +344,7 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
             const int slot = localBase[digit] + cnt[wave][digit] + rank[r];
             sKeys[slot] = key[r];
             sVals[slot] = val[r];
+            if constexpr (CARRY) sCarry[slot] = carried[r];
         }
     }
     __syncthreads();
@@ -351,11 +359,18 @@ __global__ __launch_bounds__(kThreads) void radixScatterKernel(const K* __restri
             const K k = sKeys[j];
             const int digit = (int) ((k >> shift) & kDigitMask);
             const int pos = globalBase[digit] + (j - localBase[digit]);
-            const int32_t v = sVals[j];
-            // (the staged buildTileList: the reference's key -- tile | quantised depth of the entry's splat -- instead of the tile index)
-            if (keys64Out != nullptr) keys64Out[pos] = ((uint64_t) k << 32) | (uint64_t) quantizeDepth(clipZ[v]);
+            valuesOut[pos] = sVals[j];
+            if constexpr (CARRY)
+            {
+                // (the staged buildTileList: the last pass leaves the reference's key, tile | quantised depth, instead of the tile index)
+                if (keys64Out != nullptr) keys64Out[pos] = ((uint64_t) k << 32) | (uint64_t) sCarry[j];
+                else
+                {
+                    keysOut[pos] = k;
+                    carryOut[pos] = sCarry[j];
+                }
+            }
             else keysOut[pos] = k;
-            valuesOut[pos] = v;
             if (rangeTable != nullptr)
             {
                 // The last pass of the renderer's tile sort finds the tile ranges itself (GaussianRender.cu:857-888; no range kernel):
@@ -375,8 +390,7 @@ template <typename K, int BITS, int ITEMS>
 void runPassItems(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, const DepthKeySource* keySource, K* keysOut, int32_t* valuesOut, int n,
                   int shift, bool skewed, RadixScratch& s, int32_t* lastPassRanges)
 {
-    // (lastPassRanges != nullptr marks the last pass of a sort: the 64-bit keys of the staged builder are written there, if asked for)
-    uint64_t* keys64 = (lastPassRanges != nullptr || s.lastPassIsNow) ? s.lastPassKeys64 : nullptr;
+
     constexpr int kTile = kThreads * ITEMS;
     const int numTiles = (n + kTile - 1) / kTile;
     const int stride = (numTiles + 3) & ~3; // tiles per digit row of the tables
@@ -407,8 +421,19 @@ void runPassItems(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, 
         hipLaunchKernelGGL(radixColumnScanKernel<256>, dim3(BITS > 8 ? 2 * kDigits : kDigits), dim3(256), 0, stream, n, s.countDevice, kTile, stride, s.table, s.scanned, s.chunkTotals);
     else
         hipLaunchKernelGGL(radixColumnScanKernel<1024>, dim3(BITS > 8 ? 2 * kDigits : kDigits), dim3(1024), 0, stream, n, s.countDevice, kTile, stride, s.table, s.scanned, s.chunkTotals);
-    hipLaunchKernelGGL((radixScatterKernel<K, BITS, ITEMS>), dim3(8 * ((numTiles + 7) / 8)), dim3(kThreads), 0, stream, keysIn, valuesIn, keysOut,
-                       valuesOut, n, s.countDevice, shift, s.scanned, s.chunkTotals, stride, lastPassRanges, keys64, s.lastPassClipZ);
+    const dim3 scatterGrid(8 * ((numTiles + 7) / 8));
+    if (s.carry[0] != nullptr)
+    {
+        // the staged builder's pairs: depths travel with the values; the last pass turns them into 64-bit keys
+        hipLaunchKernelGGL((radixScatterKernel<K, BITS, ITEMS, true>), scatterGrid, dim3(kThreads), 0, stream, keysIn, valuesIn, keysOut, valuesOut, n,
+                           s.countDevice, shift, s.scanned, s.chunkTotals, stride, lastPassRanges, (const uint32_t*) s.carry[s.carrySel],
+                           s.carry[s.carrySel ^ 1], s.lastPassIsNow ? s.lastPassKeys64 : (uint64_t*) nullptr);
+        s.carrySel ^= 1;
+        return;
+    }
+    hipLaunchKernelGGL((radixScatterKernel<K, BITS, ITEMS, false>), scatterGrid, dim3(kThreads), 0, stream, keysIn, valuesIn, keysOut, valuesOut, n,
+                       s.countDevice, shift, s.scanned, s.chunkTotals, stride, lastPassRanges, (const uint32_t*) nullptr, (uint32_t*) nullptr,
+                       (uint64_t*) nullptr);
 }
 
 template <typename K, int BITS>

@@ -9,8 +9,10 @@
 //   2. count / emit over the depth-sorted splats (gs_tiles_fast.hip: the reference's overlap predicate bit for bit, guard band +
 //      gs_overlap_exact.h), the emit pass carrying the first pass of the tile sort;
 //   3. the remaining pass(es) of the stable tile sort, ending in the CALLER's value buffer,
-//   4. the last scatter writing the 64-bit keys (tile << 32 | getKey's quantised depth of the entry's splat) beside them into the
-//      caller's key buffer instead of the tile indices (gs_radix.hip, RadixScratch::lastPassKeys64).
+//   4. every pair's quantised depth (getKey's low word, decoded from its splat's sorted code by the emit pass) carried along, and the
+//      last scatter writing tile << 32 | depth beside the values into the caller's key buffer instead of the tile indices
+//      (gs_radix.hip CARRY, RadixScratch::lastPassKeys64): no gather of positionClipSpaceZ per pair -- at 5 M splats that gather alone
+//      took 0.9 ms (profiles/r05_staged_path.txt).
 // That is the renderer's two-level sort: N splats through three passes and P pairs of 6 bytes through two,
 // instead of P pairs of 12 bytes through six.  Equal keys (same tile, same depth code) are in splat-index order: the depth sort is
 // stable over the index order and so is the tile sort -- the tie-break the oracle uses.
@@ -81,6 +83,11 @@ void ensureStagedScratch(StagedScratch& s, int splats, int capacityPairs, int ti
     {
         if (s.values) GS_CHECK(hipFree(s.values));
         GS_CHECK(hipMalloc((void**) &s.values, sizeof(int32_t) * (size_t) capacityPairs));
+        for (int i = 0; i != 2; ++i)
+        {
+            if (s.depth[i]) GS_CHECK(hipFree(s.depth[i]));
+            GS_CHECK(hipMalloc((void**) &s.depth[i], sizeof(uint32_t) * (size_t) capacityPairs));
+        }
         s.capacityPairs = capacityPairs;
     }
 }
@@ -126,6 +133,8 @@ int32_t stagedBuildTileListSorted(GsTimer* timer, int32_t tileListCapacity)
         const int sortBits = cfg.listFusion ? tileListFusedSortBits(tBits, tileKeyBytes) : 0;
         g.scratch.tileRecord = nullptr;
         g.scratch.countDevice = nullptr;
+        g.scratch.depthSorted = st.depthKey[orderSel]; // the emit pass decodes every pair's quantised depth from its splat's sorted code ...
+        g.scratch.carryOut = st.depth[0];              // ... and leaves it beside the pair (no gather of clipZ anywhere)
         launchTileListFastCount(g.stream, n, scr, order, clipXY, ellipse, g.scratch, sortBits);
         // The passes that are left flip between two buffer pairs; the value half they END in is the caller's list.
         const int passes = radixSortPasses(sortBits, tBits);
@@ -133,6 +142,8 @@ int32_t stagedBuildTileListSorted(GsTimer* timer, int32_t tileListCapacity)
         int32_t* v0 = (passes % 2 == 0) ? caller : st.values;
         int32_t* v1 = (passes % 2 == 0) ? st.values : caller;
         launchTileListFastEmit(g.stream, n, scr, order, clipXY, ellipse, g.scratch, st.tileKeys[0], tileKeyBytes, v0, capacity, 0, sortBits);
+        g.scratch.depthSorted = nullptr;
+        g.scratch.carryOut = nullptr;
         if (capacity > 0)
         {
             // (3) the rest of the stable tile sort; the list length stays on the device (the pair total the emit pass left, low word of
@@ -143,11 +154,13 @@ int32_t stagedBuildTileListSorted(GsTimer* timer, int32_t tileListCapacity)
             st.radixPairs.countDevice = sizeDevice;
             st.radixPairs.rangeTableForLastPass = nullptr;
             st.radixPairs.lastPassKeys64 = g.tileList.keys;
-            st.radixPairs.lastPassClipZ = clipZ;
+            st.radixPairs.carry[0] = st.depth[0];
+            st.radixPairs.carry[1] = st.depth[1];
+            st.radixPairs.carrySel = 0;
             launchRadixSortPairs(g.stream, st.radixPairs, tileKeyBytes, st.tileKeys[0], st.tileKeys[1], v0, v1, capacity, sortBits, tBits);
             st.radixPairs.countDevice = nullptr;
             st.radixPairs.lastPassKeys64 = nullptr;
-            st.radixPairs.lastPassClipZ = nullptr;
+            st.radixPairs.carry[0] = st.radixPairs.carry[1] = nullptr;
         }
     }
     gs_timer_stop(timer);

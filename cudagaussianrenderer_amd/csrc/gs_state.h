@@ -37,7 +37,8 @@ struct StagedScratch
     int capacitySplats = 0;
     void* tileKeys[2] = {nullptr, nullptr};
     int32_t* values = nullptr;
-    int64_t capacityPairBytes = 0; // bytes of each tileKeys half; values holds capacityPairs entries
+    uint32_t* depth[2] = {nullptr, nullptr}; // the pairs' quantised depths, carried through the tile sort beside the values
+    int64_t capacityPairBytes = 0; // bytes of each tileKeys half; values and depth[] hold capacityPairs entries
     int capacityPairs = 0;
     gs::RadixScratch radixPairs;
     int* unsortedEpoch = nullptr;     // device word: the epoch of the last check that found a descent

@@ -71,9 +71,10 @@ static_assert(kStageFlushAt > 0, "a round's pairs must fit the staging buffer");
 
 // OPERANDS = false (the emit pass that carries the tile sort's first pass, whose LDS goes to the staging buffer): without the operands of
 // the overlap tests -- the rare rounds past the recorded ones fetch their unit's splat record again and derive them on the spot.
-template <bool OPERANDS>
+template <bool OPERANDS, bool CARRY = false>
 struct GroupStage
 {
+    unsigned depth[CARRY ? kGroup : 1]; // CARRY (the staged buildTileList): getKey's quantised depth of the group's splats, the low word of their pairs' 64-bit keys
     int excl[kGroup];   // exclusive prefix of units
     int area[kGroup];   // AABB tiles
     int origin[kGroup]; // x0 | y0 << 16
@@ -192,7 +193,21 @@ __device__ __forceinline__ int centreTileOnAxis(float c, float size, float tiles
     return count == 1 ? found : (count == 0 ? -1 : -2);
 }
 
-template <bool EMIT, typename TileKey, int SORT_BITS>
+// Inverse of compactDepthKey (gs_depth_key.h): the 32-bit quantised depth of getKey() back from its lossless 27-bit re-coding.
+__device__ __forceinline__ unsigned expandDepthKey(unsigned code)
+{
+    const unsigned cls = code >> 23;
+    if (cls == 0u) return code;
+    if (cls >= 10u) return 0xFFFFFFFFu;
+    const unsigned top = cls + 22u;
+    return (1u << top) | ((code & 0x7FFFFFu) << (top - 23u));
+}
+
+// CARRY (EMIT only; the staged buildTileList, gs_staged.hip): every pair also gets the quantised depth of its splat (decoded from the
+// depth-sorted codes, `depthSorted`) written to carryOut at the pair's position -- the sort's remaining passes carry it along and the
+// last one writes tile << 32 | depth as the reference's 64-bit key, without a gather.  The staging buffer then holds the splat's
+// LOCAL index; splat index and depth come from the group's LDS tables when the pair is written.
+template <bool EMIT, typename TileKey, int SORT_BITS, bool CARRY = false>
 __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, const int* __restrict__ countDevice, Screen scr, const uint32_t* __restrict__ order,
                                                              const float2* __restrict__ clipXY, const float4* __restrict__ screenEllipse,
                                                              int32_t* __restrict__ groupCounts, const int32_t* __restrict__ groupOffsets,
@@ -200,8 +215,10 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                                                              uint8_t* __restrict__ hitMasks, const float4* __restrict__ tileRecord,
                                                              int64_t* __restrict__ total, int64_t* __restrict__ totalHostMapped, int viewSplats,
                                                              int4* __restrict__ boxRecords, int32_t* __restrict__ digitTable,
-                                                             const int32_t* __restrict__ digitTotals, int digitStride)
+                                                             const int32_t* __restrict__ digitTotals, int digitStride,
+                                                             const uint32_t* __restrict__ depthSorted, uint32_t* __restrict__ carryOut)
 {
+    static_assert(!CARRY || EMIT, "only the emit pass carries depths");
     // SORT_BITS > 0: the first pass of the tile sort happens here.  COUNT also counts the pairs' low tile digits (digitTable[digit][group],
     // raw); EMIT gets the table scanned over the groups + the digit totals and writes every pair where a stable scatter on that digit
     // would have put it.
@@ -209,7 +226,7 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
     constexpr int kBins = FUSED ? (1 << SORT_BITS) : 1;
     static_assert(kBins <= kGroup, "one digit per lane");
     constexpr bool LEAN = EMIT && FUSED; // no overlap operands in LDS
-    __shared__ GroupStage<!LEAN> st;
+    __shared__ GroupStage<!LEAN, CARRY> st;
     __shared__ int digitHist[!EMIT && FUSED ? kBins : 1];
     __shared__ int sortCnt[EMIT && FUSED ? kWavesPerBlock : 1][kBins];
     __shared__ int sortLocalBase[EMIT && FUSED ? kBins : 1];
@@ -438,6 +455,7 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
         overlapOperands();
         if (poisoned) guard = __builtin_inff();
     }
+    if constexpr (CARRY) st.depth[t] = sorted < count ? expandDepthKey(depthSorted[sorted]) : 0u;
     st.excl[t] = unitsBefore + incl - units;
     st.area[t] = area;
     st.origin[t] = x0 | (y0 << 16);
@@ -543,7 +561,13 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                 if (pos < (unsigned) capacity)
                 {
                     tileKeys[pos] = k;
-                    values[pos] = stageValues[j];
+                    if constexpr (CARRY)
+                    {
+                        const int local = stageValues[j]; // the splat's index in this group
+                        values[pos] = st.splat[local];
+                        carryOut[pos] = st.depth[local];
+                    }
+                    else values[pos] = stageValues[j];
                 }
             }
         }
@@ -793,12 +817,13 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                     if (FUSED)
                     {
                         stageKeys[pos] = (TileKey) (gy * scr.tilesX + gx + viewTileBase);
-                        stageValues[pos] = splatK;
+                        stageValues[pos] = CARRY ? k : splatK;
                     }
                     else if (pos < (unsigned) capacity)
                     {
                         tileKeys[pos] = (TileKey) (gy * scr.tilesX + gx + viewTileBase);
                         values[pos] = splatK;
+                        if constexpr (CARRY) carryOut[pos] = st.depth[k];
                     }
                     ++pos;
                 }
@@ -927,9 +952,15 @@ void launchEmit(hipStream_t stream, dim3 grid, dim3 block, int count, const Scre
                 const float4* screenEllipse, const TileListScratch& s, const int32_t* groupOffsets, void* tileKeys, int32_t* values, int capacity,
                 int viewSplats)
 {
-    hipLaunchKernelGGL((tileListFastKernel<true, TileKey, SORT_BITS>), grid, block, 0, stream, count, s.countDevice, scr, order, clipXY, screenEllipse,
-                       s.waveCounts, groupOffsets, (TileKey*) tileKeys, values, capacity, s.hitMasks, s.tileRecord, s.total,
-                       s.totalHostMapped, viewSplats, (int4*) s.boxRecords, s.digitScanned, s.digitTotals, s.digitStride);
+    if (s.carryOut != nullptr) // (the staged buildTileList: see CARRY)
+        hipLaunchKernelGGL((tileListFastKernel<true, TileKey, SORT_BITS, true>), grid, block, 0, stream, count, s.countDevice, scr, order, clipXY, screenEllipse,
+                           s.waveCounts, groupOffsets, (TileKey*) tileKeys, values, capacity, s.hitMasks, s.tileRecord, s.total,
+                           s.totalHostMapped, viewSplats, (int4*) s.boxRecords, s.digitScanned, s.digitTotals, s.digitStride, s.depthSorted, s.carryOut);
+    else
+        hipLaunchKernelGGL((tileListFastKernel<true, TileKey, SORT_BITS, false>), grid, block, 0, stream, count, s.countDevice, scr, order, clipXY, screenEllipse,
+                           s.waveCounts, groupOffsets, (TileKey*) tileKeys, values, capacity, s.hitMasks, s.tileRecord, s.total,
+                           s.totalHostMapped, viewSplats, (int4*) s.boxRecords, s.digitScanned, s.digitTotals, s.digitStride, (const uint32_t*) nullptr,
+                           (uint32_t*) nullptr);
 }
 
 template <int SORT_BITS>
@@ -940,7 +971,8 @@ void launchCount(hipStream_t stream, int groups, int count, const Screen& scr, c
         groups = (groups + 8 * GS_FUSED_XCD_CHUNK - 1) / (8 * GS_FUSED_XCD_CHUNK) * (8 * GS_FUSED_XCD_CHUNK); // whole chunks on every XCD
     hipLaunchKernelGGL((tileListFastKernel<false, uint16_t, SORT_BITS>), dim3(groups), dim3(kGroup), 0, stream, count, s.countDevice, scr, order, clipXY,
                        screenEllipse, s.waveCounts, (const int32_t*) nullptr, (uint16_t*) nullptr, (int32_t*) nullptr, 0, s.hitMasks, s.tileRecord,
-                       (int64_t*) nullptr, (int64_t*) nullptr, viewSplats, (int4*) s.boxRecords, s.digitTable, (const int32_t*) nullptr, s.digitStride);
+                       (int64_t*) nullptr, (int64_t*) nullptr, viewSplats, (int4*) s.boxRecords, s.digitTable, (const int32_t*) nullptr, s.digitStride,
+                       (const uint32_t*) nullptr, (uint32_t*) nullptr);
 }
 
 } // namespace
