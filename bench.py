@@ -446,26 +446,35 @@ def stage_report(rig, args, stage_ms, p_mean, pc_mean, nonempty, band_tiles, ban
 
 
 def offline_counters(args, world):
-    """PMC figures of the raster kernel from the committed counter passes (profiles/r04_pmc_raster.json: separate rocprofv3
+    """PMC figures of the raster kernel from the committed counter passes (profiles/rNN_pmc_raster.json: separate rocprofv3
     --pmc passes of this very workload, tools/profile_round.sh).  Counters cannot be collected from inside the timed run, so
     they are attached only when the run IS that workload and the kernel sources are the ones the counters were collected
     with (source hash); otherwise every field is null.  "counters" says so in the line itself: OFFLINE, and from which file."""
     empty = {"traffic": None, "valu_issue_frac": None, "waves_per_simd": None, "counters": None}
     default_scene = (world == 1 and args.splats == 1_000_000 and (args.width, args.height) == (1920, 1080) and args.sh_degree == 3
                      and args.seed == 1234 and args.opacity_mean == 1.0 and args.log_scale_mean == -3.6 and not args.epanechnikov)
-    path = os.path.join(ROOT, "profiles", "r04_pmc_raster.json")
-    if not default_scene or not os.path.exists(path):
+    # the newest committed counter file of this workload whose kernel sources are the ones this run executes
+    import glob
+
+    candidates = sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_pmc_raster.json")), reverse=True)
+    if not default_scene or not candidates:
         return empty
-    with open(path) as f:
-        d = json.load(f)
-    if d.get("source_hash") != source_hash():
-        return dict(empty, counters_note=f"profiles/r04_pmc_raster.json was collected with other kernel sources ({d.get('source_hash')})")
+    here = source_hash()
+    d, name = None, None
+    for path in candidates:
+        with open(path) as f:
+            c = json.load(f)
+        if c.get("source_hash") == here:
+            d, name = c, "profiles/" + os.path.basename(path)
+            break
+    if d is None:
+        return dict(empty, counters_note=f"profiles/{os.path.basename(candidates[0])} (the newest) was collected with other kernel sources; this run's hash is {here}")
     out = {"traffic": round(d["traffic_bytes_per_launch"]), "traffic_unit": "bytes per launch", "traffic_source": d["traffic_source"],
            "traffic_low": round(d.get("traffic_bytes_per_launch_low", d["traffic_bytes_per_launch"])),
            "traffic_high": round(d.get("traffic_bytes_per_launch_high", d["traffic_bytes_per_launch"])),
            "fetch_requests_per_launch": d.get("fetch_requests_per_launch"),
            "valu_issue_frac": d.get("valu_issue_frac"), "waves_per_simd": d.get("waves_per_simd"), "counters_source": d.get("sq_source"),
-           "counters": "OFFLINE: traffic, valu_issue_frac and waves_per_simd are read from profiles/r04_pmc_raster.json (separate rocprofv3 --pmc "
+           "counters": f"OFFLINE: traffic, valu_issue_frac and waves_per_simd are read from {name} (separate rocprofv3 --pmc "
                        "passes of this workload with one frame in flight and plain launches, same kernel sources by hash), not measured in this run"}
     return out
 
