@@ -1430,3 +1430,57 @@ print("AUDIT " + json.dumps(report))
         assert exact <= audited and slow <= units, entry
     # the audit saw the machinery at work: the band was entered, and the tight box did drop tiles
     assert sum(e["stats"][2] for e in report) > 0 and sum(e["stats"][6] for e in report) > 0
+
+
+@pytest.mark.parametrize("w,h,n,scales,rows,capacity", [
+    (7680, 4320, 3000, (0.002, 0.6), (0, 0), None),      # 129 600 tiles: 32-bit tile indices, two 9 / 8-bit passes, depths carried through both
+    (4096, 4096, 20000, (0.002, 0.2), (0, 0), None),     # 65 536 tiles: the last size with 16-bit indices (8 + 8, fused first pass)
+    (1920, 1080, 50000, (0.005, 0.2), (20, 29), None),   # a tile-row band of a multi-GPU split (GsGlobalArgs.tileRowBegin/End)
+    (1000, 600, 30000, (0.005, 0.3), (0, 0), 777),       # a capacity far below the demand
+    (256, 256, 20000, (0.01, 0.5), (0, 0), 1),           # ... of one entry
+    (640, 368, 0, (0.01, 0.5), (0, 0), None),            # no splats
+    (300, 200, 1, (0.5, 0.5), (0, 0), None),             # one splat
+    (16, 16, 5000, (0.01, 0.5), (0, 0), None),           # one tile (one key bit)
+])
+def test_staged_sorted_builder_matches_reference_order_builder(gs, w, h, n, scales, rows, capacity):
+    """The eight staged calls with the SORTED builder (default) against the same calls with the REFERENCE_ORDER builder + rocPRIM's
+    64-bit sort, on shapes the oracle comparison of test_tile_list_sort_ranges_bit_exact does not reach: the sorted lists (keys AND
+    values), the ranges and the image bytes are the same; with a capacity below the demand both keep `capacity` pairs, the demand they
+    report is the same and the SORTED one's subset is in order."""
+    pos, sr, col = _procedural(gs, max(n, 1), seed=21, min_scale=scales[0], max_scale=scales[1])
+    pos, sr, col = pos[:n], sr[:n], col[:n]
+    cam = gs.camera_from_bounds([-4] * 3, [4] * 3, w, h)
+    results = {}
+    probe = StagedFrame(pos, sr, col, cam, w, h, capacity=64, tile_rows=rows)  # how long is the list? (both builders report the demand)
+    probe.begin()
+    probe.run_clip()
+    probe.run_build()
+    room = int(gs.lib().gs_last_tile_list_demand()) + 16
+    try:
+        for builder in (gs.STAGED_BUILDER_REFERENCE_ORDER, gs.STAGED_BUILDER_SORTED):
+            gs.lib().gs_set_staged_builder(builder)
+            f = StagedFrame(pos, sr, col, cam, w, h, capacity=capacity if capacity is not None else room, tile_rows=rows)
+            f.begin()
+            f.run_clip()
+            keys, values, size = f.run_build()
+            demand = gs.lib().gs_last_tile_list_demand()
+            if builder == gs.STAGED_BUILDER_SORTED:
+                assert np.all(np.diff(keys) >= 0) or size < 2
+                assert len(set(zip(keys.tolist(), values.tolist()))) == size  # no pair twice, nothing stale
+            sk, sv = f.run_sort()
+            rng = f.run_ranges()
+            img = f.run_raster()
+            results[builder] = (size, demand, sk, sv, rng, img)
+            f.free_sort_temp()
+    finally:
+        gs.lib().gs_set_staged_builder(gs.STAGED_BUILDER_SORTED)
+    a, b = results[gs.STAGED_BUILDER_REFERENCE_ORDER], results[gs.STAGED_BUILDER_SORTED]
+    assert a[0] == b[0] and a[1] == b[1], (a[:2], b[:2])
+    if capacity is None:
+        assert a[1] == a[0]  # nothing cut off: the lists must be the same list
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+        assert np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+        if n > 1:
+            assert a[0] > 0
+    else:
+        assert a[0] == min(capacity, a[1]) and a[1] > capacity
