@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void stagedDepthKeysKernel(int n, const float*
 // One lane = two consecutive keys (16 bytes) + the key in front of them; a wave that sees a descent on the compared bits stores the
 // epoch of this check (plain store: every writer writes the same value).
 __global__ __launch_bounds__(256) void stagedSortedCheckKernel(int size, const uint64_t* __restrict__ keys, uint64_t mask, int epoch,
-                                                               int* __restrict__ unsortedEpoch)
+                                                               int* __restrict__ unsortedEpoch, int* __restrict__ unsortedEpochHostMapped)
 {
     const int first = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
     bool descent = false;
@@ -53,7 +53,13 @@ __global__ __launch_bounds__(256) void stagedSortedCheckKernel(int size, const u
         const uint64_t before = first > 0 ? (keys[first - 1] & mask) : 0ull;
         descent = before > a || a > b;
     }
-    if (__any(descent) && (threadIdx.x & (kWave - 1)) == 0) *unsortedEpoch = epoch;
+    // The verdict goes straight into a pinned, device-mapped host word (no copy behind the kernel).  A list in order writes nothing;
+    // of an unordered one only the waves that have not yet seen the device-side word set cross the bus (benign race: all write `epoch`).
+    if (__any(descent) && (threadIdx.x & (kWave - 1)) == 0 && __builtin_nontemporal_load(unsortedEpoch) != epoch)
+    {
+        *unsortedEpoch = epoch;
+        *unsortedEpochHostMapped = epoch;
+    }
 }
 
 void ensureStagedScratch(StagedScratch& s, int splats, int capacityPairs, int tileKeyBytes)
@@ -95,10 +101,11 @@ void ensureStagedScratch(StagedScratch& s, int splats, int capacityPairs, int ti
 void ensureSortedCheck(StagedScratch& s)
 {
     if (s.unsortedEpoch != nullptr) return;
-    GS_CHECK(hipMalloc((void**) &s.unsortedEpoch, sizeof(int)));
-    GS_CHECK(hipMemset(s.unsortedEpoch, 0, sizeof(int)));
-    GS_CHECK(hipHostMalloc((void**) &s.unsortedEpochHost, sizeof(int)));
+    GS_CHECK(hipMalloc((void**) &s.unsortedEpoch, 2 * sizeof(int)));
+    GS_CHECK(hipMemset(s.unsortedEpoch, 0, 2 * sizeof(int)));
+    GS_CHECK(hipHostMalloc((void**) &s.unsortedEpochHost, sizeof(int), hipHostMallocMapped));
     *s.unsortedEpochHost = 0;
+    if (hipHostGetDevicePointer((void**) &s.unsortedEpochHostMapped, s.unsortedEpochHost, 0) != hipSuccess) s.unsortedEpochHostMapped = nullptr;
 }
 
 } // namespace
@@ -179,8 +186,10 @@ bool stagedListIsSorted(int32_t size, const uint64_t* keys, int endBit)
     st.epoch = st.epoch == 0x7FFFFFFF ? 1 : st.epoch + 1;
     const uint64_t mask = endBit >= 64 ? ~0ull : ((1ull << endBit) - 1ull);
     const int lanes = (size + 1) / 2;
-    hipLaunchKernelGGL(stagedSortedCheckKernel, dim3((lanes + 255) / 256), dim3(256), 0, g.stream, size, keys, mask, st.epoch, st.unsortedEpoch);
-    GS_CHECK(hipMemcpyAsync(st.unsortedEpochHost, st.unsortedEpoch, sizeof(int), hipMemcpyDeviceToHost, g.stream));
+    // (no mapped word: the verdict lands in a device-side scratch word next to the epoch word and is copied behind the kernel)
+    int* verdict = st.unsortedEpochHostMapped != nullptr ? st.unsortedEpochHostMapped : st.unsortedEpoch + 1;
+    hipLaunchKernelGGL(stagedSortedCheckKernel, dim3((lanes + 255) / 256), dim3(256), 0, g.stream, size, keys, mask, st.epoch, st.unsortedEpoch, verdict);
+    if (st.unsortedEpochHostMapped == nullptr) GS_CHECK(hipMemcpyAsync(st.unsortedEpochHost, verdict, sizeof(int), hipMemcpyDeviceToHost, g.stream));
     GS_CHECK(hipStreamSynchronize(g.stream));
     return *st.unsortedEpochHost != st.epoch;
 }

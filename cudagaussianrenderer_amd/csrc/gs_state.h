@@ -42,7 +42,8 @@ struct StagedScratch
     int capacityPairs = 0;
     gs::RadixScratch radixPairs;
     int* unsortedEpoch = nullptr;     // device word: the epoch of the last check that found a descent
-    int* unsortedEpochHost = nullptr; // pinned mirror
+    int* unsortedEpochHost = nullptr; // pinned host word the check kernel writes its verdict to ...
+    int* unsortedEpochHostMapped = nullptr; // ... through this device address
     int epoch = 0;
 };
 

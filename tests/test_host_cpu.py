@@ -4,9 +4,12 @@ import ctypes as C
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _load_npz(path):
@@ -85,6 +88,43 @@ def test_parse_ply_empty_and_large_roundtrip(gs, gsref, tmp_path):
         assert a["shDegree"] == b["shDegree"] == degree
         for key in ["boundsMin", "boundsMax", "position", "scaleAndRotation", "color", "sh"]:
             assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), (degree, key)
+
+
+def test_parse_ply_on_several_threads_and_when_threads_cannot_be_had(gs, gsref, tmp_path):
+    """gs_parse_ply converts files of 65 536 vertices and more on several host threads (pread slices): same arrays as the oracle's
+    serial parse bit for bit.  ADVICE r04: when the threads cannot be created (EAGAIN under a process limit) the slices are converted
+    by the calling thread instead -- same arrays, error text and return code intact, no std::terminate.  The limit can only be
+    provoked by an ordinary user (RLIMIT_NPROC does not bind root): that half runs on the GPU box, or wherever the suite is not root."""
+    import subprocess
+
+    from cudagaussianrenderer_amd import scenes
+
+    names, table = scenes.synthetic_vertex_table(200_000, sh_degree=1, seed=9)
+    p = tmp_path / "big.ply"
+    scenes.write_ply(str(p), names, table)
+    a, b = gs.parse_ply(str(p)), gsref.parse_ply(str(p))
+    for key in ["boundsMin", "boundsMax", "position", "scaleAndRotation", "color", "sh"]:
+        assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), key
+    if os.geteuid() == 0:
+        return
+    code = ("import resource, sys, hashlib\n"
+            f"sys.path.insert(0, {ROOT!r})\n"
+            "import cudagaussianrenderer_amd as gs\n"
+            "gs.lib()\n"
+            "resource.setrlimit(resource.RLIMIT_NPROC, (1, 1))  # this user already runs more than one process: no new thread can start\n"
+            f"ply = gs.parse_ply({str(p)!r})\n"
+            "h = hashlib.sha256()\n"
+            "for key in ['boundsMin', 'boundsMax', 'position', 'scaleAndRotation', 'color', 'sh']:\n"
+            "    h.update(ply[key].tobytes())\n"
+            "print('DIGEST', ply['vertexCount'], h.hexdigest())\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1500:]
+    import hashlib
+
+    h = hashlib.sha256()
+    for key in ["boundsMin", "boundsMax", "position", "scaleAndRotation", "color", "sh"]:
+        h.update(a[key].tobytes())
+    assert f"DIGEST 200000 {h.hexdigest()}" in out.stdout
 
 
 def test_encode_vec4_matches_reference(gs, golden_dir):
