@@ -145,7 +145,8 @@ class Rig:
         self.V = args.views_per_chain if args.views_per_chain > 0 else (4 if world > 1 else 1)
         if args.no_graph:
             self.V = 1  # several views per chain exist for captured frames only
-        self.streams = [torch.cuda.Stream(device) for _ in range(depth)]
+        prios = [int(v) for v in args.stream_priorities.split(",")] if args.stream_priorities else []
+        self.streams = [torch.cuda.Stream(device, priority=prios[d % len(prios)]) if prios else torch.cuda.Stream(device) for d in range(depth)]
         self.renderers, self.framebuffers = [], []
         for d in range(depth):
             r = gs.Renderer(self.W, self.H, tile_rows=self.band if world > 1 else None, band_cull=args.band_cull, pipeline=args.pipeline,
@@ -511,6 +512,7 @@ def main():
     ap.add_argument("--watchdog", type=float, default=180.0, help="multi-GPU: seconds without progress after which a rank prints where it was and exits 5 (0 = off)")
     ap.add_argument("--storage-order", choices=["auto", "caller", "morton"], default="auto", help="how the renderers store the splats (gs_renderer_set_storage_order): the file's order, or along a 3-D Morton curve (same frames byte for byte; +2 %% frames/s on one GPU, -10 %% per band frame of an 8-way split: profiles/r04_ab_experiments.txt, r04_band_sim.txt); auto = morton")
     ap.add_argument("--list-fusion", type=int, default=-1, help="gs_set_list_fusion: 1 the emit pass carries the first pass of the tile sort, 0 plain emit + full tile sort, -1 the library's default")
+    ap.add_argument("--stream-priorities", default="", help="diagnostics: comma-separated HIP stream priorities of the frames in flight (0 normal, -1 high), cycled; empty = default streams")
     ap.add_argument("--inflight", type=int, default=0, help="frames in flight per GPU (renderers on separate HIP streams); 0 = 4 (the measured optimum with 8 hardware queues)")
     args = ap.parse_args()
     if args.storage_order == "auto":

@@ -100,6 +100,13 @@ def test_cpp_host_ply_frame_equals_python_reference_pipeline(gs, demo_binary, tm
     scenes.write_synthetic_ply(ply_path, 20000, sh_degree=3, seed=3, log_scale_mean=-1.0)  # ~14 pairs per splat
     out = str(tmp_path / "ply.ppm")
     subprocess.run([demo_binary, ply_path, "333", "177", "4", out], stdout=subprocess.DEVNULL, check=True)
+    # the same loop with the (splat, local tile) emission order and the unconditional sort, and with warm-up frames the printed averages
+    # leave out: the same bytes, and the reference's Stats table plus the loop's wall clock
+    other = str(tmp_path / "ply_reference_order.ppm")
+    log = subprocess.run([demo_binary, ply_path, "333", "177", "3", other, "--builder", "reference-order", "--warm-up", "2"], stdout=subprocess.PIPE,
+                         text=True, check=True).stdout
+    assert open(out, "rb").read() == open(other, "rb").read()
+    assert "Frame loop wall clock" in log and "(reference-order builder)" in log and "Total" in log
     ply = gs.parse_ply(ply_path)
     cam = gs.camera_from_bounds(ply["boundsMin"], ply["boundsMax"], 333, 177)
     r = gs.Renderer(333, 177, pipeline=gs.PIPELINE_REFERENCE)
