@@ -325,3 +325,35 @@ def test_camera_controls_default_pose_is_the_reference_default_pose(gs, golden_d
         for name in ("position", "view", "projection", "viewProjection", "fovCotangent", "depthScaleBias"):
             assert np.array_equal(np.array(getattr(cam, name)[:], np.float32), np.array(c[name], np.float32)), name
         assert np.float32(cam.aspect) == np.float32(c["aspect"])
+
+
+def test_ingest_is_clean_under_address_undefined_and_thread_sanitizers(tmp_path):
+    """csrc/gs_host.cpp (PLY ingest on several threads, Morton order, procedural scene) rebuilt for the CPU with
+    -fsanitize=address,undefined and again with -fsanitize=thread (sanitizers run on the CPU build only: the GPU pool has none), driven
+    through gs_parse_ply on a multi-threaded file, a small one, a truncated one and a missing one: no report, same return codes."""
+    import shutil
+    import subprocess
+
+    from cudagaussianrenderer_amd import scenes
+
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    main = tmp_path / "main.cpp"
+    main.write_text('#include <cstdio>\n#include "gsplat_hip.h"\nint main(int argc, char** argv) {\n  GsPly ply; char err[512];\n'
+                    '  for (int i = 1; i < argc; ++i) {\n    int n = gs_parse_ply(argv[i], &ply, err, sizeof err);\n'
+                    '    std::printf("%d\\n", n);\n    if (n >= 0) gs_free_ply(&ply);\n  }\n  return 0;\n}\n')
+    big, small, cut = tmp_path / "big.ply", tmp_path / "small.ply", tmp_path / "cut.ply"
+    scenes.write_synthetic_ply(str(big), 150_000, sh_degree=2, seed=3)
+    scenes.write_synthetic_ply(str(small), 500, sh_degree=0, seed=3)
+    cut.write_bytes(big.read_bytes()[:3_000_000])
+    src = os.path.join(ROOT, "cudagaussianrenderer_amd", "csrc", "gs_host.cpp")
+    for flags in (["-fsanitize=address,undefined"], ["-fsanitize=thread"]):
+        exe = tmp_path / ("t" + flags[0][-6:].replace("=", "").replace(",", ""))
+        build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fno-omit-frame-pointer", "-pthread", *flags, "-I", os.path.join(ROOT, "include"),
+                                str(main), src, "-o", str(exe)], capture_output=True, text=True)
+        if build.returncode != 0:
+            pytest.skip("sanitizer runtime not available: " + build.stderr[-200:])
+        run = subprocess.run([str(exe), str(big), str(small), str(cut), str(tmp_path / "missing.ply")], capture_output=True, text=True, timeout=300)
+        assert run.returncode == 0, run.stderr[-2000:]
+        assert run.stdout.split() == ["150000", "500", "150000", "-1"], run.stdout
+        assert "runtime error" not in run.stderr and "Sanitizer" not in run.stderr, run.stderr[-2000:]
