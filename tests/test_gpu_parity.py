@@ -1414,6 +1414,13 @@ w, h = 1920, 1080
 cams = [gs.camera_from_pose(p, q, w, h) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 8)]
 for order in ("caller", "morton"):
     run(f"clustered ply 200000 @ 1080p, 8-view orbit, {order}", w, h, (ply["position"], ply["scaleAndRotation"], ply["color"]), cams, storage_order=order)
+# the same builder behind the staged buildTileList (gs_staged.hip: clip data from the caller's arrays instead of the packed records)
+from tests.gpu_helpers import StagedFrame
+pos, sr, col = gs.generate_random_gaussians(40000, seed=11, min_scale=0.0004, max_scale=0.9)
+f = StagedFrame(pos, sr, col, gs.camera_from_bounds([-4] * 3, [4] * 3, 1280, 720), 1280, 720, capacity=40_000_000)
+f.begin(); f.run_clip(); _, _, size = f.run_build()
+fn(out, 1)
+report.append({"scene": "staged buildTileList (sorted builder), procedural 40000 @ 1280x720", "pairs": int(size), "stats": [int(v) for v in out]})
 print("AUDIT " + json.dumps(report))
 """ % (root, str(tmp_path / "audit_scene.ply"))
     env = dict(os.environ, GSPLAT_HIP_LIBRARY=audit)
@@ -1421,7 +1428,7 @@ print("AUDIT " + json.dumps(report))
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("AUDIT ")][-1]
     report = json.loads(line[6:])
-    assert len(report) == 9
+    assert len(report) == 10
     for entry in report:
         units, slow, exact, changed, audited, differing, dropped, dropped_hits = entry["stats"]
         assert audited > entry["pairs"] > 0, entry  # every listed pair is a tile that was decided, and audited
