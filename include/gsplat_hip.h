@@ -124,7 +124,7 @@ int32_t gs_build_tile_list(GsTimer* timer, int32_t numBlocks, int32_t tileListCa
  * the second pass ends in the caller's value buffer and the 64-bit keys are written beside it: the list leaves buildTileList in
  * (tile, depth, splat index) order.  gs_sort_tile_list then looks before it sorts (one pass over the keys): a stable sort of a
  * list that is already in order on the compared bits is the identity, so it returns with the selectors untouched; any other list is
- * sorted as before.  Same sorted list as REFERENCE_ORDER + sort, bit for bit (keys and values), at 0.2 instead of 0.65 ms for the two
+ * sorted as before.  Same sorted list as REFERENCE_ORDER + sort, bit for bit (keys and values), at 0.23 instead of 0.62 ms for the two
  * calls at BASELINE.json configs[2] (profiles/r05_staged_path.txt).  A list cut off by the capacity is a sorted subset of the full
  * list (the reference's is an arbitrary subset, .cu:700-703).
  * REFERENCE_ORDER: (splat, local tile) emission order (gs_tiles.hip, the order the oracle emits in) and an unconditional sort. */
