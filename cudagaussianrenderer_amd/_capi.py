@@ -149,6 +149,7 @@ SIGNATURES = {
     "gs_set_sort_backend": (None, [C.c_int]),
     "gs_set_staged_builder": (None, [C.c_int]),
     "gs_get_staged_builder": (C.c_int, []),
+    "gs_release_thread_scratch": (None, []),
     "gs_set_list_fusion": (None, [C.c_int]),
     "gs_get_list_fusion": (C.c_int, []),
     "gs_renderer_colours_on_demand": (C.c_int, [C.c_void_p]),

@@ -198,6 +198,28 @@ bool stagedListIsSorted(int32_t size, const uint64_t* keys, int endBit)
 
 using namespace gs;
 
+// Everything the staged calls of THIS host thread allocated behind the scenes (builder scratch, sort tables, the sorted check's
+// words): freed; the next staged call allocates again.  For hosts that run the staged loop on short-lived threads.
+extern "C" void gs_release_thread_scratch(void)
+{
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    freeTileListScratch(g.scratch);
+    freeRadixScratch(g.radix);
+    StagedScratch& st = g.staged;
+    freeRadixScratch(st.radixPairs);
+    for (int i = 0; i != 2; ++i)
+    {
+        if (st.depthKey[i]) (void) hipFree(st.depthKey[i]);
+        if (st.order[i]) (void) hipFree(st.order[i]);
+        if (st.tileKeys[i]) (void) hipFree(st.tileKeys[i]);
+        if (st.depth[i]) (void) hipFree(st.depth[i]);
+    }
+    if (st.values) (void) hipFree(st.values);
+    if (st.unsortedEpoch) (void) hipFree(st.unsortedEpoch);
+    if (st.unsortedEpochHost) (void) hipHostFree(st.unsortedEpochHost);
+    st = StagedScratch{};
+}
+
 extern "C" void gs_set_staged_builder(int mode)
 {
     cfg.stagedBuilder = mode == GS_STAGED_BUILDER_REFERENCE_ORDER ? GS_STAGED_BUILDER_REFERENCE_ORDER : GS_STAGED_BUILDER_SORTED;

@@ -132,6 +132,9 @@ int32_t gs_build_tile_list(GsTimer* timer, int32_t numBlocks, int32_t tileListCa
 #define GS_STAGED_BUILDER_SORTED 1
 void gs_set_staged_builder(int mode);
 int gs_get_staged_builder(void);
+/* Addition: frees the scratch the staged calls of the CALLING host thread allocated behind the scenes (state is per host thread, like
+ * the reference's file-scope symbols are per process); the next staged call allocates again.  Waits for the thread's stream first. */
+void gs_release_thread_scratch(void);
 /* Addition: pairs the last gs_build_tile_list would have emitted with unlimited capacity. */
 int64_t gs_last_tile_list_demand(void);
 /* sortTileList .cu:806-855: stable sort on key bits [0, 32+ceil(log2(tiles))) (rocPRIM radix sort; skipped when the list is

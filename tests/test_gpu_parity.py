@@ -1491,3 +1491,39 @@ def test_staged_sorted_builder_matches_reference_order_builder(gs, w, h, n, scal
             assert a[0] > 0
     else:
         assert a[0] == min(capacity, a[1]) and a[1] > capacity
+
+
+def test_release_thread_scratch_and_carry_on(gs, gsref):
+    """gs_release_thread_scratch frees what the staged calls of this host thread allocated behind the scenes; the next staged frame
+    allocates again and gives the same lists (both builders), also from a second host thread with its own state."""
+    import threading
+
+    w, h = 640, 368
+    pos, sr, col = _procedural(gs, 8000, seed=4)
+    cam = gs.camera_from_bounds([-4] * 3, [4] * 3, w, h)
+
+    def frame():
+        f = StagedFrame(pos, sr, col, cam, w, h)
+        f.begin()
+        f.run_clip()
+        f.run_build()
+        sk, sv = f.run_sort()
+        f.free_sort_temp()
+        return sk, sv
+
+    first = frame()
+    gs.lib().gs_release_thread_scratch()
+    gs.lib().gs_release_thread_scratch()  # twice: nothing left to free
+    again = frame()
+    assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1]) and len(first[0]) > 8000
+    other = {}
+
+    def worker():
+        gs.lib().gs_set_device(0)
+        other["lists"] = frame()
+        gs.lib().gs_release_thread_scratch()
+
+    t = threading.Thread(target=worker)
+    t.start()
+    t.join()
+    assert np.array_equal(other["lists"][0], first[0]) and np.array_equal(other["lists"][1], first[1])
