@@ -1445,6 +1445,7 @@ print("AUDIT " + json.dumps(report))
     (1920, 1080, 50000, (0.005, 0.2), (20, 29), None),   # a tile-row band of a multi-GPU split (GsGlobalArgs.tileRowBegin/End)
     (1000, 600, 30000, (0.005, 0.3), (0, 0), 777),       # a capacity far below the demand
     (256, 256, 20000, (0.01, 0.5), (0, 0), 1),           # ... of one entry
+    (256, 256, 2000, (0.01, 0.5), (0, 0), 0),            # ... of none (the call still reports the demand)
     (640, 368, 0, (0.01, 0.5), (0, 0), None),            # no splats
     (300, 200, 1, (0.5, 0.5), (0, 0), None),             # one splat
     (16, 16, 5000, (0.01, 0.5), (0, 0), None),           # one tile (one key bit)
