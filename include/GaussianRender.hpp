@@ -127,6 +127,10 @@ struct DoubleBuffer
 // GaussianRender.cuh:118-143
 // GaussianRender.cu:8-9: `#define EPANECHNIKOV_KERNEL`, a build option of the reference, is a run-time switch here.
 inline void setEpanechnikovKernel(bool enabled) { gs_set_footprint(enabled ? GS_FOOTPRINT_EPANECHNIKOV : GS_FOOTPRINT_GAUSSIAN); }
+// Additions of the library (no counterpart in the reference): how buildTileList emits (sorted: sortTileList then finds nothing to do), and
+// the per-thread scratch of the staged calls handed back.
+inline void setSortedTileListBuilder(bool enabled) { gs_set_staged_builder(enabled ? GS_STAGED_BUILDER_SORTED : GS_STAGED_BUILDER_REFERENCE_ORDER); }
+inline void releaseThreadScratch() { gs_release_thread_scratch(); }
 inline void setGlobalArgs(GlobalArgs* globalArgs) { gs_set_global_args(globalArgs); }
 inline void setTileListArgs(TileListArgs* tileListArgs) { gs_set_tile_list_args(tileListArgs); }
 inline void evaluateSphericalHarmonics(GpuTimer& timer, int32_t count) { gs_evaluate_spherical_harmonics(timer.handle, count); }

@@ -11,7 +11,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cudagaussianrenderer_amd as gs  # noqa: E402
-from tests.gpu_helpers import StagedFrame  # noqa: E402
+from cudagaussianrenderer_amd.staged import StagedFrame  # noqa: E402
 
 
 def main():
