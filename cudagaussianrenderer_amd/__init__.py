@@ -311,6 +311,19 @@ def parse_ply(path):
         lib().gs_free_ply(C.byref(ply))
 
 
+def render(position, scale_and_rotation, color, camera, width, height, sh=None, sh_degree=0, sh_count=0):
+    """gs_render: the scene (host arrays, as parse_ply returns them) and a camera in, the RGBA8 image (H, W, 4) out -- one frame; keep a
+    Renderer for more than one."""
+    pos, sr, col = _f32(position), _f32(scale_and_rotation), _f32(color)
+    rows = _f32(sh).reshape(-1) if sh_degree else None
+    scene = _capi.Scene(pos.shape[0], _fp(pos), _fp(sr), _fp(col), _fp(rows) if rows is not None else None, int(sh_degree), int(sh_count))
+    img = np.empty((height, width, 4), np.uint8)
+    rc = lib().gs_render(C.byref(scene), C.byref(camera), width, height, img.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise RuntimeError(f"gs_render failed ({rc})")
+    return img
+
+
 # ---- render(scene, camera) ----------------------------------------------------------------------------
 class Renderer:
     """The frame loop body of src/Demo.cpp:352-479 behind one call."""

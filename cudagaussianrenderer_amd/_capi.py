@@ -77,6 +77,13 @@ class DoubleBufferI32(C.Structure):
     _fields_ = [("buffers", C.c_void_p * 2), ("selector", C.c_int32)]
 
 
+class Scene(C.Structure):
+    """GsScene (gs_render)."""
+    _fields_ = [("splatCount", C.c_int32), ("position", C.POINTER(C.c_float)), ("scaleAndRotation", C.POINTER(C.c_float)),
+                ("color", C.POINTER(C.c_float)), ("sphericalHarmonics", C.POINTER(C.c_float)), ("sphericalHarmonicsDegree", C.c_int32),
+                ("sphericalHarmonicsCount", C.c_int32)]
+
+
 class Ply(C.Structure):
     _fields_ = [
         ("vertexCount", C.c_int32),
@@ -189,6 +196,7 @@ SIGNATURES = {
                                             C.POINTER(C.c_float)]),
     "gs_parse_ply": (C.c_int, [C.c_char_p, C.POINTER(Ply), C.c_char_p, C.c_size_t]),
     "gs_free_ply": (None, [C.POINTER(Ply)]),
+    "gs_render": (C.c_int, [C.POINTER(Scene), C.POINTER(CameraData), C.c_int, C.c_int, C.c_void_p]),
     "gs_renderer_create": (C.c_void_p, [C.c_int, C.c_int]),
     "gs_renderer_destroy": (None, [C.c_void_p]),
     "gs_renderer_set_tile_rows": (None, [C.c_void_p, C.c_int, C.c_int]),

@@ -825,3 +825,16 @@ extern "C" int gs_renderer_collect_stage_times(GsRenderer* r, GsFrameStats* sums
     return frames;
 }
 
+
+// the fused convenience -- scene in, image out.
+extern "C" int gs_render(const GsScene* scene, const GsCameraData* camera, int width, int height, uint8_t* rgbaOutHostOrNull)
+{
+    if (scene == nullptr || camera == nullptr || width <= 0 || height <= 0 || scene->splatCount < 0) return -1;
+    GsRenderer* r = gs_renderer_create(width, height);
+    int rc = gs_renderer_set_scene(r, scene->splatCount, scene->position, scene->scaleAndRotation, scene->color, scene->sphericalHarmonics,
+                                   scene->sphericalHarmonicsDegree, scene->sphericalHarmonicsCount);
+    if (rc == 0) rc = gs_renderer_render(r, camera, 0, nullptr);
+    if (rc == 0 && rgbaOutHostOrNull != nullptr) gs_renderer_read_back_buffer(r, rgbaOutHostOrNull);
+    gs_renderer_destroy(r);
+    return rc;
+}

@@ -277,6 +277,20 @@ typedef struct GsFrameStats
 
 GsRenderer* gs_renderer_create(int width, int height);
 void gs_renderer_destroy(GsRenderer* r);
+/* The whole of Demo.cpp:278-479 for ONE frame as one call (SURVEY.md section 8(b)'s fused convenience): the scene as parsePly returns it
+ * (host arrays; sphericalHarmonics as [splat][count] rows, NULL with degree 0), a camera, a size -- upload, render, and the RGBA8 image
+ * (row 0 = clip y -1, GaussianRender.cu:1014) copied to rgbaOutHost when that is not NULL.  Returns 0, or the code of the call that
+ * failed.  A renderer is created and destroyed inside: a loop over cameras keeps a GsRenderer instead (gs_renderer_set_scene once). */
+typedef struct GsScene
+{
+    int32_t splatCount;
+    const float* position;         /* float4[n]: xyz, opacity */
+    const float* scaleAndRotation; /* float4[n]: scale xyz, packed quaternion */
+    const float* color;            /* float4[n] */
+    const float* sphericalHarmonics;
+    int32_t sphericalHarmonicsDegree, sphericalHarmonicsCount;
+} GsScene;
+int gs_render(const GsScene* scene, const GsCameraData* camera, int width, int height, uint8_t* rgbaOutHostOrNull);
 /* Multi-GPU: this renderer only builds/sorts/rasterises tile rows [begin,end). 0,0 = all. */
 void gs_renderer_set_tile_rows(GsRenderer* r, int tileRowBegin, int tileRowEnd);
 /* Two pipelines give the same frame. REFERENCE runs the eight staged calls in the reference's order (one

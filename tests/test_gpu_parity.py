@@ -1528,3 +1528,27 @@ def test_release_thread_scratch_and_carry_on(gs, gsref):
     t.start()
     t.join()
     assert np.array_equal(other["lists"][0], first[0]) and np.array_equal(other["lists"][1], first[1])
+
+
+def test_one_shot_render_equals_the_renderer(gs, tmp_path):
+    """gs_render (scene and camera in, image out) gives the bytes a Renderer gives, SH degree 3 and 0, and an
+    empty scene gives an empty image."""
+    w, h = 640, 368
+    ply = _ply_scene(gs, tmp_path, 20000, 3, log_scale_mean=-3.0)
+    cam = gs.camera_from_bounds(ply["boundsMin"], ply["boundsMax"], w, h)
+    r = gs.Renderer(w, h)
+    r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+    r.render(cam)
+    want = r.read_image()
+    r.close()
+    got = gs.render(ply["position"], ply["scaleAndRotation"], ply["color"], cam, w, h, ply["sh"], ply["shDegree"], ply["shCount"])
+    assert np.array_equal(got, want) and got[..., :3].max() > 0
+    pos, sr, col = _procedural(gs, 3000, seed=2)
+    cam0 = gs.camera_from_bounds([-4] * 3, [4] * 3, w, h)
+    r = gs.Renderer(w, h)
+    r.set_scene(pos, sr, col)
+    r.render(cam0)
+    want0 = r.read_image()
+    r.close()
+    assert np.array_equal(gs.render(pos, sr, col, cam0, w, h), want0)
+    assert not gs.render(pos[:0], sr[:0], col[:0], cam0, w, h).any()
