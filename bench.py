@@ -274,6 +274,24 @@ class Rig:
             torch.cuda.synchronize(self.ctx["device"])
         return (time.perf_counter() - t0) / frames
 
+    def per_view_ms(self, repeats=64):
+        """Every view of the orbit by itself (mean / min over the views): one renderer, captured frames of ONE camera
+        back to back, milliseconds per frame."""
+        import torch
+
+        r = self.renderers[0]
+        out = []
+        for cam in self.cameras:
+            for _ in range(8):
+                r.render(cam)
+            torch.cuda.synchronize(self.ctx["device"])
+            t0 = time.perf_counter()
+            for _ in range(repeats):
+                r.render(cam)
+            torch.cuda.synchronize(self.ctx["device"])
+            out.append(1e3 * (time.perf_counter() - t0) / repeats)
+        return out
+
     def gather_frame_ms(self, chains=4):
         """What the exchange costs this rank's GPU per FRAME when nothing overlaps it (multigpu.rebalance_bands adds it to the rank's
         band time: the root's 7 x V receives per chain are invisible to a band timed without the gather).  A collective."""
@@ -648,7 +666,11 @@ def main():
             frames += rig.run_frames(512)
             rig.sync_all()
         sustained_s = time.perf_counter() - t0
+        view_ms = rig.per_view_ms()
         latency = {
+            "per_view": {"ms": [round(v, 4) for v in view_ms], "mean_frames_per_s": round(1e3 * len(view_ms) / sum(view_ms), 1),
+                         "min_frames_per_s": round(1e3 / max(view_ms), 1),
+                         "what": "every view of the orbit by itself, one renderer, captured frames of that camera back to back (SURVEY.md 8(d): mean / min over the views)"},
             "one_frame_in_flight": {"frames_per_s": round(1.0 / serial, 1), "ms": round(1e3 * serial, 4),
                                     "what": "ONE renderer on one stream, captured frames back to back (render() returns when the frame's pair total "
                                             "is known; the next frame is launched behind it)"},
