@@ -273,7 +273,7 @@ def test_end_to_end_config1(gs, gsref):
     assert got[..., :3].max() > 0
 
 
-@pytest.mark.parametrize("w,h,degree", [(640, 360, 3), (333, 177, 1), (1024, 1024, 0)])
+@pytest.mark.parametrize("w,h,degree", [(640, 360, 3), (333, 177, 1), (1024, 1024, 0), (800, 448, 2), (512, 300, 4)])
 def test_end_to_end_ply(gs, gsref, tmp_path, w, h, degree):
     ply = _ply_scene(gs, tmp_path, 30000, degree, log_scale_mean=-3.0)
     cam = gs.camera_from_bounds(ply["boundsMin"], ply["boundsMax"], w, h)
