@@ -319,7 +319,7 @@ def test_edge_cases(gs, gsref):
 
 @pytest.mark.parametrize("w,h,n,scales", [(640, 360, 50000, (0.01, 0.3)), (1920, 1080, 200000, (0.005, 0.08)), (333, 177, 20000, (0.01, 1.0)),
                                           (1920, 1080, 5_000_000, (0.002, 0.03)), (1280, 720, 40_000, (0.0004, 0.9)), (3840, 2160, 60_000, (0.0002, 0.4)),
-                                          (256, 256, 30_000, (0.001, 2.5))])
+                                          (256, 256, 30_000, (0.001, 2.5)), (7680, 4320, 30_000, (0.002, 0.25))])
 def test_two_level_pipeline_equals_reference_pipeline(gs, w, h, n, scales):
     """The default two-level sort (depth-sort splats, emit, stable tile sort) gives the SAME sorted pair list as the
     reference-shaped pipeline (bit-exact staged builder + 64-bit tile|depth radix sort), entry for entry: the fast builder decides
