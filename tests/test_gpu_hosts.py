@@ -107,6 +107,10 @@ def test_cpp_host_ply_frame_equals_python_reference_pipeline(gs, demo_binary, tm
                          text=True, check=True).stdout
     assert open(out, "rb").read() == open(other, "rb").read()
     assert "Frame loop wall clock" in log and "(reference-order builder)" in log and "Total" in log
+    # ... and the loop body as ONE call from the same C++ host (gs_renderer_render, captured frames): the same bytes again
+    one = str(tmp_path / "ply_one_call.ppm")
+    log = subprocess.run([demo_binary, ply_path, "333", "177", "3", one, "--one-call", "--warm-up", "2"], stdout=subprocess.PIPE, text=True, check=True).stdout
+    assert open(out, "rb").read() == open(one, "rb").read() and "(one-call renderer)" in log
     ply = gs.parse_ply(ply_path)
     cam = gs.camera_from_bounds(ply["boundsMin"], ply["boundsMax"], 333, 177)
     r = gs.Renderer(333, 177, pipeline=gs.PIPELINE_REFERENCE)

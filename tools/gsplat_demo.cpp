@@ -15,6 +15,9 @@
 //                                                            The pose after the last frame is printed.
 //   ... --builder sorted|reference-order                     gs_set_staged_builder (default sorted: buildTileList emits in the order the
 //                                                            sort leaves, sortTileList looks before it sorts)
+//   ... --one-call                                           the same frames through gs_renderer_render (one call
+//                                                            instead of eight, captured frames, a device synchronise after each like
+//                                                            Demo.cpp:478); prints the wall clock per frame
 //   ... --warm-up W                                          W more frames first that the printed averages leave out
 //   ... --dump-every K                                       every K-th frame as <out.ppm>.<frame>.ppm (the session as an image sequence)
 //
@@ -43,6 +46,7 @@ int main(int argc, char** argv)
     const char* eventsFile = nullptr;
     int dumpEvery = 0;
     int warmUp = 0; // frames rendered before the statistics start (first frames allocate scratch and meet cold clocks)
+    bool oneCall = false; // the frame loop body as ONE call (gs_renderer_render, captured frames) instead of the eight staged ones
     std::vector<char*> positional;
     for (int i = 0; i < argc; ++i)
     {
@@ -54,6 +58,7 @@ int main(int argc, char** argv)
         else if (std::strcmp(argv[i], "--builder") == 0 && i + 1 < argc)
             gs_set_staged_builder(std::strcmp(argv[++i], "reference-order") == 0 ? GS_STAGED_BUILDER_REFERENCE_ORDER : GS_STAGED_BUILDER_SORTED);
         else if (std::strcmp(argv[i], "--warm-up") == 0 && i + 1 < argc) warmUp = std::atoi(argv[++i]);
+        else if (std::strcmp(argv[i], "--one-call") == 0) oneCall = true;
         else positional.push_back(argv[i]);
     }
     argc = (int) positional.size();
@@ -116,6 +121,51 @@ int main(int argc, char** argv)
     const int frames = argc > arg + 2 ? std::atoi(argv[arg + 2]) : 100;
     const char* outPath = argc > arg + 3 ? argv[arg + 3] : nullptr;
     const int32_t splatCount = (int32_t) position.size();
+
+    if (oneCall && world == 1)
+    {
+        // the loop body of Demo.cpp:352-479 as one call.  (The scene goes in as parsePly returned it: the
+        // coefficient rows are re-read in the file's [splat][count] layout, so they are parsed again rather than un-aligned.)
+        std::vector<float> rows;
+        if (shDegree != 0)
+        {
+            std::vector<gs::float4_t> p2, s2, c2;
+            int d2 = 0, n2 = 0;
+            gs::vec3_t lo2{}, hi2{};
+            gs::parsePly(argv[1], p2, s2, c2, rows, d2, n2, lo2, hi2);
+        }
+        GsRenderer* renderer = gs_renderer_create(width, height);
+        if (gs_renderer_set_scene(renderer, splatCount, &position[0].x, &scaleAndRotation[0].x, &color[0].x, shDegree != 0 ? rows.data() : nullptr, shDegree,
+                                  shCount) != 0)
+            return 1;
+        gs_renderer_set_graph(renderer, 1);
+        gs::CameraControls controls((float) width, (float) height);
+        controls.setBounds(boundsMin, boundsMax);
+        const gs::CameraData cam = controls.getCameraData();
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        for (int frame = -warmUp; frame != frames; ++frame)
+        {
+            if (frame == 0) t0 = std::chrono::steady_clock::now();
+            if (gs_renderer_render(renderer, &cam, 0, nullptr) != 0) return 1;
+            gs_synchronize(); // Demo.cpp:478 (the renderer's frames run on the library's current stream here)
+        }
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (frames > 0 ? frames : 1);
+        std::printf("splats %d, %dx%d, %d frames (one call per frame, captured, synchronised after each)\n", splatCount, width, height, frames);
+        std::printf("Frame loop wall clock %.6f ms per frame (one-call renderer)\n", ms);
+        if (outPath != nullptr)
+        {
+            std::vector<unsigned char> image((size_t) width * height * 4);
+            gs_renderer_read_back_buffer(renderer, image.data());
+            std::FILE* fp = std::fopen(outPath, "wb");
+            if (fp == nullptr) return 1;
+            std::fprintf(fp, "P6\n%d %d\n255\n", width, height);
+            for (int y = height - 1; y >= 0; --y)
+                for (int x = 0; x != width; ++x) std::fwrite(&image[((size_t) y * width + x) * 4], 1, 3, fp);
+            std::fclose(fp);
+        }
+        gs_renderer_destroy(renderer);
+        return 0;
+    }
 
     int tilesX = 0, tilesY = 0;
     gs_tile_counts(width, height, &tilesX, &tilesY);

@@ -17,6 +17,8 @@ scenes.write_synthetic_ply(sys.argv[1] + "/lilly.ply", 815_957, sh_degree=0, see
 PY
 echo "== (a) 1 M splats, SH 3, 1920x1080, $FRAMES frames"
 ./tools/gsplat_demo "$TMP/c3.ply" 1920 1080 "$FRAMES"
+echo "== (a') the same scene and camera, the loop body as ONE call per frame from the same C++ host (gs_renderer_render, synchronised after each)"
+./tools/gsplat_demo "$TMP/c3.ply" 1920 1080 "$FRAMES" --one-call --warm-up 16
 echo "== (b) 815 957 splats, SH 0, 1024x1024, $FRAMES frames (README.md:144-153 shape; reference: 12.50 ms on an RTX 3050 laptop)"
 ./tools/gsplat_demo "$TMP/lilly.ply" 1024 1024 "$FRAMES"
 rm -rf "$TMP"
