@@ -394,6 +394,16 @@ class Renderer:
         if rc != 0:
             raise RuntimeError(f"gs_renderer_render_views failed ({rc})")
 
+    def set_depth_layers(self, layers, fractions=None):
+        """gs_renderer_set_depth_layers: list / sort / blend the depth-sorted splats in `layers` layers (captured frames; same image bytes)."""
+        arr = (C.c_float * len(fractions))(*fractions) if fractions else None
+        if lib().gs_renderer_set_depth_layers(self.handle, int(layers), arr) != 0:
+            raise ValueError("gs_renderer_set_depth_layers: 1..4 layers, ascending fractions in (0, 1)")
+
+    def listed_pairs(self):
+        """Pairs the last captured frame listed, summed over its depth layers."""
+        return int(lib().gs_renderer_listed_pairs(self.handle))
+
     def colours_on_demand(self):
         """True when this renderer's frames evaluate SH colours inside the raster kernel (no SH pass)."""
         return bool(lib().gs_renderer_colours_on_demand(self.handle))

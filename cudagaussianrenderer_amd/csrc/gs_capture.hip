@@ -43,9 +43,14 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
 
     if (!GS_PARAMS_FROM_HOST)
         GS_CHECK(hipMemcpyAsync(r->paramsDevice, r->paramsHost + slot * kMaxViews, sizeof(FrameParams) * views, hipMemcpyHostToDevice, g.stream));
-    // the range table is reset to -1 by the clip kernel (one node less than a memset; see gs_ranges.hip)
+    // Depth layers (gs_renderer_set_depth_layers): only where the emit pass carries the tile sort's first pass (two-pass sorts of 16-bit tile
+    // indices), without a band cull (its splat count lives on the device) and with enough splats for every layer to have some
+    const int fusedBits = cfg.listFusion ? tileListFusedSortBits(tBits, tileKeyBytes) : 0;
+    const int layers = (r->depthLayers > 1 && !cull && fusedBits > 0 && nv >= 4096 && g_ablation == 0) ? r->depthLayers : 1;
+    // the range table is reset to -1 by the clip kernel (one node less than a memset; see gs_ranges.hip) -- and the layers' tile status
+    // bytes behind it with it (0xFF = untouched)
     int32_t* clearTable = r->tileRange;
-    const int clearEntries = 2 * virtualTiles;
+    const int clearEntries = layers > 1 ? (int) rangeTableInts(scr.totalTiles, views) : 2 * virtualTiles;
 #ifdef GS_DEBUG_MEMSET_NODE
     // audit build (tools/micro/graph_memset.hip): the table is cleared by a memset NODE instead
     if (clearTable != nullptr) GS_CHECK(hipMemsetAsync(clearTable, 0xFF, sizeof(int32_t) * (size_t) clearEntries, g.stream));
@@ -122,7 +127,50 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
     const uint32_t* order = (const uint32_t*) r->order[orderSel];
     // (gs_set_list_fusion: the emit pass carries the first pass of the tile sort.  Under ablation -- cumulative from the back -- the
     // stages in front of a missing one still run as in the product; every position the emit pass writes is checked against the capacity)
-    const int sortBits = cfg.listFusion ? tileListFusedSortBits(tBits, tileKeyBytes) : 0;
+    const int sortBits = fusedBits;
+    if (layers > 1)
+    {
+        // layer l = sorted (virtual) splats [begin, end): count / emit / second tile pass / raster, each later layer without the pairs of the
+        // tiles an earlier one stopped.  Every launch below reuses the same scratch and list buffers: the layers run one after another.
+        int begin = 0;
+        for (int l = 0; l != layers; ++l)
+        {
+            const int end = l + 1 == layers ? nv : std::min(nv, std::max(begin + 1, (int) ((double) r->layerFraction[l] * (double) nv)));
+            const int cnt = end - begin;
+            r->scratch.tileStatus = l > 0 ? r->tileStatus : nullptr;
+            r->scratch.frameTotals = r->frameTotals;
+            r->scratch.layerFlags = (l == 0 ? 1 : 0) | (l + 1 == layers ? 2 : 0);
+            launchTileListFastCount(g.stream, cnt, scr, order + begin, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, sortBits,
+                                    views > 1 ? n : 0);
+            launchTileListFastEmit(g.stream, cnt, scr, order + begin, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],
+                                   tileKeyBytes, r->values[0], r->tileListCapacity, views > 1 ? n : 0, sortBits);
+            r->radix.countDevice = (const int*) r->scratch.total;
+            r->radix.rangeTableForLastPass = r->tileRange;
+            const int sel = launchRadixSortPairs(g.stream, r->radix, tileKeyBytes, r->keys[0], r->keys[1], r->values[0], r->values[1],
+                                                 r->tileListCapacity, sortBits, tBits);
+            r->radix.countDevice = nullptr;
+            r->radix.rangeTableForLastPass = nullptr;
+            RasterLayer layer;
+            layer.status = r->tileStatus;
+            layer.state = r->layerState;
+            layer.consumedSoFar = r->layerConsumed;
+            layer.rangeToReset = r->tileRange;
+            layer.isFirst = l == 0;
+            layer.isLast = l + 1 == layers;
+            launchRasterize(g.stream, scr, r->tileRange, r->values[sel], (const float2*) r->clipXY, (const float4*) r->conic, (const float4*) r->color,
+                            (uchar4*) r->backBuffer, nullptr, true, lazyColours, (const float4*) r->rasterRecord, views, n, &layer);
+            r->graphSelector = sel;
+            begin = end;
+        }
+        r->scratch.tileStatus = nullptr;
+        r->scratch.frameTotals = nullptr;
+        r->scratch.layerFlags = 0;
+        r->scratch.countDevice = nullptr;
+        r->graphKeyBytes = tileKeyBytes;
+        r->graphLayersActive = true;
+        return 0;
+    }
+    r->graphLayersActive = false;
     if (!(g_ablation & 4))
         launchTileListFastCount(g.stream, nv, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, sortBits,
                                 views > 1 ? n : 0);
@@ -252,7 +300,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
         if (r->graphValid && (r->graphCapacity != r->tileListCapacity || r->graphSplats != n || r->graphRowBegin != scr.rowBegin ||
                               r->graphRowEnd != scr.rowEnd || r->graphCull != (int) cull ||
                               r->graphFootprint != scr.epanechnikov || r->graphLazy != (int) lazy || r->graphAblation != g_ablation ||
-                              r->graphFusion != ((int) cfg.listFusion | ((int) cfg.clipScanFusion << 1))))
+                              r->graphFusion != ((int) cfg.listFusion | ((int) cfg.clipScanFusion << 1)) || r->graphLayers != r->depthLayers))
             r->graphValid = false;
         if (!r->graphValid)
         {
@@ -262,6 +310,12 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
             ensureTileListFastScratch(r->scratch, n * r->views);
             ensureRadixScratch(r->radix, n * r->views);
             ensureRadixScratch(r->radix, r->tileListCapacity);
+            if (r->depthLayers > 1)
+            {
+                if (r->layerState == nullptr) r->layerState = (float4*) gs_device_alloc(sizeof(float4) * (size_t) r->width * r->height * r->views);
+                if (r->layerConsumed == nullptr) r->layerConsumed = (int32_t*) gs_device_alloc(sizeof(int32_t) * (size_t) scr.totalTiles * r->views);
+                if (r->frameTotals == nullptr) r->frameTotals = (int64_t*) gs_device_alloc(sizeof(int64_t) * 2);
+            }
             for (int slot = 0; slot != 2; ++slot)
             {
                 if (r->graphExec[slot]) (void) hipGraphExecDestroy(r->graphExec[slot]);
@@ -283,6 +337,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
             r->graphLazy = (int) lazy;
             r->graphAblation = g_ablation;
             r->graphFusion = (int) cfg.listFusion | ((int) cfg.clipScanFusion << 1);
+            r->graphLayers = r->depthLayers;
         }
         const int slot = r->graphSlot;
         r->graphSlot ^= 1;
@@ -321,6 +376,19 @@ extern "C" void gs_renderer_set_graph(GsRenderer* r, int enabled)
 }
 
 extern "C" int gs_renderer_captured_retries(const GsRenderer* r) { return r->capturedRetries; }
+// Pairs the last captured frame listed, summed over its depth layers (with one layer: the frame's pair total).
+extern "C" int64_t gs_renderer_listed_pairs(GsRenderer* r)
+{
+    StreamScope scope(r);
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    if (r->depthLayers > 1 && r->graphValid && r->frameTotals != nullptr && r->graphLayersActive)
+    {
+        int64_t totals[2] = {0, 0};
+        GS_CHECK(hipMemcpy(totals, r->frameTotals, sizeof(totals), hipMemcpyDeviceToHost));
+        return totals[1];
+    }
+    return r->scratch.totalHost != nullptr ? *r->scratch.totalHost : 0;
+}
 extern "C" void gs_debug_set_ablation(int mask) { g_ablation = mask; }
 extern "C" void gs_debug_set_clip_scan_fusion(int enabled) { cfg.clipScanFusion = enabled != 0; }
 extern "C" int gs_debug_get_clip_scan_fusion(void) { return cfg.clipScanFusion ? 1 : 0; }

@@ -33,6 +33,7 @@ constexpr int kRasterChunk = 32; // GaussianRender.cu:439,950,995: termination i
 // "virtual splat" v*N + i (own clip data, shared inputs) and its tile t the "virtual tile" v*totalTiles + t, so ONE depth sort and
 // ONE tile sort order the pairs of all views and every kernel of the chain runs once per V frames.
 constexpr int kMaxViews = 4;
+constexpr int kMaxDepthLayers = 4; // gs_renderer_set_depth_layers
 
 // Everything the reference derives from the compile-time k_ScreenSize (Consts.h:4-8), per frame here.
 // Passed to kernels by value (kernarg segment -> SGPRs) instead of a __constant__ symbol.
@@ -128,6 +129,11 @@ struct TileListScratch
     // the emit pass leaves every pair's 32-bit quantised depth (gs_tiles_fast.hip CARRY); null otherwise
     const uint32_t* depthSorted = nullptr;
     uint32_t* carryOut = nullptr;
+    // depth layers (gs_renderer_set_depth_layers), set per layer by the frame driver: the per-tile status table of the raster (pairs of
+    // tiles with status 2 are not listed), the frame's {largest, summed} layer totals on the device, 1 = first layer | 2 = last layer
+    const uint8_t* tileStatus = nullptr;
+    int64_t* frameTotals = nullptr;
+    int layerFlags = 0;
 };
 void ensureTileListScratch(TileListScratch& s, int count);
 void freeTileListScratch(TileListScratch& s);
@@ -275,12 +281,21 @@ struct RasterColourSource
     float3 cameraPosition = {0.f, 0.f, 0.f};
     const FrameParams* params = nullptr; // captured frames: the camera position lives on the device
 };
+// Depth layers (gs_renderer_set_depth_layers, gs_raster.hip LAYERED): what a layer's raster launch needs besides the usual arguments.
+struct RasterLayer
+{
+    uint8_t* status = nullptr;        // per (virtual) tile: 0xFF untouched, 1 open with state, 2 stopped by a vote
+    float4* state = nullptr;          // per pixel (of every view): colour sums and transmittance of an open tile
+    int32_t* consumedSoFar = nullptr; // per (virtual) tile: list entries consumed by the layers so far
+    int32_t* rangeToReset = nullptr;  // the range table (all views): a tile's entries go back to -1 once it has read them
+    int isFirst = 1, isLast = 1;
+};
 bool rasterCanEvaluateColours(int degree, int shCount);
 void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileRange, const int32_t* values,
                      const float2* clipXY, const float4* conic, const float4* color, uchar4* backBuffer,
                      unsigned long long* consumedPairsOrNull, bool clearEmptyTiles = false,
                      const RasterColourSource* lazyColoursOrNull = nullptr, const float4* rasterRecordOrNull = nullptr, int views = 1,
-                     int viewSplats = 0);
+                     int viewSplats = 0, const RasterLayer* layerOrNull = nullptr);
 
 // The renderer sorts its splats on a 27-bit re-coding of getKey()'s 32-bit quantised depth (GaussianRender.cu:446-454): the
 // quantised value comes from a float, so it has at most 24 significant bits -- (position of the top bit, next 23 bits) says

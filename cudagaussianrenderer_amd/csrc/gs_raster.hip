@@ -88,7 +88,14 @@ __device__ __forceinline__ uint32_t quantize8(float c)
 //     1..4 = the colour of a list entry is evaluated HERE from the splat's coefficient row when the entry is staged, with the
 //     routine the SH kernels use (same bits).  A frame consumes the lists' front only -- at C3 88 K distinct splats of 1 M --
 //     so evaluating on demand replaces the 224 MB pass over all coefficients by ~4 memory sectors per staged entry.
-template <int PPL, bool EPAN, int SH>
+// LAYERED (gs_renderer_set_depth_layers): the frame's depth-sorted splats are listed, sorted and blended in several layers, nearest
+// first, and a layer's list holds no pairs of tiles that an earlier layer already finished.  A tile's blend is the same sequence of
+// operations as over its whole list: a tile whose list ran out before a vote stopped it leaves its per-pixel state (colour sums and
+// transmittance) and the number of entries it has consumed; the next layer that holds entries for it loads them and goes on, with as
+// many zero-opacity lead entries as the tile is past its last vote, so that the votes stay at multiples of 32 entries of the WHOLE
+// list (GaussianRender.cu:945-998); a vote is only taken on a full chunk unless this is the last layer (the list's real end).
+// status[tile]: 0xFF untouched (the per-frame fill of the range table reaches it), 1 open with state, 2 stopped by a vote.
+template <int PPL, bool EPAN, int SH, bool LAYERED = false>
 __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, int firstTile, int numTiles,
                                                                   const int32_t* __restrict__ tileRange,
                                                                   const int32_t* __restrict__ values,
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
                                                                   const float4* __restrict__ color, uchar4* __restrict__ backBuffer,
                                                                   unsigned long long* __restrict__ consumedPairs, int clearEmptyTiles,
                                                                   RasterColourSource lazy, unsigned long long* __restrict__ trace,
-                                                                  const float4* __restrict__ rasterRecord, int viewSplats)
+                                                                  const float4* __restrict__ rasterRecord, int viewSplats, RasterLayer layer)
 {
     constexpr int THREADS = 256 / PPL;
     constexpr int GROUPS_X = kTileSize / PPL;
@@ -137,9 +144,16 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
     backBuffer += (size_t) view * scr.width * scr.height;
 
     // GaussianRender.cu:917-931 (wave-uniform: scalar loads)
+    const int vtile = view * scr.totalTiles + tile; // (tileRange already points at this view's table: the range is tileRange[tile * 2])
+    unsigned tileStatus = 0xFFu;
+    if constexpr (LAYERED)
+    {
+        tileStatus = layer.status[vtile];
+        if (tileStatus == 2u) return; // an earlier layer's vote stopped this tile: its list in this layer is empty anyway
+    }
     int first = tileRange[tile * 2];
-    const int count = tileRange[tile * 2 + 1] - first;
-    if (count == 0 && !clearEmptyTiles) return;
+    int count = tileRange[tile * 2 + 1] - first;
+    if (count == 0 && (!clearEmptyTiles || (LAYERED && !layer.isFirst))) return; // (a later layer leaves an idle tile as it is)
 
     const int t = threadIdx.x;
     const int tileX = tile % scr.tilesX, tileY = tile / scr.tilesX;
@@ -171,6 +185,29 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
     const float clipPy = (float) py * scr.pixelClipSizeY - 1.0f;
 
     V cr = V(0.0f), cg = V(0.0f), cb = V(0.0f), tr = V(1.0f);
+    int lead = 0, consumedBefore = 0; // LAYERED: zero-opacity entries in front of this layer's list; entries consumed by earlier layers
+    if constexpr (LAYERED)
+    {
+        if (tileStatus == 1u)
+        {
+            consumedBefore = layer.consumedSoFar[vtile];
+            lead = consumedBefore & (kRasterChunk - 1);
+            const float4* state = layer.state + (size_t) view * scr.width * scr.height;
+#pragma unroll
+            for (int i = 0; i != PPL; ++i)
+                if (onScreen[i])
+                {
+                    const float4 v = state[(size_t) py * scr.width + px0 + i];
+                    PV::set(cr, i, v.x);
+                    PV::set(cg, i, v.y);
+                    PV::set(cb, i, v.z);
+                    PV::set(tr, i, v.w);
+                }
+        }
+        // virtual list: `lead` no-op entries, then this layer's entries
+        first -= lead;
+        count += lead;
+    }
 
     // Register-staged gather of one list entry per lane.
     float2 gCentre = make_float2(0.f, 0.f);
@@ -190,11 +227,11 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
     // The list entry (a splat index) of the batch AFTER the one being gathered is already on its way: a gather is two dependent
     // loads (index, then the splat's records), and a tile that runs alone on its SIMD -- the kernel's tail -- would otherwise wait
     // for both, one after the other, once per batch (measured: 62-70 ns per entry for a lone tile whatever its arithmetic costs).
-    int nextSrc = (t < kBatch && t < count) ? values[first + t] : 0;
+    int nextSrc = (t < kBatch && t < count && t >= lead) ? values[first + t] : 0;
     auto gather = [&](int base) {
         const int src = nextSrc;
-        if (t < kBatch && base + kBatch + t < count) nextSrc = values[first + base + kBatch + t]; // GaussianRender.cu:957-960
-        if (t < kBatch && base + t < count)
+        if (t < kBatch && base + kBatch + t < count) nextSrc = values[first + base + kBatch + t]; // GaussianRender.cu:957-960 (lead < 32 <= base + kBatch)
+        if (t < kBatch && base + t < count && base + t >= lead)
         {
             if (rasterRecord != nullptr)
             {
@@ -240,7 +277,7 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
         {
             // Entries past the end of the list are staged as all-zero records: opacity 0 makes them exact no-ops
             // (w = T*0, C += c*0, T -= T*0), so the blend loop can always run whole groups of four.
-            const bool live = t < n;
+            const bool live = t < n && base + t >= lead; // (lead entries: all-zero records like the ones past the end)
             if constexpr (SH != 0)
             {
                 if (live) gColor = sheval::colourFromQuads<SH>(gRow, gColor, lazyCam);
@@ -323,7 +360,8 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
             for (int p = 0; p != PPL; ++p) alive |= onScreen[p] && PV::get(tr, p) > 0.02f;
             const bool any = anyInBlock<THREADS>(alive);
             GS_PHASE(4);
-            if (!any)
+            // (LAYERED, not the last layer: the list goes on in a later layer -- the reference votes after FULL chunks of 32 only)
+            if (!any && (!LAYERED || layer.isLast || m == kRasterChunk))
             {
                 stop = true;
                 break;
@@ -333,7 +371,39 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
         if (stop || base >= count) break;
     }
 
-    if (consumedPairs != nullptr && t == 0) atomicAdd(consumedPairs, (unsigned long long) consumed);
+    if (consumedPairs != nullptr && t == 0) atomicAdd(consumedPairs, (unsigned long long) (consumed - lead));
+    if constexpr (LAYERED)
+    {
+        // `stop` is the loop's exit by a vote (uniform over the workgroup: the vote is block-wide)
+        bool stopped = consumed < count; // the loop left entries behind: only a vote does that
+        if (consumed == count)
+        {
+            // the list ran out on this batch: stopped only if the last vote (taken on a full chunk, or at the frame's real end) said so
+            bool alive = false;
+#pragma unroll
+            for (int p = 0; p != PPL; ++p) alive |= onScreen[p] && PV::get(tr, p) > 0.02f;
+            const bool any = anyInBlock<THREADS>(alive);
+            stopped = !any && (layer.isLast || (count & (kRasterChunk - 1)) == 0);
+        }
+        if (t == 0)
+        {
+            layer.status[vtile] = stopped ? 2 : 1;
+            layer.consumedSoFar[vtile] = consumedBefore + consumed - lead;
+            if (!layer.isLast)
+            {
+                // the next layer's tile sort fills the range table again (atomic min / max against -1)
+                layer.rangeToReset[(size_t) vtile * 2] = -1;
+                layer.rangeToReset[(size_t) vtile * 2 + 1] = -1;
+            }
+        }
+        if (!stopped && !layer.isLast)
+        {
+            float4* state = layer.state + (size_t) view * scr.width * scr.height;
+#pragma unroll
+            for (int i = 0; i != PPL; ++i)
+                if (onScreen[i]) state[(size_t) py * scr.width + px0 + i] = make_float4(PV::get(cr, i), PV::get(cg, i), PV::get(cb, i), PV::get(tr, i));
+        }
+    }
 #ifdef GS_RASTER_PHASE_TRACE
     if (trace != nullptr && t == 0)
     {
@@ -390,7 +460,7 @@ int rasterPixelsPerLane() { return g_rasterPixelsPerLane; }
 void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileRange, const int32_t* values,
                      const float2* clipXY, const float4* conic, const float4* color, uchar4* backBuffer,
                      unsigned long long* consumedPairsOrNull, bool clearEmptyTiles, const RasterColourSource* lazyColours,
-                     const float4* rasterRecord, int views, int viewSplats)
+                     const float4* rasterRecord, int views, int viewSplats, const RasterLayer* layerOrNull)
 {
     const int firstTile = scr.rowBegin * scr.tilesX;
     const int numTiles = (scr.rowEnd - scr.rowBegin) * scr.tilesX;
@@ -400,11 +470,23 @@ void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileR
     const int gridTiles = ((blocks + 7) / 8) * 8 * GS_RASTER_BLOCK_W * bh; // every XCD walks the same number of blocks
     RasterColourSource lazy{};
     if (lazyColours != nullptr) lazy = *lazyColours;
-#define GS_LAUNCH_RASTER(PPL, EPAN, SH)                                                                                                  \
-    hipLaunchKernelGGL((rasterizeTilesKernel<PPL, EPAN, SH>), dim3(gridTiles, views), dim3(256 / PPL), 0, stream, scr, firstTile, numTiles, \
+    const RasterLayer noLayer{};
+#define GS_LAUNCH_RASTER_L(PPL, EPAN, SH, LAYERED, LAYER)                                                                                 \
+    hipLaunchKernelGGL((rasterizeTilesKernel<PPL, EPAN, SH, LAYERED>), dim3(gridTiles, views), dim3(256 / PPL), 0, stream, scr, firstTile, numTiles, \
                        tileRange, values, clipXY, conic, color, backBuffer, consumedPairsOrNull, clearEmptyTiles ? 1 : 0, lazy, g_rasterTrace, rasterRecord, \
-                       views > 1 ? viewSplats : 0)
+                       views > 1 ? viewSplats : 0, LAYER)
+#define GS_LAUNCH_RASTER(PPL, EPAN, SH) GS_LAUNCH_RASTER_L(PPL, EPAN, SH, false, noLayer)
     const bool epan = scr.epanechnikov != 0;
+    if (layerOrNull != nullptr)
+    {
+        // depth layers: the default shape only (two pixels per lane); colours from the buffer or on demand
+        const int sh = (lazyColours != nullptr && rasterCanEvaluateColours(lazy.degree, lazy.shCount)) ? lazy.degree : 0;
+        const RasterLayer layer = *layerOrNull;
+        if (sh == 3) { if (epan) GS_LAUNCH_RASTER_L(2, true, 3, true, layer); else GS_LAUNCH_RASTER_L(2, false, 3, true, layer); }
+        else if (sh == 1) { if (epan) GS_LAUNCH_RASTER_L(2, true, 1, true, layer); else GS_LAUNCH_RASTER_L(2, false, 1, true, layer); }
+        else { if (epan) GS_LAUNCH_RASTER_L(2, true, 0, true, layer); else GS_LAUNCH_RASTER_L(2, false, 0, true, layer); }
+        return;
+    }
     // on-demand colours: two pixels per lane only (the default shape), degrees whose coefficient rows are 16-byte multiples
     if (lazyColours != nullptr && g_rasterPixelsPerLane == 2 && rasterCanEvaluateColours(lazy.degree, lazy.shCount))
     {
@@ -437,6 +519,7 @@ void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileR
         break;
     }
 #undef GS_LAUNCH_RASTER
+#undef GS_LAUNCH_RASTER_L
 }
 
 bool rasterCanEvaluateColours(int degree, int shCount)

@@ -123,14 +123,26 @@ bool growTileListIfNeeded(GsRenderer* r, int64_t demand)
 }
 } // namespace gs
 
+namespace gs
+{
+// The range table of `views` views, with the depth layers' per-tile status bytes right behind it: one allocation, one 0xFF fill.
+size_t rangeTableInts(int totalTiles, int views) { return 2 * (size_t) totalTiles * views + ((size_t) totalTiles * views + 3) / 4; }
+static void allocRangeTable(GsRenderer* r, int totalTiles)
+{
+    const size_t ints = rangeTableInts(totalTiles, r->views);
+    r->tileRange = (int32_t*) gs_device_alloc(sizeof(int32_t) * ints);
+    GS_CHECK(hipMemset(r->tileRange, 0xFF, sizeof(int32_t) * ints));
+    r->tileStatus = (uint8_t*) (r->tileRange + 2 * (size_t) totalTiles * r->views);
+}
+} // namespace gs
+
 extern "C" GsRenderer* gs_renderer_create(int width, int height)
 {
     GsRenderer* r = new GsRenderer{};
     const Screen scr = makeScreen(width, height, 0, 0);
     r->width = scr.width;
     r->height = scr.height;
-    r->tileRange = (int32_t*) gs_device_alloc(sizeof(int32_t) * 2 * (size_t) scr.totalTiles);
-    GS_CHECK(hipMemset(r->tileRange, 0xFF, sizeof(int32_t) * 2 * (size_t) scr.totalTiles));
+    allocRangeTable(r, scr.totalTiles);
     r->backBufferOwned = (uint8_t*) gs_device_alloc((size_t) scr.width * scr.height * 4);
     r->backBuffer = r->backBufferOwned;
     GS_CHECK(hipMemset(r->backBufferOwned, 0, (size_t) scr.width * scr.height * 4)); // rows outside a band stay zero
@@ -151,6 +163,9 @@ extern "C" void gs_renderer_destroy(GsRenderer* r)
     freeScene(r);
     freeTileList(r);
     gs_device_free(r->tileRange);
+    gs_device_free(r->layerState);
+    gs_device_free(r->layerConsumed);
+    gs_device_free(r->frameTotals);
     gs_device_free(r->backBufferOwned);
     gs_device_free(r->sortTemp);
     freeTileListScratch(r->scratch);
@@ -197,6 +212,27 @@ extern "C" int gs_renderer_set_pipeline(GsRenderer* r, int pipeline)
     r->graphValid = false;
     return 0;
 }
+
+// Depth layers (header): 1..kMaxDepthLayers; fractions = ascending upper bounds of the first layers - 1 layers, or NULL for the defaults.
+extern "C" int gs_renderer_set_depth_layers(GsRenderer* r, int layers, const float* fractions)
+{
+    static const float defaults[gs::kMaxDepthLayers + 1][gs::kMaxDepthLayers] = {
+        {1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}, {0.15f, 1.f, 1.f, 1.f}, {0.06f, 0.25f, 1.f, 1.f}, {0.05f, 0.15f, 0.4f, 1.f}};
+    if (layers < 1 || layers > gs::kMaxDepthLayers) return -1;
+    float f[gs::kMaxDepthLayers];
+    for (int l = 0; l != gs::kMaxDepthLayers; ++l) f[l] = defaults[layers][l];
+    if (fractions != nullptr)
+        for (int l = 0; l + 1 < layers; ++l)
+        {
+            if (!(fractions[l] > (l ? fractions[l - 1] : 0.0f)) || !(fractions[l] < 1.0f)) return -1;
+            f[l] = fractions[l];
+        }
+    r->depthLayers = layers;
+    for (int l = 0; l != gs::kMaxDepthLayers; ++l) r->layerFraction[l] = l + 1 < layers ? f[l] : 1.0f;
+    r->graphValid = false;
+    return 0;
+}
+extern "C" int gs_renderer_depth_layers(const GsRenderer* r) { return r->depthLayers; }
 
 extern "C" int gs_renderer_colours_on_demand(const GsRenderer* r) { return useLazyColours(r) ? 1 : 0; }
 
@@ -373,8 +409,11 @@ extern "C" int gs_renderer_set_views(GsRenderer* r, int views)
     gs_device_free(r->tileRange);
     gs_device_free(r->backBufferOwned);
     r->views = views;
-    r->tileRange = (int32_t*) gs_device_alloc(sizeof(int32_t) * 2 * (size_t) scr.totalTiles * views);
-    GS_CHECK(hipMemset(r->tileRange, 0xFF, sizeof(int32_t) * 2 * (size_t) scr.totalTiles * views));
+    allocRangeTable(r, scr.totalTiles);
+    gs_device_free(r->layerState); // (sized per view: allocated again with the next layered frame)
+    gs_device_free(r->layerConsumed);
+    r->layerState = nullptr;
+    r->layerConsumed = nullptr;
     r->backBufferOwned = (uint8_t*) gs_device_alloc((size_t) scr.width * scr.height * 4 * views);
     GS_CHECK(hipMemset(r->backBufferOwned, 0, (size_t) scr.width * scr.height * 4 * views)); // rows outside a band stay zero
     if (!external) r->backBuffer = r->backBufferOwned;

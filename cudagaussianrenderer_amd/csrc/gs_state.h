@@ -146,6 +146,16 @@ struct GsRenderer
     hipGraphExec_t graphExec[2] = {nullptr, nullptr};
     int graphSlot = 0; // instance of the NEXT launch
     int views = 1;     // cameras per captured chain (gs_renderer_set_views)
+    // Depth layers (gs_renderer_set_depth_layers): the depth-sorted splats are listed, sorted and blended in `depthLayers` layers
+    // (layer l = sorted splats [layerFraction[l-1], layerFraction[l]) of the frame's), later layers without the tiles earlier ones stopped.
+    int depthLayers = 1;
+    float layerFraction[gs::kMaxDepthLayers] = {1.f, 1.f, 1.f, 1.f}; // upper bounds, ascending; the last used one is 1
+    uint8_t* tileStatus = nullptr;      // inside the range table's allocation, right behind the ranges (the same 0xFF fill resets both)
+    float4* layerState = nullptr;       // per pixel and view, allocated with the first layered frame
+    int32_t* layerConsumed = nullptr;   // per (virtual) tile
+    int64_t* frameTotals = nullptr;     // device: {largest, summed} layer pair totals of the frame
+    int graphLayers = 0;
+    bool graphLayersActive = false; // the captured frame really is layered (not with a band cull, a one-pass tile sort, a tiny scene)
     gs::FrameParams* paramsDevice = nullptr;
     gs::FrameParams* paramsHost = nullptr; // pinned, two slots
     int graphCapacity = 0, graphSplats = 0, graphRowBegin = -1, graphRowEnd = -1, graphCull = -1, graphFootprint = -1, graphLazy = -1, graphAblation = 0, graphSelector = 0, graphKeyBytes = 2, graphFusion = -1;
@@ -194,6 +204,7 @@ struct StreamScope
 bool useLazyColours(const GsRenderer* r);
 RasterColourSource colourSource(const GsRenderer* r, const float* cameraPosition, const FrameParams* paramsDevice);
 bool growTileListIfNeeded(GsRenderer* r, int64_t demand);
+size_t rangeTableInts(int totalTiles, int views); // ranges of all views + the depth layers' status bytes behind them, in ints
 // Captured path (gs_capture.hip).  `cameras`: r->views of them (one frame per view, rendered by one chain).
 int renderCaptured(GsRenderer* r, const GsCameraData* cameras);
 // Allocation / legacy-stream work of one host thread must not overlap another thread's stream capture: set-up and capture

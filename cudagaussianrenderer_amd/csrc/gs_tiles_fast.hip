@@ -48,6 +48,10 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kGroup = kWave * kWavesPerBlock; // splats (and lanes) per workgroup
 constexpr int kTilesPerUnit = 4;
 constexpr int kMaskRounds = 16;                // rounds of a workgroup whose hit masks are kept for the emit pass
+#ifndef GS_DONE_BOX_TILES
+#define GS_DONE_BOX_TILES 24
+#endif
+constexpr int kDoneBoxTiles = GS_DONE_BOX_TILES; // depth layers: largest tile box that is checked against the stopped tiles as a whole
 // The emit pass sums the group totals in front of each group itself up to this many groups (1 M splats: 3 906); longer lists get
 // the scan kernel.  A band-culled list (device-side count) keeps only a fraction of the groups the grid was sized for, so the
 // limit on the host-side group count is wider there.
@@ -216,9 +220,13 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                                                              int64_t* __restrict__ total, int64_t* __restrict__ totalHostMapped, int viewSplats,
                                                              int4* __restrict__ boxRecords, int32_t* __restrict__ digitTable,
                                                              const int32_t* __restrict__ digitTotals, int digitStride,
-                                                             const uint32_t* __restrict__ depthSorted, uint32_t* __restrict__ carryOut)
+                                                             const uint32_t* __restrict__ depthSorted, uint32_t* __restrict__ carryOut,
+                                                             const uint8_t* __restrict__ tileStatus, int64_t* __restrict__ frameTotals, int layerFlags)
 {
     static_assert(!CARRY || EMIT, "only the emit pass carries depths");
+    // Depth layers (gs_renderer_set_depth_layers): tileStatus != nullptr -- a later layer lists no pair of a tile that an earlier layer's
+    // raster already stopped (status 2); frameTotals != nullptr -- the emit pass keeps the frame's largest layer total ([0], what the list
+    // capacity must hold) and the sum ([1]) and hands the largest to the host when this is the last layer (layerFlags: 1 first, 2 last).
     // SORT_BITS > 0: the first pass of the tile sort happens here.  COUNT also counts the pairs' low tile digits (digitTable[digit][group],
     // raw); EMIT gets the table scanned over the groups + the digit totals and writes every pair where a stable scatter on that digit
     // would have put it.
@@ -343,6 +351,20 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
             w = box.x1 - box.x0;
             const int h = box.y1 - box.y0;
             area = (w > 0 && h > 0) ? w * h : 0;
+            // Depth layers: a splat whose whole box lies in tiles that earlier layers have stopped makes no work units at all (the per-tile
+            // mask further down would take its pairs out one by one, but a wave only saves instructions when whole units disappear).
+            // Boxes of up to kDoneBoxTiles tiles are looked at; larger ones keep their units.
+            if (tileStatus != nullptr && area > 0 && area <= kDoneBoxTiles)
+            {
+                int statusBase = 0;
+                if (viewSplats > 0)
+#pragma unroll
+                    for (int v = 1; v != kMaxViews; ++v) statusBase += (splat >= v * viewSplats) ? scr.totalTiles : 0;
+                bool open = false;
+                for (int gy = box.y0; gy < box.y1 && !open; ++gy)
+                    for (int gx = box.x0; gx < box.x1 && !open; ++gx) open = tileStatus[gy * scr.tilesX + gx + statusBase] != 2;
+                if (!open) area = 0;
+            }
             overlapOperands();
             // The tile that holds the centre (GaussianRender.cu:382-386), found once per splat with the reference's rounding.
             const int cgx = centreTileOnAxis(cx, scr.tileClipSizeX, scr.tilesPerScreenX), cgy = centreTileOnAxis(cy, scr.tileClipSizeY, scr.tilesPerScreenY);
@@ -416,7 +438,14 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
         if (group == lastGroup && t == 0)
         {
             *total = all;
-            if (totalHostMapped != nullptr) *totalHostMapped = all;
+            if (frameTotals != nullptr)
+            {
+                const long long largest = (layerFlags & 1) ? all : max(all, (long long) frameTotals[0]);
+                frameTotals[0] = largest;
+                frameTotals[1] = (layerFlags & 1) ? all : frameTotals[1] + all;
+                if ((layerFlags & 2) && totalHostMapped != nullptr) *totalHostMapped = largest;
+            }
+            else if (totalHostMapped != nullptr) *totalHostMapped = all;
         }
         if (totalUnits == 0) return;
     }
@@ -645,6 +674,34 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
 #pragma unroll
                 for (int v = 1; v != kMaxViews; ++v) histTileBase += (splatK >= v * viewSplats) ? scr.totalTiles : 0;
             }
+            // depth layers: tiles that an earlier layer's raster has stopped take no more pairs
+            unsigned doneBits = 0;
+            if (tileStatus != nullptr && valid)
+            {
+                int dvBase = 0; // (several views per chain: the status table is indexed by virtual tile)
+                if (viewSplats > 0)
+                {
+                    const int splatD = st.splat[k];
+#pragma unroll
+                    for (int v = 1; v != kMaxViews; ++v) dvBase += (splatD >= v * viewSplats) ? scr.totalTiles : 0;
+                }
+                int dx_ = lx0, dy_ = ly0;
+#pragma unroll
+                for (int e = 0; e != kTilesPerUnit; ++e)
+                {
+                    if (local0 + e < areaK)
+                    {
+                        const int gx = (origin & 0xFFFF) + dx_, gy = (origin >> 16) + dy_;
+                        doneBits |= (tileStatus[gy * scr.tilesX + gx + dvBase] == 2) ? (1u << e) : 0u;
+                    }
+                    ++dx_;
+                    if (dx_ == wk)
+                    {
+                        dx_ = 0;
+                        ++dy_;
+                    }
+                }
+            }
             float dev[kTilesPerUnit]; // |decision value - 1| of the unit's tiles (tiles past the box: certain)
 #pragma unroll
             for (int e = 0; e != kTilesPerUnit; ++e)
@@ -694,6 +751,7 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                     hit |= decision < 1.0f;
                     dev[e] = fabsf(decision - 1.0f);
 #endif
+                    hit = hit && !(doneBits & (1u << e));
                     // digit histogram of this group's pairs (the emit pass will rank them by it), by the cheap decision: a decision the
                     // guard band turns over is put right below
                     if (!EMIT && FUSED && hit) atomicAdd(&digitHist[(gy * scr.tilesX + gx + histTileBase) & (kBins - 1)], 1);
@@ -719,7 +777,8 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
             {
                 const unsigned cheapMask = hitMask;
                 hitMask = decideInsideGuardBand(hitMask, make_float4(dev[0], dev[1], dev[2], dev[3]), seK, local0, areaK, wk, rcpW, origin, cm,
-                                                mi, sx, sy);
+                                                mi, sx, sy) &
+                          ~doneBits;
                 if (!EMIT && FUSED && hitMask != cheapMask)
                 {
                     // (a handful of tiles per frame) the histogram follows the exact decision
@@ -955,12 +1014,13 @@ void launchEmit(hipStream_t stream, dim3 grid, dim3 block, int count, const Scre
     if (s.carryOut != nullptr) // (the staged buildTileList: see CARRY)
         hipLaunchKernelGGL((tileListFastKernel<true, TileKey, SORT_BITS, true>), grid, block, 0, stream, count, s.countDevice, scr, order, clipXY, screenEllipse,
                            s.waveCounts, groupOffsets, (TileKey*) tileKeys, values, capacity, s.hitMasks, s.tileRecord, s.total,
-                           s.totalHostMapped, viewSplats, (int4*) s.boxRecords, s.digitScanned, s.digitTotals, s.digitStride, s.depthSorted, s.carryOut);
+                           s.totalHostMapped, viewSplats, (int4*) s.boxRecords, s.digitScanned, s.digitTotals, s.digitStride, s.depthSorted, s.carryOut,
+                           s.tileStatus, s.frameTotals, s.layerFlags);
     else
         hipLaunchKernelGGL((tileListFastKernel<true, TileKey, SORT_BITS, false>), grid, block, 0, stream, count, s.countDevice, scr, order, clipXY, screenEllipse,
                            s.waveCounts, groupOffsets, (TileKey*) tileKeys, values, capacity, s.hitMasks, s.tileRecord, s.total,
                            s.totalHostMapped, viewSplats, (int4*) s.boxRecords, s.digitScanned, s.digitTotals, s.digitStride, (const uint32_t*) nullptr,
-                           (uint32_t*) nullptr);
+                           (uint32_t*) nullptr, s.tileStatus, s.frameTotals, s.layerFlags);
 }
 
 template <int SORT_BITS>
@@ -972,7 +1032,7 @@ void launchCount(hipStream_t stream, int groups, int count, const Screen& scr, c
     hipLaunchKernelGGL((tileListFastKernel<false, uint16_t, SORT_BITS>), dim3(groups), dim3(kGroup), 0, stream, count, s.countDevice, scr, order, clipXY,
                        screenEllipse, s.waveCounts, (const int32_t*) nullptr, (uint16_t*) nullptr, (int32_t*) nullptr, 0, s.hitMasks, s.tileRecord,
                        (int64_t*) nullptr, (int64_t*) nullptr, viewSplats, (int4*) s.boxRecords, s.digitTable, (const int32_t*) nullptr, s.digitStride,
-                       (const uint32_t*) nullptr, (uint32_t*) nullptr);
+                       (const uint32_t*) nullptr, (uint32_t*) nullptr, s.tileStatus, (int64_t*) nullptr, 0);
 }
 
 } // namespace

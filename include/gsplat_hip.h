@@ -314,6 +314,20 @@ int gs_renderer_set_pipeline(GsRenderer* r, int pipeline);
  * of 1 M at BASELINE.json configs[2] -- so most of the reference's evaluateSphericalHarmonics work is never needed.
  * GsRendererBuffers.color is brought up to date (one SH pass) when gs_renderer_buffers is called. */
 int gs_renderer_colours_on_demand(const GsRenderer* r);
+/* Addition: DEPTH LAYERS for captured frames.  A frame lists every (splat, tile) pair of the scene, but its tiles stop blending long
+ * before their lists end (GaussianRender.cu:995: every pixel below T = 0.02) -- at BASELINE.json configs[2] 0.39 M of 5.45 M pairs are
+ * ever consumed.  With `layers` > 1 the depth-sorted splats are listed, sorted and blended in that many layers, nearest first (layer l
+ * = sorted splats [fraction[l-1], fraction[l]) of the frame's; `fractions` = the layers - 1 ascending upper bounds, NULL = defaults),
+ * and a later layer lists no pair of a tile that an earlier layer's votes already stopped.  A tile that is still open when a layer's
+ * list ends leaves its per-pixel sums and transmittance and goes on in the next layer that has entries for it, its votes still at
+ * multiples of 32 entries of its whole list: the image is the same bytes as with one layer.  What changes: the pair list the renderer
+ * hands out (gs_renderer_buffers) is the LAST layer's only, and tileListSize sums the pairs that were listed.  Takes effect on
+ * captured frames of the two-level pipeline whose tile sort is a two-pass sort of 16-bit indices (list fusion on, no band cull). */
+int gs_renderer_set_depth_layers(GsRenderer* r, int layers, const float* fractions);
+int gs_renderer_depth_layers(const GsRenderer* r);
+/* Pairs the last captured frame listed: summed over its depth layers (gs_last_tile_list_demand then holds the largest layer's total,
+ * which is what the list capacity must hold); the frame's pair total with one layer.  Waits for the renderer's stream. */
+int64_t gs_renderer_listed_pairs(GsRenderer* r);
 /* Addition: how the renderer STORES the splats of the next gs_renderer_set_scene.  CALLER (default): in the caller's order, like the
  * reference (Demo.cpp:314-331).  MORTON: along a 3-D Morton curve through their positions -- the spatial ordering the reference's
  * author names as the cure for the raster's scattered gathers (README.md:138).  Frames are byte-identical either way, for every scene:

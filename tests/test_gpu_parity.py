@@ -1552,3 +1552,114 @@ def test_one_shot_render_equals_the_renderer(gs, tmp_path):
     r.close()
     assert np.array_equal(gs.render(pos, sr, col, cam0, w, h), want0)
     assert not gs.render(pos[:0], sr[:0], col[:0], cam0, w, h).any()
+
+
+@pytest.mark.parametrize("degree,w,h,n,kw", [(3, 1920, 1080, 300_000, {}), (0, 1280, 720, 120_000, {"log_scale_mean": -3.0}),
+                                             (3, 800, 448, 60_000, {"log_scale_mean": -2.5, "opacity_mean": -3.0}), (1, 333, 177, 20_000, {})])
+def test_depth_layers_give_byte_identical_frames(gs, gsref, tmp_path, degree, w, h, n, kw):
+    """gs_renderer_set_depth_layers: the depth-sorted splats listed, sorted and blended in 2, 3 or 4 layers -- later layers without the
+    pairs of tiles that earlier layers' votes stopped, open tiles resuming from their saved per-pixel state with their votes still at
+    multiples of 32 entries of the whole list (GaussianRender.cu:945-998) -- give the SAME BYTES as one layer, on every view of an orbit,
+    for default and hand-picked fractions (a first layer of a handful of splats; a last layer of a handful), colours from the buffer
+    and on demand, low opacities (tiles that never stop), a partial last tile row and column; fewer pairs are listed; and the image
+    equals the oracle's within the usual tolerance."""
+    from cudagaussianrenderer_amd import scenes
+
+    opacity = kw.pop("opacity_mean", None)
+    path = str(tmp_path / "layers.ply")
+    names, table = scenes.synthetic_vertex_table(n, sh_degree=degree, seed=77, **kw)
+    if opacity is not None:
+        table[:, names.index("opacity")] += np.float32(opacity - 1.0)
+    scenes.write_ply(path, names, table)
+    ply = gs.parse_ply(path)
+    scene = (ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+    cams = [gs.camera_from_pose(p, q, w, h) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 4)]
+
+    def frames(layers, fractions=None, storage="morton"):
+        r = gs.Renderer(w, h, storage_order=storage)
+        r.set_scene(*scene)
+        r.set_graph(True)
+        if layers > 1:
+            r.set_depth_layers(layers, fractions)
+        out, listed = [], []
+        for cam in cams:
+            r.render(cam)
+            r.render(cam)  # (both graph instances)
+            out.append(r.read_image())
+            listed.append(r.listed_pairs())
+        r.close()
+        return out, listed
+
+    want, full = frames(1)
+    assert want[0][..., :3].max() > 0
+    for layers, fractions in ((2, None), (3, None), (4, None), (2, [0.0005]), (2, [0.9995]), (3, [0.3, 0.31]), (4, [0.01, 0.02, 0.5])):
+        got, listed = frames(layers, fractions)
+        for v in range(len(cams)):
+            assert np.array_equal(got[v], want[v]), (layers, fractions, v, int((got[v] != want[v]).sum()))
+            assert listed[v] <= full[v], (layers, fractions, v)  # a layer never lists what one list would not
+        if fractions is None and opacity is None and n >= 100_000:
+            assert sum(listed) < 0.8 * sum(full), (layers, listed, full)  # ... and the default cuts leave a good part of the pairs out
+    got, _ = frames(3, None, storage="caller")
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    sh_al = gs.realign_spherical_harmonics(ply["sh"], ply["shCount"], n) if degree else None
+    ref, _, _ = gsref.render(ply["position"], ply["scaleAndRotation"], ply["color"], sh_al, degree, ply["shCount"], cams[0], w, h)
+    _assert_image_close(want[0], ref, "one layer vs oracle")
+
+
+def test_depth_layers_with_views_bands_and_a_list_that_must_grow(gs, tmp_path):
+    """Depth layers beside the renderer's other options: several views per chain (virtual tiles: the status table and the saved state are
+    per view), a tile-row band with its cull (the layers stand aside: the culled splat count lives on the device), and a scene whose
+    first layered frame overflows the list (the frame is rendered again with a grown list before it is handed out) -- the same bytes
+    as one layer every time."""
+    from cudagaussianrenderer_amd import scenes
+
+    w, h = 1280, 720
+    ply = _ply_scene(gs, tmp_path, 80_000, 3, log_scale_mean=-3.2)
+    scene = (ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+    cams = [gs.camera_from_pose(p, q, w, h) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 8)]
+    single = gs.Renderer(w, h, storage_order="morton")
+    single.set_scene(*scene)
+    single.set_graph(True)
+    want = []
+    for cam in cams:
+        single.render(cam)
+        want.append(single.read_image())
+    single.close()
+    for views in (2, 4):
+        r = gs.Renderer(w, h, views=views, storage_order="morton")
+        r.set_scene(*scene)
+        r.set_graph(True)
+        r.set_depth_layers(3)
+        for first in (0, views):
+            r.render_views([cams[(first + v) % 8] for v in range(views)])
+            r.render_views([cams[(first + v) % 8] for v in range(views)])
+            for v in range(views):
+                assert np.array_equal(r.read_image(view=v), want[(first + v) % 8]), (views, first, v)
+        r.close()
+    band = gs.Renderer(w, h, tile_rows=(10, 20), storage_order="morton")
+    band.set_scene(*scene)
+    band.set_graph(True)
+    band.set_depth_layers(2)
+    band.render(cams[1])
+    img = band.read_image()
+    assert np.array_equal(img[160:320], want[1][160:320])
+    band.close()
+    # a list that must grow: ~40 pairs per splat against the 8 provisioned
+    w2 = h2 = 512
+    pos, sr, col = _procedural(gs, 6000, seed=9, min_scale=0.3, max_scale=1.5)
+    cam = gs.camera_from_bounds([-4] * 3, [4] * 3, w2, h2)
+    ref = gs.Renderer(w2, h2)
+    ref.set_scene(pos, sr, col)
+    ref.set_graph(True)
+    ref.render(cam)
+    want2 = ref.read_image()
+    ref.close()
+    r = gs.Renderer(w2, h2)
+    r.set_scene(pos, sr, col)
+    r.set_graph(True)
+    r.set_depth_layers(2, [0.5])
+    r.render(cam)
+    assert r.captured_retries() >= 1 and np.array_equal(r.read_image(), want2)
+    r.render(cam)
+    assert np.array_equal(r.read_image(), want2)
+    r.close()
