@@ -50,7 +50,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
     // the range table is reset to -1 by the clip kernel (one node less than a memset; see gs_ranges.hip) -- and the layers' tile status
     // bytes behind it with it (0xFF = untouched)
     int32_t* clearTable = r->tileRange;
-    const int clearEntries = layers > 1 ? (int) rangeTableInts(scr.totalTiles, views) : 2 * virtualTiles;
+    const int clearEntries = layers > 1 ? (int) rangeTableInts(scr, views) : 2 * virtualTiles;
 #ifdef GS_DEBUG_MEMSET_NODE
     // audit build (tools/micro/graph_memset.hip): the table is cleared by a memset NODE instead
     if (clearTable != nullptr) GS_CHECK(hipMemsetAsync(clearTable, 0xFF, sizeof(int32_t) * (size_t) clearEntries, g.stream));
@@ -137,7 +137,8 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
         {
             const int end = l + 1 == layers ? nv : std::min(nv, std::max(begin + 1, (int) ((double) r->layerFraction[l] * (double) nv)));
             const int cnt = end - begin;
-            r->scratch.tileStatus = l > 0 ? r->tileStatus : nullptr;
+            r->scratch.openBits = l > 0 ? r->tileOpenBits : nullptr;
+            r->scratch.openWordsPerRow = openWordsPerRow(scr.tilesX);
             r->scratch.frameTotals = r->frameTotals;
             r->scratch.layerFlags = (l == 0 ? 1 : 0) | (l + 1 == layers ? 2 : 0);
             launchTileListFastCount(g.stream, cnt, scr, order + begin, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, sortBits,
@@ -155,6 +156,8 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
             layer.state = r->layerState;
             layer.consumedSoFar = r->layerConsumed;
             layer.rangeToReset = r->tileRange;
+            layer.openBits = r->tileOpenBits;
+            layer.openWordsPerRow = openWordsPerRow(scr.tilesX);
             layer.isFirst = l == 0;
             layer.isLast = l + 1 == layers;
             launchRasterize(g.stream, scr, r->tileRange, r->values[sel], (const float2*) r->clipXY, (const float4*) r->conic, (const float4*) r->color,
@@ -162,7 +165,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
             r->graphSelector = sel;
             begin = end;
         }
-        r->scratch.tileStatus = nullptr;
+        r->scratch.openBits = nullptr;
         r->scratch.frameTotals = nullptr;
         r->scratch.layerFlags = 0;
         r->scratch.countDevice = nullptr;

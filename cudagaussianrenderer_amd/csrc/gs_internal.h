@@ -129,9 +129,10 @@ struct TileListScratch
     // the emit pass leaves every pair's 32-bit quantised depth (gs_tiles_fast.hip CARRY); null otherwise
     const uint32_t* depthSorted = nullptr;
     uint32_t* carryOut = nullptr;
-    // depth layers (gs_renderer_set_depth_layers), set per layer by the frame driver: the per-tile status table of the raster (pairs of
-    // tiles with status 2 are not listed), the frame's {largest, summed} layer totals on the device, 1 = first layer | 2 = last layer
-    const uint8_t* tileStatus = nullptr;
+    // depth layers (gs_renderer_set_depth_layers), set per layer by the frame driver: the raster's open-tile bits (pairs of tiles whose
+    // bit is clear are not listed), the frame's {largest, summed} layer totals on the device, 1 = first layer | 2 = last layer
+    const uint32_t* openBits = nullptr; // one bit per (virtual) tile, 1 = still open; rows of openWordsPerRow words (RasterLayer)
+    int openWordsPerRow = 0;
     int64_t* frameTotals = nullptr;
     int layerFlags = 0;
 };
@@ -288,6 +289,8 @@ struct RasterLayer
     float4* state = nullptr;          // per pixel (of every view): colour sums and transmittance of an open tile
     int32_t* consumedSoFar = nullptr; // per (virtual) tile: list entries consumed by the layers so far
     int32_t* rangeToReset = nullptr;  // the range table (all views): a tile's entries go back to -1 once it has read them
+    uint32_t* openBits = nullptr;     // one bit per (virtual) tile, rows of openWordsPerRow words: cleared when a vote stops the tile
+    int openWordsPerRow = 0;          //   (what the list builder of the next layers looks at)
     int isFirst = 1, isLast = 1;
 };
 bool rasterCanEvaluateColours(int degree, int shCount);

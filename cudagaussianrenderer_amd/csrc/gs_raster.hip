@@ -388,6 +388,8 @@ __global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, in
         if (t == 0)
         {
             layer.status[vtile] = stopped ? 2 : 1;
+            if (stopped && !layer.isLast)
+                atomicAnd(&layer.openBits[((size_t) view * scr.tilesY + tileY) * layer.openWordsPerRow + (tileX >> 5)], ~(1u << (tileX & 31)));
             layer.consumedSoFar[vtile] = consumedBefore + consumed - lead;
             if (!layer.isLast)
             {

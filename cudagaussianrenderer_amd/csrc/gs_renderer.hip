@@ -126,13 +126,19 @@ bool growTileListIfNeeded(GsRenderer* r, int64_t demand)
 namespace gs
 {
 // The range table of `views` views, with the depth layers' per-tile status bytes right behind it: one allocation, one 0xFF fill.
-size_t rangeTableInts(int totalTiles, int views) { return 2 * (size_t) totalTiles * views + ((size_t) totalTiles * views + 3) / 4; }
-static void allocRangeTable(GsRenderer* r, int totalTiles)
+// (ranges, then one status byte per virtual tile, then one open bit per virtual tile in rows of openWordsPerRow(tilesX) words)
+int openWordsPerRow(int tilesX) { return (tilesX + 31) / 32 + 1; } // (+1: a box that straddles a word boundary reads the word behind its first)
+size_t rangeTableInts(const Screen& scr, int views)
 {
-    const size_t ints = rangeTableInts(totalTiles, r->views);
+    return 2 * (size_t) scr.totalTiles * views + ((size_t) scr.totalTiles * views + 3) / 4 + (size_t) scr.tilesY * views * openWordsPerRow(scr.tilesX);
+}
+static void allocRangeTable(GsRenderer* r, const Screen& scr)
+{
+    const size_t ints = rangeTableInts(scr, r->views);
     r->tileRange = (int32_t*) gs_device_alloc(sizeof(int32_t) * ints);
     GS_CHECK(hipMemset(r->tileRange, 0xFF, sizeof(int32_t) * ints));
-    r->tileStatus = (uint8_t*) (r->tileRange + 2 * (size_t) totalTiles * r->views);
+    r->tileStatus = (uint8_t*) (r->tileRange + 2 * (size_t) scr.totalTiles * r->views);
+    r->tileOpenBits = (uint32_t*) (r->tileRange + 2 * (size_t) scr.totalTiles * r->views + ((size_t) scr.totalTiles * r->views + 3) / 4);
 }
 } // namespace gs
 
@@ -142,7 +148,7 @@ extern "C" GsRenderer* gs_renderer_create(int width, int height)
     const Screen scr = makeScreen(width, height, 0, 0);
     r->width = scr.width;
     r->height = scr.height;
-    allocRangeTable(r, scr.totalTiles);
+    allocRangeTable(r, scr);
     r->backBufferOwned = (uint8_t*) gs_device_alloc((size_t) scr.width * scr.height * 4);
     r->backBuffer = r->backBufferOwned;
     GS_CHECK(hipMemset(r->backBufferOwned, 0, (size_t) scr.width * scr.height * 4)); // rows outside a band stay zero
@@ -409,7 +415,7 @@ extern "C" int gs_renderer_set_views(GsRenderer* r, int views)
     gs_device_free(r->tileRange);
     gs_device_free(r->backBufferOwned);
     r->views = views;
-    allocRangeTable(r, scr.totalTiles);
+    allocRangeTable(r, scr);
     gs_device_free(r->layerState); // (sized per view: allocated again with the next layered frame)
     gs_device_free(r->layerConsumed);
     r->layerState = nullptr;

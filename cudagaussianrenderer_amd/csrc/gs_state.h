@@ -151,6 +151,7 @@ struct GsRenderer
     int depthLayers = 1;
     float layerFraction[gs::kMaxDepthLayers] = {1.f, 1.f, 1.f, 1.f}; // upper bounds, ascending; the last used one is 1
     uint8_t* tileStatus = nullptr;      // inside the range table's allocation, right behind the ranges (the same 0xFF fill resets both)
+    uint32_t* tileOpenBits = nullptr;   // behind the status bytes: one bit per (virtual) tile, 1 = open (the fill sets them all)
     float4* layerState = nullptr;       // per pixel and view, allocated with the first layered frame
     int32_t* layerConsumed = nullptr;   // per (virtual) tile
     int64_t* frameTotals = nullptr;     // device: {largest, summed} layer pair totals of the frame
@@ -204,7 +205,8 @@ struct StreamScope
 bool useLazyColours(const GsRenderer* r);
 RasterColourSource colourSource(const GsRenderer* r, const float* cameraPosition, const FrameParams* paramsDevice);
 bool growTileListIfNeeded(GsRenderer* r, int64_t demand);
-size_t rangeTableInts(int totalTiles, int views); // ranges of all views + the depth layers' status bytes behind them, in ints
+size_t rangeTableInts(const Screen& scr, int views); // ranges of all views + the depth layers' status bytes and open bits behind them, in ints
+int openWordsPerRow(int tilesX);
 // Captured path (gs_capture.hip).  `cameras`: r->views of them (one frame per view, rendered by one chain).
 int renderCaptured(GsRenderer* r, const GsCameraData* cameras);
 // Allocation / legacy-stream work of one host thread must not overlap another thread's stream capture: set-up and capture

@@ -48,10 +48,7 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kGroup = kWave * kWavesPerBlock; // splats (and lanes) per workgroup
 constexpr int kTilesPerUnit = 4;
 constexpr int kMaskRounds = 16;                // rounds of a workgroup whose hit masks are kept for the emit pass
-#ifndef GS_DONE_BOX_TILES
-#define GS_DONE_BOX_TILES 24
-#endif
-constexpr int kDoneBoxTiles = GS_DONE_BOX_TILES; // depth layers: largest tile box that is checked against the stopped tiles as a whole
+constexpr int kDoneBoxRows = 8; // depth layers: tile boxes of up to 8 rows x 32 columns are checked against the stopped tiles as a whole
 // The emit pass sums the group totals in front of each group itself up to this many groups (1 M splats: 3 906); longer lists get
 // the scan kernel.  A band-culled list (device-side count) keeps only a fraction of the groups the grid was sized for, so the
 // limit on the host-side group count is wider there.
@@ -221,11 +218,12 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                                                              int4* __restrict__ boxRecords, int32_t* __restrict__ digitTable,
                                                              const int32_t* __restrict__ digitTotals, int digitStride,
                                                              const uint32_t* __restrict__ depthSorted, uint32_t* __restrict__ carryOut,
-                                                             const uint8_t* __restrict__ tileStatus, int64_t* __restrict__ frameTotals, int layerFlags)
+                                                             const uint32_t* __restrict__ openBits, int openWordsPerRow, int64_t* __restrict__ frameTotals,
+                                                             int layerFlags)
 {
     static_assert(!CARRY || EMIT, "only the emit pass carries depths");
-    // Depth layers (gs_renderer_set_depth_layers): tileStatus != nullptr -- a later layer lists no pair of a tile that an earlier layer's
-    // raster already stopped (status 2); frameTotals != nullptr -- the emit pass keeps the frame's largest layer total ([0], what the list
+    // Depth layers (gs_renderer_set_depth_layers): openBits != nullptr -- a later layer lists no pair of a tile that an earlier layer's
+    // raster already stopped (its bit is clear; rows of openWordsPerRow words per tile row, one table per view); frameTotals != nullptr -- the emit pass keeps the frame's largest layer total ([0], what the list
     // capacity must hold) and the sum ([1]) and hands the largest to the host when this is the last layer (layerFlags: 1 first, 2 last).
     // SORT_BITS > 0: the first pass of the tile sort happens here.  COUNT also counts the pairs' low tile digits (digitTable[digit][group],
     // raw); EMIT gets the table scanned over the groups + the digit totals and writes every pair where a stable scatter on that digit
@@ -353,17 +351,29 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
             area = (w > 0 && h > 0) ? w * h : 0;
             // Depth layers: a splat whose whole box lies in tiles that earlier layers have stopped makes no work units at all (the per-tile
             // mask further down would take its pairs out one by one, but a wave only saves instructions when whole units disappear).
-            // Boxes of up to kDoneBoxTiles tiles are looked at; larger ones keep their units.
-            if (tileStatus != nullptr && area > 0 && area <= kDoneBoxTiles)
+            // Boxes of up to 8 x 32 tiles are looked at (one or two words of open bits per row); larger ones keep their units.
+            if (openBits != nullptr && area > 0 && w <= 32 && h <= kDoneBoxRows)
             {
-                int statusBase = 0;
+                int rowBase = 0; // (several views per chain: one table per view)
                 if (viewSplats > 0)
 #pragma unroll
-                    for (int v = 1; v != kMaxViews; ++v) statusBase += (splat >= v * viewSplats) ? scr.totalTiles : 0;
-                bool open = false;
-                for (int gy = box.y0; gy < box.y1 && !open; ++gy)
-                    for (int gx = box.x0; gx < box.x1 && !open; ++gx) open = tileStatus[gy * scr.tilesX + gx + statusBase] != 2;
-                if (!open) area = 0;
+                    for (int v = 1; v != kMaxViews; ++v) rowBase += (splat >= v * viewSplats) ? scr.tilesY : 0;
+                const int wi = box.x0 >> 5, sh = box.x0 & 31;
+                const unsigned mask = w == 32 ? 0xFFFFFFFFu : ((1u << w) - 1u);
+                const bool straddles = sh + w > 32;
+                unsigned open = 0;
+#pragma unroll
+                for (int r = 0; r != kDoneBoxRows; ++r) // (independent loads: no early exit)
+                {
+                    if (r < h)
+                    {
+                        const uint32_t* row = openBits + (size_t) (rowBase + box.y0 + r) * openWordsPerRow + wi;
+                        unsigned bits = row[0] >> sh;
+                        if (straddles) bits |= row[1] << (32 - sh);
+                        open |= bits & mask;
+                    }
+                }
+                if (open == 0) area = 0;
             }
             overlapOperands();
             // The tile that holds the centre (GaussianRender.cu:382-386), found once per splat with the reference's rounding.
@@ -676,14 +686,14 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
             }
             // depth layers: tiles that an earlier layer's raster has stopped take no more pairs
             unsigned doneBits = 0;
-            if (tileStatus != nullptr && valid)
+            if (openBits != nullptr && valid)
             {
-                int dvBase = 0; // (several views per chain: the status table is indexed by virtual tile)
+                int rowBase = 0; // (several views per chain: one table per view)
                 if (viewSplats > 0)
                 {
                     const int splatD = st.splat[k];
 #pragma unroll
-                    for (int v = 1; v != kMaxViews; ++v) dvBase += (splatD >= v * viewSplats) ? scr.totalTiles : 0;
+                    for (int v = 1; v != kMaxViews; ++v) rowBase += (splatD >= v * viewSplats) ? scr.tilesY : 0;
                 }
                 int dx_ = lx0, dy_ = ly0;
 #pragma unroll
@@ -692,7 +702,8 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                     if (local0 + e < areaK)
                     {
                         const int gx = (origin & 0xFFFF) + dx_, gy = (origin >> 16) + dy_;
-                        doneBits |= (tileStatus[gy * scr.tilesX + gx + dvBase] == 2) ? (1u << e) : 0u;
+                        const unsigned word = openBits[(size_t) (rowBase + gy) * openWordsPerRow + (gx >> 5)];
+                        doneBits |= ((word >> (gx & 31)) & 1u) ? 0u : (1u << e);
                     }
                     ++dx_;
                     if (dx_ == wk)
@@ -1015,12 +1026,12 @@ void launchEmit(hipStream_t stream, dim3 grid, dim3 block, int count, const Scre
         hipLaunchKernelGGL((tileListFastKernel<true, TileKey, SORT_BITS, true>), grid, block, 0, stream, count, s.countDevice, scr, order, clipXY, screenEllipse,
                            s.waveCounts, groupOffsets, (TileKey*) tileKeys, values, capacity, s.hitMasks, s.tileRecord, s.total,
                            s.totalHostMapped, viewSplats, (int4*) s.boxRecords, s.digitScanned, s.digitTotals, s.digitStride, s.depthSorted, s.carryOut,
-                           s.tileStatus, s.frameTotals, s.layerFlags);
+                           s.openBits, s.openWordsPerRow, s.frameTotals, s.layerFlags);
     else
         hipLaunchKernelGGL((tileListFastKernel<true, TileKey, SORT_BITS, false>), grid, block, 0, stream, count, s.countDevice, scr, order, clipXY, screenEllipse,
                            s.waveCounts, groupOffsets, (TileKey*) tileKeys, values, capacity, s.hitMasks, s.tileRecord, s.total,
                            s.totalHostMapped, viewSplats, (int4*) s.boxRecords, s.digitScanned, s.digitTotals, s.digitStride, (const uint32_t*) nullptr,
-                           (uint32_t*) nullptr, s.tileStatus, s.frameTotals, s.layerFlags);
+                           (uint32_t*) nullptr, s.openBits, s.openWordsPerRow, s.frameTotals, s.layerFlags);
 }
 
 template <int SORT_BITS>
@@ -1032,7 +1043,7 @@ void launchCount(hipStream_t stream, int groups, int count, const Screen& scr, c
     hipLaunchKernelGGL((tileListFastKernel<false, uint16_t, SORT_BITS>), dim3(groups), dim3(kGroup), 0, stream, count, s.countDevice, scr, order, clipXY,
                        screenEllipse, s.waveCounts, (const int32_t*) nullptr, (uint16_t*) nullptr, (int32_t*) nullptr, 0, s.hitMasks, s.tileRecord,
                        (int64_t*) nullptr, (int64_t*) nullptr, viewSplats, (int4*) s.boxRecords, s.digitTable, (const int32_t*) nullptr, s.digitStride,
-                       (const uint32_t*) nullptr, (uint32_t*) nullptr, s.tileStatus, (int64_t*) nullptr, 0);
+                       (const uint32_t*) nullptr, (uint32_t*) nullptr, s.openBits, s.openWordsPerRow, (int64_t*) nullptr, 0);
 }
 
 } // namespace
