@@ -398,7 +398,11 @@ class Renderer:
         """gs_renderer_set_depth_layers: list / sort / blend the depth-sorted splats in `layers` layers (captured frames; same image bytes)."""
         arr = (C.c_float * len(fractions))(*fractions) if fractions else None
         if lib().gs_renderer_set_depth_layers(self.handle, int(layers), arr) != 0:
-            raise ValueError("gs_renderer_set_depth_layers: 1..4 layers, ascending fractions in (0, 1)")
+            raise ValueError("gs_renderer_set_depth_layers: 0 (the renderer chooses) or 1..4 layers, ascending fractions in (0, 1)")
+
+    def depth_layers_in_use(self):
+        """Layers the last captured frame was made of."""
+        return int(lib().gs_renderer_depth_layers_in_use(self.handle))
 
     def listed_pairs(self):
         """Pairs the last captured frame listed, summed over its depth layers."""

@@ -46,7 +46,9 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
     // Depth layers (gs_renderer_set_depth_layers): only where the emit pass carries the tile sort's first pass (two-pass sorts of 16-bit tile
     // indices), without a band cull (its splat count lives on the device) and with enough splats for every layer to have some
     const int fusedBits = cfg.listFusion ? tileListFusedSortBits(tBits, tileKeyBytes) : 0;
-    const int layers = (r->depthLayers > 1 && !cull && fusedBits > 0 && nv >= 4096 && g_ablation == 0) ? r->depthLayers : 1;
+    float layerFraction[kMaxDepthLayers];
+    const int wantLayers = effectiveDepthLayers(r, layerFraction);
+    const int layers = (wantLayers > 1 && !cull && fusedBits > 0 && nv >= 4096 && g_ablation == 0) ? wantLayers : 1;
     // the range table is reset to -1 by the clip kernel (one node less than a memset; see gs_ranges.hip) -- and the layers' tile status
     // bytes behind it with it (0xFF = untouched)
     int32_t* clearTable = r->tileRange;
@@ -135,7 +137,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
         int begin = 0;
         for (int l = 0; l != layers; ++l)
         {
-            const int end = l + 1 == layers ? nv : std::min(nv, std::max(begin + 1, (int) ((double) r->layerFraction[l] * (double) nv)));
+            const int end = l + 1 == layers ? nv : std::min(nv, std::max(begin + 1, (int) ((double) layerFraction[l] * (double) nv)));
             const int cnt = end - begin;
             r->scratch.openBits = l > 0 ? r->tileOpenBits : nullptr;
             r->scratch.openWordsPerRow = openWordsPerRow(scr.tilesX);
@@ -303,7 +305,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
         if (r->graphValid && (r->graphCapacity != r->tileListCapacity || r->graphSplats != n || r->graphRowBegin != scr.rowBegin ||
                               r->graphRowEnd != scr.rowEnd || r->graphCull != (int) cull ||
                               r->graphFootprint != scr.epanechnikov || r->graphLazy != (int) lazy || r->graphAblation != g_ablation ||
-                              r->graphFusion != ((int) cfg.listFusion | ((int) cfg.clipScanFusion << 1)) || r->graphLayers != r->depthLayers))
+                              r->graphFusion != ((int) cfg.listFusion | ((int) cfg.clipScanFusion << 1)) || r->graphLayers != (r->depthLayers > 0 ? r->depthLayers : r->autoLayers)))
             r->graphValid = false;
         if (!r->graphValid)
         {
@@ -313,7 +315,6 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
             ensureTileListFastScratch(r->scratch, n * r->views);
             ensureRadixScratch(r->radix, n * r->views);
             ensureRadixScratch(r->radix, r->tileListCapacity);
-            if (r->depthLayers > 1)
             {
                 if (r->layerState == nullptr) r->layerState = (float4*) gs_device_alloc(sizeof(float4) * (size_t) r->width * r->height * r->views);
                 if (r->layerConsumed == nullptr) r->layerConsumed = (int32_t*) gs_device_alloc(sizeof(int32_t) * (size_t) scr.totalTiles * r->views);
@@ -340,7 +341,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
             r->graphLazy = (int) lazy;
             r->graphAblation = g_ablation;
             r->graphFusion = (int) cfg.listFusion | ((int) cfg.clipScanFusion << 1);
-            r->graphLayers = r->depthLayers;
+            r->graphLayers = r->depthLayers > 0 ? r->depthLayers : r->autoLayers;
         }
         const int slot = r->graphSlot;
         r->graphSlot ^= 1;
@@ -359,6 +360,19 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
         g_hostFrames.fetch_add(1, std::memory_order_relaxed);
         g.lastDemand = demand;
         r->tileListSize = (int32_t) std::min<int64_t>(demand, r->tileListCapacity);
+        if (r->depthLayers == 0)
+        {
+            // The renderer chooses the layer count of the NEXT frame from this one's pairs (profiles/r05_depth_layers.txt: two layers pay
+            // from ~8 M pairs per frame, three from ~40 M).  A frame of one layer knows the scene's pair total; a layered one knows what it
+            // listed (the second host word), which is less -- it falls back when that gets small, and the one-layer frame measures again.
+            const int64_t listed = r->graphLayersActive ? r->scratch.totalHost[1] : demand;
+            int next = r->autoLayers;
+            if (!r->graphLayersActive || r->autoLayers == 1) next = demand >= 40000000 ? 3 : demand >= 8000000 ? 2 : 1;
+            else if (r->autoLayers == 2) next = listed < 2500000 ? 1 : listed >= 18000000 ? 3 : 2; // (two layers list ~0.4 of the pairs ...
+            else next = listed < 6000000 ? 2 : r->autoLayers;                                      //  ... three ~0.2-0.25)
+            // (a frame that cannot be layered -- band cull, one-pass tile sort -- keeps measuring totals; the wish costs nothing)
+            r->autoLayers = next;
+        }
         if (demand <= r->tileListCapacity) return 0;
         if (demand > 0x7FFFFFFF) return -2;
         GS_CHECK(hipStreamSynchronize(g.stream)); // the truncated frame drains before its buffers are replaced
@@ -379,12 +393,14 @@ extern "C" void gs_renderer_set_graph(GsRenderer* r, int enabled)
 }
 
 extern "C" int gs_renderer_captured_retries(const GsRenderer* r) { return r->capturedRetries; }
+// Depth layers the last captured frame was made of (1 when it was not layered: band cull, one-pass tile sort, a small scene, or the choice).
+extern "C" int gs_renderer_depth_layers_in_use(const GsRenderer* r) { return (r->graphValid && r->graphLayersActive) ? r->graphLayers : 1; }
 // Pairs the last captured frame listed, summed over its depth layers (with one layer: the frame's pair total).
 extern "C" int64_t gs_renderer_listed_pairs(GsRenderer* r)
 {
     StreamScope scope(r);
     GS_CHECK(hipStreamSynchronize(g.stream));
-    if (r->depthLayers > 1 && r->graphValid && r->frameTotals != nullptr && r->graphLayersActive)
+    if (r->graphValid && r->frameTotals != nullptr && r->graphLayersActive)
     {
         int64_t totals[2] = {0, 0};
         GS_CHECK(hipMemcpy(totals, r->frameTotals, sizeof(totals), hipMemcpyDeviceToHost));

@@ -224,7 +224,14 @@ extern "C" int gs_renderer_set_depth_layers(GsRenderer* r, int layers, const flo
 {
     static const float defaults[gs::kMaxDepthLayers + 1][gs::kMaxDepthLayers] = {
         {1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}, {0.15f, 1.f, 1.f, 1.f}, {0.06f, 0.25f, 1.f, 1.f}, {0.05f, 0.15f, 0.4f, 1.f}};
-    if (layers < 1 || layers > gs::kMaxDepthLayers) return -1;
+    if (layers < 0 || layers > gs::kMaxDepthLayers) return -1;
+    if (layers == 0) // the renderer chooses (header): the cuts are the defaults of the count it picks
+    {
+        r->depthLayers = 0;
+        r->autoLayers = 1;
+        r->graphValid = false;
+        return 0;
+    }
     float f[gs::kMaxDepthLayers];
     for (int l = 0; l != gs::kMaxDepthLayers; ++l) f[l] = defaults[layers][l];
     if (fractions != nullptr)
@@ -239,6 +246,18 @@ extern "C" int gs_renderer_set_depth_layers(GsRenderer* r, int layers, const flo
     return 0;
 }
 extern "C" int gs_renderer_depth_layers(const GsRenderer* r) { return r->depthLayers; }
+namespace gs
+{
+// The layer count and cuts the next captured frame uses: as set, or -- depthLayers == 0 -- what the previous frames' pair totals suggest.
+int effectiveDepthLayers(const GsRenderer* r, float fraction[kMaxDepthLayers])
+{
+    static const float defaults[kMaxDepthLayers + 1][kMaxDepthLayers] = {
+        {1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}, {0.15f, 1.f, 1.f, 1.f}, {0.06f, 0.25f, 1.f, 1.f}, {0.05f, 0.15f, 0.4f, 1.f}};
+    const int layers = r->depthLayers > 0 ? r->depthLayers : r->autoLayers;
+    for (int l = 0; l != kMaxDepthLayers; ++l) fraction[l] = r->depthLayers > 0 ? r->layerFraction[l] : defaults[layers][l];
+    return layers;
+}
+} // namespace gs
 
 extern "C" int gs_renderer_colours_on_demand(const GsRenderer* r) { return useLazyColours(r) ? 1 : 0; }
 

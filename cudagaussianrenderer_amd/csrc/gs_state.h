@@ -148,7 +148,8 @@ struct GsRenderer
     int views = 1;     // cameras per captured chain (gs_renderer_set_views)
     // Depth layers (gs_renderer_set_depth_layers): the depth-sorted splats are listed, sorted and blended in `depthLayers` layers
     // (layer l = sorted splats [layerFraction[l-1], layerFraction[l]) of the frame's), later layers without the tiles earlier ones stopped.
-    int depthLayers = 1;
+    int depthLayers = 0;  // 0 = chosen from the previous frame's pair total (autoLayers), 1..4 = as set
+    int autoLayers = 1;
     float layerFraction[gs::kMaxDepthLayers] = {1.f, 1.f, 1.f, 1.f}; // upper bounds, ascending; the last used one is 1
     uint8_t* tileStatus = nullptr;      // inside the range table's allocation, right behind the ranges (the same 0xFF fill resets both)
     uint32_t* tileOpenBits = nullptr;   // behind the status bytes: one bit per (virtual) tile, 1 = open (the fill sets them all)
@@ -205,6 +206,7 @@ struct StreamScope
 bool useLazyColours(const GsRenderer* r);
 RasterColourSource colourSource(const GsRenderer* r, const float* cameraPosition, const FrameParams* paramsDevice);
 bool growTileListIfNeeded(GsRenderer* r, int64_t demand);
+int effectiveDepthLayers(const GsRenderer* r, float fraction[kMaxDepthLayers]);
 size_t rangeTableInts(const Screen& scr, int views); // ranges of all views + the depth layers' status bytes and open bits behind them, in ints
 int openWordsPerRow(int tilesX);
 // Captured path (gs_capture.hip).  `cameras`: r->views of them (one frame per view, rendered by one chain).

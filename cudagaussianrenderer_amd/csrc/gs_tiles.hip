@@ -237,8 +237,8 @@ void ensureTileListScratch(TileListScratch& s, int count)
     if (s.total == nullptr)
     {
         GS_CHECK(hipMalloc((void**) &s.total, sizeof(int64_t)));
-        GS_CHECK(hipHostMalloc((void**) &s.totalHost, sizeof(int64_t), hipHostMallocMapped));
-        *s.totalHost = 0;
+        GS_CHECK(hipHostMalloc((void**) &s.totalHost, 2 * sizeof(int64_t), hipHostMallocMapped)); // [1]: the pairs a layered frame listed in all
+        s.totalHost[0] = s.totalHost[1] = 0;
         if (hipHostGetDevicePointer((void**) &s.totalHostMapped, s.totalHost, 0) != hipSuccess) s.totalHostMapped = nullptr;
     }
     if (waves > s.capacityWaves)

@@ -453,7 +453,12 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                 const long long largest = (layerFlags & 1) ? all : max(all, (long long) frameTotals[0]);
                 frameTotals[0] = largest;
                 frameTotals[1] = (layerFlags & 1) ? all : frameTotals[1] + all;
-                if ((layerFlags & 2) && totalHostMapped != nullptr) *totalHostMapped = largest;
+                if ((layerFlags & 2) && totalHostMapped != nullptr)
+                {
+                    totalHostMapped[1] = frameTotals[1]; // (the sum first: the host waits for word 0)
+                    __threadfence_system();
+                    totalHostMapped[0] = largest;
+                }
             }
             else if (totalHostMapped != nullptr) *totalHostMapped = all;
         }

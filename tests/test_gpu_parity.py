@@ -1579,8 +1579,7 @@ def test_depth_layers_give_byte_identical_frames(gs, gsref, tmp_path, degree, w,
         r = gs.Renderer(w, h, storage_order=storage)
         r.set_scene(*scene)
         r.set_graph(True)
-        if layers > 1:
-            r.set_depth_layers(layers, fractions)
+        r.set_depth_layers(layers, fractions)
         out, listed = [], []
         for cam in cams:
             r.render(cam)
@@ -1662,4 +1661,40 @@ def test_depth_layers_with_views_bands_and_a_list_that_must_grow(gs, tmp_path):
     assert r.captured_retries() >= 1 and np.array_equal(r.read_image(), want2)
     r.render(cam)
     assert np.array_equal(r.read_image(), want2)
+    r.close()
+
+
+def test_the_renderer_chooses_its_depth_layers(gs, tmp_path):
+    """gs_renderer_set_depth_layers(0), the default: one layer while the frames' pair totals stay below 8 M, two from there -- decided
+    from the previous frame's total, so the second frame of a large scene is the first layered one; the bytes do not change."""
+    w, h = 1920, 1080
+    small = _ply_scene(gs, tmp_path, 150_000, 0, log_scale_mean=-3.6)
+    r = gs.Renderer(w, h)
+    assert gs.lib().gs_renderer_depth_layers(r.handle) == 0
+    r.set_scene(small["position"], small["scaleAndRotation"], small["color"])
+    r.set_graph(True)
+    cam = gs.camera_from_bounds(small["boundsMin"], small["boundsMax"], w, h)
+    for _ in range(3):
+        r.render(cam)
+    assert r.depth_layers_in_use() == 1 and r.listed_pairs() < 8_000_000
+    r.close()
+    big = _ply_scene(gs, tmp_path, 1_600_000, 0, log_scale_mean=-3.4)  # ~ 12 M pairs per frame
+    cam = gs.camera_from_bounds(big["boundsMin"], big["boundsMax"], w, h)
+    one = gs.Renderer(w, h)
+    one.set_scene(big["position"], big["scaleAndRotation"], big["color"])
+    one.set_graph(True)
+    one.set_depth_layers(1)
+    one.render(cam)
+    want, full = one.read_image(), one.listed_pairs()
+    one.close()
+    assert full >= 8_000_000
+    r = gs.Renderer(w, h)
+    r.set_scene(big["position"], big["scaleAndRotation"], big["color"])
+    r.set_graph(True)
+    r.render(cam)
+    assert r.depth_layers_in_use() == 1 and np.array_equal(r.read_image(), want)  # the first frame measures
+    for _ in range(3):
+        r.render(cam)
+        assert r.depth_layers_in_use() == 2 and np.array_equal(r.read_image(), want)
+    assert r.listed_pairs() < full
     r.close()
