@@ -160,7 +160,7 @@ class Rig:
             r.set_back_buffer(fb.data_ptr())
             r.set_stream(self.streams[d].cuda_stream)
             r.set_graph(not args.no_graph)
-            if args.depth_layers >= 0:
+            if not args.no_graph:
                 r.set_depth_layers(args.depth_layers, [float(v) for v in args.layer_fractions.split(",")] if args.layer_fractions else None)
             self.renderers.append(r)
             self.framebuffers.append(fb)
@@ -534,7 +534,7 @@ def main():
     ap.add_argument("--watchdog", type=float, default=180.0, help="multi-GPU: seconds without progress after which a rank prints where it was and exits 5 (0 = off)")
     ap.add_argument("--storage-order", choices=["auto", "caller", "morton"], default="auto", help="how the renderers store the splats (gs_renderer_set_storage_order): the file's order, or along a 3-D Morton curve (same frames byte for byte; +2 %% frames/s on one GPU, -10 %% per band frame of an 8-way split: profiles/r04_ab_experiments.txt, r04_band_sim.txt); auto = morton")
     ap.add_argument("--list-fusion", type=int, default=-1, help="gs_set_list_fusion: 1 the emit pass carries the first pass of the tile sort, 0 plain emit + full tile sort, -1 the library's default")
-    ap.add_argument("--depth-layers", type=int, default=-1, help="gs_renderer_set_depth_layers: list / sort / blend the depth-sorted splats in this many layers (captured frames; same image bytes); 0 = the renderer chooses from the pair total, -1 = the library's default (0)")
+    ap.add_argument("--depth-layers", type=int, default=0, help="gs_renderer_set_depth_layers: list / sort / blend the depth-sorted splats in this many layers (captured frames; same image bytes); 0 = the renderer chooses from the pair total (one layer below 8 M pairs per frame: the default workload), 1 = the library's default")
     ap.add_argument("--layer-fractions", default="", help="comma-separated ascending upper bounds of the first layers - 1 depth layers (fractions of the sorted splats); empty = the library's defaults")
     ap.add_argument("--stream-priorities", default="", help="diagnostics: comma-separated HIP stream priorities of the frames in flight (0 normal, -1 high), cycled; empty = default streams")
     ap.add_argument("--inflight", type=int, default=0, help="frames in flight per GPU (renderers on separate HIP streams); 0 = 4 (the measured optimum with 8 hardware queues)")

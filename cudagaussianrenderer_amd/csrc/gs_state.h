@@ -148,7 +148,7 @@ struct GsRenderer
     int views = 1;     // cameras per captured chain (gs_renderer_set_views)
     // Depth layers (gs_renderer_set_depth_layers): the depth-sorted splats are listed, sorted and blended in `depthLayers` layers
     // (layer l = sorted splats [layerFraction[l-1], layerFraction[l]) of the frame's), later layers without the tiles earlier ones stopped.
-    int depthLayers = 0;  // 0 = chosen from the previous frame's pair total (autoLayers), 1..4 = as set
+    int depthLayers = 1;  // 1..4 = as set (default 1: the reference's one list per frame), 0 = chosen from the previous frame's pair total (autoLayers)
     int autoLayers = 1;
     float layerFraction[gs::kMaxDepthLayers] = {1.f, 1.f, 1.f, 1.f}; // upper bounds, ascending; the last used one is 1
     uint8_t* tileStatus = nullptr;      // inside the range table's allocation, right behind the ranges (the same 0xFF fill resets both)

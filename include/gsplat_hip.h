@@ -323,9 +323,9 @@ int gs_renderer_colours_on_demand(const GsRenderer* r);
  * multiples of 32 entries of its whole list: the image is the same bytes as with one layer.  What changes: the pair list the renderer
  * hands out (gs_renderer_buffers) is the LAST layer's only, and tileListSize sums the pairs that were listed.  Takes effect on
  * captured frames of the two-level pipeline whose tile sort is a two-pass sort of 16-bit indices (list fusion on, no band cull).
- * layers = 0 (the default): the renderer chooses from the previous frame's pair total -- one layer below 8 M pairs per frame (where
- * layers cost more than they save: BASELINE.json configs[2] stays as it is), two from there, three from 40 M (configs[4] on one GPU:
- * +35 % / +46 %, profiles/r05_depth_layers.txt).  1 = never. */
+ * layers = 1 (the default): one list per frame, as the reference has it.  layers = 0: the renderer chooses from the previous frame's
+ * pair total -- one layer below 8 M pairs per frame (where layers cost more than they save: BASELINE.json configs[2] stays as it is),
+ * two from there, three from 40 M (configs[4] on one GPU: +35 % / +46 %, profiles/r05_depth_layers.txt); what bench.py asks for. */
 int gs_renderer_set_depth_layers(GsRenderer* r, int layers, const float* fractions);
 int gs_renderer_depth_layers(const GsRenderer* r);        /* the setting (0 = the renderer chooses) */
 int gs_renderer_depth_layers_in_use(const GsRenderer* r); /* layers the last captured frame was made of */

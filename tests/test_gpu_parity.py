@@ -1665,14 +1665,16 @@ def test_depth_layers_with_views_bands_and_a_list_that_must_grow(gs, tmp_path):
 
 
 def test_the_renderer_chooses_its_depth_layers(gs, tmp_path):
-    """gs_renderer_set_depth_layers(0), the default: one layer while the frames' pair totals stay below 8 M, two from there -- decided
-    from the previous frame's total, so the second frame of a large scene is the first layered one; the bytes do not change."""
+    """gs_renderer_set_depth_layers(0): one layer while the frames' pair totals stay below 8 M, two from there -- decided from the previous
+    frame's total, so the second frame of a large scene is the first layered one; the bytes do not change.  (The library's default is one
+    layer: the list a renderer hands out is then the reference's whole list.)"""
     w, h = 1920, 1080
     small = _ply_scene(gs, tmp_path, 150_000, 0, log_scale_mean=-3.6)
     r = gs.Renderer(w, h)
-    assert gs.lib().gs_renderer_depth_layers(r.handle) == 0
+    assert gs.lib().gs_renderer_depth_layers(r.handle) == 1
     r.set_scene(small["position"], small["scaleAndRotation"], small["color"])
     r.set_graph(True)
+    r.set_depth_layers(0)
     cam = gs.camera_from_bounds(small["boundsMin"], small["boundsMax"], w, h)
     for _ in range(3):
         r.render(cam)
@@ -1691,6 +1693,7 @@ def test_the_renderer_chooses_its_depth_layers(gs, tmp_path):
     r = gs.Renderer(w, h)
     r.set_scene(big["position"], big["scaleAndRotation"], big["color"])
     r.set_graph(True)
+    r.set_depth_layers(0)
     r.render(cam)
     assert r.depth_layers_in_use() == 1 and np.array_equal(r.read_image(), want)  # the first frame measures
     for _ in range(3):
