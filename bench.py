@@ -138,6 +138,8 @@ class Rig:
         self.beat = ctx.get("beat", lambda what: None)
         self.frames_timed = 0
         self.depth_layers_in_use = 1
+        self.listed_pairs = 0
+        self.depth_layer_changes = []
         self.W, self.H = args.width, args.height
         world, rank, device = ctx["world"], ctx["rank"], ctx["device"]
         self.band = bands[rank]
@@ -259,6 +261,8 @@ class Rig:
         elapsed, self.frames_timed, self.own_seconds = self.ctx["multigpu"].timed_frames(self, steps, warmup, self.ctx["world"],
                                                                                          self.ctx["tensor_device"])
         self.depth_layers_in_use = self.renderers[0].depth_layers_in_use()  # (of the timed region's last captured frame)
+        self.listed_pairs = self.renderers[0].listed_pairs()  # (same frame: pairs listed, summed over its depth layers)
+        self.depth_layer_changes = [int(self.ctx["lib"].gs_renderer_depth_layer_changes(r.handle)) for r in self.renderers]
         return elapsed
 
     def serial_frames(self, frames, sync_each):
@@ -739,8 +743,8 @@ def main():
                 "pairs_per_frame": round(p_mean), "consumed_pairs_per_frame": round(pc_mean), "nonempty_tiles": round(nonempty),
                 "log_scale_mean": args.log_scale_mean, "opacity_mean_raw": args.opacity_mean, "seed": args.seed, "storage_order": args.storage_order,
                 "list_fusion": int(lib.gs_get_list_fusion()),
-                "depth_layers": {"setting": int(lib.gs_renderer_depth_layers(rig.renderers[0].handle)), "in_use": rig.depth_layers_in_use,
-                                 "what": "gs_renderer_set_depth_layers: 0 = the renderer chooses from the pair total (one layer below 8 M pairs per frame)"},
+                "depth_layers": {"setting": int(lib.gs_renderer_depth_layers(rig.renderers[0].handle)), "in_use": rig.depth_layers_in_use, "listed_pairs_last_frame": rig.listed_pairs, "changes_per_renderer": rig.depth_layer_changes,
+                                 "what": "gs_renderer_set_depth_layers: 0 = the renderer chooses from the pair total (one layer below 8 M pairs per frame); listed_pairs_last_frame = pairs the last timed frame put into its lists (all layers; = pairs_per_frame with one layer)"},
                 "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": device_name(lib), "frames_in_flight": depth, "frames_per_chain": rig.V, "frames_ahead": depth * rig.V,
                 "frames_ahead_what": "cameras the caller must hand over before the first image of them is complete (frames per chain x chains in flight); "
                                      "the reference's loop is 1 -- extra.latency has that figure",

@@ -164,6 +164,7 @@ SIGNATURES = {
     "gs_renderer_depth_layers": (C.c_int, [C.c_void_p]),
     "gs_renderer_listed_pairs": (C.c_int64, [C.c_void_p]),
     "gs_renderer_depth_layers_in_use": (C.c_int, [C.c_void_p]),
+    "gs_renderer_depth_layer_changes": (C.c_int, [C.c_void_p]),
     "gs_set_footprint": (None, [C.c_int]),
     "gs_get_footprint": (C.c_int, []),
     "gs_get_sort_backend": (C.c_int, []),

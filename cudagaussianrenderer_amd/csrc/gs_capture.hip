@@ -371,6 +371,16 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
             else if (r->autoLayers == 2) next = listed < 2500000 ? 1 : listed >= 18000000 ? 3 : 2; // (two layers list ~0.4 of the pairs ...
             else next = listed < 6000000 ? 2 : r->autoLayers;                                      //  ... three ~0.2-0.25)
             // (a frame that cannot be layered -- band cull, one-pass tile sort -- keeps measuring totals; the wish costs nothing)
+            // A change re-captures the frame (milliseconds), so a camera path whose totals straddle a threshold must not flap: steps up
+            // are taken at once, steps down only after autoHoldFrames frames, and a step down that the next frames undo doubles the hold.
+            r->autoFramesSinceChange += 1;
+            if (next < r->autoLayers && r->autoFramesSinceChange < r->autoHoldFrames) next = r->autoLayers;
+            if (next != r->autoLayers)
+            {
+                if (next > r->autoLayers && r->autoLayerChanges > 0 && r->autoFramesSinceChange <= 4) r->autoHoldFrames = std::min(r->autoHoldFrames * 2, 1 << 16);
+                r->autoLayerChanges += 1;
+                r->autoFramesSinceChange = 0;
+            }
             r->autoLayers = next;
         }
         if (demand <= r->tileListCapacity) return 0;
@@ -393,6 +403,7 @@ extern "C" void gs_renderer_set_graph(GsRenderer* r, int enabled)
 }
 
 extern "C" int gs_renderer_captured_retries(const GsRenderer* r) { return r->capturedRetries; }
+extern "C" int gs_renderer_depth_layer_changes(const GsRenderer* r) { return r->autoLayerChanges; }
 // Depth layers the last captured frame was made of (1 when it was not layered: band cull, one-pass tile sort, a small scene, or the choice).
 extern "C" int gs_renderer_depth_layers_in_use(const GsRenderer* r) { return (r->graphValid && r->graphLayersActive) ? r->graphLayers : 1; }
 // Pairs the last captured frame listed, summed over its depth layers (with one layer: the frame's pair total).

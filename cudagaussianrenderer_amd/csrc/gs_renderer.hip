@@ -229,6 +229,8 @@ extern "C" int gs_renderer_set_depth_layers(GsRenderer* r, int layers, const flo
     {
         r->depthLayers = 0;
         r->autoLayers = 1;
+        r->autoFramesSinceChange = 0;
+        r->autoHoldFrames = 16;
         r->graphValid = false;
         return 0;
     }

@@ -150,6 +150,9 @@ struct GsRenderer
     // (layer l = sorted splats [layerFraction[l-1], layerFraction[l]) of the frame's), later layers without the tiles earlier ones stopped.
     int depthLayers = 1;  // 1..4 = as set (default 1: the reference's one list per frame), 0 = chosen from the previous frame's pair total (autoLayers)
     int autoLayers = 1;
+    int autoLayerChanges = 0;       // times the choice changed (each one re-captures the frame)
+    int autoFramesSinceChange = 0;
+    int autoHoldFrames = 16;        // frames a choice is kept before it may go DOWN; doubles when a step down is undone at once
     float layerFraction[gs::kMaxDepthLayers] = {1.f, 1.f, 1.f, 1.f}; // upper bounds, ascending; the last used one is 1
     uint8_t* tileStatus = nullptr;      // inside the range table's allocation, right behind the ranges (the same 0xFF fill resets both)
     uint32_t* tileOpenBits = nullptr;   // behind the status bytes: one bit per (virtual) tile, 1 = open (the fill sets them all)

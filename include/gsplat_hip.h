@@ -329,6 +329,8 @@ int gs_renderer_colours_on_demand(const GsRenderer* r);
 int gs_renderer_set_depth_layers(GsRenderer* r, int layers, const float* fractions);
 int gs_renderer_depth_layers(const GsRenderer* r);        /* the setting (0 = the renderer chooses) */
 int gs_renderer_depth_layers_in_use(const GsRenderer* r); /* layers the last captured frame was made of */
+int gs_renderer_depth_layer_changes(const GsRenderer* r); /* layers = 0: times the renderer changed its choice (each one re-captures the frame; steps
+                                                           * down wait 16 frames, doubled whenever one is undone within 4 frames) */
 /* Pairs the last captured frame listed: summed over its depth layers (gs_last_tile_list_demand then holds the largest layer's total,
  * which is what the list capacity must hold); the frame's pair total with one layer.  Waits for the renderer's stream. */
 int64_t gs_renderer_listed_pairs(GsRenderer* r);
