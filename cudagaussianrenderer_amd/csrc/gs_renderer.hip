@@ -498,6 +498,13 @@ extern "C" void gs_renderer_buffers(GsRenderer* r, GsRendererBuffers* out)
         StreamScope scope(r);
         GS_CHECK(hipStreamSynchronize(g.stream));
         r->tileListSize = (int32_t) std::min<int64_t>(*r->scratch.totalHost, r->tileListCapacity);
+        if (r->graphLayersActive)
+        {
+            // depth layers: the list in the buffers is the LAST layer's (the host word holds the largest layer's total)
+            int64_t lastLayer = 0;
+            GS_CHECK(hipMemcpy(&lastLayer, r->scratch.total, sizeof(int64_t), hipMemcpyDeviceToHost));
+            r->tileListSize = (int32_t) std::min<int64_t>(lastLayer, r->tileListCapacity);
+        }
         out->keys = r->keys[r->selector];
         out->values = r->values[r->selector];
     }

@@ -321,7 +321,7 @@ int gs_renderer_colours_on_demand(const GsRenderer* r);
  * and a later layer lists no pair of a tile that an earlier layer's votes already stopped.  A tile that is still open when a layer's
  * list ends leaves its per-pixel sums and transmittance and goes on in the next layer that has entries for it, its votes still at
  * multiples of 32 entries of its whole list: the image is the same bytes as with one layer.  What changes: the pair list the renderer
- * hands out (gs_renderer_buffers) is the LAST layer's only, and tileListSize sums the pairs that were listed.  Takes effect on
+ * hands out (gs_renderer_buffers: keys, values, ranges, tileListSize) is the LAST layer's only (gs_renderer_listed_pairs: all layers).  Takes effect on
  * captured frames of the two-level pipeline whose tile sort is a two-pass sort of 16-bit indices (list fusion on, no band cull).
  * layers = 1 (the default): one list per frame, as the reference has it.  layers = 0: the renderer chooses from the previous frame's
  * pair total -- one layer below 8 M pairs per frame (where layers cost more than they save: BASELINE.json configs[2] stays as it is),

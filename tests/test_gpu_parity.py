@@ -1586,6 +1586,16 @@ def test_depth_layers_give_byte_identical_frames(gs, gsref, tmp_path, degree, w,
             r.render(cam)  # (both graph instances)
             out.append(r.read_image())
             listed.append(r.listed_pairs())
+        if layers > 1 and r.depth_layers_in_use() > 1:
+            # what the renderer hands out after a layered frame is its LAST layer's list: sorted by tile, as long as its size says,
+            # and the range table is that list's
+            tiles = ((w + 15) // 16) * ((h + 15) // 16)
+            keys, values, ranges, _ = _sorted_list_ranges_image(gs, r, tiles)
+            assert len(keys) <= listed[-1] and np.all(np.diff(keys) >= 0) and (len(values) == 0 or 0 <= values.min())
+            ranges = ranges.reshape(tiles, 2)
+            have = ranges[:, 0] >= 0
+            assert int((ranges[have, 1] - ranges[have, 0]).sum()) == len(keys)
+            assert np.array_equal(keys[ranges[have, 0]], np.nonzero(have)[0]) and np.array_equal(keys[ranges[have, 1] - 1], np.nonzero(have)[0])
         r.close()
         return out, listed
 
