@@ -134,7 +134,7 @@ class Rig:
         from concurrent.futures import ThreadPoolExecutor
 
         gs, lib = ctx["gs"], ctx["lib"]
-        self.ctx, self.ply, self.cameras, self.bands, self.depth = ctx, ply, cameras, bands, depth
+        self.ctx, self.ply, self.cameras, self.bands, self.depth, self.args = ctx, ply, cameras, bands, depth, args
         self.beat = ctx.get("beat", lambda what: None)
         self.frames_timed = 0
         self.depth_layers_in_use = 1
@@ -162,6 +162,8 @@ class Rig:
             r.set_back_buffer(fb.data_ptr())
             r.set_stream(self.streams[d].cuda_stream)
             r.set_graph(not args.no_graph)
+            if args.no_layer_compaction:
+                lib.gs_renderer_debug_set_layer_compaction(r.handle, 0)
             if not args.no_graph:
                 r.set_depth_layers(args.depth_layers, [float(v) for v in args.layer_fractions.split(",")] if args.layer_fractions else None)
             self.renderers.append(r)
@@ -272,6 +274,7 @@ class Rig:
         import torch
 
         r, stream = self.renderers[0], self.streams[0]
+        self.lone_frame_layers(r)
         for phase in range(2):
             torch.cuda.synchronize(self.ctx["device"])
             t0 = time.perf_counter()
@@ -280,7 +283,19 @@ class Rig:
                 if sync_each:
                     stream.synchronize()
             torch.cuda.synchronize(self.ctx["device"])
-        return (time.perf_counter() - t0) / frames
+            elapsed = time.perf_counter() - t0
+        self.pipelined_layers(r)
+        return elapsed / frames
+
+    def lone_frame_layers(self, r):
+        """The depth-layer choice of a host that renders ONE frame at a time: GS_DEPTH_LAYERS_CHOOSE where the timed loop runs under
+        GS_DEPTH_LAYERS_CHOOSE_PIPELINED (the default); an explicit --depth-layers stays."""
+        if self.args.depth_layers == -1 and not self.args.no_graph:
+            r.set_depth_layers(0)
+
+    def pipelined_layers(self, r):
+        if self.args.depth_layers == -1 and not self.args.no_graph:
+            r.set_depth_layers(-1)
 
     def per_view_ms(self, repeats=64):
         """Every view of the orbit by itself (mean / min over the views): one renderer, captured frames of ONE camera
@@ -288,6 +303,7 @@ class Rig:
         import torch
 
         r = self.renderers[0]
+        self.lone_frame_layers(r)
         out = []
         for cam in self.cameras:
             for _ in range(8):
@@ -298,6 +314,7 @@ class Rig:
                 r.render(cam)
             torch.cuda.synchronize(self.ctx["device"])
             out.append(1e3 * (time.perf_counter() - t0) / repeats)
+        self.pipelined_layers(r)
         return out
 
     def gather_frame_ms(self, chains=4):
@@ -538,7 +555,8 @@ def main():
     ap.add_argument("--watchdog", type=float, default=180.0, help="multi-GPU: seconds without progress after which a rank prints where it was and exits 5 (0 = off)")
     ap.add_argument("--storage-order", choices=["auto", "caller", "morton"], default="auto", help="how the renderers store the splats (gs_renderer_set_storage_order): the file's order, or along a 3-D Morton curve (same frames byte for byte; +2 %% frames/s on one GPU, -10 %% per band frame of an 8-way split: profiles/r04_ab_experiments.txt, r04_band_sim.txt); auto = morton")
     ap.add_argument("--list-fusion", type=int, default=-1, help="gs_set_list_fusion: 1 the emit pass carries the first pass of the tile sort, 0 plain emit + full tile sort, -1 the library's default")
-    ap.add_argument("--depth-layers", type=int, default=0, help="gs_renderer_set_depth_layers: list / sort / blend the depth-sorted splats in this many layers (captured frames; same image bytes); 0 = the renderer chooses from the pair total (one layer below 8 M pairs per frame: the default workload), 1 = the library's default")
+    ap.add_argument("--no-layer-compaction", action="store_true", help="A/B: gs_renderer_debug_set_layer_compaction(0)")
+    ap.add_argument("--depth-layers", type=int, default=-1, help="gs_renderer_set_depth_layers: list / sort / blend the depth-sorted splats in this many layers (captured frames; same image bytes); 0 = the renderer chooses from the pair total (two layers from 8 M pairs per frame, three from 40 M), -1 (default) = the same for a host with several frames in flight, which the timed loop is (two layers from 4.5 M pairs) -- the one-frame-at-a-time legs of extra.latency then run under 0; 1 = the library's default")
     ap.add_argument("--layer-fractions", default="", help="comma-separated ascending upper bounds of the first layers - 1 depth layers (fractions of the sorted splats); empty = the library's defaults")
     ap.add_argument("--stream-priorities", default="", help="diagnostics: comma-separated HIP stream priorities of the frames in flight (0 normal, -1 high), cycled; empty = default streams")
     ap.add_argument("--inflight", type=int, default=0, help="frames in flight per GPU (renderers on separate HIP streams); 0 = 4 (the measured optimum with 8 hardware queues)")
@@ -744,7 +762,7 @@ def main():
                 "log_scale_mean": args.log_scale_mean, "opacity_mean_raw": args.opacity_mean, "seed": args.seed, "storage_order": args.storage_order,
                 "list_fusion": int(lib.gs_get_list_fusion()),
                 "depth_layers": {"setting": int(lib.gs_renderer_depth_layers(rig.renderers[0].handle)), "in_use": rig.depth_layers_in_use, "listed_pairs_last_frame": rig.listed_pairs, "changes_per_renderer": rig.depth_layer_changes,
-                                 "what": "gs_renderer_set_depth_layers: 0 = the renderer chooses from the pair total (one layer below 8 M pairs per frame); listed_pairs_last_frame = pairs the last timed frame put into its lists (all layers; = pairs_per_frame with one layer)"},
+                                 "what": "gs_renderer_set_depth_layers: -1 = the renderer chooses from the pair total, for a host with several frames in flight (two layers from 4.5 M pairs per frame, three from 40 M; the timed loop); 0 = the same for a lone frame (two layers from 8 M; extra.latency's legs when the setting is -1); in_use = layers of the timed region's last frame; listed_pairs_last_frame = pairs the last timed frame put into its lists (all layers; = pairs_per_frame with one layer)"},
                 "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": device_name(lib), "frames_in_flight": depth, "frames_per_chain": rig.V, "frames_ahead": depth * rig.V,
                 "frames_ahead_what": "cameras the caller must hand over before the first image of them is complete (frames per chain x chains in flight); "
                                      "the reference's loop is 1 -- extra.latency has that figure",

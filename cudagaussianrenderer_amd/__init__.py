@@ -20,6 +20,8 @@ PIPELINE_REFERENCE = 0  # the reference's stage order: one 64-bit tile|depth rad
 PIPELINE_TWO_LEVEL = 1  # default: depth-sort the splats, emit, stable-sort the pairs on the tile bits
 STORAGE_ORDER_CALLER = 0  # splats stored in the caller's order (the reference's behaviour)
 STAGED_BUILDER_REFERENCE_ORDER = 0  # gs_set_staged_builder: (splat, local tile) emission order + unconditional sort
+DEPTH_LAYERS_CHOOSE = 0  # gs_renderer_set_depth_layers: the renderer chooses from the frames' pair totals (two layers from 8 M pairs, three from 40 M)
+DEPTH_LAYERS_CHOOSE_PIPELINED = -1  # ... for a host with several frames in flight on the GPU (two layers from 4.5 M pairs)
 STAGED_BUILDER_SORTED = 1  # default: buildTileList emits in the order the sort leaves, sortTileList looks before it sorts
 STORAGE_ORDER_MORTON = 1  # splats stored along a Morton curve: same frames, faster (include/gsplat_hip.h)
 
@@ -398,7 +400,7 @@ class Renderer:
         """gs_renderer_set_depth_layers: list / sort / blend the depth-sorted splats in `layers` layers (captured frames; same image bytes)."""
         arr = (C.c_float * len(fractions))(*fractions) if fractions else None
         if lib().gs_renderer_set_depth_layers(self.handle, int(layers), arr) != 0:
-            raise ValueError("gs_renderer_set_depth_layers: 0 (the renderer chooses) or 1..4 layers, ascending fractions in (0, 1)")
+            raise ValueError("gs_renderer_set_depth_layers: 0 / -1 (the renderer chooses; -1: for several frames in flight) or 1..4 layers, ascending fractions in (0, 1)")
 
     def depth_layers_in_use(self):
         """Layers the last captured frame was made of."""

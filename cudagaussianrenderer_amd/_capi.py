@@ -165,6 +165,7 @@ SIGNATURES = {
     "gs_renderer_listed_pairs": (C.c_int64, [C.c_void_p]),
     "gs_renderer_depth_layers_in_use": (C.c_int, [C.c_void_p]),
     "gs_renderer_depth_layer_changes": (C.c_int, [C.c_void_p]),
+    "gs_renderer_debug_set_layer_compaction": (None, [C.c_void_p, C.c_int]),
     "gs_set_footprint": (None, [C.c_int]),
     "gs_get_footprint": (C.c_int, []),
     "gs_get_sort_backend": (C.c_int, []),

@@ -49,6 +49,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
     float layerFraction[kMaxDepthLayers];
     const int wantLayers = effectiveDepthLayers(r, layerFraction);
     const int layers = (wantLayers > 1 && !cull && fusedBits > 0 && nv >= 4096 && g_ablation == 0) ? wantLayers : 1;
+    ushort4* tileBox = (layers > 1 && r->layerCompaction) ? r->layerTileBox : nullptr; // (the later layers' live test, gs_tiles_fast.hip)
     // the range table is reset to -1 by the clip kernel (one node less than a memset; see gs_ranges.hip) -- and the layers' tile status
     // bytes behind it with it (0xFF = untouched)
     int32_t* clearTable = r->tileRange;
@@ -69,7 +70,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
         launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation, nullptr, nullptr, nullptr,
                             nullptr, r->splatToStorage != nullptr ? nullptr : r->depthKey[0],
                             r->splatToStorage != nullptr ? nullptr : (uint32_t*) r->order[0], nullptr, nullptr, nullptr, params, clearTable,
-                            clearEntries, (float4*) r->tileRecord, (float4*) r->rasterRecord, views);
+                            clearEntries, (float4*) r->tileRecord, (float4*) r->rasterRecord, views, nullptr, tileBox);
     };
     if (!cull)
     {
@@ -87,6 +88,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
                 deferredClip.tileRecord = (float4*) r->tileRecord;
                 deferredClip.rasterRecord = (float4*) r->rasterRecord;
                 deferredClip.views = views;
+                deferredClip.tileBox = tileBox;
                 r->radix.firstScanCompanion = RadixScanCompanion{&clipWithScanCompanion, &deferredClip};
             }
             else launchClip();
@@ -143,10 +145,23 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
             r->scratch.openWordsPerRow = openWordsPerRow(scr.tilesX);
             r->scratch.frameTotals = r->frameTotals;
             r->scratch.layerFlags = (l == 0 ? 1 : 0) | (l + 1 == layers ? 2 : 0);
-            launchTileListFastCount(g.stream, cnt, scr, order + begin, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, sortBits,
+            const uint32_t* layerOrder = order + begin;
+            r->scratch.countDevice = nullptr;
+            if (l > 0 && r->layerCompaction)
+            {
+                // the later layers walk only the splats that still have an open tile under their box (gs_tiles_fast.hip); the depth sort's
+                // other buffer is free by now
+                uint32_t* live = (uint32_t*) r->order[orderSel ^ 1];
+                launchLayerCompaction(g.stream, scr, nv, views > 1 ? n : 0, r->layerTileBox, r->tileOpenBits, openWordsPerRow(scr.tilesX), r->layerAlive, order + begin, cnt, r->layerBlockCounts, r->layerLiveNibbles, live,
+                                      r->layerLiveCount);
+                layerOrder = live;
+                r->scratch.countDevice = r->layerLiveCount;
+            }
+            launchTileListFastCount(g.stream, cnt, scr, layerOrder, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, sortBits,
                                     views > 1 ? n : 0);
-            launchTileListFastEmit(g.stream, cnt, scr, order + begin, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],
+            launchTileListFastEmit(g.stream, cnt, scr, layerOrder, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],
                                    tileKeyBytes, r->values[0], r->tileListCapacity, views > 1 ? n : 0, sortBits);
+            r->scratch.countDevice = nullptr;
             r->radix.countDevice = (const int*) r->scratch.total;
             r->radix.rangeTableForLastPass = r->tileRange;
             const int sel = launchRadixSortPairs(g.stream, r->radix, tileKeyBytes, r->keys[0], r->keys[1], r->values[0], r->values[1],
@@ -319,6 +334,15 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
                 if (r->layerState == nullptr) r->layerState = (float4*) gs_device_alloc(sizeof(float4) * (size_t) r->width * r->height * r->views);
                 if (r->layerConsumed == nullptr) r->layerConsumed = (int32_t*) gs_device_alloc(sizeof(int32_t) * (size_t) scr.totalTiles * r->views);
                 if (r->frameTotals == nullptr) r->frameTotals = (int64_t*) gs_device_alloc(sizeof(int64_t) * 2);
+                if (r->layerAlive == nullptr)
+                {
+                    const size_t virtualSplats = (size_t) n * r->views;
+                    r->layerAlive = (unsigned long long*) gs_device_alloc(sizeof(unsigned long long) * (virtualSplats / 64 + 2));
+                    r->layerBlockCounts = (int32_t*) gs_device_alloc(sizeof(int32_t) * (virtualSplats / 1024 + 2));
+                    r->layerLiveCount = (int32_t*) gs_device_alloc(sizeof(int32_t));
+                    r->layerLiveNibbles = (uint8_t*) gs_device_alloc(virtualSplats / 4 + 1024);
+                    r->layerTileBox = (ushort4*) gs_device_alloc(sizeof(ushort4) * (virtualSplats + 1));
+                }
             }
             for (int slot = 0; slot != 2; ++slot)
             {
@@ -362,19 +386,38 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
         r->tileListSize = (int32_t) std::min<int64_t>(demand, r->tileListCapacity);
         if (r->depthLayers == 0)
         {
-            // The renderer chooses the layer count of the NEXT frame from this one's pairs (profiles/r05_depth_layers.txt: two layers pay
-            // from ~8 M pairs per frame, three from ~40 M).  A frame of one layer knows the scene's pair total; a layered one knows what it
-            // listed (the second host word), which is less -- it falls back when that gets small, and the one-layer frame measures again.
+            // The renderer chooses the layer count of the NEXT frame from this one's pairs (profiles/r05_depth_layers.txt).  A frame of one
+            // layer knows the scene's pair total P; a layered one knows what it listed (the second host word), which is less.
+            //   one layer:     two from P >= 8 M, three from 40 M -- and two from 4.5 M when the host has said that it keeps several frames in
+            //                  flight (GS_DEPTH_LAYERS_CHOOSE_PIPELINED; BASELINE.json configs[2], 5.45 M: +5..6 % frames/s with four in flight,
+            //                  -14 % for a lone frame: ten more launches on one stream; 3.7 M: break-even; 2.7 M: -13 %);
+            //   first layered frame after a one-layer frame, P < 8 M: layers pay when most of the list lies behind the tiles' stop points --
+            //                  listed / P was 0.32-0.38 where they paid and 0.66 on a scene of low opacities where they cost 10 % -- so above
+            //                  0.5 the renderer goes back to one layer and does not try again for a while (256 frames, doubling);
+            //   two layers:    one below 1.5 M listed (the scene has become small), three from 18 M listed;   three: two below 6 M listed.
             const int64_t listed = r->graphLayersActive ? r->scratch.totalHost[1] : demand;
             int next = r->autoLayers;
-            if (!r->graphLayersActive || r->autoLayers == 1) next = demand >= 40000000 ? 3 : demand >= 8000000 ? 2 : 1;
-            else if (r->autoLayers == 2) next = listed < 2500000 ? 1 : listed >= 18000000 ? 3 : 2; // (two layers list ~0.4 of the pairs ...
-            else next = listed < 6000000 ? 2 : r->autoLayers;                                      //  ... three ~0.2-0.25)
+            bool atOnce = false; // (a failed trial is undone at once, whatever the hold says)
+            if (r->autoBanFrames > 0) r->autoBanFrames -= 1;
+            if (!r->graphLayersActive || r->autoLayers == 1)
+            {
+                r->autoLastTotal = demand;
+                next = demand >= 40000000 ? 3 : demand >= 8000000 ? 2 : (r->autoPipelined && demand >= 4500000 && r->autoBanFrames == 0) ? 2 : 1;
+            }
+            else if (r->autoFramesSinceChange == 0 && r->autoLastTotal > 0 && r->autoLastTotal < 8000000 && 2 * listed > r->autoLastTotal)
+            {
+                next = 1;
+                atOnce = true;
+                r->autoBanFrames = r->autoBanLength;
+                r->autoBanLength = std::min(r->autoBanLength * 2, 1 << 16);
+            }
+            else if (r->autoLayers == 2) next = listed < 1500000 ? 1 : listed >= 18000000 ? 3 : 2;
+            else next = listed < 6000000 ? 2 : r->autoLayers;
             // (a frame that cannot be layered -- band cull, one-pass tile sort -- keeps measuring totals; the wish costs nothing)
             // A change re-captures the frame (milliseconds), so a camera path whose totals straddle a threshold must not flap: steps up
             // are taken at once, steps down only after autoHoldFrames frames, and a step down that the next frames undo doubles the hold.
             r->autoFramesSinceChange += 1;
-            if (next < r->autoLayers && r->autoFramesSinceChange < r->autoHoldFrames) next = r->autoLayers;
+            if (next < r->autoLayers && !atOnce && r->autoFramesSinceChange < r->autoHoldFrames) next = r->autoLayers;
             if (next != r->autoLayers)
             {
                 if (next > r->autoLayers && r->autoLayerChanges > 0 && r->autoFramesSinceChange <= 4) r->autoHoldFrames = std::min(r->autoHoldFrames * 2, 1 << 16);
@@ -404,6 +447,12 @@ extern "C" void gs_renderer_set_graph(GsRenderer* r, int enabled)
 
 extern "C" int gs_renderer_captured_retries(const GsRenderer* r) { return r->capturedRetries; }
 extern "C" int gs_renderer_depth_layer_changes(const GsRenderer* r) { return r->autoLayerChanges; }
+// A/B runs: 0 = the later layers walk every splat of their slice of the depth order instead of the compacted live ones (same lists).
+extern "C" void gs_renderer_debug_set_layer_compaction(GsRenderer* r, int enabled)
+{
+    r->layerCompaction = enabled != 0;
+    r->graphValid = false;
+}
 // Depth layers the last captured frame was made of (1 when it was not layered: band cull, one-pass tile sort, a small scene, or the choice).
 extern "C" int gs_renderer_depth_layers_in_use(const GsRenderer* r) { return (r->graphValid && r->graphLayersActive) ? r->graphLayers : 1; }
 // Pairs the last captured frame listed, summed over its depth layers (with one layer: the frame's pair total).

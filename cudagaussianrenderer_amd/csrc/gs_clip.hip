@@ -44,6 +44,7 @@ struct ClipOutputs
     uint32_t* splatOrder;
     float4* tileRecord;
     float4* rasterRecord;
+    ushort4* tileBox; // depth layers: the box the list builder will walk for the splat (gs_aabb.h splatTileBox), for the layers' live test
 };
 
 // World-space covariance of a splat, Sigma = (R S)(R S)^T (GaussianRender.cu:215-224): the camera-independent half of the projection.
@@ -167,6 +168,12 @@ __device__ __forceinline__ bool projectCovariance(const float4 pd, const Sym3 S,
         // (random access), where two separate arrays cost two memory sectors per splat
         o.tileRecord[2 * (size_t) out] = make_float4(clipX, clipY, cosA, sinA);
         o.tileRecord[2 * (size_t) out + 1] = make_float4(extentX, extentY, 0.0f, 0.0f);
+    }
+    if (o.tileBox != nullptr)
+    {
+        // (from the six numbers of the tile record, by the builder's own routine: the same box, bit for bit)
+        const TileAabb b = splatTileBox(clipX, clipY, cosA, sinA, extentX, extentY, scr);
+        o.tileBox[out] = make_ushort4((unsigned short) b.x0, (unsigned short) b.y0, (unsigned short) b.x1, (unsigned short) b.y1);
     }
     if (o.conic != nullptr) o.conic[out] = make_float4(covC * invDet, -covB * invDet, covA * invDet, 0.0f);
     if (o.rasterRecord != nullptr)
@@ -418,11 +425,11 @@ void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const
                          const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic,
                          uint32_t* depthKey, uint32_t* splatOrder, unsigned long long* bandMask, int32_t* bandSlotPrefix,
                          int32_t* bandBlockCounts, const FrameParams* paramsDevice, int32_t* rangeTableToClear, int rangeEntries,
-                         float4* tileRecord, float4* rasterRecord, int views, const int32_t* bandOutSlot)
+                         float4* tileRecord, float4* rasterRecord, int views, const int32_t* bandOutSlot, ushort4* tileBox)
 {
     if (count <= 0) return;
     // views > 1: cameras from paramsDevice[view], results under view * count + splat
-    const ClipOutputs o{clipXY, clipZ, screenEllipse, conic, depthKey, splatOrder, tileRecord, rasterRecord};
+    const ClipOutputs o{clipXY, clipZ, screenEllipse, conic, depthKey, splatOrder, tileRecord, rasterRecord, tileBox};
 #ifndef GS_CLIP_ALL_VIEWS
 #define GS_CLIP_ALL_VIEWS 1 // A/B builds: 0 = one grid row per view (round 3)
 #endif
@@ -440,7 +447,7 @@ void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const
 
 void launchSplatClipDataWithScan(hipStream_t stream, const ClipWithScan& c, const RadixScanArgs& scan)
 {
-    const ClipOutputs o{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c.tileRecord, c.rasterRecord};
+    const ClipOutputs o{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c.tileRecord, c.rasterRecord, c.tileBox};
     const int clipBlocks = (c.count + 255) / 256;
     hipLaunchKernelGGL(splatClipDataScanKernel, dim3(scan.rows + clipBlocks, c.views), dim3(256), 0, stream, scan, c.count, c.scr, c.camera, c.params, c.position,
                        c.scaleAndRotation, o, c.rangeTableToClear, c.rangeEntries);

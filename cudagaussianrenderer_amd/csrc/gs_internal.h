@@ -80,7 +80,8 @@ void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const
                          int32_t* bandSlotPrefixOrNull = nullptr, int32_t* bandBlockCountsOrNull = nullptr,
                          const FrameParams* paramsDeviceOrNull = nullptr,
                          int32_t* rangeTableToClearOrNull = nullptr, int rangeEntries = 0, float4* tileRecordOrNull = nullptr,
-                         float4* rasterRecordOrNull = nullptr, int views = 1, const int32_t* bandOutSlotOrNull = nullptr);
+                         float4* rasterRecordOrNull = nullptr, int views = 1, const int32_t* bandOutSlotOrNull = nullptr,
+                         ushort4* tileBoxOrNull = nullptr /* depth layers: the list builder's box per splat (gs_aabb.h splatTileBox) */);
 // screenEllipse[i] = (cos, sin, extent x, extent y) from the 32-byte tile records the clip kernel can write instead.
 void launchUnpackEllipse(hipStream_t stream, int count, const float4* tileRecord, float4* screenEllipse);
 // positionClipSpaceXY / Z / conic from the 32-byte raster records (cx, cy, conic.x, conic.y | conic.z, depth, 0, 0) the clip kernel can
@@ -156,6 +157,10 @@ void ensureTileListFastScratch(TileListScratch& s, int count);
 // emit pass stages its pairs in LDS, ranks them stably by that digit and writes them where the first scatter would have put them
 // (no histogram kernel, no scatter kernel, the unsorted list is never written or read).  The caller then sorts on bits
 // [sortBits, tileBits) only.  Both passes must be given the same sortBits and viewSplats.
+// depth layers: liveOrder[0 .. *liveCount) = the splats of order[0 .. count) that still have an open tile under their box, in order
+void launchLayerCompaction(hipStream_t stream, const Screen& scr, int splats, int viewSplats, const ushort4* tileBox, const uint32_t* openBits, int openWordsPerRow, unsigned long long* aliveWords,
+                           const uint32_t* order, int count, int32_t* blockCounts, uint8_t* liveNibbles /* [ceil(count / 4)] */, uint32_t* liveOrder,
+                           int32_t* liveCount);
 void launchTileListFastCount(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
                              const float4* screenEllipse, TileListScratch& s, int sortBits = 0, int viewSplats = 0);
 void launchTileListFastEmit(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
@@ -232,6 +237,7 @@ struct ClipWithScan
     float4* tileRecord = nullptr;
     float4* rasterRecord = nullptr;
     int views = 1;
+    ushort4* tileBox = nullptr;
 };
 void launchSplatClipDataWithScan(hipStream_t stream, const ClipWithScan& clip, const RadixScanArgs& scan);
 inline void clipWithScanCompanion(hipStream_t stream, const RadixScanArgs& scan, void* user)

@@ -61,8 +61,24 @@ void allocTileList(GsRenderer* r, int32_t capacity)
     }
     r->tileListCapacity = capacity;
 }
+void freeLayerCompaction(GsRenderer* r)
+{
+    // (sized by splats x views: allocated again with the next layered frame)
+    gs_device_free(r->layerAlive);
+    gs_device_free(r->layerBlockCounts);
+    gs_device_free(r->layerLiveCount);
+    gs_device_free(r->layerTileBox);
+    gs_device_free(r->layerLiveNibbles);
+    r->layerLiveNibbles = nullptr;
+    r->layerTileBox = nullptr;
+    r->layerAlive = nullptr;
+    r->layerBlockCounts = nullptr;
+    r->layerLiveCount = nullptr;
+}
+
 void freeScene(GsRenderer* r)
 {
+    freeLayerCompaction(r);
     if (r->sceneShared)
     {
         // the read-only inputs are the owner's
@@ -224,13 +240,17 @@ extern "C" int gs_renderer_set_depth_layers(GsRenderer* r, int layers, const flo
 {
     static const float defaults[gs::kMaxDepthLayers + 1][gs::kMaxDepthLayers] = {
         {1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}, {0.15f, 1.f, 1.f, 1.f}, {0.06f, 0.25f, 1.f, 1.f}, {0.05f, 0.15f, 0.4f, 1.f}};
-    if (layers < 0 || layers > gs::kMaxDepthLayers) return -1;
-    if (layers == 0) // the renderer chooses (header): the cuts are the defaults of the count it picks
+    if (layers < GS_DEPTH_LAYERS_CHOOSE_PIPELINED || layers > gs::kMaxDepthLayers) return -1;
+    if (layers <= 0) // the renderer chooses (header): the cuts are the defaults of the count it picks
     {
         r->depthLayers = 0;
+        r->autoPipelined = layers == GS_DEPTH_LAYERS_CHOOSE_PIPELINED;
         r->autoLayers = 1;
         r->autoFramesSinceChange = 0;
         r->autoHoldFrames = 16;
+        r->autoBanFrames = 0;
+        r->autoBanLength = 256;
+        r->autoLastTotal = 0;
         r->graphValid = false;
         return 0;
     }
@@ -247,7 +267,7 @@ extern "C" int gs_renderer_set_depth_layers(GsRenderer* r, int layers, const flo
     r->graphValid = false;
     return 0;
 }
-extern "C" int gs_renderer_depth_layers(const GsRenderer* r) { return r->depthLayers; }
+extern "C" int gs_renderer_depth_layers(const GsRenderer* r) { return (r->depthLayers == 0 && r->autoPipelined) ? GS_DEPTH_LAYERS_CHOOSE_PIPELINED : r->depthLayers; }
 namespace gs
 {
 // The layer count and cuts the next captured frame uses: as set, or -- depthLayers == 0 -- what the previous frames' pair totals suggest.
@@ -441,6 +461,7 @@ extern "C" int gs_renderer_set_views(GsRenderer* r, int views)
     gs_device_free(r->layerConsumed);
     r->layerState = nullptr;
     r->layerConsumed = nullptr;
+    freeLayerCompaction(r);
     r->backBufferOwned = (uint8_t*) gs_device_alloc((size_t) scr.width * scr.height * 4 * views);
     GS_CHECK(hipMemset(r->backBufferOwned, 0, (size_t) scr.width * scr.height * 4 * views)); // rows outside a band stay zero
     if (!external) r->backBuffer = r->backBufferOwned;

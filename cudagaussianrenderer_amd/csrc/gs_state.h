@@ -150,8 +150,18 @@ struct GsRenderer
     // (layer l = sorted splats [layerFraction[l-1], layerFraction[l]) of the frame's), later layers without the tiles earlier ones stopped.
     int depthLayers = 1;  // 1..4 = as set (default 1: the reference's one list per frame), 0 = chosen from the previous frame's pair total (autoLayers)
     int autoLayers = 1;
+    bool autoPipelined = false;     // GS_DEPTH_LAYERS_CHOOSE_PIPELINED: the host keeps several frames in flight on the GPU -- two layers from 4.5 M pairs
+    unsigned long long* layerAlive = nullptr; // depth layers: one bit per (virtual) splat -- an open tile under its box (launchLayerCompaction)
+    int32_t* layerBlockCounts = nullptr;
+    int32_t* layerLiveCount = nullptr;
+    uint8_t* layerLiveNibbles = nullptr;
+    ushort4* layerTileBox = nullptr;          // the list builder's box per (virtual) splat, written by the clip kernel of a layered frame
+    bool layerCompaction = true;
     int autoLayerChanges = 0;       // times the choice changed (each one re-captures the frame)
     int autoFramesSinceChange = 0;
+    int64_t autoLastTotal = 0;      // the pair total of the last one-layer frame
+    int autoBanFrames = 0;          // frames left in which a scene below 8 M pairs is not tried with layers again (its listed / total was > 0.5)
+    int autoBanLength = 256;
     int autoHoldFrames = 16;        // frames a choice is kept before it may go DOWN; doubles when a step down is undone at once
     float layerFraction[gs::kMaxDepthLayers] = {1.f, 1.f, 1.f, 1.f}; // upper bounds, ascending; the last used one is 1
     uint8_t* tileStatus = nullptr;      // inside the range table's allocation, right behind the ranges (the same 0xFF fill resets both)

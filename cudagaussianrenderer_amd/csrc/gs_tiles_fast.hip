@@ -101,6 +101,10 @@ constexpr float kGuard = 1.0e-5f;
 // the host model alone), [6] tiles of the reference's box that the ellipse's own bounding box left out, [7] of those, tiles the
 // reference's predicate would have listed (must stay 0: the tight box's claim).
 __device__ unsigned long long g_guardStats[8];
+// depth layers (later layers' count passes): [0] splats with a box on screen, [1] of those, dropped because every tile under the box is
+// stopped, [2] boxes too large for that test, [3] units of those, [4] units of the boxes that were tested and kept, [5] units those
+// boxes would have had before being shrunk to their open tiles
+__device__ unsigned long long g_layerStats[8];
 #endif
 
 // Squared distance of the origin to the segment q + t e, t in [0,1]: the edge comes within the unit circle when it is
@@ -144,34 +148,9 @@ __device__ __forceinline__ unsigned decideInsideGuardBand(unsigned hitMask, floa
     return hitMask;
 }
 
-// The reference's box (GaussianRender.cu:408-436) bounds the ellipse's oriented bounding RECTANGLE: half width |cos| ex + |sin| ey.  The
-// ellipse itself reaches sqrt((cos ex)^2 + (sin ey)^2) -- for a round splat at 45 degrees 1/sqrt(2) of that -- and a tile outside the
-// ellipse's own bounding box cannot pass the overlap predicate.  Testing only the tiles of the intersection changes nothing but the
-// number of tests (9.0 M -> 7.x M per frame at C3) as long as the tighter box errs on the large side: the half extents are inflated
-// by 1e-4 relative + 1e-6 clip units, forty times what the predicate's own rounding can move a decision (see the guard band), and
-// floor / ceil keep every tile the inflated box touches.  A NaN ellipse keeps the reference's box (it emits no pairs anyway).
-#ifndef GS_TIGHT_BOX
-#define GS_TIGHT_BOX 1
-#endif
 #ifndef GS_VISIBLE_EDGES
 #define GS_VISIBLE_EDGES 1 // A/B builds: 0 = all four edges and the centre term of every tile (round 3's hot loop)
 #endif
-__device__ __forceinline__ void tightenToEllipse(TileAabb& box, float cx, float cy, float4 se, const Screen& scr)
-{
-    const float rx = se.x * se.z, ux = se.y * se.w; // x components of the half axes (cos ex, sin ey)
-    const float ry = se.y * se.z, uy = se.x * se.w; // y components (sin ex, -cos ey)
-    const float hx = sqrtf(fmaf(rx, rx, ux * ux)), hy = sqrtf(fmaf(ry, ry, uy * uy));
-    if (!(hx < 1.0e30f && hy < 1.0e30f)) return; // NaN or absurd: the reference's box stands
-    const float mx = fmaf(hx, 1.0e-4f, 1.0e-6f) + hx, my = fmaf(hy, 1.0e-4f, 1.0e-6f) + hy;
-    const float fx0 = floorf(((cx - mx) + 1.0f) * 0.5f * scr.tilesPerScreenX), fx1 = ceilf(((cx + mx) + 1.0f) * 0.5f * scr.tilesPerScreenX);
-    const float fy0 = floorf(((cy - my) + 1.0f) * 0.5f * scr.tilesPerScreenY), fy1 = ceilf(((cy + my) + 1.0f) * 0.5f * scr.tilesPerScreenY);
-    // (compared as floats: a bound far off screen stays far off screen; the reference's box is already clamped to the screen)
-    if (fx0 > (float) box.x0) box.x0 = (int) fminf(fx0, (float) box.x1);
-    if (fx1 < (float) box.x1) box.x1 = (int) fmaxf(fx1, (float) box.x0);
-    if (fy0 > (float) box.y0) box.y0 = (int) fminf(fy0, (float) box.y1);
-    if (fy1 < (float) box.y1) box.y1 = (int) fmaxf(fy1, (float) box.y0);
-}
-
 // Which tile strictly contains the centre along one axis, by the reference's arithmetic (GaussianRender.cu:382-386,656-664:
 // min = g * size - 1 and max = min + size, each rounded): the candidates around floor((c + 1) / size) are tested exactly.  Returns the
 // tile, -1 when none does (a centre on a boundary), -2 when two neighbours both do (their rounded intervals overlap by an ulp).
@@ -257,7 +236,18 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
         // nothing reached the band: no workgroup gets as far as the pair total below.  (With the scan kernel in front -- groupOffsets --
         // the total is the scan's to write, once per frame: the host may re-arm the mapped word as soon as it has seen that value.)
         *total = 0;
-        if (totalHostMapped != nullptr) *totalHostMapped = 0;
+        if (frameTotals != nullptr)
+        {
+            // (depth layers: a layer none of whose splats still has an open tile)
+            if (layerFlags & 1) frameTotals[0] = frameTotals[1] = 0;
+            if ((layerFlags & 2) && totalHostMapped != nullptr)
+            {
+                totalHostMapped[1] = frameTotals[1];
+                __threadfence_system();
+                totalHostMapped[0] = frameTotals[0];
+            }
+        }
+        else if (totalHostMapped != nullptr) *totalHostMapped = 0;
     }
     if (group * kGroup >= count) return; // whole workgroup
     const int sorted = group * kGroup + t;
@@ -374,7 +364,20 @@ __global__ __launch_bounds__(kGroup) void tileListFastKernel(int countHost, cons
                     }
                 }
                 if (open == 0) area = 0;
+#ifdef GS_AB_GUARD_COUNT
+                atomicAdd(&g_layerStats[0], 1ull);
+                if (open == 0) atomicAdd(&g_layerStats[1], 1ull);
+                else atomicAdd(&g_layerStats[4], (unsigned long long) ((area + kTilesPerUnit - 1) / kTilesPerUnit));
+#endif
             }
+#ifdef GS_AB_GUARD_COUNT
+            else if (openBits != nullptr && area > 0)
+            {
+                atomicAdd(&g_layerStats[0], 1ull);
+                atomicAdd(&g_layerStats[2], 1ull);
+                atomicAdd(&g_layerStats[3], (unsigned long long) ((area + kTilesPerUnit - 1) / kTilesPerUnit));
+            }
+#endif
             overlapOperands();
             // The tile that holds the centre (GaussianRender.cu:382-386), found once per splat with the reference's rounding.
             const int cgx = centreTileOnAxis(cx, scr.tileClipSizeX, scr.tilesPerScreenX), cgy = centreTileOnAxis(cy, scr.tileClipSizeY, scr.tilesPerScreenY);
@@ -1064,6 +1067,16 @@ extern "C" void gs_debug_guard_stats(unsigned long long out[4], int reset)
         GS_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_guardStats), zero, sizeof(zero)));
     }
 }
+extern "C" void gs_debug_layer_stats(unsigned long long out[8], int reset)
+{
+    GS_CHECK(hipDeviceSynchronize());
+    GS_CHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_layerStats), sizeof(unsigned long long) * 8));
+    if (reset)
+    {
+        const unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        GS_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_layerStats), zero, sizeof(zero)));
+    }
+}
 // all eight counters (the audit build's four after the guard band's four, see g_guardStats)
 extern "C" void gs_debug_overlap_audit(unsigned long long out[8], int reset)
 {
@@ -1101,6 +1114,159 @@ void ensureTileListFastScratch(TileListScratch& s, int count)
         if (s.digitTotals == nullptr) GS_CHECK(hipMalloc((void**) &s.digitTotals, sizeof(int32_t) * 256));
         s.capacityMaskGroups = groups;
     }
+}
+
+// ---- depth layers: the later layers walk only the splats that still have an open tile under their box ----------------------------------
+// A later layer's count / emit passes spend their time per GROUP of 256 depth-sorted splats (prologue, prefix sums, at least one round,
+// the digit table), and at BASELINE.json configs[4] 87-93 % of a later layer's splats lie wholly in stopped tiles -- spread evenly over
+// the groups, so no group disappears (profiles/r05_depth_layers.txt).  Three small kernels in front of the count pass make the groups
+// dense again: (1) every splat, in STORAGE order, has its box (8 bytes, left by the clip kernel) tested against the open bits and leaves one bit; (2) the layer's
+// slice of the depth order counts its live splats per block of 1 024 and (3) writes them out, in order, with the count for the passes'
+// device-side count.  The test is the count pass's own (same box, same limit on its size).
+constexpr int kCompactItems = 4;
+constexpr int kCompactBlock = kGroup * kCompactItems;
+
+constexpr int kAliveTableWords = 8192; // the open-bit table of all views in LDS when it fits (3840x2160: 1 215 words per view)
+template <bool TABLE_IN_LDS>
+__global__ __launch_bounds__(kGroup) void layerAliveKernel(int count, Screen scr, const ushort4* __restrict__ tileBox, int viewSplats,
+                                                           const uint32_t* __restrict__ openBitsGlobal, int openWordsPerRow, int tableWords,
+                                                           unsigned long long* __restrict__ aliveWords)
+{
+    // Sixteen scattered one-word loads per splat keep the texture path busy for ~16 cycles each (28 us at configs[4], the 40 MB of boxes
+    // would take 8): the table is a few KB, so every workgroup copies it into LDS once and walks many splats.
+    __shared__ uint32_t table[TABLE_IN_LDS ? kAliveTableWords : 1];
+    if (TABLE_IN_LDS)
+    {
+        for (int i = threadIdx.x; i < tableWords; i += kGroup) table[i] = openBitsGlobal[i];
+        __syncthreads();
+    }
+    const uint32_t* openBits = TABLE_IN_LDS ? table : openBitsGlobal;
+    // (four splats per lane and round: their box loads are in flight together -- one load per round left every wave waiting for memory,
+    // 23 us for 5 M splats whatever the test cost)
+    constexpr int kPerLane = 4;
+    for (int base = (int) blockIdx.x * kGroup * kPerLane; base < count; base += (int) gridDim.x * kGroup * kPerLane)
+    {
+        ushort4 boxes[kPerLane];
+#pragma unroll
+        for (int k = 0; k != kPerLane; ++k)
+        {
+            const int splat = base + k * kGroup + (int) threadIdx.x;
+            boxes[k] = splat < count ? tileBox[splat] : make_ushort4(0, 0, 0, 0); // (x0, y0, x1, y1) as the clip kernel left it
+        }
+#pragma unroll
+        for (int k = 0; k != kPerLane; ++k)
+        {
+            const int splat = base + k * kGroup + (int) threadIdx.x;
+            const ushort4 box = boxes[k];
+            bool alive = false;
+            const int w = (int) box.z - (int) box.x, h = (int) box.w - (int) box.y;
+            if (w > 0 && h > 0)
+            {
+                int rowBase = 0;
+                if (viewSplats > 0)
+#pragma unroll
+                    for (int v = 1; v != kMaxViews; ++v) rowBase += (splat >= v * viewSplats) ? scr.tilesY : 0;
+                const uint32_t* row = openBits + (size_t) (rowBase + box.y) * openWordsPerRow;
+                const int w0 = box.x >> 5, w1 = (box.z - 1) >> 5;
+                const unsigned firstMask = 0xFFFFFFFFu << (box.x & 31), lastMask = 0xFFFFFFFFu >> (31 - ((box.z - 1) & 31));
+                unsigned open = 0;
+                if (w1 - w0 <= 1 && h <= kDoneBoxRows)
+                {
+#pragma unroll
+                    for (int r = 0; r != kDoneBoxRows; ++r) // (independent loads)
+                        if (r < h)
+                        {
+                            const unsigned a = row[(size_t) r * openWordsPerRow + w0], b = row[(size_t) r * openWordsPerRow + w1];
+                            open |= w0 == w1 ? (a & firstMask & lastMask) : ((a & firstMask) | (b & lastMask));
+                        }
+                }
+                else open = 1u; // a larger box is kept unseen: 3 % of the splats, nearly all of them over some open tile, and one of them in
+                                // a wave would keep the other 63 lanes waiting for its rows
+                alive = open != 0;
+            }
+            const unsigned long long ballot = __ballot(alive);
+            if ((threadIdx.x & (kWave - 1)) == 0 && splat < count) aliveWords[splat >> 6] = ballot;
+        }
+    }
+}
+
+// SCATTER = false: blockCounts[b] = live splats among order[b * 1024 ...), and every lane's four live bits in liveNibbles (the gather from the
+// bit table is the expensive part: once is enough); true: the live ones written to out[] behind those of the blocks in front (every
+// block sums the counts in front of it itself: a few thousand words), the last block leaves the total.
+template <bool SCATTER>
+__global__ __launch_bounds__(kGroup) void layerCompactKernel(int count, const uint32_t* __restrict__ order, const unsigned long long* __restrict__ aliveWords,
+                                                             int32_t* __restrict__ blockCounts, uint8_t* __restrict__ liveNibbles,
+                                                             uint32_t* __restrict__ out, int32_t* __restrict__ countOut)
+{
+    __shared__ int waveSums[kWavesPerBlock];
+    __shared__ int baseSums[kWavesPerBlock];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & (kWave - 1);
+    const int first = (int) blockIdx.x * kCompactBlock + t * kCompactItems;
+    uint32_t ids[kCompactItems];
+    unsigned live = 0;
+#pragma unroll
+    for (int k = 0; k != kCompactItems; ++k) ids[k] = first + k < count ? order[first + k] : 0u;
+    if (SCATTER) live = liveNibbles[(size_t) blockIdx.x * kGroup + t];
+    else
+    {
+#pragma unroll
+        for (int k = 0; k != kCompactItems; ++k)
+            if (first + k < count) live |= (unsigned) ((aliveWords[ids[k] >> 6] >> (ids[k] & 63u)) & 1ull) << k;
+        liveNibbles[(size_t) blockIdx.x * kGroup + t] = (uint8_t) live;
+    }
+    const int mine = __popc(live);
+    const int incl = waveInclusiveSum(mine);
+    if (lane == kWave - 1) waveSums[wave] = incl;
+    if (SCATTER)
+    {
+        // the live splats of the blocks in front
+        int before = 0;
+        for (int b = t; b < (int) blockIdx.x; b += kGroup) before += blockCounts[b];
+        const int beforeIncl = waveInclusiveSum(before);
+        if (lane == kWave - 1) baseSums[wave] = beforeIncl;
+    }
+    __syncthreads();
+    int inFront = 0, blockTotal = 0, base = 0;
+#pragma unroll
+    for (int wv = 0; wv != kWavesPerBlock; ++wv)
+    {
+        const int v = waveSums[wv];
+        inFront += (wv < wave) ? v : 0;
+        blockTotal += v;
+        if (SCATTER) base += baseSums[wv];
+    }
+    if (!SCATTER)
+    {
+        if (t == 0) blockCounts[blockIdx.x] = blockTotal;
+        return;
+    }
+    int at = base + inFront + incl - mine;
+#pragma unroll
+    for (int k = 0; k != kCompactItems; ++k)
+        if (live & (1u << k)) out[at++] = ids[k];
+    if (t == 0 && (int) blockIdx.x == (int) gridDim.x - 1) *countOut = base + blockTotal;
+}
+
+// order[0 .. count): a layer's slice of the depth order; liveOrder[0 .. *liveCount): its splats that still have an open tile under their box.
+void launchLayerCompaction(hipStream_t stream, const Screen& scr, int splats, int viewSplats, const ushort4* tileBox, const uint32_t* openBits, int openWordsPerRow, unsigned long long* aliveWords,
+                           const uint32_t* order, int count, int32_t* blockCounts, uint8_t* liveNibbles, uint32_t* liveOrder, int32_t* liveCount)
+{
+    const int views = viewSplats > 0 ? (splats + viewSplats - 1) / viewSplats : 1;
+    const int tableWords = views * scr.tilesY * openWordsPerRow;
+    if (count <= 0)
+    {
+        GS_CHECK(hipMemsetAsync(liveCount, 0, sizeof(int32_t), stream));
+        return;
+    }
+    if (tableWords <= kAliveTableWords)
+        hipLaunchKernelGGL((layerAliveKernel<true>), dim3(std::min((splats + 4 * kGroup - 1) / (4 * kGroup), 2048)), dim3(kGroup), 0, stream, splats, scr, tileBox,
+                           viewSplats, openBits, openWordsPerRow, tableWords, aliveWords);
+    else
+        hipLaunchKernelGGL((layerAliveKernel<false>), dim3(std::min((splats + 4 * kGroup - 1) / (4 * kGroup), 4096)), dim3(kGroup), 0, stream, splats, scr, tileBox,
+                           viewSplats, openBits, openWordsPerRow, tableWords, aliveWords);
+    const int blocks = (count + kCompactBlock - 1) / kCompactBlock;
+    hipLaunchKernelGGL((layerCompactKernel<false>), dim3(blocks), dim3(kGroup), 0, stream, count, order, aliveWords, blockCounts, liveNibbles, liveOrder, liveCount);
+    hipLaunchKernelGGL((layerCompactKernel<true>), dim3(blocks), dim3(kGroup), 0, stream, count, order, aliveWords, blockCounts, liveNibbles, liveOrder, liveCount);
 }
 
 int tileListFusedSortBits(int tileBitCount, int tileKeyBytes)

@@ -323,14 +323,23 @@ int gs_renderer_colours_on_demand(const GsRenderer* r);
  * multiples of 32 entries of its whole list: the image is the same bytes as with one layer.  What changes: the pair list the renderer
  * hands out (gs_renderer_buffers: keys, values, ranges, tileListSize) is the LAST layer's only (gs_renderer_listed_pairs: all layers).  Takes effect on
  * captured frames of the two-level pipeline whose tile sort is a two-pass sort of 16-bit indices (list fusion on, no band cull).
- * layers = 1 (the default): one list per frame, as the reference has it.  layers = 0: the renderer chooses from the previous frame's
- * pair total -- one layer below 8 M pairs per frame (where layers cost more than they save: BASELINE.json configs[2] stays as it is),
- * two from there, three from 40 M (configs[4] on one GPU: +35 % / +46 %, profiles/r05_depth_layers.txt); what bench.py asks for. */
+ * layers = 1 (the default): one list per frame, as the reference has it.
+ * layers = GS_DEPTH_LAYERS_CHOOSE (0): the renderer chooses from the previous frame's pair total -- one layer below 8 M pairs per frame,
+ * two from there, three from 40 M (BASELINE.json configs[4] on one GPU: 870 -> 1 500 frames/s, profiles/r05_depth_layers.txt).
+ * layers = GS_DEPTH_LAYERS_CHOOSE_PIPELINED (-1): the same for a host that keeps SEVERAL frames in flight on the GPU (several renderers on
+ * their own streams, as bench.py's timed loop does): two layers already from 4.5 M pairs per frame -- BASELINE.json configs[2] (5.45 M):
+ * +5-6 % frames/s with four frames in flight, but -14 % for a lone frame (ten more launches on one stream), hence not under 0.  A scene
+ * below 8 M pairs whose first layered frame lists more than half of its pairs (low opacities: the tiles hardly stop) goes back to one
+ * layer and is not tried again for 256 frames (doubling). */
+#define GS_DEPTH_LAYERS_CHOOSE 0
+#define GS_DEPTH_LAYERS_CHOOSE_PIPELINED (-1)
 int gs_renderer_set_depth_layers(GsRenderer* r, int layers, const float* fractions);
-int gs_renderer_depth_layers(const GsRenderer* r);        /* the setting (0 = the renderer chooses) */
+int gs_renderer_depth_layers(const GsRenderer* r);        /* the setting (0 / -1 = the renderer chooses) */
 int gs_renderer_depth_layers_in_use(const GsRenderer* r); /* layers the last captured frame was made of */
 int gs_renderer_depth_layer_changes(const GsRenderer* r); /* layers = 0: times the renderer changed its choice (each one re-captures the frame; steps
                                                            * down wait 16 frames, doubled whenever one is undone within 4 frames) */
+void gs_renderer_debug_set_layer_compaction(GsRenderer* r, int enabled); /* A/B: 0 = later layers walk all their splats, not only those with an open
+                                                                           * tile under their box (default 1; same lists and images) */
 /* Pairs the last captured frame listed: summed over its depth layers (gs_last_tile_list_demand then holds the largest layer's total,
  * which is what the list capacity must hold); the frame's pair total with one layer.  Waits for the renderer's stream. */
 int64_t gs_renderer_listed_pairs(GsRenderer* r);

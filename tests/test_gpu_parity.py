@@ -1675,9 +1675,11 @@ def test_depth_layers_with_views_bands_and_a_list_that_must_grow(gs, tmp_path):
 
 
 def test_the_renderer_chooses_its_depth_layers(gs, tmp_path):
-    """gs_renderer_set_depth_layers(0): one layer while the frames' pair totals stay below 8 M, two from there -- decided from the previous
-    frame's total, so the second frame of a large scene is the first layered one; the bytes do not change.  (The library's default is one
-    layer: the list a renderer hands out is then the reference's whole list.)"""
+    """gs_renderer_set_depth_layers(0): one layer while the frames' pair totals stay below 8 M (-1, for hosts with several frames in
+    flight: 4.5 M), two from there -- decided from the previous frame's total, so the second frame of a large scene is the first layered
+    one; under -1 a scene between 4.5 and 8 M pairs whose first layered frame lists more than half of its pairs (low opacities: the tiles
+    hardly stop) goes back to one layer at once and stays there; the bytes never change.  (The library's default is one layer: the list a
+    renderer hands out is then the reference's whole list.)"""
     w, h = 1920, 1080
     small = _ply_scene(gs, tmp_path, 150_000, 0, log_scale_mean=-3.6)
     r = gs.Renderer(w, h)
@@ -1688,7 +1690,38 @@ def test_the_renderer_chooses_its_depth_layers(gs, tmp_path):
     cam = gs.camera_from_bounds(small["boundsMin"], small["boundsMax"], w, h)
     for _ in range(3):
         r.render(cam)
-    assert r.depth_layers_in_use() == 1 and r.listed_pairs() < 8_000_000
+    assert r.depth_layers_in_use() == 1 and r.listed_pairs() < 4_500_000
+    r.close()
+    # a trial that does not pay: ~ 6 M pairs of low opacity
+    from cudagaussianrenderer_amd import scenes
+
+    names, table = scenes.synthetic_vertex_table(800_000, sh_degree=0, seed=5, log_scale_mean=-3.4)
+    table[:, names.index("opacity")] -= np.float32(4.5)
+    scenes.write_ply(str(tmp_path / "faint.ply"), names, table)
+    faint = gs.parse_ply(str(tmp_path / "faint.ply"))
+    cam = gs.camera_from_bounds(faint["boundsMin"], faint["boundsMax"], w, h)
+    r = gs.Renderer(w, h)
+    r.set_scene(faint["position"], faint["scaleAndRotation"], faint["color"])
+    r.set_graph(True)
+    r.set_depth_layers(1)
+    r.render(cam)
+    want, full = r.read_image(), r.listed_pairs()
+    assert 4_500_000 <= full < 8_000_000, full
+    r.set_depth_layers(0)
+    for _ in range(3):
+        r.render(cam)
+        assert r.depth_layers_in_use() == 1  # (a lone frame of this size: one layer)
+    r.set_depth_layers(gs.DEPTH_LAYERS_CHOOSE_PIPELINED)
+    assert gs.lib().gs_renderer_depth_layers(r.handle) == -1
+    before = gs.lib().gs_renderer_depth_layer_changes(r.handle)
+    in_use, listed = [], []
+    for _ in range(6):
+        r.render(cam)
+        assert np.array_equal(r.read_image(), want)
+        in_use.append(r.depth_layers_in_use())
+        listed.append(r.listed_pairs())
+    assert in_use == [1, 2, 1, 1, 1, 1] and 2 * listed[1] > full, (in_use, listed, full)
+    assert gs.lib().gs_renderer_depth_layer_changes(r.handle) - before == 2
     r.close()
     big = _ply_scene(gs, tmp_path, 1_600_000, 0, log_scale_mean=-3.4)  # ~ 12 M pairs per frame
     cam = gs.camera_from_bounds(big["boundsMin"], big["boundsMax"], w, h)
