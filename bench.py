@@ -791,6 +791,11 @@ def main():
                                            "coefficient row instead of the colour when colours are evaluated on demand)"},
                 "note": "VALU/exp-bound kernel (~2800 VALU lane-ops per consumed pair against 44 algorithmic bytes): the HBM fraction "
                         "cannot approach 1 on any hardware; see DESIGN.md section 5",
+                "timed_loop": (f"the timed loop's frames are made of {rig.depth_layers_in_use} depth layers: this kernel runs once per layer there (its LAYERED "
+                               "instantiation: per-pixel state kept between the layers, same arithmetic, same image bytes) and the tile-list stages "
+                               "once per layer over fewer pairs; kernel_ms, the stages and the algorithmic bytes above are those of the SAME frame "
+                               "as one list (plain launches, one frame at a time); the layered launches' durations are in the rocprofv3 statistics "
+                               "of this command under profiles/ (kernel_stats_pipelined)") if rig.depth_layers_in_use > 1 else "one list per frame",
                 "dominant_stage": dominant, "dominant_stage_ms": round(stage_ms[dominant], 4),
                 "dominant_stage_GBps": stages[dominant]["GBps"],
                 "dominant_stage_frac": round((stages[dominant]["GBps"] or 0.0) / HBM_PEAK_GBS, 4),
