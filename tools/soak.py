@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Soak test of the pipelined product path: D renderers (one scene, shared), D host threads, captured frames back to back for S
 seconds; every CHECK-th frame of every renderer is read back and compared byte for byte with the first image of its view; free
-device memory before and after.  usage (GPU box): python tools/soak.py [seconds=60] [renderers=4] [splats=1000000]"""
+device memory before and after.  The first images are one-list frames; the soak runs under gs_renderer_set_depth_layers(layers)
+(-1 = the renderer chooses, for several frames in flight: two layers at the default workload), so it also holds the layered frames to the
+one-list frames' bytes.  usage (GPU box): python tools/soak.py [seconds=60] [renderers=4] [splats=1000000] [layers=-1]"""
 import ctypes as C
 import os
 import sys
@@ -26,6 +28,7 @@ def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     depth = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
+    layers = int(sys.argv[4]) if len(sys.argv) > 4 else -1
     W, H, CHECK = 1920, 1080, 997
     lib = gs.lib()
     lib.gs_set_device(0)
@@ -53,7 +56,8 @@ def main():
         renderers[0].render(cam)
         want.append(renderers[0].read_image().copy())
     for r in renderers:  # every renderer captures its frames and sizes its scratch before the memory baseline is taken
-        for cam in cams[:2]:
+        r.set_depth_layers(layers)
+        for cam in cams[:4]:
             r.render(cam)
     torch.cuda.synchronize(0)
     before = free_bytes()
@@ -88,6 +92,7 @@ def main():
     elapsed = time.perf_counter() - t0
     after = free_bytes()
     retries = [r.captured_retries() for r in renderers]
+    print(f"depth layers: setting {layers}, in use {[r.depth_layers_in_use() for r in renderers]}, choice changes {[int(lib.gs_renderer_depth_layer_changes(r.handle)) for r in renderers]}")
     print(f"{sum(frames)} frames in {elapsed:.1f} s = {sum(frames) / elapsed:.0f} frames/s on {depth} renderers; {sum(checks)} read-backs compared byte for byte, "
           f"{len(bad)} differing {bad[:3]}; captured retries {retries}; free device memory {before / 2**20:.0f} -> {after / 2**20:.0f} MiB")
     for r in reversed(renderers):
