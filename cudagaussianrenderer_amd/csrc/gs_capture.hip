@@ -389,7 +389,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
             // The renderer chooses the layer count of the NEXT frame from this one's pairs (profiles/r05_depth_layers.txt).  A frame of one
             // layer knows the scene's pair total P; a layered one knows what it listed (the second host word), which is less.
             //   one layer:     two from P >= 8 M, three from 40 M -- and two from 4.5 M when the host has said that it keeps several frames in
-            //                  flight (GS_DEPTH_LAYERS_CHOOSE_PIPELINED; BASELINE.json configs[2], 5.45 M: +5..6 % frames/s with four in flight,
+            //                  flight (GS_DEPTH_LAYERS_CHOOSE_PIPELINED; BASELINE.json configs[2], 5.45 M: +4 % frames/s with four in flight,
             //                  -14 % for a lone frame: ten more launches on one stream; 3.7 M: break-even; 2.7 M: -13 %);
             //   first layered frame after a one-layer frame, P < 8 M: layers pay when most of the list lies behind the tiles' stop points --
             //                  listed / P was 0.32-0.38 where they paid and 0.66 on a scene of low opacities where they cost 10 % -- so above

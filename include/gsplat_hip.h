@@ -328,7 +328,7 @@ int gs_renderer_colours_on_demand(const GsRenderer* r);
  * two from there, three from 40 M (BASELINE.json configs[4] on one GPU: 870 -> 1 500 frames/s, profiles/r05_depth_layers.txt).
  * layers = GS_DEPTH_LAYERS_CHOOSE_PIPELINED (-1): the same for a host that keeps SEVERAL frames in flight on the GPU (several renderers on
  * their own streams, as bench.py's timed loop does): two layers already from 4.5 M pairs per frame -- BASELINE.json configs[2] (5.45 M):
- * +5-6 % frames/s with four frames in flight, but -14 % for a lone frame (ten more launches on one stream), hence not under 0.  A scene
+ * +4 % frames/s with four frames in flight, but -14 % for a lone frame (ten more launches on one stream), hence not under 0.  A scene
  * below 8 M pairs whose first layered frame lists more than half of its pairs (low opacities: the tiles hardly stop) goes back to one
  * layer and is not tried again for 256 frames (doubling). */
 #define GS_DEPTH_LAYERS_CHOOSE 0
