@@ -149,7 +149,12 @@ class Rig:
         if args.no_graph:
             self.V = 1  # several views per chain exist for captured frames only
         prios = [int(v) for v in args.stream_priorities.split(",")] if args.stream_priorities else []
-        self.streams = [torch.cuda.Stream(device, priority=prios[d % len(prios)]) if prios else torch.cuda.Stream(device) for d in range(depth)]
+        # (the rigs of one run share their streams: a stream keeps its hardware queue for the life of the process, and a second rig's
+        # new streams would land on queues five to eight, where chains no longer run side by side -- DESIGN.md section 5)
+        pool = ctx.setdefault("stream_pool", [])
+        while not prios and len(pool) < depth:
+            pool.append(torch.cuda.Stream(device))
+        self.streams = [torch.cuda.Stream(device, priority=prios[d % len(prios)]) for d in range(depth)] if prios else pool[:depth]
         self.renderers, self.framebuffers = [], []
         for d in range(depth):
             r = gs.Renderer(self.W, self.H, tile_rows=self.band if world > 1 else None, band_cull=args.band_cull, pipeline=args.pipeline,
@@ -819,19 +824,40 @@ def main():
     if keep_dir is not None:
         keep_dir.cleanup()
 
+    # ---- the same workload with more cameras handed over in advance (N = 1): several frames per chain of kernels ----
+    if world == 1 and not args.no_extra and not args.no_graph and args.views_per_chain <= 0 and args.inflight <= 0:
+        import copy
+        table = []
+        for views_per_chain, chains in ((2, 4), (4, 3)):
+            args3 = copy.copy(args)
+            args3.views_per_chain = views_per_chain
+            rig3 = Rig(ctx, ply, cameras, bands, chains, args3)
+            steps3 = 1024 if args.steps >= 512 else args.steps
+            el3 = rig3.timed_run(steps3, max(args.warmup, 16 * views_per_chain * chains))  # (the renderer settles its depth layers in the warm-up)
+            table.append({"frames_per_chain": views_per_chain, "chains_in_flight": chains, "frames_ahead": views_per_chain * chains,
+                          "value": round(rig3.frames_timed / el3, 2), "ms_per_step": round(1e3 * el3 / rig3.frames_timed, 4),
+                          "depth_layers_in_use": rig3.depth_layers_in_use})
+            rig3.close()
+        result["extra"]["more_cameras_ahead"] = {
+            "what": "gs_renderer_set_views: V cameras per chain of kernels (one depth sort, one tile sort per layer, ... over V x the elements; "
+                    "byte-identical frames), for hosts that know their cameras further in advance than `value` assumes (config.frames_ahead); "
+                    "same scene, orbit, timing and depth-layer choice as `value`",
+            "unit": "frames/s", "runs": table}
+        beat("more cameras ahead done")
+
     # ---- second workload (N = 1): the same scene with low opacities -- tiles saturate late, the raster dominates --------
     if world == 1 and not args.no_extra and args.opacity_mean == 1.0:
         ply2, _ = make_scene(ctx, args, -3.0)
         rig2 = Rig(ctx, ply2, cameras, bands, depth, args)
         steps2 = min(args.steps, 256)
-        el2 = rig2.timed_run(steps2, min(args.warmup, 16))
+        el2 = rig2.timed_run(steps2, max(min(args.warmup, 16), 8 * depth))  # (a depth-layer trial and its undoing happen in the warm-up)
         ms2 = rig2.stage_times(steps2)
         p2, pc2, ne2, _ = rig2.list_sizes()
         st2, ab2, mb2, ms2, _ = stage_report(rig2, args, ms2, p2, pc2, ne2, band_tiles, band_h)
         a2 = ab2["raster"] / 1e9 / (ms2["raster"] / 1e3)
         result["extra"]["low_opacity_scene"] = {
             "what": "same generator with raw opacity mean -3 (alpha ~0.05): P_c/P ~ 27 %, the raster kernel is the dominant stage",
-            "opacity_mean_raw": -3.0, "value": round(steps2 / el2, 2), "unit": "frames/s", "steps": steps2, "ms_per_step": round(1e3 * el2 / steps2, 4),
+            "opacity_mean_raw": -3.0, "depth_layers_in_use": rig2.depth_layers_in_use, "value": round(steps2 / el2, 2), "unit": "frames/s", "steps": steps2, "ms_per_step": round(1e3 * el2 / steps2, 4),
             "pairs_per_frame": round(p2), "consumed_pairs_per_frame": round(pc2),
             "raster_ms": round(ms2["raster"], 4), "raster_algorithmic_GBps": round(a2, 1), "raster_frac": round(a2 / HBM_PEAK_GBS, 5),
             "stages_ms": {k: round(v, 4) for k, v in ms2.items()}}
