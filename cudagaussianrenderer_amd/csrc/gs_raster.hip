@@ -95,8 +95,14 @@ __device__ __forceinline__ uint32_t quantize8(float c)
 // many zero-opacity lead entries as the tile is past its last vote, so that the votes stay at multiples of 32 entries of the WHOLE
 // list (GaussianRender.cu:945-998); a vote is only taken on a full chunk unless this is the last layer (the list's real end).
 // status[tile]: 0xFF untouched (the per-frame fill of the range table reaches it), 1 open with state, 2 stopped by a vote.
+#ifndef GS_RASTER_LAYERED_WAVES
+#define GS_RASTER_LAYERED_WAVES 1 // A/B builds: 4 = four waves per SIMD asked for (127 VGPRs + 16 bytes of scratch)
+#endif
 template <int PPL, bool EPAN, int SH, bool LAYERED = false>
-__global__ __launch_bounds__(256 / PPL) void rasterizeTilesKernel(Screen scr, int firstTile, int numTiles,
+// (the layered SH-3 instantiation comes out at 130 VGPRs -- three waves per SIMD where the one-list kernel has four.  Asking for four
+// (127 VGPRs, 16 bytes of scratch) was measured: -3.6 % frames/s at BASELINE.json configs[2], -1.3 % at configs[4], order-balanced runs on
+// one box, tools/r05_ab_lib.sh -- so it stays as the compiler allocates it)
+__global__ __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(LAYERED && SH == 3 ? GS_RASTER_LAYERED_WAVES : 1, 8))) void rasterizeTilesKernel(Screen scr, int firstTile, int numTiles,
                                                                   const int32_t* __restrict__ tileRange,
                                                                   const int32_t* __restrict__ values,
                                                                   const float2* __restrict__ clipXY,
