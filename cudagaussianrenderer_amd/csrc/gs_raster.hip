@@ -98,11 +98,14 @@ __device__ __forceinline__ uint32_t quantize8(float c)
 #ifndef GS_RASTER_LAYERED_WAVES
 #define GS_RASTER_LAYERED_WAVES 1 // A/B builds: 4 = four waves per SIMD asked for (127 VGPRs + 16 bytes of scratch)
 #endif
+#ifndef GS_RASTER_LAYERED_MAX_WAVES
+#define GS_RASTER_LAYERED_MAX_WAVES 8
+#endif
 template <int PPL, bool EPAN, int SH, bool LAYERED = false>
 // (the layered SH-3 instantiation comes out at 130 VGPRs -- three waves per SIMD where the one-list kernel has four.  Asking for four
 // (127 VGPRs, 16 bytes of scratch) was measured: -3.6 % frames/s at BASELINE.json configs[2], -1.3 % at configs[4], order-balanced runs on
 // one box, tools/r05_ab_lib.sh -- so it stays as the compiler allocates it)
-__global__ __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(LAYERED && SH == 3 ? GS_RASTER_LAYERED_WAVES : 1, 8))) void rasterizeTilesKernel(Screen scr, int firstTile, int numTiles,
+__global__ __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(LAYERED && SH == 3 ? GS_RASTER_LAYERED_WAVES : 1, LAYERED && SH == 3 ? GS_RASTER_LAYERED_MAX_WAVES : 8))) void rasterizeTilesKernel(Screen scr, int firstTile, int numTiles,
                                                                   const int32_t* __restrict__ tileRange,
                                                                   const int32_t* __restrict__ values,
                                                                   const float2* __restrict__ clipXY,
