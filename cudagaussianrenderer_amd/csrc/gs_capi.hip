@@ -141,8 +141,10 @@ extern "C" void gs_device_download(void* dst, const void* src, size_t bytes)
 {
     if (bytes)
     {
+        // on the calling thread's stream, not the legacy stream: a legacy-stream copy depends on every blocking stream of the process,
+        // and another renderer's thread may be capturing on one (a frame re-captured after a list growth or a change of depth layers)
+        GS_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g.stream));
         GS_CHECK(hipStreamSynchronize(g.stream));
-        GS_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     }
 }
 extern "C" void gs_device_memset(void* p, int value, size_t bytes)

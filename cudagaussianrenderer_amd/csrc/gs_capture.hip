@@ -243,7 +243,11 @@ int64_t awaitPairTotal(GsRenderer* r)
                 const int64_t w = *word;
                 if (w >= 0) return w;
                 int64_t fromDevice = 0; // (no host-mapped address: the total was left in device memory)
-                GS_CHECK(hipMemcpy(&fromDevice, r->scratch.total, sizeof(int64_t), hipMemcpyDeviceToHost));
+                // (on the renderer's own stream: a copy on the legacy stream would depend on every blocking stream of the process, and
+                // another renderer's thread may be CAPTURING on one -- "operation would make the legacy stream depend on a capturing
+                // blocking stream")
+                GS_CHECK(hipMemcpyAsync(&fromDevice, r->scratch.total, sizeof(int64_t), hipMemcpyDeviceToHost, g.stream));
+                GS_CHECK(hipStreamSynchronize(g.stream));
                 return fromDevice;
             }
             if (status != hipErrorNotReady)
@@ -463,7 +467,8 @@ extern "C" int64_t gs_renderer_listed_pairs(GsRenderer* r)
     if (r->graphValid && r->frameTotals != nullptr && r->graphLayersActive)
     {
         int64_t totals[2] = {0, 0};
-        GS_CHECK(hipMemcpy(totals, r->frameTotals, sizeof(totals), hipMemcpyDeviceToHost));
+        GS_CHECK(hipMemcpyAsync(totals, r->frameTotals, sizeof(totals), hipMemcpyDeviceToHost, g.stream)); // (never the legacy stream: see awaitPairTotal)
+        GS_CHECK(hipStreamSynchronize(g.stream));
         return totals[1];
     }
     return r->scratch.totalHost != nullptr ? *r->scratch.totalHost : 0;

@@ -523,7 +523,8 @@ extern "C" void gs_renderer_buffers(GsRenderer* r, GsRendererBuffers* out)
         {
             // depth layers: the list in the buffers is the LAST layer's (the host word holds the largest layer's total)
             int64_t lastLayer = 0;
-            GS_CHECK(hipMemcpy(&lastLayer, r->scratch.total, sizeof(int64_t), hipMemcpyDeviceToHost));
+            GS_CHECK(hipMemcpyAsync(&lastLayer, r->scratch.total, sizeof(int64_t), hipMemcpyDeviceToHost, g.stream));
+            GS_CHECK(hipStreamSynchronize(g.stream));
             r->tileListSize = (int32_t) std::min<int64_t>(lastLayer, r->tileListCapacity);
         }
         out->keys = r->keys[r->selector];

@@ -1744,3 +1744,46 @@ def test_the_renderer_chooses_its_depth_layers(gs, tmp_path):
         assert r.depth_layers_in_use() == 2 and np.array_equal(r.read_image(), want)
     assert r.listed_pairs() < full
     r.close()
+
+
+def test_read_backs_while_another_renderer_recaptures_its_frame(gs, tmp_path):
+    """A renderer re-captures its frame whenever its list grows or its depth-layer choice changes -- at any time, on its own thread.  What
+    other threads do with THEIR renderers meanwhile (read an image back, fetch the buffers, ask for the listed pairs) must not touch the
+    legacy stream: a copy there would depend on the capturing stream and HIP refuses it ("operation would make the legacy stream depend on
+    a capturing blocking stream": what bench.py --ablate 120 died of when the renderers began to choose their layers)."""
+    import threading
+
+    w, h = 1280, 720
+    ply = _ply_scene(gs, tmp_path, 60_000, 0, log_scale_mean=-3.2)
+    cam = gs.camera_from_bounds(ply["boundsMin"], ply["boundsMax"], w, h)
+    a, b = gs.Renderer(w, h), gs.Renderer(w, h)
+    for r in (a, b):
+        r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"])
+        r.set_graph(True)
+        r.render(cam)
+    want = b.read_image()
+    stop, failures = threading.Event(), []
+
+    def recapturing():
+        try:
+            for i in range(60):
+                a.set_depth_layers(1 + i % 2)  # every render() below captures the frame anew
+                a.render(cam)
+        except Exception as e:  # noqa: BLE001
+            failures.append(repr(e))
+        stop.set()
+
+    t = threading.Thread(target=recapturing)
+    t.start()
+    reads = 0
+    while not stop.is_set():
+        b.render(cam)
+        assert np.array_equal(b.read_image(), want)
+        assert b.buffers().tileListSize > 0 and b.listed_pairs() > 0
+        reads += 1
+    t.join()
+    assert not failures and reads > 0
+    assert np.array_equal(a.read_image(), want)
+    a.close()
+    b.close()
+
