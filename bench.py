@@ -693,6 +693,8 @@ def main():
     if world == 1 and not args.no_graph:
         serial = rig.serial_frames(256, sync_each=False)
         synced = rig.serial_frames(256, sync_each=True)
+        rig.run_frames(16 * depth)  # (renderer 0 comes back from the one-frame legs: it settles its depth layers again, untimed)
+        rig.sync_all()
         t0 = time.perf_counter()
         frames = 0
         while time.perf_counter() - t0 < 1.5:  # >= 1.5 s of the pipelined loop, timed as a whole
