@@ -561,7 +561,7 @@ def main():
     ap.add_argument("--storage-order", choices=["auto", "caller", "morton"], default="auto", help="how the renderers store the splats (gs_renderer_set_storage_order): the file's order, or along a 3-D Morton curve (same frames byte for byte; +2 %% frames/s on one GPU, -10 %% per band frame of an 8-way split: profiles/r04_ab_experiments.txt, r04_band_sim.txt); auto = morton")
     ap.add_argument("--list-fusion", type=int, default=-1, help="gs_set_list_fusion: 1 the emit pass carries the first pass of the tile sort, 0 plain emit + full tile sort, -1 the library's default")
     ap.add_argument("--no-layer-compaction", action="store_true", help="A/B: gs_renderer_debug_set_layer_compaction(0)")
-    ap.add_argument("--depth-layers", type=int, default=-1, help="gs_renderer_set_depth_layers: list / sort / blend the depth-sorted splats in this many layers (captured frames; same image bytes); 0 = the renderer chooses from the pair total (two layers from 8 M pairs per frame, three from 40 M), -1 (default) = the same for a host with several frames in flight, which the timed loop is (two layers from 4.5 M pairs) -- the one-frame-at-a-time legs of extra.latency then run under 0; 1 = the library's default")
+    ap.add_argument("--depth-layers", type=int, default=-1, help="gs_renderer_set_depth_layers: list / sort / blend the depth-sorted splats in this many layers (captured frames; same image bytes); 0 = the renderer chooses from the pair total for a lone frame (two layers from 16 M pairs per frame, three from 40 M), -1 (default) = the same for a host with several frames in flight, which the timed loop is (two layers from 4.5 M pairs) -- the one-frame-at-a-time legs of extra.latency then run under 0; 1 = the library's default")
     ap.add_argument("--layer-fractions", default="", help="comma-separated ascending upper bounds of the first layers - 1 depth layers (fractions of the sorted splats); empty = the library's defaults")
     ap.add_argument("--stream-priorities", default="", help="diagnostics: comma-separated HIP stream priorities of the frames in flight (0 normal, -1 high), cycled; empty = default streams")
     ap.add_argument("--inflight", type=int, default=0, help="frames in flight per GPU (renderers on separate HIP streams); 0 = 4 (the measured optimum with 8 hardware queues)")
@@ -769,7 +769,7 @@ def main():
                 "log_scale_mean": args.log_scale_mean, "opacity_mean_raw": args.opacity_mean, "seed": args.seed, "storage_order": args.storage_order,
                 "list_fusion": int(lib.gs_get_list_fusion()),
                 "depth_layers": {"setting": int(lib.gs_renderer_depth_layers(rig.renderers[0].handle)), "in_use": rig.depth_layers_in_use, "listed_pairs_last_frame": rig.listed_pairs, "changes_per_renderer": rig.depth_layer_changes,
-                                 "what": "gs_renderer_set_depth_layers: -1 = the renderer chooses from the pair total, for a host with several frames in flight (two layers from 4.5 M pairs per frame, three from 40 M; the timed loop); 0 = the same for a lone frame (two layers from 8 M; extra.latency's legs when the setting is -1); in_use = layers of the timed region's last frame; listed_pairs_last_frame = pairs the last timed frame put into its lists (all layers; = pairs_per_frame with one layer)"},
+                                 "what": "gs_renderer_set_depth_layers: -1 = the renderer chooses from the pair total, for a host with several frames in flight (two layers from 4.5 M pairs per frame, three from 40 M; the timed loop); 0 = the same for a lone frame (two layers from 16 M; extra.latency's legs when the setting is -1); in_use = layers of the timed region's last frame; listed_pairs_last_frame = pairs the last timed frame put into its lists (all layers; = pairs_per_frame with one layer)"},
                 "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": device_name(lib), "frames_in_flight": depth, "frames_per_chain": rig.V, "frames_ahead": depth * rig.V,
                 "frames_ahead_what": "cameras the caller must hand over before the first image of them is complete (frames per chain x chains in flight); "
                                      "the reference's loop is 1 -- extra.latency has that figure",

@@ -20,7 +20,7 @@ PIPELINE_REFERENCE = 0  # the reference's stage order: one 64-bit tile|depth rad
 PIPELINE_TWO_LEVEL = 1  # default: depth-sort the splats, emit, stable-sort the pairs on the tile bits
 STORAGE_ORDER_CALLER = 0  # splats stored in the caller's order (the reference's behaviour)
 STAGED_BUILDER_REFERENCE_ORDER = 0  # gs_set_staged_builder: (splat, local tile) emission order + unconditional sort
-DEPTH_LAYERS_CHOOSE = 0  # gs_renderer_set_depth_layers: the renderer chooses from the frames' pair totals (two layers from 8 M pairs, three from 40 M)
+DEPTH_LAYERS_CHOOSE = 0  # gs_renderer_set_depth_layers: the renderer chooses from the frames' pair totals (for one frame at a time: two layers from 16 M pairs, three from 40 M)
 DEPTH_LAYERS_CHOOSE_PIPELINED = -1  # ... for a host with several frames in flight on the GPU (two layers from 4.5 M pairs)
 STAGED_BUILDER_SORTED = 1  # default: buildTileList emits in the order the sort leaves, sortTileList looks before it sorts
 STORAGE_ORDER_MORTON = 1  # splats stored along a Morton curve: same frames, faster (include/gsplat_hip.h)

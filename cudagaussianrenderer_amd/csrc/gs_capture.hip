@@ -392,13 +392,16 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
         {
             // The renderer chooses the layer count of the NEXT frame from this one's pairs (profiles/r05_depth_layers.txt).  A frame of one
             // layer knows the scene's pair total P; a layered one knows what it listed (the second host word), which is less.
-            //   one layer:     two from P >= 8 M, three from 40 M -- and two from 4.5 M when the host has said that it keeps several frames in
-            //                  flight (GS_DEPTH_LAYERS_CHOOSE_PIPELINED; BASELINE.json configs[2], 5.45 M: +4 % frames/s with four in flight,
-            //                  -14 % for a lone frame: ten more launches on one stream; 3.7 M: break-even; 2.7 M: -13 %);
+            //   one layer:     two from P >= 16 M, three from 40 M (a LONE frame: two layers at 10.9 / 12.8 M pairs cost it 3 / 14 %, at 27 M
+            //                  they save 16 %) -- and two from 4.5 M when the host has said that it keeps several frames in flight
+            //                  (GS_DEPTH_LAYERS_CHOOSE_PIPELINED; BASELINE.json configs[2], 5.45 M: +4 % frames/s with four in flight, -14 %
+            //                  for a lone frame: ten more launches on one stream; 10.9 M: +22 %; 3.7 M: break-even; 2.7 M: -13 %);
             //   first layered frame after a one-layer frame, P < 8 M: layers pay when most of the list lies behind the tiles' stop points --
             //                  listed / P was 0.32-0.38 where they paid and 0.66 on a scene of low opacities where they cost 10 % -- so above
             //                  0.5 the renderer goes back to one layer and does not try again for a while (256 frames, doubling);
-            //   two layers:    one below 1.5 M listed (the scene has become small), three from 18 M listed;   three: two below 6 M listed.
+            //   two layers:    one below 1.5 M listed (pipelined) / 3.5 M (lone): the scene has become small; three from 18 M listed;
+            //   three:         two below 6 M listed.
+            const int64_t upToTwo = r->autoPipelined ? 4500000 : 16000000, downToOne = r->autoPipelined ? 1500000 : 3500000;
             const int64_t listed = r->graphLayersActive ? r->scratch.totalHost[1] : demand;
             int next = r->autoLayers;
             bool atOnce = false; // (a failed trial is undone at once, whatever the hold says)
@@ -406,7 +409,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
             if (!r->graphLayersActive || r->autoLayers == 1)
             {
                 r->autoLastTotal = demand;
-                next = demand >= 40000000 ? 3 : demand >= 8000000 ? 2 : (r->autoPipelined && demand >= 4500000 && r->autoBanFrames == 0) ? 2 : 1;
+                next = demand >= 40000000 ? 3 : (demand >= upToTwo && (demand >= 8000000 || r->autoBanFrames == 0)) ? 2 : 1;
             }
             else if (r->autoFramesSinceChange == 0 && r->autoLastTotal > 0 && r->autoLastTotal < 8000000 && 2 * listed > r->autoLastTotal)
             {
@@ -415,7 +418,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
                 r->autoBanFrames = r->autoBanLength;
                 r->autoBanLength = std::min(r->autoBanLength * 2, 1 << 16);
             }
-            else if (r->autoLayers == 2) next = listed < 1500000 ? 1 : listed >= 18000000 ? 3 : 2;
+            else if (r->autoLayers == 2) next = listed < downToOne ? 1 : listed >= 18000000 ? 3 : 2;
             else next = listed < 6000000 ? 2 : r->autoLayers;
             // (a frame that cannot be layered -- band cull, one-pass tile sort -- keeps measuring totals; the wish costs nothing)
             // A change re-captures the frame (milliseconds), so a camera path whose totals straddle a threshold must not flap: steps up

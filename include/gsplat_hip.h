@@ -324,13 +324,15 @@ int gs_renderer_colours_on_demand(const GsRenderer* r);
  * hands out (gs_renderer_buffers: keys, values, ranges, tileListSize) is the LAST layer's only (gs_renderer_listed_pairs: all layers).  Takes effect on
  * captured frames of the two-level pipeline whose tile sort is a two-pass sort of 16-bit indices (list fusion on, no band cull).
  * layers = 1 (the default): one list per frame, as the reference has it.
- * layers = GS_DEPTH_LAYERS_CHOOSE (0): the renderer chooses from the previous frame's pair total -- one layer below 8 M pairs per frame,
- * two from there, three from 40 M (BASELINE.json configs[4] on one GPU: 870 -> 1 500 frames/s, profiles/r05_depth_layers.txt).
+ * layers = GS_DEPTH_LAYERS_CHOOSE (0): the renderer chooses from the previous frame's pair total, for a host that renders ONE frame at a
+ * time -- one layer below 16 M pairs per frame, two from there (27 M pairs: -16 % frame time), three from 40 M (BASELINE.json configs[4]
+ * on one GPU: 1 258 -> 965 us of kernels per frame, profiles/r05_depth_layers.txt).
  * layers = GS_DEPTH_LAYERS_CHOOSE_PIPELINED (-1): the same for a host that keeps SEVERAL frames in flight on the GPU (several renderers on
  * their own streams, as bench.py's timed loop does): two layers already from 4.5 M pairs per frame -- BASELINE.json configs[2] (5.45 M):
- * +4 % frames/s with four frames in flight, but -14 % for a lone frame (ten more launches on one stream), hence not under 0.  A scene
- * below 8 M pairs whose first layered frame lists more than half of its pairs (low opacities: the tiles hardly stop) goes back to one
- * layer and is not tried again for 256 frames (doubling). */
+ * +4 % frames/s with four frames in flight (10.9 M: +22 %, configs[4]: 870 -> 1 500 frames/s), where a lone frame would lose 14 % (ten
+ * more launches on one stream; at 10.9 / 12.8 M pairs it still loses 3 / 14 %), hence the two forms.  Under -1 a scene below 8 M pairs
+ * whose first layered frame lists more than half of its pairs (low opacities: the tiles hardly stop) goes back to one layer and is not
+ * tried again for 256 frames (doubling). */
 #define GS_DEPTH_LAYERS_CHOOSE 0
 #define GS_DEPTH_LAYERS_CHOOSE_PIPELINED (-1)
 int gs_renderer_set_depth_layers(GsRenderer* r, int layers, const float* fractions);

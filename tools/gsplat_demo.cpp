@@ -139,7 +139,7 @@ int main(int argc, char** argv)
                                   shCount) != 0)
             return 1;
         gs_renderer_set_graph(renderer, 1);
-        // one frame at a time: the renderer chooses its depth layers for a lone frame (two from 8 M pairs per frame; same image bytes)
+        // one frame at a time: the renderer chooses its depth layers for a lone frame (two from 16 M pairs per frame; same image bytes)
         gs_renderer_set_depth_layers(renderer, GS_DEPTH_LAYERS_CHOOSE, nullptr);
         gs::CameraControls controls((float) width, (float) height);
         controls.setBounds(boundsMin, boundsMax);
