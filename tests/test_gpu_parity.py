@@ -1788,3 +1788,28 @@ def test_read_backs_while_another_renderer_recaptures_its_frame(gs, tmp_path):
     a.close()
     b.close()
 
+
+def test_depth_layers_survive_a_change_of_scene(gs, tmp_path):
+    """The layers' per-splat buffers (boxes, live bits, the compacted order's counts) are sized by the scene: a renderer that is given a
+    LARGER scene after layered frames allocates them again, and its frames are a fresh renderer's frames."""
+    w, h = 1280, 720
+    first = _ply_scene(gs, tmp_path, 20_000, 0, seed=3, log_scale_mean=-3.0)
+    second = _ply_scene(gs, tmp_path, 90_000, 0, seed=4, log_scale_mean=-3.3)
+    cam = gs.camera_from_bounds(second["boundsMin"], second["boundsMax"], w, h)
+    fresh = gs.Renderer(w, h)
+    fresh.set_scene(second["position"], second["scaleAndRotation"], second["color"])
+    fresh.set_graph(True)
+    fresh.render(cam)
+    want = fresh.read_image()
+    fresh.close()
+    r = gs.Renderer(w, h)
+    r.set_graph(True)
+    r.set_depth_layers(3)
+    for scene in (first, second, first, second):
+        r.set_scene(scene["position"], scene["scaleAndRotation"], scene["color"])
+        r.render(cam)
+        r.render(cam)
+        assert r.depth_layers_in_use() == 3
+    assert np.array_equal(r.read_image(), want)
+    r.close()
+
