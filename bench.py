@@ -561,6 +561,7 @@ def main():
     ap.add_argument("--storage-order", choices=["auto", "caller", "morton"], default="auto", help="how the renderers store the splats (gs_renderer_set_storage_order): the file's order, or along a 3-D Morton curve (same frames byte for byte; +2 %% frames/s on one GPU, -10 %% per band frame of an 8-way split: profiles/r04_ab_experiments.txt, r04_band_sim.txt); auto = morton")
     ap.add_argument("--list-fusion", type=int, default=-1, help="gs_set_list_fusion: 1 the emit pass carries the first pass of the tile sort, 0 plain emit + full tile sort, -1 the library's default")
     ap.add_argument("--no-layer-compaction", action="store_true", help="A/B: gs_renderer_debug_set_layer_compaction(0)")
+    ap.add_argument("--clip-scan-fusion", action="store_true", help="A/B: gs_debug_set_clip_scan_fusion(1) -- the clip kernel shares the launch of the depth sort's first column scan")
     ap.add_argument("--depth-layers", type=int, default=-1, help="gs_renderer_set_depth_layers: list / sort / blend the depth-sorted splats in this many layers (captured frames; same image bytes); 0 = the renderer chooses from the pair total for a lone frame (two layers from 16 M pairs per frame, three from 40 M), -1 (default) = the same for a host with several frames in flight, which the timed loop is (two layers from 4.5 M pairs) -- the one-frame-at-a-time legs of extra.latency then run under 0; 1 = the library's default")
     ap.add_argument("--layer-fractions", default="", help="comma-separated ascending upper bounds of the first layers - 1 depth layers (fractions of the sorted splats); empty = the library's defaults")
     ap.add_argument("--stream-priorities", default="", help="diagnostics: comma-separated HIP stream priorities of the frames in flight (0 normal, -1 high), cycled; empty = default streams")
@@ -664,6 +665,8 @@ def main():
         if rank == 0:
             print("bench.py: " + message, file=sys.stderr, flush=True)
 
+    if args.clip_scan_fusion:
+        lib.gs_debug_set_clip_scan_fusion(1)
     rig = Rig(ctx, ply, cameras, bands, depth, args)
     beat("rig ready")
     band_times = None
