@@ -3,7 +3,8 @@
 TAG=${1:-r03}
 G=gpurun_out
 [ -s $G/${TAG}_bench_c3.json ] && [ -s $G/${TAG}_pmc_FETCH_SIZE.txt ] || { echo "no $TAG outputs under $G (was gpurun_out/ copied back?)"; exit 1; }
-tail -1 $G/${TAG}_bench_c3.json > profiles/${TAG}_bench_c3.json
+# (a bench line taken AFTER the counters were collected carries them -- roofline.traffic; it is kept as gpurun_out/TAG_bench_final.json)
+if [ -s $G/${TAG}_bench_final.json ]; then tail -1 $G/${TAG}_bench_final.json > profiles/${TAG}_bench_c3.json; else tail -1 $G/${TAG}_bench_c3.json > profiles/${TAG}_bench_c3.json; fi
 tail -1 $G/${TAG}_bench_under_rocprof.json > profiles/${TAG}_bench_under_rocprof_pipelined.json
 tail -1 $G/${TAG}_bench_under_rocprof_serial.json > profiles/${TAG}_bench_under_rocprof_serial.json
 cp $G/${TAG}_stats/stats_kernel_stats.csv profiles/${TAG}_kernel_stats_pipelined.csv
