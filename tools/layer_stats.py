@@ -23,6 +23,7 @@ r = gs.Renderer(w, h, storage_order="morton")
 r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
 r.set_graph(True)
 r.set_depth_layers(layers)
+lib.gs_renderer_debug_set_layer_compaction(r.handle, 0)  # (the counters sit in the count pass's own test: every splat of the later layers must reach it)
 out = (C.c_ulonglong * 8)()
 for v, cam in enumerate(cams[:3]):
     r.render(cam)
