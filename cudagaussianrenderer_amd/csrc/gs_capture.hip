@@ -334,7 +334,11 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
             ensureTileListFastScratch(r->scratch, n * r->views);
             ensureRadixScratch(r->radix, n * r->views);
             ensureRadixScratch(r->radix, r->tileListCapacity);
+            float cutsUnused[kMaxDepthLayers];
+            if (effectiveDepthLayers(r, cutsUnused) > 1)
             {
+                // what layered frames keep between their layers: 16 bytes per pixel and view, 8.4 bytes per (virtual) splat, 4 per tile --
+                // only a renderer that is about to capture a layered frame pays for it
                 if (r->layerState == nullptr) r->layerState = (float4*) gs_device_alloc(sizeof(float4) * (size_t) r->width * r->height * r->views);
                 if (r->layerConsumed == nullptr) r->layerConsumed = (int32_t*) gs_device_alloc(sizeof(int32_t) * (size_t) scr.totalTiles * r->views);
                 if (r->frameTotals == nullptr) r->frameTotals = (int64_t*) gs_device_alloc(sizeof(int64_t) * 2);
