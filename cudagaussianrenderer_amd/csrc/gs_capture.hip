@@ -153,7 +153,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
                 // other buffer is free by now
                 uint32_t* live = (uint32_t*) r->order[orderSel ^ 1];
                 launchLayerCompaction(g.stream, scr, nv, views > 1 ? n : 0, r->layerTileBox, r->tileOpenBits, openWordsPerRow(scr.tilesX), r->layerAlive, order + begin, cnt, r->layerBlockCounts, r->layerLiveNibbles, live,
-                                      r->layerLiveCount);
+                                      r->layerLiveCount, r->layerBlockOffsets, r->layerScanTotal);
                 layerOrder = live;
                 r->scratch.countDevice = r->layerLiveCount;
             }
@@ -346,7 +346,9 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
                 {
                     const size_t virtualSplats = (size_t) n * r->views;
                     r->layerAlive = (unsigned long long*) gs_device_alloc(sizeof(unsigned long long) * (virtualSplats / 64 + 2));
-                    r->layerBlockCounts = (int32_t*) gs_device_alloc(sizeof(int32_t) * (virtualSplats / 1024 + 2));
+                    r->layerBlockCounts = (int32_t*) gs_device_alloc(sizeof(int32_t) * (virtualSplats / 1024 + 20));
+                    r->layerBlockOffsets = (int32_t*) gs_device_alloc(sizeof(int32_t) * (virtualSplats / 1024 + 20));
+                    r->layerScanTotal = (int64_t*) gs_device_alloc(sizeof(int64_t));
                     r->layerLiveCount = (int32_t*) gs_device_alloc(sizeof(int32_t));
                     r->layerLiveNibbles = (uint8_t*) gs_device_alloc(virtualSplats / 4 + 1024);
                     r->layerTileBox = (ushort4*) gs_device_alloc(sizeof(ushort4) * (virtualSplats + 1));

@@ -66,6 +66,10 @@ void freeLayerCompaction(GsRenderer* r)
     // (sized by splats x views: allocated again with the next layered frame)
     gs_device_free(r->layerAlive);
     gs_device_free(r->layerBlockCounts);
+    gs_device_free(r->layerBlockOffsets);
+    gs_device_free(r->layerScanTotal);
+    r->layerBlockOffsets = nullptr;
+    r->layerScanTotal = nullptr;
     gs_device_free(r->layerLiveCount);
     gs_device_free(r->layerTileBox);
     gs_device_free(r->layerLiveNibbles);

@@ -153,6 +153,8 @@ struct GsRenderer
     bool autoPipelined = false;     // GS_DEPTH_LAYERS_CHOOSE_PIPELINED: the host keeps several frames in flight on the GPU -- two layers from 4.5 M pairs
     unsigned long long* layerAlive = nullptr; // depth layers: one bit per (virtual) splat -- an open tile under its box (launchLayerCompaction)
     int32_t* layerBlockCounts = nullptr;
+    int32_t* layerBlockOffsets = nullptr;     // (slices of more than 4 M splats: the scanned counts)
+    int64_t* layerScanTotal = nullptr;
     int32_t* layerLiveCount = nullptr;
     uint8_t* layerLiveNibbles = nullptr;
     ushort4* layerTileBox = nullptr;          // the list builder's box per (virtual) splat, written by the clip kernel of a layered frame

@@ -1125,6 +1125,7 @@ void ensureTileListFastScratch(TileListScratch& s, int count)
 // device-side count.  The test is the count pass's own (same box, same limit on its size).
 constexpr int kCompactItems = 4;
 constexpr int kCompactBlock = kGroup * kCompactItems;
+constexpr int kCompactSelfSumBlocks = 4096; // (4 M splats in a layer's slice)
 
 constexpr int kAliveTableWords = 8192; // the open-bit table of all views in LDS when it fits (3840x2160: 1 215 words per view)
 template <bool TABLE_IN_LDS>
@@ -1196,7 +1197,8 @@ __global__ __launch_bounds__(kGroup) void layerAliveKernel(int count, Screen scr
 template <bool SCATTER>
 __global__ __launch_bounds__(kGroup) void layerCompactKernel(int count, const uint32_t* __restrict__ order, const unsigned long long* __restrict__ aliveWords,
                                                              int32_t* __restrict__ blockCounts, uint8_t* __restrict__ liveNibbles,
-                                                             uint32_t* __restrict__ out, int32_t* __restrict__ countOut)
+                                                             uint32_t* __restrict__ out, int32_t* __restrict__ countOut,
+                                                             const int32_t* __restrict__ blockOffsets)
 {
     __shared__ int waveSums[kWavesPerBlock];
     __shared__ int baseSums[kWavesPerBlock];
@@ -1219,9 +1221,12 @@ __global__ __launch_bounds__(kGroup) void layerCompactKernel(int count, const ui
     if (lane == kWave - 1) waveSums[wave] = incl;
     if (SCATTER)
     {
-        // the live splats of the blocks in front
+        // the live splats of the blocks in front: summed here (a few thousand words), or -- slices of more than kCompactSelfSumBlocks
+        // blocks, where that would be quadratic work -- read from a scan the host put in between
         int before = 0;
-        for (int b = t; b < (int) blockIdx.x; b += kGroup) before += blockCounts[b];
+        if (blockOffsets != nullptr) before = t == 0 ? blockOffsets[blockIdx.x] : 0;
+        else
+            for (int b = t; b < (int) blockIdx.x; b += kGroup) before += blockCounts[b];
         const int beforeIncl = waveInclusiveSum(before);
         if (lane == kWave - 1) baseSums[wave] = beforeIncl;
     }
@@ -1249,7 +1254,8 @@ __global__ __launch_bounds__(kGroup) void layerCompactKernel(int count, const ui
 
 // order[0 .. count): a layer's slice of the depth order; liveOrder[0 .. *liveCount): its splats that still have an open tile under their box.
 void launchLayerCompaction(hipStream_t stream, const Screen& scr, int splats, int viewSplats, const ushort4* tileBox, const uint32_t* openBits, int openWordsPerRow, unsigned long long* aliveWords,
-                           const uint32_t* order, int count, int32_t* blockCounts, uint8_t* liveNibbles, uint32_t* liveOrder, int32_t* liveCount)
+                           const uint32_t* order, int count, int32_t* blockCounts, uint8_t* liveNibbles, uint32_t* liveOrder, int32_t* liveCount,
+                           int32_t* blockOffsets, int64_t* scanTotal)
 {
     const int views = viewSplats > 0 ? (splats + viewSplats - 1) / viewSplats : 1;
     const int tableWords = views * scr.tilesY * openWordsPerRow;
@@ -1265,8 +1271,12 @@ void launchLayerCompaction(hipStream_t stream, const Screen& scr, int splats, in
         hipLaunchKernelGGL((layerAliveKernel<false>), dim3(std::min((splats + 4 * kGroup - 1) / (4 * kGroup), 4096)), dim3(kGroup), 0, stream, splats, scr, tileBox,
                            viewSplats, openBits, openWordsPerRow, tableWords, aliveWords);
     const int blocks = (count + kCompactBlock - 1) / kCompactBlock;
-    hipLaunchKernelGGL((layerCompactKernel<false>), dim3(blocks), dim3(kGroup), 0, stream, count, order, aliveWords, blockCounts, liveNibbles, liveOrder, liveCount);
-    hipLaunchKernelGGL((layerCompactKernel<true>), dim3(blocks), dim3(kGroup), 0, stream, count, order, aliveWords, blockCounts, liveNibbles, liveOrder, liveCount);
+    hipLaunchKernelGGL((layerCompactKernel<false>), dim3(blocks), dim3(kGroup), 0, stream, count, order, aliveWords, blockCounts, liveNibbles, liveOrder, liveCount,
+                       (const int32_t*) nullptr);
+    const bool scanned = blocks > kCompactSelfSumBlocks;
+    if (scanned) launchScanInt32(stream, blocks, blockCounts, blockOffsets, scanTotal);
+    hipLaunchKernelGGL((layerCompactKernel<true>), dim3(blocks), dim3(kGroup), 0, stream, count, order, aliveWords, blockCounts, liveNibbles, liveOrder, liveCount,
+                       scanned ? (const int32_t*) blockOffsets : (const int32_t*) nullptr);
 }
 
 int tileListFusedSortBits(int tileBitCount, int tileKeyBytes)

@@ -1813,3 +1813,24 @@ def test_depth_layers_survive_a_change_of_scene(gs, tmp_path):
     assert np.array_equal(r.read_image(), want)
     r.close()
 
+
+def test_depth_layers_with_a_slice_of_more_than_four_million_splats(gs):
+    """The compaction of a later layer's slice sums its blocks' counts inside every block up to 4 096 blocks (4 M splats) and takes them from
+    a scan kernel beyond: 6 M procedural splats in two layers (second slice 5.1 M) give the one-list frame's bytes."""
+    w, h = 1280, 720
+    pos, sr, col = gs.generate_random_gaussians(6_000_000, seed=17, min_scale=0.002, max_scale=0.03)
+    cam = gs.camera_from_bounds([-4] * 3, [4] * 3, w, h)
+    images = []
+    for layers in (1, 2):
+        r = gs.Renderer(w, h, storage_order="morton")
+        r.set_scene(pos, sr, col)
+        r.set_graph(True)
+        r.set_depth_layers(layers)
+        r.render(cam)
+        r.render(cam)
+        assert r.depth_layers_in_use() == layers
+        images.append((r.read_image(), r.listed_pairs()))
+        r.close()
+    assert images[0][0][..., :3].max() > 0 and np.array_equal(images[0][0], images[1][0])
+    assert images[1][1] < images[0][1]
+
