@@ -44,11 +44,12 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
     if (!GS_PARAMS_FROM_HOST)
         GS_CHECK(hipMemcpyAsync(r->paramsDevice, r->paramsHost + slot * kMaxViews, sizeof(FrameParams) * views, hipMemcpyHostToDevice, g.stream));
     // Depth layers (gs_renderer_set_depth_layers): only where the emit pass carries the tile sort's first pass (two-pass sorts of 16-bit tile
-    // indices), without a band cull (its splat count lives on the device) and with enough splats for every layer to have some
+    // indices) and with enough splats for every layer to have some.  Under a band cull the list's length lives on the device: every layer's
+    // slice, the first one's too, is then cut out by the compaction kernels (gs_tiles_fast.hip LayerSlice), which needs the compaction on
     const int fusedBits = cfg.listFusion ? tileListFusedSortBits(tBits, tileKeyBytes) : 0;
     float layerFraction[kMaxDepthLayers];
     const int wantLayers = effectiveDepthLayers(r, layerFraction);
-    const int layers = (wantLayers > 1 && !cull && fusedBits > 0 && nv >= 4096 && g_ablation == 0) ? wantLayers : 1;
+    const int layers = (wantLayers > 1 && (!cull || r->layerCompaction) && fusedBits > 0 && nv >= 4096 && g_ablation == 0) ? wantLayers : 1;
     ushort4* tileBox = (layers > 1 && r->layerCompaction) ? r->layerTileBox : nullptr; // (the later layers' live test, gs_tiles_fast.hip)
     // the range table is reset to -1 by the clip kernel (one node less than a memset; see gs_ranges.hip) -- and the layers' tile status
     // bytes behind it with it (0xFF = untouched)
@@ -101,7 +102,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
         launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) (callerOrder ? r->positionCaller : r->position),
                             (const float4*) (callerOrder ? r->scaleAndRotationCaller : r->scaleAndRotation), nullptr, r->clipZ, nullptr, nullptr, nullptr,
                             nullptr, r->bandMask, r->bandSlotPrefix, r->bandCounts, params, clearTable, clearEntries, (float4*) r->tileRecord,
-                            (float4*) r->rasterRecord, views, r->splatToStorage);
+                            (float4*) r->rasterRecord, views, r->splatToStorage, tileBox);
         launchBandCompaction(g.stream, n, views, r->bandMask, r->bandSlotPrefix, r->bandCounts, r->bandOffsets, r->bandTotal, r->clipZ, r->depthKey[0],
                              (uint32_t*) r->order[0], r->splatToStorage);
         countDevice = (const int*) r->bandTotal;
@@ -147,19 +148,29 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
             r->scratch.layerFlags = (l == 0 ? 1 : 0) | (l + 1 == layers ? 2 : 0);
             const uint32_t* layerOrder = order + begin;
             r->scratch.countDevice = nullptr;
-            if (l > 0 && r->layerCompaction)
+            uint32_t* live = (uint32_t*) r->order[orderSel ^ 1]; // (the depth sort's other buffer is free by now)
+            if (cull)
             {
-                // the later layers walk only the splats that still have an open tile under their box (gs_tiles_fast.hip); the depth sort's
-                // other buffer is free by now
-                uint32_t* live = (uint32_t*) r->order[orderSel ^ 1];
+                // a band's culled list: its length is on the device, so the compaction kernels cut the layer's slice out of the whole list
+                // themselves -- the first layer's too, with every splat of it live
+                launchLayerCompaction(g.stream, scr, nv, views > 1 ? n : 0, r->layerTileBox, l > 0 ? r->tileOpenBits : nullptr, openWordsPerRow(scr.tilesX),
+                                      r->layerAlive, order, nv, r->layerBlockCounts, r->layerLiveNibbles, live, r->layerLiveCount, r->layerBlockOffsets,
+                                      r->layerScanTotal, countDevice, layerFraction, l, layers);
+                layerOrder = live;
+                r->scratch.countDevice = r->layerLiveCount;
+            }
+            else if (l > 0 && r->layerCompaction)
+            {
+                // the later layers walk only the splats that still have an open tile under their box (gs_tiles_fast.hip)
                 launchLayerCompaction(g.stream, scr, nv, views > 1 ? n : 0, r->layerTileBox, r->tileOpenBits, openWordsPerRow(scr.tilesX), r->layerAlive, order + begin, cnt, r->layerBlockCounts, r->layerLiveNibbles, live,
                                       r->layerLiveCount, r->layerBlockOffsets, r->layerScanTotal);
                 layerOrder = live;
                 r->scratch.countDevice = r->layerLiveCount;
             }
-            launchTileListFastCount(g.stream, cnt, scr, layerOrder, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, sortBits,
+            const int walk = cull ? nv : cnt; // (splats the list passes' grids are sized for)
+            launchTileListFastCount(g.stream, walk, scr, layerOrder, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, sortBits,
                                     views > 1 ? n : 0);
-            launchTileListFastEmit(g.stream, cnt, scr, layerOrder, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],
+            launchTileListFastEmit(g.stream, walk, scr, layerOrder, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],
                                    tileKeyBytes, r->values[0], r->tileListCapacity, views > 1 ? n : 0, sortBits);
             r->scratch.countDevice = nullptr;
             r->radix.countDevice = (const int*) r->scratch.total;

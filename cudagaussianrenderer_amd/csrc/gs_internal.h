@@ -160,7 +160,11 @@ void ensureTileListFastScratch(TileListScratch& s, int count);
 // depth layers: liveOrder[0 .. *liveCount) = the splats of order[0 .. count) that still have an open tile under their box, in order
 void launchLayerCompaction(hipStream_t stream, const Screen& scr, int splats, int viewSplats, const ushort4* tileBox, const uint32_t* openBits, int openWordsPerRow, unsigned long long* aliveWords,
                            const uint32_t* order, int count, int32_t* blockCounts, uint8_t* liveNibbles /* [ceil(count / 4)] */, uint32_t* liveOrder,
-                           int32_t* liveCount, int32_t* blockOffsets /* [as blockCounts] */, int64_t* scanTotal);
+                           int32_t* liveCount, int32_t* blockOffsets /* [as blockCounts] */, int64_t* scanTotal,
+                           // a list whose length only the device knows (a band's culled list): `order` / `count` are the WHOLE list and its
+                           // capacity, the slice of layer `layer` of `layers` is cut on the device from *listCountDevice by the cuts (null: the
+                           // host cut it); openBits == null: a first layer, every splat of the slice is live
+                           const int* listCountDevice = nullptr, const float* cuts = nullptr, int layer = 0, int layers = 1);
 void launchTileListFastCount(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,
                              const float4* screenEllipse, TileListScratch& s, int sortBits = 0, int viewSplats = 0);
 void launchTileListFastEmit(hipStream_t stream, int count, const Screen& scr, const uint32_t* order, const float2* clipXY,

@@ -1194,15 +1194,51 @@ __global__ __launch_bounds__(kGroup) void layerAliveKernel(int count, Screen scr
 // SCATTER = false: blockCounts[b] = live splats among order[b * 1024 ...), and every lane's four live bits in liveNibbles (the gather from the
 // bit table is the expensive part: once is enough); true: the live ones written to out[] behind those of the blocks in front (every
 // block sums the counts in front of it itself: a few thousand words), the last block leaves the total.
+// Where a layer's slice of the depth order begins and ends when the list's length is only known on the device (a band's culled list):
+// the frame driver's own rule (gs_capture.hip), cut by cut.
+struct LayerSlice
+{
+    const int* listCountDevice; // null: the host cut the slice itself (order and count are the slice's)
+    float cut[kMaxDepthLayers];
+    int layer, layers;
+};
+__device__ __forceinline__ void layerSliceBounds(const LayerSlice& sl, int listCount, int& begin, int& end)
+{
+    begin = 0;
+    end = listCount;
+    for (int l = 0; l <= sl.layer; ++l)
+    {
+        end = l + 1 == sl.layers ? listCount : min(listCount, max(begin + 1, (int) ((double) sl.cut[l] * (double) listCount)));
+        if (l != sl.layer) begin = end;
+    }
+    if (begin > listCount) begin = listCount;
+}
+
 template <bool SCATTER>
-__global__ __launch_bounds__(kGroup) void layerCompactKernel(int count, const uint32_t* __restrict__ order, const unsigned long long* __restrict__ aliveWords,
+__global__ __launch_bounds__(kGroup) void layerCompactKernel(int countHost, const uint32_t* __restrict__ order, const unsigned long long* __restrict__ aliveWords,
                                                              int32_t* __restrict__ blockCounts, uint8_t* __restrict__ liveNibbles,
                                                              uint32_t* __restrict__ out, int32_t* __restrict__ countOut,
-                                                             const int32_t* __restrict__ blockOffsets)
+                                                             const int32_t* __restrict__ blockOffsets, LayerSlice slice)
 {
     __shared__ int waveSums[kWavesPerBlock];
     __shared__ int baseSums[kWavesPerBlock];
     const int t = threadIdx.x, wave = t >> 6, lane = t & (kWave - 1);
+    int count = countHost;
+    if (slice.listCountDevice != nullptr)
+    {
+        // (a band's culled list: `order` is the whole list, countHost its capacity; the grid is sized for that)
+        int begin, end;
+        layerSliceBounds(slice, min(*slice.listCountDevice, countHost), begin, end);
+        order += begin;
+        count = end - begin;
+    }
+    const int activeBlocks = (count + kCompactBlock - 1) / kCompactBlock;
+    if ((int) blockIdx.x >= activeBlocks)
+    {
+        if (!SCATTER && t == 0) blockCounts[blockIdx.x] = 0;
+        if (SCATTER && activeBlocks == 0 && blockIdx.x == 0 && t == 0) *countOut = 0; // an empty slice: nobody else leaves the total
+        return;
+    }
     const int first = (int) blockIdx.x * kCompactBlock + t * kCompactItems;
     uint32_t ids[kCompactItems];
     unsigned live = 0;
@@ -1213,7 +1249,7 @@ __global__ __launch_bounds__(kGroup) void layerCompactKernel(int count, const ui
     {
 #pragma unroll
         for (int k = 0; k != kCompactItems; ++k)
-            if (first + k < count) live |= (unsigned) ((aliveWords[ids[k] >> 6] >> (ids[k] & 63u)) & 1ull) << k;
+            if (first + k < count) live |= (aliveWords == nullptr ? 1u : (unsigned) ((aliveWords[ids[k] >> 6] >> (ids[k] & 63u)) & 1ull)) << k; // (null: a first layer)
         liveNibbles[(size_t) blockIdx.x * kGroup + t] = (uint8_t) live;
     }
     const int mine = __popc(live);
@@ -1249,13 +1285,13 @@ __global__ __launch_bounds__(kGroup) void layerCompactKernel(int count, const ui
 #pragma unroll
     for (int k = 0; k != kCompactItems; ++k)
         if (live & (1u << k)) out[at++] = ids[k];
-    if (t == 0 && (int) blockIdx.x == (int) gridDim.x - 1) *countOut = base + blockTotal;
+    if (t == 0 && (int) blockIdx.x == activeBlocks - 1) *countOut = base + blockTotal;
 }
 
 // order[0 .. count): a layer's slice of the depth order; liveOrder[0 .. *liveCount): its splats that still have an open tile under their box.
 void launchLayerCompaction(hipStream_t stream, const Screen& scr, int splats, int viewSplats, const ushort4* tileBox, const uint32_t* openBits, int openWordsPerRow, unsigned long long* aliveWords,
                            const uint32_t* order, int count, int32_t* blockCounts, uint8_t* liveNibbles, uint32_t* liveOrder, int32_t* liveCount,
-                           int32_t* blockOffsets, int64_t* scanTotal)
+                           int32_t* blockOffsets, int64_t* scanTotal, const int* listCountDevice, const float* cuts, int layer, int layers)
 {
     const int views = viewSplats > 0 ? (splats + viewSplats - 1) / viewSplats : 1;
     const int tableWords = views * scr.tilesY * openWordsPerRow;
@@ -1264,19 +1300,29 @@ void launchLayerCompaction(hipStream_t stream, const Screen& scr, int splats, in
         GS_CHECK(hipMemsetAsync(liveCount, 0, sizeof(int32_t), stream));
         return;
     }
-    if (tableWords <= kAliveTableWords)
-        hipLaunchKernelGGL((layerAliveKernel<true>), dim3(std::min((splats + 4 * kGroup - 1) / (4 * kGroup), 2048)), dim3(kGroup), 0, stream, splats, scr, tileBox,
-                           viewSplats, openBits, openWordsPerRow, tableWords, aliveWords);
-    else
-        hipLaunchKernelGGL((layerAliveKernel<false>), dim3(std::min((splats + 4 * kGroup - 1) / (4 * kGroup), 4096)), dim3(kGroup), 0, stream, splats, scr, tileBox,
-                           viewSplats, openBits, openWordsPerRow, tableWords, aliveWords);
+    LayerSlice slice{};
+    slice.listCountDevice = listCountDevice;
+    for (int l = 0; l != kMaxDepthLayers; ++l) slice.cut[l] = cuts != nullptr ? cuts[l] : 1.0f;
+    slice.layer = layer;
+    slice.layers = layers;
+    const bool everySplatLive = openBits == nullptr; // (a first layer: only cut out of a list whose length the host does not know)
+    if (!everySplatLive)
+    {
+        if (tableWords <= kAliveTableWords)
+            hipLaunchKernelGGL((layerAliveKernel<true>), dim3(std::min((splats + 4 * kGroup - 1) / (4 * kGroup), 2048)), dim3(kGroup), 0, stream, splats, scr, tileBox,
+                               viewSplats, openBits, openWordsPerRow, tableWords, aliveWords);
+        else
+            hipLaunchKernelGGL((layerAliveKernel<false>), dim3(std::min((splats + 4 * kGroup - 1) / (4 * kGroup), 4096)), dim3(kGroup), 0, stream, splats, scr, tileBox,
+                               viewSplats, openBits, openWordsPerRow, tableWords, aliveWords);
+    }
+    const unsigned long long* alive = everySplatLive ? nullptr : aliveWords;
     const int blocks = (count + kCompactBlock - 1) / kCompactBlock;
-    hipLaunchKernelGGL((layerCompactKernel<false>), dim3(blocks), dim3(kGroup), 0, stream, count, order, aliveWords, blockCounts, liveNibbles, liveOrder, liveCount,
-                       (const int32_t*) nullptr);
+    hipLaunchKernelGGL((layerCompactKernel<false>), dim3(blocks), dim3(kGroup), 0, stream, count, order, alive, blockCounts, liveNibbles, liveOrder, liveCount,
+                       (const int32_t*) nullptr, slice);
     const bool scanned = blocks > kCompactSelfSumBlocks;
     if (scanned) launchScanInt32(stream, blocks, blockCounts, blockOffsets, scanTotal);
-    hipLaunchKernelGGL((layerCompactKernel<true>), dim3(blocks), dim3(kGroup), 0, stream, count, order, aliveWords, blockCounts, liveNibbles, liveOrder, liveCount,
-                       scanned ? (const int32_t*) blockOffsets : (const int32_t*) nullptr);
+    hipLaunchKernelGGL((layerCompactKernel<true>), dim3(blocks), dim3(kGroup), 0, stream, count, order, alive, blockCounts, liveNibbles, liveOrder, liveCount,
+                       scanned ? (const int32_t*) blockOffsets : (const int32_t*) nullptr, slice);
 }
 
 int tileListFusedSortBits(int tileBitCount, int tileKeyBytes)

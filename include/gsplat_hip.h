@@ -322,7 +322,8 @@ int gs_renderer_colours_on_demand(const GsRenderer* r);
  * list ends leaves its per-pixel sums and transmittance and goes on in the next layer that has entries for it, its votes still at
  * multiples of 32 entries of its whole list: the image is the same bytes as with one layer.  What changes: the pair list the renderer
  * hands out (gs_renderer_buffers: keys, values, ranges, tileListSize) is the LAST layer's only (gs_renderer_listed_pairs: all layers).  Takes effect on
- * captured frames of the two-level pipeline whose tile sort is a two-pass sort of 16-bit indices (list fusion on, no band cull).
+ * captured frames of the two-level pipeline whose tile sort is a two-pass sort of 16-bit indices (list fusion on); tile-row bands with
+ * their cull included (the layers' slices of the culled list are cut on the device).
  * layers = 1 (the default): one list per frame, as the reference has it.
  * layers = GS_DEPTH_LAYERS_CHOOSE (0): the renderer chooses from the previous frame's pair total, for a host that renders ONE frame at a
  * time -- one layer below 16 M pairs per frame, two from there (27 M pairs: -16 % frame time), three from 40 M (BASELINE.json configs[4]

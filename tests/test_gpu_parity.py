@@ -1617,7 +1617,7 @@ def test_depth_layers_give_byte_identical_frames(gs, gsref, tmp_path, degree, w,
 
 def test_depth_layers_with_views_bands_and_a_list_that_must_grow(gs, tmp_path):
     """Depth layers beside the renderer's other options: several views per chain (virtual tiles: the status table and the saved state are
-    per view), a tile-row band with its cull (the layers stand aside: the culled splat count lives on the device), and a scene whose
+    per view), tile-row bands with their cull (the culled list's length lives on the device: the slices are cut there), and a scene whose
     first layered frame overflows the list (the frame is rendered again with a grown list before it is handed out) -- the same bytes
     as one layer every time."""
     from cudagaussianrenderer_amd import scenes
@@ -1645,14 +1645,26 @@ def test_depth_layers_with_views_bands_and_a_list_that_must_grow(gs, tmp_path):
             for v in range(views):
                 assert np.array_equal(r.read_image(view=v), want[(first + v) % 8]), (views, first, v)
         r.close()
-    band = gs.Renderer(w, h, tile_rows=(10, 20), storage_order="morton")
-    band.set_scene(*scene)
-    band.set_graph(True)
-    band.set_depth_layers(2)
-    band.render(cams[1])
-    img = band.read_image()
-    assert np.array_equal(img[160:320], want[1][160:320])
-    band.close()
+    # tile-row bands with their cull: the culled list's length lives on the device, so every layer's slice (the first one's too) is cut
+    # out by the compaction kernels -- the bands' rows are the full frame's rows, for 2..4 layers, both storage orders, one and two views
+    ty = (h + 15) // 16
+    for layers, storage, views, rows in ((2, "morton", 1, (10, 20)), (3, "caller", 1, (0, 7)), (4, "morton", 1, (30, ty)), (3, "morton", 2, (12, 31)),
+                                         (2, "morton", 1, (44, ty))):  # (the last band: nearly nothing reaches it)
+        band = gs.Renderer(w, h, tile_rows=rows, storage_order=storage, views=views)
+        band.set_scene(*scene)
+        band.set_graph(True)
+        band.set_depth_layers(layers)
+        lo, hi = rows[0] * 16, min(rows[1] * 16, h)
+        for rep in range(2):
+            if views == 1:
+                band.render(cams[1])
+                assert np.array_equal(band.read_image()[lo:hi], want[1][lo:hi]), (layers, storage, rows, rep)
+            else:
+                band.render_views([cams[2], cams[5]])
+                for v, c in enumerate((2, 5)):
+                    assert np.array_equal(band.read_image(view=v)[lo:hi], want[c][lo:hi]), (layers, storage, rows, rep, v)
+        assert band.depth_layers_in_use() == layers
+        band.close()
     # a list that must grow: ~40 pairs per splat against the 8 provisioned
     w2 = h2 = 512
     pos, sr, col = _procedural(gs, 6000, seed=9, min_scale=0.3, max_scale=1.5)

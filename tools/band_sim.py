@@ -24,8 +24,11 @@ ap.add_argument("--rebalance", type=int, default=0, help="iterations of re-cutti
 ap.add_argument("--gamma", type=float, default=2.0)
 ap.add_argument("--storage-order", choices=["caller", "morton"], default="morton", help="gs_renderer_set_storage_order: the caller's order, or along a 3-D Morton curve")
 ap.add_argument("--ablate", type=int, default=0, help="gs_debug_set_ablation mask for the timed frames (diagnostic: stages left out)")
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--depth-layers", type=int, default=1, help="gs_renderer_set_depth_layers of the bands' renderers (0 / -1: the renderer chooses)")
 args = ap.parse_args()
-W, H = 1920, 1080
+W, H = args.width, args.height
 gs.lib().gs_set_sort_backend(args.sort_backend)
 gs.lib().gs_set_raster_pixels_per_lane(args.ppl)
 with tempfile.TemporaryDirectory() as tmp:
@@ -59,6 +62,8 @@ def measure(world, bands):
             r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
             r.set_stream(streams[d].cuda_stream)
             r.set_graph(bool(args.graph))
+            if args.graph:
+                r.set_depth_layers(args.depth_layers)
             rs.append(r)
         from concurrent.futures import ThreadPoolExecutor
         from collections import deque

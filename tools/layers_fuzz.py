@@ -3,7 +3,7 @@
 compaction on and off) with one-list frames of the same renderer settings: random resolutions (tile counts that are and are not
 multiples of 32: the open-bit words' edges), splat counts, scale ranges (sub-pixel splats next to splats larger than the screen: boxes
 beyond the live test's 32 x 8 tiles), opacity shifts (tiles that stop at once ... never), SH degree 0 and 3 (colours from the buffer and
-on demand), one to three views per chain, storage orders.  The images must be the same bytes.
+on demand), one to three views per chain, storage orders, tile-row bands (culled lists).  The images must be the same bytes.
 usage (GPU box): python tools/layers_fuzz.py [iterations] [seed]"""
 import os
 import sys
@@ -47,9 +47,14 @@ def main():
             if any(b - a < 1e-4 for a, b in zip(fractions, fractions[1:])):
                 fractions = None
         compaction = int(rng.random() < 0.8)
+        rows = None  # a tile-row band (with its cull: the culled list's length lives on the device, the layers' slices are cut there)
+        ty = (h + 15) // 16
+        if rng.random() < 0.35 and ty > 3:
+            a = int(rng.integers(0, ty - 1))
+            rows = (a, int(rng.integers(a + 1, ty + 1)))
 
         def frames(count, fr):
-            r = gs.Renderer(w, h, storage_order=storage, views=views) if views > 1 else gs.Renderer(w, h, storage_order=storage)
+            r = gs.Renderer(w, h, storage_order=storage, views=views, tile_rows=rows)
             r.set_scene(*scene)
             r.set_graph(True)
             r.set_depth_layers(count, fr)
@@ -72,7 +77,7 @@ def main():
             skipped += 1
             continue
         got, used, listed = frames(layers, fractions)
-        what = (f"iteration {it}: {w}x{h} n {n} degree {degree} views {views} {storage} scales e^{mean:.2f}+-{sigma:.2f} layers {layers} "
+        what = (f"iteration {it}: {w}x{h} rows {rows} n {n} degree {degree} views {views} {storage} scales e^{mean:.2f}+-{sigma:.2f} layers {layers} "
                 f"cuts {fractions} compaction {compaction}: in use {used}, listed {listed} of {full}")
         for a, b in zip(want, got):
             for x, y in zip(a, b):
