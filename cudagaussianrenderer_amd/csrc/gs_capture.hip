@@ -418,7 +418,9 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
             //                  0.5 the renderer goes back to one layer and does not try again for a while (256 frames, doubling);
             //   two layers:    one below 1.5 M listed (pipelined) / 3.5 M (lone): the scene has become small; three from 18 M listed;
             //   three:         two below 6 M listed.
-            const int64_t upToTwo = r->autoPipelined ? 4500000 : 16000000, downToOne = r->autoPipelined ? 1500000 : 3500000;
+            // (a band under its cull -- a rank of a multi-GPU split -- skips the 4.5-8 M zone and its trial: layered bands gain 8 % at 8-11 M
+            // pairs per chain, and a trial that does not pay costs two re-captures)
+            const int64_t upToTwo = r->autoPipelined ? (cull ? 8000000 : 4500000) : 16000000, downToOne = r->autoPipelined ? (cull ? 2500000 : 1500000) : 3500000;
             const int64_t listed = r->graphLayersActive ? r->scratch.totalHost[1] : demand;
             int next = r->autoLayers;
             bool atOnce = false; // (a failed trial is undone at once, whatever the hold says)

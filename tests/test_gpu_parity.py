@@ -1649,7 +1649,7 @@ def test_depth_layers_with_views_bands_and_a_list_that_must_grow(gs, tmp_path):
     # out by the compaction kernels -- the bands' rows are the full frame's rows, for 2..4 layers, both storage orders, one and two views
     ty = (h + 15) // 16
     for layers, storage, views, rows in ((2, "morton", 1, (10, 20)), (3, "caller", 1, (0, 7)), (4, "morton", 1, (30, ty)), (3, "morton", 2, (12, 31)),
-                                         (2, "morton", 1, (44, ty))):  # (the last band: nearly nothing reaches it)
+                                         (2, "morton", 4, (0, 23)), (2, "morton", 1, (44, ty))):  # (the last band: nearly nothing reaches it)
         band = gs.Renderer(w, h, tile_rows=rows, storage_order=storage, views=views)
         band.set_scene(*scene)
         band.set_graph(True)
@@ -1660,8 +1660,9 @@ def test_depth_layers_with_views_bands_and_a_list_that_must_grow(gs, tmp_path):
                 band.render(cams[1])
                 assert np.array_equal(band.read_image()[lo:hi], want[1][lo:hi]), (layers, storage, rows, rep)
             else:
-                band.render_views([cams[2], cams[5]])
-                for v, c in enumerate((2, 5)):
+                chain = (2, 5, 7, 0)[:views]
+                band.render_views([cams[c] for c in chain])
+                for v, c in enumerate(chain):
                     assert np.array_equal(band.read_image(view=v)[lo:hi], want[c][lo:hi]), (layers, storage, rows, rep, v)
         assert band.depth_layers_in_use() == layers
         band.close()
