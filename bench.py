@@ -772,7 +772,7 @@ def main():
                 "log_scale_mean": args.log_scale_mean, "opacity_mean_raw": args.opacity_mean, "seed": args.seed, "storage_order": args.storage_order,
                 "list_fusion": int(lib.gs_get_list_fusion()),
                 "depth_layers": {"setting": int(lib.gs_renderer_depth_layers(rig.renderers[0].handle)), "in_use": rig.depth_layers_in_use, "listed_pairs_last_frame": rig.listed_pairs, "changes_per_renderer": rig.depth_layer_changes,
-                                 "what": "gs_renderer_set_depth_layers: -1 = the renderer chooses from the pair total, for a host with several frames in flight (two layers from 4.5 M pairs per frame, three from 40 M; the timed loop); 0 = the same for a lone frame (two layers from 16 M; extra.latency's legs when the setting is -1); in_use = layers of the timed region's last frame; listed_pairs_last_frame = pairs the last timed frame put into its lists (all layers; = pairs_per_frame with one layer)"},
+                                 "what": "gs_renderer_set_depth_layers: -1 = the renderer chooses from the pair total, for a host with several frames in flight (two layers from 4.5 M pairs per frame -- a band under its cull: from 8 M per chain --, three from 40 M; the timed loop); 0 = the same for a lone frame (two layers from 16 M; extra.latency's legs when the setting is -1); in_use = layers of the timed region's last frame; listed_pairs_last_frame = pairs the last timed frame put into its lists (all layers; = pairs_per_frame with one layer)"},
                 "raster_pixels_per_lane": lib.gs_get_raster_pixels_per_lane(), "device": device_name(lib), "frames_in_flight": depth, "frames_per_chain": rig.V, "frames_ahead": depth * rig.V,
                 "frames_ahead_what": "cameras the caller must hand over before the first image of them is complete (frames per chain x chains in flight); "
                                      "the reference's loop is 1 -- extra.latency has that figure",
