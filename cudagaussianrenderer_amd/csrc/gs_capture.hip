@@ -107,7 +107,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
                              (uint32_t*) r->order[0], r->splatToStorage);
         countDevice = (const int*) r->bandTotal;
         if (r->shDegree != 0 && !lazy)
-            launchSphericalHarmonicsGather(g.stream, n, countDevice, r->shDegree, r->shCount, r->order[0], (const float4*) r->position,
+            launchSphericalHarmonicsGather(g.stream, n, countDevice, r->shDegree, r->shRowStride, r->order[0], (const float4*) r->position,
                                            r->shPerSplat, unused, (float4*) r->color, params);
     }
     r->radix.countDevice = countDevice;
@@ -512,7 +512,9 @@ extern "C" int gs_renderer_render_views(GsRenderer* r, const GsCameraData* camer
 {
     if (r == nullptr || cameras == nullptr) return -1;
     if (r->views == 1) return gs_renderer_render(r, cameras, 0, nullptr);
-    const bool coloursPerView = r->shDegree != 0 && !useLazyColours(r); // an SH pass would need one colour buffer per view
+    // every degree 1..4 has its colours evaluated by the raster kernel; only a process that keeps the SH pass (GS_NO_LAZY_SH, or a raster
+    // shape other than two pixels per lane: diagnostics) would need one colour buffer per view
+    const bool coloursPerView = r->shDegree != 0 && !useLazyColours(r);
     if (!r->useGraph || r->pipeline != GS_PIPELINE_TWO_LEVEL || cfg.sortBackend != GS_SORT_BACKEND_NATIVE || cfg.collectRasterStats ||
         r->splatCount <= 0 || coloursPerView || !radixSortSupported(4, r->splatCount * r->views))
         return -3;

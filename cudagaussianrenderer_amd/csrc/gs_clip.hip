@@ -193,6 +193,11 @@ __device__ __forceinline__ bool projectSplat(const float4 pd, const float4 sr, c
     return projectCovariance<BAND>(pd, splatCovariance(sr), cam, scr, out, zOut, o);
 }
 
+__device__ __forceinline__ ClipCamera cam_or(const FrameParams* __restrict__ params, int view, const ClipCamera& camArg)
+{
+    return params ? params[view].camera : camArg; // device-resident when the frame is a captured graph
+}
+
 constexpr int kBandBlock = 256;                // splats per workgroup of the band-cull kernel; the compaction's scan runs over these blocks
 constexpr int kBandSlots = kBandBlock / kWave; // 64-splat slots (one kept mask each) per workgroup
 
@@ -260,7 +265,8 @@ __global__ __launch_bounds__(256) void splatClipBandKernel(int count, Screen scr
                                                             const float4* __restrict__ scaleAndRotation, ClipOutputs o,
                                                             unsigned long long* __restrict__ bandMask, int32_t* __restrict__ bandSlotPrefix,
                                                             int32_t* __restrict__ bandBlockCounts, int32_t* __restrict__ rangeTable,
-                                                            int rangeEntries, const int32_t* __restrict__ outSlot)
+                                                            int rangeEntries, const int32_t* __restrict__ outSlot,
+                                                            const uint8_t* __restrict__ blockFlags)
 {
     __shared__ int slotKept[kBandSlots];
     const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
@@ -271,6 +277,19 @@ __global__ __launch_bounds__(256) void splatClipBandKernel(int count, Screen scr
             rangeTable[i] = -1;
     const int blockBase = blockIdx.x * kBandBlock;
     if (blockBase >= count) return; // whole workgroup
+    const int slotsPerView = (count + kWave - 1) / kWave, blocksPerView = (count + kBandBlock - 1) / kBandBlock;
+    if (blockFlags != nullptr)
+    {
+        // Block cull (see blockBandTestKernel): the splats are walked in STORAGE order -- along the Morton curve -- and a block of 256
+        // neighbours that provably cannot reach the band is not projected at all; the kept mask of the others is left in storage order
+        // (bandMask here) and bandCallerMaskKernel turns it into the caller-ordered masks and counts the compaction runs over.
+        const bool live = blockFlags[view * blocksPerView + blockIdx.x] != 0; // (uniform)
+        bool kept = false;
+        if (live && index < count) kept = projectSplat<true>(position[index], scaleAndRotation[index], cam_or(params, view, camArg), scr, view * count + index, view * count + index, o);
+        const unsigned long long mask = live ? __ballot(kept) : 0ull;
+        if (lane == 0 && blockBase + wave * kWave < count) bandMask[view * slotsPerView + (blockBase >> 6) + wave] = mask;
+        return;
+    }
     const ClipCamera cam = params ? params[view].camera : camArg;
     bool kept = false;
     if (index < count)
@@ -281,7 +300,6 @@ __global__ __launch_bounds__(256) void splatClipBandKernel(int count, Screen scr
     __syncthreads();
     if (lane == 0 && blockBase + wave * kWave < count)
     {
-        const int slotsPerView = (count + kWave - 1) / kWave, blocksPerView = (count + kBandBlock - 1) / kBandBlock;
         int prefix = 0;
         for (int s = 0; s < wave; ++s) prefix += slotKept[s];
         bandMask[view * slotsPerView + (blockBase >> 6) + wave] = mask;
@@ -300,7 +318,8 @@ __global__ __launch_bounds__(256) void splatClipBandViewsKernel(int count, int v
                                                                  const float4* __restrict__ scaleAndRotation, ClipOutputs o,
                                                                  unsigned long long* __restrict__ bandMask, int32_t* __restrict__ bandSlotPrefix,
                                                                  int32_t* __restrict__ bandBlockCounts, int32_t* __restrict__ rangeTable,
-                                                                 int rangeEntries, const int32_t* __restrict__ outSlot)
+                                                                 int rangeEntries, const int32_t* __restrict__ outSlot,
+                                                                 const uint8_t* __restrict__ blockFlags)
 {
     __shared__ int slotKept[kMaxViews][kBandSlots];
     const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
@@ -309,6 +328,38 @@ __global__ __launch_bounds__(256) void splatClipBandViewsKernel(int count, int v
         for (int i = index; i < rangeEntries; i += (int) (gridDim.x * blockDim.x)) rangeTable[i] = -1;
     const int blockBase = blockIdx.x * kBandBlock;
     if (blockBase >= count) return; // whole workgroup
+    if (blockFlags != nullptr)
+    {
+        // Block cull (see the single-view kernel): storage order, only the views whose test kept this block are projected, masks in storage order
+        const int slotsPerView = (count + kWave - 1) / kWave, blocksPerView = (count + kBandBlock - 1) / kBandBlock;
+        bool any = false;
+        bool live[kMaxViews];
+#pragma unroll
+        for (int view = 0; view != kMaxViews; ++view)
+        {
+            live[view] = view < views && blockFlags[view * blocksPerView + blockIdx.x] != 0; // (uniform)
+            any |= live[view];
+        }
+        float4 pd = make_float4(0.f, 0.f, 0.f, 0.f);
+        Sym3 S{};
+        if (any && index < count)
+        {
+            pd = position[index];
+            S = splatCovariance(scaleAndRotation[index]);
+        }
+#pragma unroll
+        for (int view = 0; view != kMaxViews; ++view)
+        {
+            if (view < views)
+            {
+                bool kept = false;
+                if (live[view] && index < count) kept = projectCovariance<true>(pd, S, params[view].camera, scr, view * count + index, view * count + index, o);
+                const unsigned long long mask = live[view] ? __ballot(kept) : 0ull;
+                if (lane == 0 && blockBase + wave * kWave < count) bandMask[view * slotsPerView + (blockBase >> 6) + wave] = mask;
+            }
+        }
+        return;
+    }
     float4 pd = make_float4(0.f, 0.f, 0.f, 0.f);
     Sym3 S{};
     int slot = index;
@@ -351,13 +402,187 @@ __global__ __launch_bounds__(256) void splatClipBandViewsKernel(int count, int v
     }
 }
 
+// ---- Block-level band cull (round 6) --------------------------------------------------------------------------------------------
+// Every rank of a multi-GPU split used to run the projection over ALL N splats to learn which ones reach its rows (the replicated
+// part of a band frame: 90 of 250 us at BASELINE.json configs[4] / 8).  With the scene stored along the Morton curve a block of 256
+// consecutive splats is a small box in space, and one cheap test per block and frame can prove that none of its splats reaches the
+// band: the per-splat test then only runs over the blocks that remain.  The test only has to be CONSERVATIVE -- the per-splat keep
+// mask (projectCovariance<true>, the list builder's own box routine) stays the decider inside every kept block, so the frame is the
+// same bytes -- and it is a bound on exactly that routine (GaussianRender.cu:227-302,316-321,408-436,537-551):
+//   * a splat whose centre is outside the frustum emits nothing (extent 0), so only the part of the block's box with clip depth in
+//     [-1, 1] counts: d = -view z in [dn, df] (a block that straddles the near plane is cut at it, not kept wholesale);
+//   * its centre row: clip y = cotY * vy / d lies between the extremes of the box's view-space y over [dn, df], and in [-1, 1];
+//   * the reference's box is the bounding box of the ellipse's ORIENTED RECTANGLE: half height |sin| ex + |cos| ey <= k sqrt(l0 + l1)
+//     = k sqrt(trace(C) + 2 bump), and trace(C) = a' S a + b' S b <= lmax(S) |W|^2 (|J row 0|^2 + |J row 1|^2)
+//     <= lmax(S) |W|^2 (cotX^2 + cotY^2 + 2) / dn^2 for a visible centre (|clip x|, |clip y| <= 1 bound the shear terms);
+//   * lmax(S) per splat by Gershgorin on the very covariance the kernel computes (un-normalised quaternions included), its maximum
+//     per block stored at set_scene; |W|^2 by Gershgorin on W W' (1 for a rigid camera).
+// Every float evaluation is padded (1 % on the extent, 1e-3 on the unit bounds, 1e-3 tiles on the row compare) and every rejection is
+// a comparison that a NaN fails: a block the bound cannot speak for is kept.
+struct BlockBoundAcc
+{
+    float lo[3], hi[3], lam;
+};
+
+// set_scene: centre box and largest covariance eigenvalue bound of every block of 256 splats in storage order.
+__global__ __launch_bounds__(256) void blockBoundsKernel(int count, const float4* __restrict__ position, const float4* __restrict__ scaleAndRotation,
+                                                          BlockBound* __restrict__ bounds)
+{
+    __shared__ float red[7][4];
+    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
+    const int index = blockIdx.x * kBandBlock + t;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, lam = 0.0f;
+    if (index < count)
+    {
+        const float4 pd = position[index];
+        const Sym3 S = splatCovariance(scaleAndRotation[index]);
+        lo[0] = hi[0] = pd.x;
+        lo[1] = hi[1] = pd.y;
+        lo[2] = hi[2] = pd.z;
+        const float g0 = fabsf(S.xx) + fabsf(S.xy) + fabsf(S.xz), g1 = fabsf(S.xy) + fabsf(S.yy) + fabsf(S.yz), g2 = fabsf(S.xz) + fabsf(S.yz) + fabsf(S.zz);
+        lam = g0 + g1 + g2; // NaN stays NaN
+        lam = (lam == lam) ? fmaxf(g0, fmaxf(g1, g2)) : lam;
+    }
+    // (a NaN eigenvalue bound must survive the reduction: the block is then kept by every test)
+    const auto maxNan = [](float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); };
+#pragma unroll
+    for (int off = 32; off != 0; off >>= 1)
+    {
+#pragma unroll
+        for (int k = 0; k != 3; ++k)
+        {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+        lam = maxNan(lam, __shfl_xor(lam, off));
+    }
+    if (lane == 0)
+    {
+#pragma unroll
+        for (int k = 0; k != 3; ++k)
+        {
+            red[k][wave] = lo[k];
+            red[3 + k][wave] = hi[k];
+        }
+        red[6][wave] = lam;
+    }
+    __syncthreads();
+    if (t == 0)
+    {
+        BlockBound b;
+#pragma unroll
+        for (int k = 0; k != 3; ++k)
+        {
+            b.cmin[k] = fminf(fminf(red[k][0], red[k][1]), fminf(red[k][2], red[k][3]));
+            b.cmax[k] = fmaxf(fmaxf(red[3 + k][0], red[3 + k][1]), fmaxf(red[3 + k][2], red[3 + k][3]));
+        }
+        b.lamMax = maxNan(maxNan(red[6][0], red[6][1]), maxNan(red[6][2], red[6][3]));
+        b.pad = 0.0f;
+        bounds[blockIdx.x] = b;
+    }
+}
+
+// Per frame: one lane per (block, view) -> flags[view][block] = 1 unless the bound proves that no splat of the block reaches the band.
+__global__ __launch_bounds__(256) void blockBandTestKernel(int blocks, Screen scr, ClipCamera camArg, const FrameParams* __restrict__ params,
+                                                            const BlockBound* __restrict__ bounds, uint8_t* __restrict__ flags)
+{
+    const int block = blockIdx.x * blockDim.x + threadIdx.x;
+    if (block >= blocks) return;
+    const int view = blockIdx.y;
+    const ClipCamera cam = cam_or(params, view, camArg);
+    const BlockBound b = bounds[block];
+    const float* v = cam.view;
+    // view-space box of the centre box (interval arithmetic per output row, padded by the rounding of its four terms)
+    float lo[3], hi[3];
+#pragma unroll
+    for (int r = 0; r != 3; ++r)
+    {
+        float l = v[12 + r], h = v[12 + r], mag = fabsf(v[12 + r]);
+#pragma unroll
+        for (int c = 0; c != 3; ++c)
+        {
+            const float p0 = v[c * 4 + r] * b.cmin[c], p1 = v[c * 4 + r] * b.cmax[c];
+            l += fminf(p0, p1);
+            h += fmaxf(p0, p1);
+            mag += fmaxf(fabsf(p0), fabsf(p1));
+        }
+        lo[r] = l - 1.0e-5f * mag;
+        hi[r] = h + 1.0e-5f * mag;
+    }
+    // the visible depth range: clip depth = depthScale * z + depthBias in [-1, 1] (GaussianRender.cu:316-318), padded
+    const float zA = (-1.0f - cam.depthBias) / cam.depthScale, zB = (1.0f - cam.depthBias) / cam.depthScale;
+    const float zvLo = fminf(zA, zB), zvHi = fmaxf(zA, zB);
+    const float zLo = fmaxf(lo[2], zvLo - 1.0e-4f * fabsf(zvLo)), zHi = fminf(hi[2], zvHi + 1.0e-4f * fabsf(zvHi));
+    bool reject = zLo > zHi; // no centre of the block inside the depth range
+    const float dn = -zHi, df = -zLo; // distances in front of the camera, nearest and farthest
+    const bool sane = dn > 0.0f && df >= dn && cam.fovCotX > 0.0f && cam.fovCotY > 0.0f; // (a camera the bound was not written for: keep)
+    if (!reject && sane)
+    {
+        // centre extremes in clip space, cut to the frustum (a visible centre has |clip x|, |clip y| <= 1)
+        const float cyMax = fminf(cam.fovCotY * hi[1] / (hi[1] >= 0.0f ? dn : df), 1.001f);
+        const float cyMin = fmaxf(cam.fovCotY * lo[1] / (lo[1] <= 0.0f ? dn : df), -1.001f);
+        const float cxMax = cam.fovCotX * hi[0] / (hi[0] >= 0.0f ? dn : df);
+        const float cxMin = cam.fovCotX * lo[0] / (lo[0] <= 0.0f ? dn : df);
+        reject = cyMin > 1.001f || cyMax < -1.001f || cxMin > 1.001f || cxMax < -1.001f; // every centre outside the frustum
+        // |W|^2 <= largest Gershgorin row sum of W W'
+        float wn = 0.0f;
+#pragma unroll
+        for (int r = 0; r != 3; ++r)
+        {
+            float row = 0.0f;
+#pragma unroll
+            for (int s = 0; s != 3; ++s) row += fabsf(v[0 + r] * v[0 + s] + v[4 + r] * v[4 + s] + v[8 + r] * v[8 + s]);
+            wn = fmaxf(wn, row);
+        }
+        const float jacobian = (cam.fovCotX * cam.fovCotX + cam.fovCotY * cam.fovCotY + 2.02f) / (dn * dn);
+        const float half = 1.01f * scr.extentFactor * sqrtf(b.lamMax * 1.001f * wn * 1.001f * jacobian + 2.0f * scr.traceBump) + 1.0e-5f;
+        // rows, as splatTileAabb takes them: kept iff (maxY + 1) / 2 * tilesPerScreenY > rowBegin and (minY + 1) / 2 * tilesPerScreenY < rowEnd
+        const float top = ((cyMax + half) + 1.0f) * 0.5f * scr.tilesPerScreenY, bottom = ((cyMin - half) + 1.0f) * 0.5f * scr.tilesPerScreenY;
+        reject = reject || top < (float) scr.rowBegin - 1.0e-3f || bottom > (float) scr.rowEnd + 1.0e-3f;
+    }
+    flags[(size_t) view * blocks + block] = reject ? 0 : 1;
+}
+
+// The storage-ordered keep mask of the block-culled band kernel -> what the compaction runs over: per 64 splats in the CALLER's order the
+// kept mask and the kept splats of the workgroup's earlier slots, per 256 their count (the tail of splatClipBandKernel, fed from a gather
+// of one bit per splat instead of a projection).  splatToStorage: caller index c of view v at entry v * count + c -> v * count + slot.
+__global__ __launch_bounds__(256) void bandCallerMaskKernel(int count, const unsigned long long* __restrict__ storageMask,
+                                                             const int32_t* __restrict__ splatToStorage, unsigned long long* __restrict__ bandMask,
+                                                             int32_t* __restrict__ bandSlotPrefix, int32_t* __restrict__ bandBlockCounts)
+{
+    __shared__ int slotKept[kBandSlots];
+    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
+    const int index = blockIdx.x * blockDim.x + t;
+    const int view = blockIdx.y;
+    const int blockBase = blockIdx.x * kBandBlock;
+    if (blockBase >= count) return; // whole workgroup
+    const int slotsPerView = (count + kWave - 1) / kWave, blocksPerView = (count + kBandBlock - 1) / kBandBlock;
+    bool kept = false;
+    if (index < count)
+    {
+        const int slot = splatToStorage[index]; // (view 0's part of the list: the slot within a view)
+        kept = (storageMask[view * slotsPerView + (slot >> 6)] >> (slot & 63)) & 1ull;
+    }
+    const unsigned long long mask = __ballot(kept);
+    if (lane == 0) slotKept[wave] = __popcll(mask);
+    __syncthreads();
+    if (lane == 0 && blockBase + wave * kWave < count)
+    {
+        int prefix = 0;
+        for (int s = 0; s < wave; ++s) prefix += slotKept[s];
+        bandMask[view * slotsPerView + (blockBase >> 6) + wave] = mask;
+        bandSlotPrefix[view * slotsPerView + (blockBase >> 6) + wave] = prefix;
+        if (wave == 0) bandBlockCounts[view * blocksPerView + blockIdx.x] = slotKept[0] + slotKept[1] + slotKept[2] + slotKept[3];
+    }
+}
+
 // Order-preserving compaction of the splats flagged by the band cull: depth key + (virtual) splat index of every kept splat at
 // blockOffsets[block of 256 splats] + (kept splats of the block's earlier slots) + (kept lanes below it).  With Morton storage
 // masks and clip depths are the caller-ordered ones (see the band kernel) and lane c compacts the splat stored in slot splatToStorage[c].
 __global__ __launch_bounds__(256) void compactBandKernel(int count, const unsigned long long* __restrict__ bandMask,
                                                           const int32_t* __restrict__ bandSlotPrefix, const int32_t* __restrict__ blockOffsets,
                                                           const float* __restrict__ clipZ, const int32_t* __restrict__ splatToStorage,
-                                                          uint32_t* __restrict__ depthKey, uint32_t* __restrict__ splatOrder)
+                                                          uint32_t* __restrict__ depthKey, uint32_t* __restrict__ splatOrder, int clipZByStorage)
 {
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= count) return;
@@ -371,7 +596,8 @@ __global__ __launch_bounds__(256) void compactBandKernel(int count, const unsign
         const int out = view * count + (splatToStorage != nullptr ? splatToStorage[index] : index); // virtual splat (see the clip kernel)
         const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
         const int pos = blockOffsets[view * blocksPerView + index / kBandBlock] + bandSlotPrefix[slot] + __popcll(mask & lower);
-        depthKey[pos] = compactDepthKey(clipZ[view * count + index]);
+        // (block cull: the band kernel walked the splats in storage order and left the clip depth under the storage slot)
+        depthKey[pos] = compactDepthKey(clipZ[clipZByStorage ? out : view * count + index]);
         splatOrder[pos] = (uint32_t) out;
     }
 }
@@ -412,34 +638,57 @@ void launchUnpackEllipse(hipStream_t stream, int count, const float4* tileRecord
 
 void launchBandCompaction(hipStream_t stream, int count, int views, const unsigned long long* bandMask, const int32_t* bandSlotPrefix,
                           const int32_t* bandBlockCounts, int32_t* bandBlockOffsets, int64_t* bandTotal, const float* clipZ,
-                          uint32_t* depthKey, uint32_t* splatOrder, const int32_t* splatToStorage)
+                          uint32_t* depthKey, uint32_t* splatOrder, const int32_t* splatToStorage, bool clipZByStorage)
 {
     if (count <= 0) return;
     const int blocks = (count + kBandBlock - 1) / kBandBlock;
     launchScanInt32(stream, blocks * views, bandBlockCounts, bandBlockOffsets, bandTotal);
     hipLaunchKernelGGL(compactBandKernel, dim3((count + 255) / 256, views), dim3(256), 0, stream, count, bandMask, bandSlotPrefix,
-                       bandBlockOffsets, clipZ, splatToStorage, depthKey, splatOrder);
+                       bandBlockOffsets, clipZ, splatToStorage, depthKey, splatOrder, clipZByStorage ? 1 : 0);
+}
+
+void launchBlockBounds(hipStream_t stream, int count, const float4* position, const float4* scaleAndRotation, BlockBound* bounds)
+{
+    if (count > 0)
+        hipLaunchKernelGGL(blockBoundsKernel, dim3((count + kBandBlock - 1) / kBandBlock), dim3(256), 0, stream, count, position, scaleAndRotation, bounds);
 }
 
 void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const ClipCamera& cam, const float4* position,
                          const float4* scaleAndRotation, float2* clipXY, float* clipZ, float4* screenEllipse, float4* conic,
                          uint32_t* depthKey, uint32_t* splatOrder, unsigned long long* bandMask, int32_t* bandSlotPrefix,
                          int32_t* bandBlockCounts, const FrameParams* paramsDevice, int32_t* rangeTableToClear, int rangeEntries,
-                         float4* tileRecord, float4* rasterRecord, int views, const int32_t* bandOutSlot, ushort4* tileBox)
+                         float4* tileRecord, float4* rasterRecord, int views, const int32_t* bandOutSlot, ushort4* tileBox,
+                         const BandBlockCull* blockCull)
 {
     if (count <= 0) return;
     // views > 1: cameras from paramsDevice[view], results under view * count + splat
     const ClipOutputs o{clipXY, clipZ, screenEllipse, conic, depthKey, splatOrder, tileRecord, rasterRecord, tileBox};
+    if (bandMask != nullptr && blockCull != nullptr)
+    {
+        // block test -> projection of the kept blocks in storage order -> caller-ordered masks and counts for the compaction
+        const int blocks = (count + kBandBlock - 1) / kBandBlock;
+        hipLaunchKernelGGL(blockBandTestKernel, dim3((blocks + 255) / 256, views), dim3(256), 0, stream, blocks, scr, cam, paramsDevice, blockCull->bounds,
+                           blockCull->flags);
+        if (views > 1 && paramsDevice != nullptr)
+            hipLaunchKernelGGL(splatClipBandViewsKernel, dim3(blocks), dim3(256), 0, stream, count, views, scr, paramsDevice, position, scaleAndRotation, o,
+                               blockCull->storageMask, nullptr, nullptr, rangeTableToClear, rangeEntries, nullptr, blockCull->flags);
+        else
+            hipLaunchKernelGGL(splatClipBandKernel, dim3(blocks, views), dim3(256), 0, stream, count, scr, cam, paramsDevice, position, scaleAndRotation, o,
+                               blockCull->storageMask, nullptr, nullptr, rangeTableToClear, rangeEntries, nullptr, blockCull->flags);
+        hipLaunchKernelGGL(bandCallerMaskKernel, dim3(blocks, views), dim3(256), 0, stream, count, blockCull->storageMask, blockCull->splatToStorage, bandMask,
+                           bandSlotPrefix, bandBlockCounts);
+        return;
+    }
 #ifndef GS_CLIP_ALL_VIEWS
 #define GS_CLIP_ALL_VIEWS 1 // A/B builds: 0 = one grid row per view (round 3)
 #endif
     if (bandMask != nullptr && views > 1 && paramsDevice != nullptr && GS_CLIP_ALL_VIEWS)
         hipLaunchKernelGGL(splatClipBandViewsKernel, dim3((count + kBandBlock - 1) / kBandBlock), dim3(256), 0, stream, count, views, scr, paramsDevice,
-                           position, scaleAndRotation, o, bandMask, bandSlotPrefix, bandBlockCounts, rangeTableToClear, rangeEntries, bandOutSlot);
+                           position, scaleAndRotation, o, bandMask, bandSlotPrefix, bandBlockCounts, rangeTableToClear, rangeEntries, bandOutSlot, nullptr);
     else if (bandMask != nullptr)
         hipLaunchKernelGGL(splatClipBandKernel, dim3((count + kBandBlock - 1) / kBandBlock, views), dim3(256), 0, stream, count, scr, cam,
                            paramsDevice, position, scaleAndRotation, o, bandMask, bandSlotPrefix, bandBlockCounts, rangeTableToClear,
-                           rangeEntries, bandOutSlot);
+                           rangeEntries, bandOutSlot, nullptr);
     else
         hipLaunchKernelGGL(splatClipDataKernel, dim3((count + 255) / 256, views), dim3(256), 0, stream, count, scr, cam, paramsDevice, position,
                            scaleAndRotation, o, rangeTableToClear, rangeEntries);

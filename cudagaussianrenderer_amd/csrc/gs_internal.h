@@ -69,6 +69,25 @@ struct FrameParams
     float pad;
 };
 
+// Block-level band cull (gs_clip.hip): per block of 256 splats in storage order, the box of the centres and a bound on the largest
+// eigenvalue of the splats' world-space covariances -- what a rank of a multi-GPU split needs to prove that a whole block of
+// Morton-neighbouring splats cannot reach its tile rows without projecting any of them.
+struct BlockBound
+{
+    float cmin[3];
+    float lamMax;
+    float cmax[3];
+    float pad;
+};
+struct BandBlockCull
+{
+    const BlockBound* bounds = nullptr;          // [ceil(N / 256)], made at set_scene (launchBlockBounds)
+    uint8_t* flags = nullptr;                    // [views][ceil(N / 256)]: 1 = the block may reach the band this frame
+    unsigned long long* storageMask = nullptr;   // [views][ceil(N / 64)]: the kept mask in storage order
+    const int32_t* splatToStorage = nullptr;     // caller index -> storage slot (the compaction runs in the caller's order)
+};
+void launchBlockBounds(hipStream_t stream, int count, const float4* position, const float4* scaleAndRotation, BlockBound* bounds);
+
 // ---- launchers (one per stage); all enqueue on `stream` and return without synchronising --------
 void launchSphericalHarmonics(hipStream_t stream, int count, int degree, int shCount, const float4* position, const float* sh,
                               float3 cameraPosition, float4* color, const FrameParams* paramsDeviceOrNull = nullptr);
@@ -81,7 +100,10 @@ void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const
                          const FrameParams* paramsDeviceOrNull = nullptr,
                          int32_t* rangeTableToClearOrNull = nullptr, int rangeEntries = 0, float4* tileRecordOrNull = nullptr,
                          float4* rasterRecordOrNull = nullptr, int views = 1, const int32_t* bandOutSlotOrNull = nullptr,
-                         ushort4* tileBoxOrNull = nullptr /* depth layers: the list builder's box per splat (gs_aabb.h splatTileBox) */);
+                         ushort4* tileBoxOrNull = nullptr /* depth layers: the list builder's box per splat (gs_aabb.h splatTileBox) */,
+                         // band cull of a Morton-stored scene by blocks (gs_clip.hip): position / scaleAndRotation are then the STORAGE-ordered
+                         // arrays, bandOutSlot is null, and the clip depth of a kept splat lies under its storage slot (launchBandCompaction: clipZByStorage)
+                         const BandBlockCull* blockCullOrNull = nullptr);
 // screenEllipse[i] = (cos, sin, extent x, extent y) from the 32-byte tile records the clip kernel can write instead.
 void launchUnpackEllipse(hipStream_t stream, int count, const float4* tileRecord, float4* screenEllipse);
 // positionClipSpaceXY / Z / conic from the 32-byte raster records (cx, cy, conic.x, conic.y | conic.z, depth, 0, 0) the clip kernel can
@@ -94,11 +116,12 @@ void launchUnpackRasterRecord(hipStream_t stream, int count, const float4* raste
 // by the caller's index and the compaction runs in the CALLER's order (gs_clip.hip).
 void launchBandCompaction(hipStream_t stream, int count, int views, const unsigned long long* bandMask, const int32_t* bandSlotPrefix,
                           const int32_t* bandBlockCounts, int32_t* bandBlockOffsets, int64_t* bandTotal, const float* clipZ,
-                          uint32_t* depthKey, uint32_t* splatOrder, const int32_t* splatToStorageOrNull = nullptr);
+                          uint32_t* depthKey, uint32_t* splatOrder, const int32_t* splatToStorageOrNull = nullptr, bool clipZByStorage = false);
 // Exclusive scan of n int32 on the device (one workgroup), total as int64.
 void launchScanInt32(hipStream_t stream, int n, const int32_t* in, int32_t* out, int64_t* total);
-// SH colour for the splats of a device-side index list only; coefficients in the [splat][shCount] layout.
-void launchSphericalHarmonicsGather(hipStream_t stream, int countHost, const int* countDevice, int degree, int shCount,
+// SH colour for the splats of a device-side index list only; coefficients in the [splat][rowStride] layout (rows of shCount floats,
+// padded to a 16-byte multiple by the renderer: gs_sh_eval.h rowStrideFloats).
+void launchSphericalHarmonicsGather(hipStream_t stream, int countHost, const int* countDevice, int degree, int rowStride,
                                     const int32_t* indices, const float4* position, const float* shPerSplat, float3 cameraPosition,
                                     float4* color, const FrameParams* paramsDeviceOrNull = nullptr);
 
@@ -287,6 +310,7 @@ void launchTileRanges(hipStream_t stream, int size, int keyBytes, const void* ke
 struct RasterColourSource
 {
     int degree = 0, shCount = 0;
+    int rowStride = 0; // floats between the rows of shPerSplat: shCount rounded up to a 16-byte multiple (27 -> 28, 75 -> 76)
     const float4* position = nullptr;
     const float* shPerSplat = nullptr;
     float3 cameraPosition = {0.f, 0.f, 0.f};

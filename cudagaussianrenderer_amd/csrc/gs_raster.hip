@@ -221,8 +221,8 @@ __global__ __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(LAYER
     // Register-staged gather of one list entry per lane.
     float2 gCentre = make_float2(0.f, 0.f);
     float4 gConic = make_float4(0.f, 0.f, 0.f, 0.f), gColor = make_float4(0.f, 0.f, 0.f, 0.f);
-    static_assert(SH == 0 || (3 * (SH + 1) * (SH + 1)) % 4 == 0, "on-demand colours need 16-byte coefficient rows (degrees 1 and 3)");
-    constexpr int kRowQuads = SH ? 3 * (SH + 1) * (SH + 1) / 4 : 1;
+    // (rows of the renderer's [splat][row] coefficient copy are padded to 16-byte multiples: degrees 2 and 4 read one pad float)
+    constexpr int kRowQuads = SH ? sheval::kRowQuads<(SH ? SH : 1)> : 1;
     float4 gRow[kRowQuads]; // SH: the splat's coefficient row, in flight while the previous batch is blended
     float3 lazyCam = make_float3(0.f, 0.f, 0.f);
     if constexpr (SH != 0)
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(LAYER
             else
             {
                 gColor = lazy.position[splat]; // xyz + opacity; becomes the colour when the entry is staged
-                const float4* row = reinterpret_cast<const float4*>(lazy.shPerSplat + (size_t) splat * lazy.shCount);
+                const float4* row = reinterpret_cast<const float4*>(lazy.shPerSplat + (size_t) splat * lazy.rowStride);
 #pragma unroll
                 for (int m = 0; m != kRowQuads; ++m) gRow[m] = row[m];
             }
@@ -493,23 +493,25 @@ void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileR
         // depth layers: the default shape only (two pixels per lane); colours from the buffer or on demand
         const int sh = (lazyColours != nullptr && rasterCanEvaluateColours(lazy.degree, lazy.shCount)) ? lazy.degree : 0;
         const RasterLayer layer = *layerOrNull;
-        if (sh == 3) { if (epan) GS_LAUNCH_RASTER_L(2, true, 3, true, layer); else GS_LAUNCH_RASTER_L(2, false, 3, true, layer); }
-        else if (sh == 1) { if (epan) GS_LAUNCH_RASTER_L(2, true, 1, true, layer); else GS_LAUNCH_RASTER_L(2, false, 1, true, layer); }
-        else { if (epan) GS_LAUNCH_RASTER_L(2, true, 0, true, layer); else GS_LAUNCH_RASTER_L(2, false, 0, true, layer); }
+        switch (sh)
+        {
+        case 4: if (epan) GS_LAUNCH_RASTER_L(2, true, 4, true, layer); else GS_LAUNCH_RASTER_L(2, false, 4, true, layer); break;
+        case 3: if (epan) GS_LAUNCH_RASTER_L(2, true, 3, true, layer); else GS_LAUNCH_RASTER_L(2, false, 3, true, layer); break;
+        case 2: if (epan) GS_LAUNCH_RASTER_L(2, true, 2, true, layer); else GS_LAUNCH_RASTER_L(2, false, 2, true, layer); break;
+        case 1: if (epan) GS_LAUNCH_RASTER_L(2, true, 1, true, layer); else GS_LAUNCH_RASTER_L(2, false, 1, true, layer); break;
+        default: if (epan) GS_LAUNCH_RASTER_L(2, true, 0, true, layer); else GS_LAUNCH_RASTER_L(2, false, 0, true, layer); break;
+        }
         return;
     }
-    // on-demand colours: two pixels per lane only (the default shape), degrees whose coefficient rows are 16-byte multiples
+    // on-demand colours: two pixels per lane only (the default shape), every degree the reference ingests (PlyParser.cpp:204-243)
     if (lazyColours != nullptr && g_rasterPixelsPerLane == 2 && rasterCanEvaluateColours(lazy.degree, lazy.shCount))
     {
-        if (lazy.degree == 1)
+        switch (lazy.degree)
         {
-            if (epan) GS_LAUNCH_RASTER(2, true, 1);
-            else GS_LAUNCH_RASTER(2, false, 1);
-        }
-        else
-        {
-            if (epan) GS_LAUNCH_RASTER(2, true, 3);
-            else GS_LAUNCH_RASTER(2, false, 3);
+        case 1: if (epan) GS_LAUNCH_RASTER(2, true, 1); else GS_LAUNCH_RASTER(2, false, 1); break;
+        case 2: if (epan) GS_LAUNCH_RASTER(2, true, 2); else GS_LAUNCH_RASTER(2, false, 2); break;
+        case 3: if (epan) GS_LAUNCH_RASTER(2, true, 3); else GS_LAUNCH_RASTER(2, false, 3); break;
+        default: if (epan) GS_LAUNCH_RASTER(2, true, 4); else GS_LAUNCH_RASTER(2, false, 4); break;
         }
         return;
     }
@@ -535,7 +537,7 @@ void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileR
 
 bool rasterCanEvaluateColours(int degree, int shCount)
 {
-    return (degree == 1 || degree == 3) && shCount == 3 * (degree + 1) * (degree + 1) && g_rasterPixelsPerLane == 2;
+    return degree >= 1 && degree <= 4 && shCount == 3 * (degree + 1) * (degree + 1) && g_rasterPixelsPerLane == 2;
 }
 
 } // namespace gs

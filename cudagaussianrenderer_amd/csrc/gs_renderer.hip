@@ -13,14 +13,15 @@
 #include <cstring>
 
 #include "gs_state.h"
+#include "gs_sh_eval.h"
 
 using namespace gs;
 
 namespace gs
 {
 // Colours on demand: the two-level frames skip the SH pass and let the raster kernel evaluate the colour of every
-// list entry it stages ("Colours on demand").  Needs the [splat][shCount] coefficient copy and a degree whose
-// rows are 16-byte multiples; GS_NO_LAZY_SH=1 keeps the reference's stage order.
+// list entry it stages ("Colours on demand").  Needs the [splat][row] coefficient copy (rows padded to 16-byte
+// multiples: every degree 1-4); GS_NO_LAZY_SH=1 keeps the reference's stage order.
 bool useLazyColours(const GsRenderer* r)
 {
     static const bool disabled = getenv("GS_NO_LAZY_SH") != nullptr;
@@ -32,6 +33,7 @@ RasterColourSource colourSource(const GsRenderer* r, const float* cameraPosition
     RasterColourSource src;
     src.degree = r->shDegree;
     src.shCount = r->shCount;
+    src.rowStride = r->shRowStride;
     src.position = (const float4*) r->position;
     src.shPerSplat = r->shPerSplat;
     if (cameraPosition) src.cameraPosition = make_float3(cameraPosition[0], cameraPosition[1], cameraPosition[2]);
@@ -387,9 +389,19 @@ extern "C" int gs_renderer_set_scene(GsRenderer* r, int32_t n, const float* posi
         gs_realign_spherical_harmonics(rows, aligned.data(), GS_SH_GROUP_SIZE, shCount, n);
         r->sh = (float*) gs_device_alloc(total * sizeof(float));
         gs_device_upload(r->sh, aligned.data(), total * sizeof(float));
-        // second copy in the file's [splat][shCount] layout for the band-culled (gathered) SH evaluation
-        r->shPerSplat = (float*) gs_device_alloc(sizeof(float) * (size_t) n * shCount);
-        gs_device_upload(r->shPerSplat, rows, sizeof(float) * (size_t) n * shCount);
+        // second copy in the file's [splat][row] layout for colours on demand (the raster kernel gathers a consumed entry's row) and the
+        // band-culled SH evaluation; rows padded to a 16-byte multiple (degrees 2 and 4: 27 -> 28, 75 -> 76 floats) so that every degree
+        // the reference ingests (PlyParser.cpp:204-243) is read as whole float4s
+        r->shRowStride = sheval::rowStrideFloats(shCount);
+        const size_t stride = (size_t) r->shRowStride;
+        r->shPerSplat = (float*) gs_device_alloc(sizeof(float) * (size_t) n * stride);
+        if (stride == (size_t) shCount) gs_device_upload(r->shPerSplat, rows, sizeof(float) * (size_t) n * stride);
+        else
+        {
+            std::vector<float> padded((size_t) n * stride, 0.0f);
+            for (int32_t k = 0; k != n; ++k) std::memcpy(padded.data() + stride * (size_t) k, rows + (size_t) shCount * (size_t) k, sizeof(float) * (size_t) shCount);
+            gs_device_upload(r->shPerSplat, padded.data(), sizeof(float) * padded.size());
+        }
     }
     return 0;
 }
@@ -427,6 +439,7 @@ extern "C" int gs_renderer_share_scene(GsRenderer* r, const GsRenderer* owner)
     r->scaleAndRotation = owner->scaleAndRotation;
     r->sh = owner->sh;
     r->shPerSplat = owner->shPerSplat;
+    r->shRowStride = owner->shRowStride;
     r->storageOrder = owner->storageOrder;
     r->splatToStorage = owner->splatToStorage;
     r->positionCaller = owner->positionCaller;
@@ -724,7 +737,7 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
             // SH colour of the kept splats only (list = the compacted, still index-ordered order[0])
             gs_timer_start(stageTimers[0]);
             const float* cp = camera->position;
-            launchSphericalHarmonicsGather(g.stream, n, countDevice, r->shDegree, r->shCount, r->order[0], (const float4*) r->position,
+            launchSphericalHarmonicsGather(g.stream, n, countDevice, r->shDegree, r->shRowStride, r->order[0], (const float4*) r->position,
                                            r->shPerSplat, make_float3(cp[0], cp[1], cp[2]), (float4*) r->color);
             gs_timer_stop(stageTimers[0]);
             if (blocking) st.msSphericalHarmonics = gs_timer_elapsed_ms(stageTimers[0]);

@@ -65,11 +65,11 @@ __global__ __launch_bounds__(kWave* kWavesPerBlock) void sphericalHarmonicsKerne
         if (first + i < count) color[first + i] = finalColour(rgb, i, p[i].w);
 }
 
-// One list entry per lane: the splat's coefficient row is 4*S contiguous, 16-byte aligned bytes (S is a multiple of 3;
-// rows of S = 3, 12, 27, 48, 75 floats -- only S % 4 == 0 rows are read as float4, the others fall back to scalar loads),
-// so a degree-3 splat is twelve 16-byte loads, all issued before the first use.
+// One list entry per lane: the splat's coefficient row starts at shPerSplat + idx * rowStride (the renderer pads its rows of
+// S = 3, 12, 27, 48, 75 floats to 4, 12, 28, 48, 76 -- gs_sh_eval.h rowStrideFloats -- so every row is read as float4; an unpadded
+// stride falls back to scalar loads), so a degree-3 splat is twelve 16-byte loads, all issued before the first use.
 template <int L>
-__global__ __launch_bounds__(256) void sphericalHarmonicsGatherKernel(int countHost, const int* __restrict__ countDevice, int shCount,
+__global__ __launch_bounds__(256) void sphericalHarmonicsGatherKernel(int countHost, const int* __restrict__ countDevice, int rowStride,
                                                                        const int32_t* __restrict__ indices,
                                                                        const float4* __restrict__ position,
                                                                        const float* __restrict__ shPerSplat, float3 camArg,
@@ -80,8 +80,8 @@ __global__ __launch_bounds__(256) void sphericalHarmonicsGatherKernel(int countH
     const int entry = blockIdx.x * blockDim.x + threadIdx.x;
     if (entry >= count) return;
     const int idx = indices[entry];
-    const float* row = shPerSplat + (size_t) idx * shCount;
-    color[idx] = colourFromRow<L>(row, shCount, position[idx], cam);
+    const float* row = shPerSplat + (size_t) idx * rowStride;
+    color[idx] = colourFromRow<L>(row, rowStride, position[idx], cam);
 }
 
 } // namespace
@@ -102,14 +102,14 @@ void launchSphericalHarmonics(hipStream_t stream, int count, int degree, int shC
     }
 }
 
-void launchSphericalHarmonicsGather(hipStream_t stream, int countHost, const int* countDevice, int degree, int shCount,
+void launchSphericalHarmonicsGather(hipStream_t stream, int countHost, const int* countDevice, int degree, int rowStride,
                                     const int32_t* indices, const float4* position, const float* shPerSplat, float3 cameraPosition,
                                     float4* color, const FrameParams* paramsDevice)
 {
     if (countHost <= 0) return;
     const dim3 grid((countHost + 255) / 256), block(256);
 #define GS_LAUNCH_GATHER(L)                                                                                                          \
-    hipLaunchKernelGGL(sphericalHarmonicsGatherKernel<L>, grid, block, 0, stream, countHost, countDevice, shCount, indices, position, \
+    hipLaunchKernelGGL(sphericalHarmonicsGatherKernel<L>, grid, block, 0, stream, countHost, countDevice, rowStride, indices, position, \
                        shPerSplat, cameraPosition, color, paramsDevice)
     switch (degree)
     {

@@ -132,6 +132,7 @@ struct GsRenderer
     // band cull (multi-GPU): per-splat coefficients in the [splat][shCount] layout for gathered SH evaluation,
     // one keep-mask and count per 64 splats, their scan, and the kept-splat count (device scalar)
     float* shPerSplat = nullptr;
+    int shRowStride = 0; // floats between its rows: shCount rounded up to a multiple of four (degrees 2 and 4: one pad float per row)
     // per-renderer stream and scratch, so that several renderers can have frames in flight at once
     hipStream_t stream = nullptr;
     bool hasStream = false;

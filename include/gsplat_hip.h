@@ -390,9 +390,11 @@ void gs_renderer_set_graph(GsRenderer* r, int enabled);
  * kernel runs once per V frames -- what a frame of a tile-row band (multi-GPU) needs, whose kernels are too small to fill the
  * time their launches take.  Every image is byte-identical to the one gs_renderer_render gives for that camera.  The back buffer
  * holds the V images one after another (an external one must be that large); gs_renderer_back_buffer_view(r, v) is view v's.
- * gs_renderer_render_views takes V cameras; it needs captured frames (gs_renderer_set_graph), the two-level pipeline and colours
- * that do not need a per-view SH pass (SH degree 0, 1 or 3) and returns -3 otherwise; overflow of the pair list is handled as for
- * single frames (all V frames are rendered again).  Returns 0 on success.  After a chain of V > 1 views gs_renderer_buffers describes
+ * gs_renderer_render_views takes V cameras; it needs captured frames (gs_renderer_set_graph) and the two-level pipeline and returns
+ * -3 otherwise; every SH degree the reference ingests (0..4, PlyParser.cpp:204-243) is rendered -- the colours of degrees 1..4 are
+ * evaluated by the raster kernel from the coefficient rows (a process that keeps the SH pass, GS_NO_LAZY_SH, is refused with -3 for
+ * those: the pass would need one colour buffer per view); overflow of the pair list is handled as for single frames (all V frames
+ * are rendered again).  Returns 0 on success.  After a chain of V > 1 views gs_renderer_buffers describes
  * the chain, not a frame: the pair list holds the pairs of all views (values are virtual splat indices v*N + i, ranges of view v start
  * at entry 2*v*T of tileRange), and the per-splat arrays it unpacks are view 0's. */
 int gs_renderer_set_views(GsRenderer* r, int views);

@@ -14,22 +14,24 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("ranks,width,height,splats", [(2, 1920, 1080, 200000), (3, 1920, 1080, 200000),
-                                                       # the widest rehearsals the GPU box allows (six processes on the card: the ranks, this process, a margin of one):
-                                                       # 1080p with its half-height last tile row, and 4K (135 tile rows)
-                                                       (4, 1920, 1080, 120000), (4, 3840, 2160, 200000)])
-def test_bench_multirank_rehearsal(ranks, width, height, splats):
+@pytest.mark.parametrize("ranks,width,height,splats,sh_degree", [(2, 1920, 1080, 200000, 3), (3, 1920, 1080, 200000, 3),
+                                                                 # the widest rehearsals the GPU box allows (six processes on the card: the ranks, this process, a margin of one):
+                                                                 # 1080p with its half-height last tile row, and 4K (135 tile rows)
+                                                                 (4, 1920, 1080, 120000, 3), (4, 3840, 2160, 200000, 3),
+                                                                 # SH degrees 2 and 4 (rows of 27 / 75 floats: refused by the chains of four views until round 6)
+                                                                 (2, 1280, 720, 80000, 2), (2, 1280, 720, 60000, 4)])
+def test_bench_multirank_rehearsal(ranks, width, height, splats, sh_degree):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29600 + ranks), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "24", "--warmup", "6",
-           "--splats", str(splats), "--width", str(width), "--height", str(height), "--cpu-frames", "0", "--rehearse",
+           "--master-port", str(29600 + ranks + 10 * sh_degree), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "24", "--warmup", "6",
+           "--splats", str(splats), "--width", str(width), "--height", str(height), "--sh-degree", str(sh_degree), "--cpu-frames", "0", "--rehearse",
            "--rebalance-frames", "64", "--spin-up", "0.2"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     result = json.loads(line)
     cfg = result["config"]
-    assert result["n_gpus"] == ranks and result["steps"] == 24 and result["value"] > 0
+    assert result["n_gpus"] == ranks and result["steps"] == 24 and result["value"] > 0 and cfg["sh_degree"] == sh_degree
     assert result["scaling"] == "strong"
     bands = cfg["tile_row_bands"]
     assert len(bands) == ranks and bands[0][0] == 0 and bands[-1][1] == (height + 15) // 16

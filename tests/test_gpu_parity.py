@@ -724,11 +724,12 @@ def test_captured_frames_never_hand_out_a_truncated_frame(gs):
 def test_views_per_chain_give_byte_identical_frames(gs, tmp_path, views):
     """gs_renderer_set_views: V cameras rendered by ONE replay of the captured chain (virtual splats v*N + i, virtual tiles
     v*T + t) give, view by view, the bytes of single-view frames -- full frame and band-culled sub-band, colours on demand
-    (SH 3) and static colours (SH 0), twice in a row (the two graph instances), odd splat counts (ragged waves per view)."""
+    (every SH degree the reference ingests, 1-4: rows of 12, 27 -> 28, 48, 75 -> 76 floats) and static colours (SH 0), twice in a
+    row (the two graph instances), odd splat counts (ragged waves per view)."""
     from cudagaussianrenderer_amd import scenes
 
     w, h = 1280, 720
-    for degree, count in ((3, 60001), (0, 20011)):
+    for degree, count in ((3, 60001), (0, 20011), (2, 30011), (4, 25003), (1, 20011)):
         ply = _ply_scene(gs, tmp_path, count, degree, log_scale_mean=-3.3)
         scene = (ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
         cams = [gs.camera_from_pose(p, q, w, h) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 8)]
@@ -755,7 +756,8 @@ def test_views_per_chain_give_byte_identical_frames(gs, tmp_path, views):
 
 def test_views_overflow_and_refusals(gs, tmp_path):
     """A chain of views whose pair demand exceeds the list is rendered again (all views) before the call returns; what the chain
-    cannot do is refused: no captured frames, an SH degree that needs a per-view colour pass, views after the scene is set."""
+    cannot do is refused: no captured frames, views after the scene is set.  (Round 5 refused SH degrees 2 and 4 -- rows of 27 and
+    75 floats -- here; their rows are padded now and the chain renders them.)"""
     w = h = 512
     pos, sr, col = _procedural(gs, 3000, seed=9, min_scale=0.3, max_scale=1.5)  # ~40 pairs per splat >> the 8 provisioned
     cams = [gs.camera_from_bounds([-4] * 3, [4] * 3, w, h), gs.camera_from_bounds([-5] * 3, [5] * 3, w, h)]
@@ -779,13 +781,21 @@ def test_views_overflow_and_refusals(gs, tmp_path):
     r.close()
     with pytest.raises(ValueError):
         gs.Renderer(w, h, views=5)
-    ply = _ply_scene(gs, tmp_path, 2000, 2)  # SH degree 2: colours need the SH pass, one buffer per view
-    r = gs.Renderer(w, h, views=2)
-    r.set_graph(True)
-    r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
-    with pytest.raises(RuntimeError):
+    for degree in (2, 4):
+        ply = _ply_scene(gs, tmp_path, 2000, degree)
+        scene = (ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+        ref = gs.Renderer(w, h, pipeline=gs.PIPELINE_REFERENCE)  # the SH pass over all splats, the reference's stage order
+        ref.set_scene(*scene)
+        r = gs.Renderer(w, h, views=2)
+        r.set_graph(True)
+        r.set_scene(*scene)
+        assert r.colours_on_demand()
         r.render_views(cams)
-    r.close()
+        for v in range(2):
+            ref.render(cams[v])
+            assert np.array_equal(r.read_image(view=v), ref.read_image()), (degree, v)
+        r.close()
+        ref.close()
 
 
 @pytest.mark.parametrize("degree", [2, 3])
@@ -864,11 +874,12 @@ def test_renderer_empty_scene_and_scene_swap(gs, graph):
         r.close()
 
 
-@pytest.mark.parametrize("degree", [1, 2, 3])
+@pytest.mark.parametrize("degree", [1, 2, 3, 4])
 def test_colours_on_demand_equal_the_sh_pass(gs, tmp_path, degree):
-    """Two-level frames of a degree-1 or degree-3 scene evaluate colours inside the raster kernel instead of running
-    the SH pass; the reference-shaped pipeline always runs it.  Same bytes in the image, and the colour buffer handed out by
-    gs_renderer_buffers equals the SH pass's.  (Degree 2: rows of 27 floats -- the SH pass stays, everything still agrees.)"""
+    """Two-level frames of a scene with SH coefficients (every degree the reference ingests, PlyParser.cpp:204-243) evaluate colours
+    inside the raster kernel instead of running the SH pass; the reference-shaped pipeline always runs it.  Same bytes in the image,
+    and the colour buffer handed out by gs_renderer_buffers equals the SH pass's.  (Degrees 2 and 4: rows of 27 / 75 floats, padded
+    to 28 / 76 in the renderer's per-splat copy; plain, captured and two-layer frames.)"""
     w, h = 800, 448
     ply = _ply_scene(gs, tmp_path, 40000, degree, log_scale_mean=-3.1)
     n = ply["vertexCount"]
@@ -880,7 +891,7 @@ def test_colours_on_demand_equal_the_sh_pass(gs, tmp_path, degree):
     for pipeline in (gs.PIPELINE_REFERENCE, gs.PIPELINE_TWO_LEVEL):
         r = gs.Renderer(w, h, pipeline=pipeline)
         r.set_scene(*scene)
-        assert r.colours_on_demand() == (pipeline != gs.PIPELINE_REFERENCE and degree in (1, 3))
+        assert r.colours_on_demand() == (pipeline != gs.PIPELINE_REFERENCE)
         frames = []
         for cam in cams:
             r.render(cam)
@@ -893,6 +904,17 @@ def test_colours_on_demand_equal_the_sh_pass(gs, tmp_path, degree):
         for (img_ref, col_ref), (img, col) in zip(results[gs.PIPELINE_REFERENCE], results[pipeline]):
             assert np.array_equal(img, img_ref)
             assert np.array_equal(col, col_ref)
+    # captured frames, as one list and in two depth layers (the LAYERED instantiation of the raster kernel), Morton storage
+    for layers in (1, 2):
+        r = gs.Renderer(w, h, storage_order=gs.STORAGE_ORDER_MORTON)
+        r.set_graph(True)
+        r.set_depth_layers(layers)
+        r.set_scene(*scene)
+        for cam, (img_ref, _) in zip(cams, results[gs.PIPELINE_REFERENCE]):
+            r.render(cam)
+            assert np.array_equal(r.read_image(), img_ref), (degree, layers)
+        assert r.depth_layers_in_use() == layers
+        r.close()
 
 
 def _tie_heavy_scene(gs, n=20000, planes=40, seed=3):
