@@ -368,6 +368,41 @@ class Rig:
         return {"sh": sums.msSphericalHarmonics / frames, "clip": sums.msClipData / frames, "tile_list": sums.msBuildTileList / frames,
                 "sort": sums.msSortTileList / frames, "ranges": sums.msTileRanges / frames, "raster": sums.msRasterize / frames}
 
+    def layered_raster(self, repeats=4):
+        """The kernel the timed loop really runs when its frames are made of depth layers -- rasterizeTilesKernel<2, ., SH, LAYERED>, once per
+        layer: the very kernels of the captured layered frame launched plainly on renderer 0's stream, one frame at a time, a HIP event pair
+        around every layer's raster launch (gs_renderer_debug_layered_raster_report), every view of the orbit `repeats` times.  Returns the
+        per-frame means: launches, their summed duration, consumed entries, tiles run, state loads / stores -- or None when the loop's frames
+        are one list.  Call right after the timed region (the renderer's captured frame must be the layered one)."""
+        import torch
+
+        r = self.renderers[0]
+        if self.V != 1 or self.args.no_graph:
+            return None
+        with torch.cuda.stream(self.streams[0]):
+            for cam in self.cameras:  # the choice settles on renderer 0 (it may come back from a one-frame leg)
+                r.render(cam)
+                r.render(cam)
+            if r.depth_layers_in_use() < 2:
+                return None
+            acc, frames = None, 0
+            for _ in range(repeats):
+                for cam in self.cameras:
+                    rep = r.layered_raster_report(cam)
+                    if rep is None:
+                        return None
+                    tot = {"launches": len(rep), "ms": sum(x["raster_ms"] for x in rep), "consumed_pairs": sum(x["consumed_pairs"] for x in rep),
+                           "tiles_run": sum(x["tiles_run"] for x in rep), "state_tile_loads": sum(x["state_tile_loads"] for x in rep),
+                           "state_tile_stores": sum(x["state_tile_stores"] for x in rep), "ms_by_layer": [x["raster_ms"] for x in rep]}
+                    if acc is None:
+                        acc = tot
+                    else:
+                        for k in acc:
+                            acc[k] = [a + b for a, b in zip(acc[k], tot[k])] if k == "ms_by_layer" else acc[k] + tot[k]
+                    frames += 1
+        out = {k: ([x / frames for x in v] if k == "ms_by_layer" else v / frames) for k, v in acc.items()}
+        return out
+
     def list_sizes(self):
         """P, P_c (from the raster kernel's own counter) and the non-empty tile count, mean over the views."""
         import torch
@@ -488,10 +523,54 @@ def stage_report(rig, args, stage_ms, p_mean, pc_mean, nonempty, band_tiles, ban
     def rate(nbytes, ms):
         return round(nbytes / 1e9 / (ms / 1e3), 1) if ms > 0 else None
 
+    # reference_bytes_over_our_time is NOT a bandwidth of this machine: it is what the reference's formulation of the stage would have to
+    # move divided by the time THIS implementation takes for the stage -- the sort and the ranges come out above the
+    # 8 000 GB/s peak because this implementation moves a fifth of those bytes (rounds 1-5 called the key reference_formulation_GBps)
     stages = {k: {"ms": round(stage_ms[k], 4), "moved_MB": round(mb[k] / 1e6, 2), "GBps": rate(mb[k], stage_ms[k]),
-                  "reference_formulation_MB": round(ab[k] / 1e6, 2), "reference_formulation_GBps": rate(ab[k], stage_ms[k])}
+                  "reference_formulation_MB": round(ab[k] / 1e6, 2), "reference_bytes_over_our_time": rate(ab[k], stage_ms[k])}
               for k in stage_ms}
     return stages, ab, mb, stage_ms, on_demand
+
+
+def timed_loop_kernel(layered, args, tiles, band_h, one_list_ms, one_list_achieved):
+    """roofline.timed_loop_kernel: the raster kernel AS THE TIMED LOOP RUNS IT.  With depth layers that is the LAYERED instantiation, launched
+    once per layer: per-frame time = the sum of its launches (HIP events around each, the layered frame's own kernels replayed one frame at
+    a time), algorithmic bytes = SURVEY.md 8(d)'s per launch -- 44 B per consumed entry, the range table once per launch, 4 B per pixel
+    of every tile a launch writes -- plus the 16 B per pixel an open tile's state costs each time it is stored or loaded.  The `valu`
+    sub-block prices the same kernel against the vector ALU's issue rate, which is what bounds it: VALU wave
+    instructions per frame from the committed counter pass (profiles/r05_layers_pmc.txt; OFFLINE, like roofline.traffic) over
+    1 024 SIMDs x one wave instruction per 4 cycles at 2.4 GHz."""
+    if layered is None:
+        return {"kernel": f"rasterizeTilesKernel<2, {'epanechnikov' if args.epanechnikov else 'gaussian'}, SH {args.sh_degree}, one list>",
+                "launches_per_frame": 1, "kernel_ms_per_frame": round(one_list_ms, 4), "achieved": round(one_list_achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(one_list_achieved / HBM_PEAK_GBS, 5), "what": "the timed loop's frames are one list: the block above IS its kernel"}
+    px = 256  # pixels of a tile (edge tiles: fewer on screen; counted whole -- an upper bound on the bytes, hence on frac)
+    nbytes = (44 * layered["consumed_pairs"] + 8 * tiles * layered["launches"] + 4 * px * layered["tiles_run"]
+              + 16 * px * (layered["state_tile_loads"] + layered["state_tile_stores"]))
+    ms = layered["ms"]
+    achieved = nbytes / 1e9 / (ms / 1e3)
+    valu = None
+    default_scene = (args.splats == 1_000_000 and (args.width, args.height) == (1920, 1080) and args.sh_degree == 3 and args.seed == 1234
+                     and args.opacity_mean == 1.0 and args.log_scale_mean == -3.6 and not args.epanechnikov)
+    if default_scene and round(layered["launches"]) == 2:
+        per_launch = 9_090_689.3  # SQ_INSTS_VALU per dispatch of rasterizeTilesKernel<2, false, 3, true>, profiles/r05_layers_pmc.txt
+        issue_peak = SIMDS * 2.4e9 / 4.0  # wave instructions per second: 1 024 SIMDs, 4 cycles per wave64 instruction
+        floor_ms = 1e3 * per_launch * layered["launches"] / issue_peak
+        valu = {"wave_instructions_per_frame": round(per_launch * layered["launches"]), "issue_peak_per_s": issue_peak,
+                "ms_at_issue_peak": round(floor_ms, 4), "frac": round(floor_ms / ms, 4),
+                "source": "OFFLINE: SQ_INSTS_VALU per dispatch from profiles/r05_layers_pmc.txt (rocprofv3 --pmc pass of this workload with two depth "
+                          "layers, round 5's kernel; the LAYERED raster loop is unchanged since), not measured in this run"}
+    return {"kernel": f"rasterizeTilesKernel<2, {'epanechnikov' if args.epanechnikov else 'gaussian'}, SH {args.sh_degree}, LAYERED>",
+            "bound": "hbm", "launches_per_frame": round(layered["launches"], 2), "kernel_ms_per_frame": round(ms, 4),
+            "kernel_ms_by_layer": [round(v, 4) for v in layered["ms_by_layer"]],
+            "kernel_ms_source": "HIP events around every layer's raster launch; the captured layered frame's kernels launched plainly, one frame at a "
+                                "time, every view of the orbit four times (gs_renderer_debug_layered_raster_report)",
+            "algorithmic_bytes": round(nbytes),
+            "algorithmic_formula": "44 P_c + 8 T x launches + 4 B x 256 px x tiles run (all launches) + 16 B x 256 px x (state loads + state stores) "
+                                   "(SURVEY.md 8(d) per launch + the open tiles' state round trip)",
+            "consumed_pairs_per_frame": round(layered["consumed_pairs"]), "tiles_run_per_frame": round(layered["tiles_run"]),
+            "state_tile_loads_per_frame": round(layered["state_tile_loads"]), "state_tile_stores_per_frame": round(layered["state_tile_stores"]),
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "valu": valu}
 
 
 def offline_counters(args, world):
@@ -736,6 +815,7 @@ def main():
             whole.close()
         dist.barrier()
 
+    layered = rig.layered_raster() if world == 1 else None  # (before the one-list replays below: they drop the captured frame)
     stage_ms = rig.stage_times(args.steps)
     p_mean, pc_mean, nonempty, pairs_per_view = rig.list_sizes()
     band = rig.band
@@ -806,6 +886,7 @@ def main():
                                "once per layer over fewer pairs; kernel_ms, the stages and the algorithmic bytes above are those of the SAME frame "
                                "as one list (plain launches, one frame at a time); the layered launches' durations are in the rocprofv3 statistics "
                                "of this command under profiles/ (kernel_stats_pipelined)") if rig.depth_layers_in_use > 1 else "one list per frame",
+                "timed_loop_kernel": timed_loop_kernel(layered, args, band_tiles, band_h, raster_ms, achieved),
                 "dominant_stage": dominant, "dominant_stage_ms": round(stage_ms[dominant], 4),
                 "dominant_stage_GBps": stages[dominant]["GBps"],
                 "dominant_stage_frac": round((stages[dominant]["GBps"] or 0.0) / HBM_PEAK_GBS, 4),
@@ -828,6 +909,25 @@ def main():
         result["extra"]["staged_api"] = staged_api_table(ply_path, W, H, frames=min(max(args.steps, 50), 200))
     if keep_dir is not None:
         keep_dir.cleanup()
+
+    # ---- the same loop under the LIBRARY'S DEFAULTS (N = 1): `value` is measured with settings a host must ask for ----
+    if world == 1 and not args.no_extra and not args.no_graph and result is not None and (args.depth_layers != 1 or args.storage_order != "caller"):
+        import copy
+        args_d = copy.copy(args)
+        args_d.depth_layers = 1
+        args_d.storage_order = "caller"
+        rig_d = Rig(ctx, ply, cameras, bands, depth, args_d)
+        steps_d = 512 if args.steps >= 512 else args.steps
+        el_d = rig_d.timed_run(steps_d, max(args.warmup, 8 * depth))
+        result["library_defaults"] = {
+            "value": round(rig_d.frames_timed / el_d, 2), "unit": "frames/s", "ms_per_step": round(1e3 * el_d / rig_d.frames_timed, 4), "steps": rig_d.frames_timed,
+            "what": "the timed loop of `value` (same scene, orbit, four captured frames in flight) with every renderer setting at the library's default: "
+                    "splats stored in the caller's order (gs_renderer_set_storage_order not called) and one list per frame (gs_renderer_set_depth_layers "
+                    "not called).  `value` asks for Morton storage and lets the renderer choose its depth layers (config.storage_order, "
+                    "config.depth_layers) -- both are documented API settings with byte-identical frames; roofline.timed_loop_kernel prices the raster "
+                    "kernel of `value`'s frame shape, `stages` and the first roofline block the one-list frame replayed serially"}
+        rig_d.close()
+        beat("library defaults done")
 
     # ---- the same workload with more cameras handed over in advance (N = 1): several frames per chain of kernels ----
     if world == 1 and not args.no_extra and not args.no_graph and args.views_per_chain <= 0 and args.inflight <= 0:

@@ -410,6 +410,34 @@ class Renderer:
         """Pairs the last captured frame listed, summed over its depth layers."""
         return int(lib().gs_renderer_listed_pairs(self.handle))
 
+    def set_footprint(self, footprint):
+        """This renderer's footprint (FOOTPRINT_GAUSSIAN / FOOTPRINT_EPANECHNIKOV; -1 = the process-wide gs_set_footprint at frame time)."""
+        lib().gs_renderer_set_footprint(self.handle, int(footprint))
+
+    def set_block_cull(self, enabled=True):
+        """A/B: the band cull of a Morton-stored scene by blocks of 256 neighbours (default) or by projecting every splat (round 5)."""
+        lib().gs_renderer_debug_set_block_cull(self.handle, 1 if enabled else 0)
+
+    def block_cull_kept(self):
+        """(blocks the last band-culled frame's block test kept, blocks x views), or (-1, total) without block bounds."""
+        total = C.c_int64(0)
+        kept = lib().gs_renderer_debug_block_cull_kept(self.handle, C.byref(total))
+        return int(kept), int(total.value)
+
+    def band_kept_splats(self):
+        """Splats the last band-culled frame kept (the culled list's length, all views)."""
+        return int(lib().gs_renderer_debug_band_kept_splats(self.handle))
+
+    def layered_raster_report(self, camera):
+        """One frame of `camera` as the captured layered frame's kernels, launched plainly with an event pair around every layer's raster
+        launch: list of per-layer dicts (ms, consumed entries, tiles run, tiles that loaded / stored their state), or None when the
+        renderer's last captured frame was not layered."""
+        rep = _capi.LayeredRasterReport()
+        if lib().gs_renderer_debug_layered_raster_report(self.handle, C.byref(camera), C.byref(rep)) != 0:
+            return None
+        return [{"raster_ms": float(rep.rasterMs[l]), "consumed_pairs": int(rep.consumedPairs[l]), "tiles_run": int(rep.tilesRun[l]),
+                 "state_tile_loads": int(rep.stateTileLoads[l]), "state_tile_stores": int(rep.stateTileStores[l])} for l in range(rep.layers)]
+
     def colours_on_demand(self):
         """True when this renderer's frames evaluate SH colours inside the raster kernel (no SH pass)."""
         return bool(lib().gs_renderer_colours_on_demand(self.handle))

@@ -114,6 +114,11 @@ class FrameStats(C.Structure):
     ]
 
 
+class LayeredRasterReport(C.Structure):
+    _fields_ = [("layers", C.c_int32), ("rasterMs", C.c_float * 4), ("consumedPairs", C.c_int64 * 4), ("tilesRun", C.c_int64 * 4),
+                ("stateTileLoads", C.c_int64 * 4), ("stateTileStores", C.c_int64 * 4)]
+
+
 class RendererBuffers(C.Structure):
     _fields_ = [
         ("position", C.c_void_p),
@@ -133,7 +138,8 @@ class RendererBuffers(C.Structure):
     ]
 
 
-# name -> (restype, argtypes); exactly the symbols include/gsplat_hip.h declares.
+# name -> (restype, argtypes); exactly the symbols include/gsplat_hip.h (the boundary) and include/gsplat_hip_debug.h (diagnostics,
+# A/B switches, counters: DEBUG_SYMBOLS below names those) declare.
 SIGNATURES = {
     "gs_timer_create": (C.c_void_p, []),
     "gs_timer_destroy": (None, [C.c_void_p]),
@@ -166,6 +172,18 @@ SIGNATURES = {
     "gs_renderer_depth_layers_in_use": (C.c_int, [C.c_void_p]),
     "gs_renderer_depth_layer_changes": (C.c_int, [C.c_void_p]),
     "gs_renderer_debug_set_layer_compaction": (None, [C.c_void_p, C.c_int]),
+    "gs_renderer_debug_set_block_cull": (None, [C.c_void_p, C.c_int]),
+    "gs_renderer_debug_set_layer_compaction_reuse": (None, [C.c_void_p, C.c_int]),
+    "gs_renderer_debug_block_cull_kept": (C.c_int64, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "gs_renderer_debug_band_kept_splats": (C.c_int64, [C.c_void_p]),
+    "gs_renderer_debug_layered_raster_report": (C.c_int, [C.c_void_p, C.POINTER(CameraData), C.POINTER(LayeredRasterReport)]),
+    "gs_renderer_debug_set_list_fusion": (None, [C.c_void_p, C.c_int]),
+    "gs_renderer_debug_raster_grid_slots": (C.c_int, [C.c_void_p]),
+    "gs_renderer_debug_set_tile_order": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
+    "gs_renderer_debug_tile_consumed": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "gs_renderer_debug_set_raster_pixels_per_lane": (None, [C.c_void_p, C.c_int]),
+    "gs_renderer_set_footprint": (None, [C.c_void_p, C.c_int]),
+    "gs_renderer_footprint": (C.c_int, [C.c_void_p]),
     "gs_set_footprint": (None, [C.c_int]),
     "gs_get_footprint": (C.c_int, []),
     "gs_get_sort_backend": (C.c_int, []),
@@ -226,6 +244,7 @@ SIGNATURES = {
     "gs_debug_set_clip_scan_fusion": (None, [C.c_int]),
     "gs_debug_get_clip_scan_fusion": (C.c_int, []),
     "gs_debug_set_await_timeout": (None, [C.c_double]),
+    "gs_debug_set_staged_scratch_limit": (None, [C.c_int64]),
     "gs_debug_host_times": (C.c_longlong, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
     "gs_renderer_set_stream": (None, [C.c_void_p, C.c_void_p]),
     "gs_renderer_begin": (C.c_int, [C.c_void_p, C.POINTER(CameraData), C.c_int]),
@@ -248,6 +267,16 @@ SIGNATURES = {
     "gs_gather_bands_views": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
     "gs_version": (C.c_char_p, []),
 }
+
+# the symbols of include/gsplat_hip_debug.h (everything else above is include/gsplat_hip.h)
+DEBUG_SYMBOLS = frozenset([
+    "gs_set_collect_raster_stats", "gs_last_raster_consumed_pairs", "gs_renderer_captured_retries", "gs_renderer_depth_layer_changes",
+    "gs_renderer_debug_set_layer_compaction", "gs_renderer_debug_set_block_cull", "gs_renderer_debug_set_layer_compaction_reuse", "gs_renderer_debug_block_cull_kept", "gs_renderer_debug_band_kept_splats", "gs_renderer_debug_layered_raster_report",
+    "gs_renderer_debug_set_list_fusion", "gs_renderer_debug_raster_grid_slots", "gs_renderer_debug_set_tile_order", "gs_renderer_debug_tile_consumed", "gs_renderer_debug_set_raster_pixels_per_lane", "gs_set_sort_backend", "gs_get_sort_backend",
+    "gs_set_list_fusion", "gs_get_list_fusion", "gs_radix_sort_pairs", "gs_set_raster_pixels_per_lane", "gs_get_raster_pixels_per_lane",
+    "gs_debug_set_raster_trace", "gs_debug_set_ablation", "gs_debug_set_clip_scan_fusion", "gs_debug_get_clip_scan_fusion",
+    "gs_debug_set_await_timeout", "gs_debug_set_staged_scratch_limit", "gs_debug_host_times", "gs_debug_rccl_self_exchange", "gs_debug_rccl_self_exchange_parts",
+    "gs_debug_rccl_self_exchange_streams"])
 
 _lib = None
 

@@ -34,7 +34,7 @@ Screen makeScreen(int width, int height, int rowBegin, int rowEnd)
     s.pixelClipSizeY = 2.0f / (float) height;
     const float pi = 3.14159265359f;
     s.traceBump = (1.0f / pi) * s.pixelClipSizeX * s.pixelClipSizeY;
-    s.epanechnikov = g_footprint == GS_FOOTPRINT_EPANECHNIKOV ? 1 : 0;
+    s.epanechnikov = effectiveFootprint() == GS_FOOTPRINT_EPANECHNIKOV ? 1 : 0; // (the calling renderer's own, or the process-wide switch)
     s.extentFactor = s.epanechnikov ? sqrtf(7.0f) : 3.0f;
     return s;
 }
@@ -133,19 +133,35 @@ extern "C" void gs_device_free(void* p)
 {
     if (p) GS_CHECK(hipFree(p));
 }
+// A copy on the LEGACY (null) stream depends on every blocking stream of the process, and another renderer's thread may be CAPTURING on
+// one (a frame re-captured after a list growth or a change of depth layers; a torch stream handed in through gs_renderer_set_stream is a
+// blocking stream): "operation would make the legacy stream depend on a capturing blocking stream".  A thread whose stream is its own
+// (StreamScope of a renderer with a stream, gs_set_stream) copies on that stream; a thread on the null stream -- the staged API and
+// DeviceBuffer<T> of a host that keeps the reference's conventions -- keeps the reference's semantics (the copy waits for everything
+// enqueued before it) and takes the capture mutex instead: captures and legacy-stream copies never overlap.
 extern "C" void gs_device_upload(void* dst, const void* src, size_t bytes)
 {
-    if (bytes) GS_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    if (!bytes) return;
+    if (g.stream != nullptr)
+    {
+        GS_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g.stream));
+        GS_CHECK(hipStreamSynchronize(g.stream)); // (the source may be pageable and is the caller's again when this returns, like hipMemcpy)
+        return;
+    }
+    std::lock_guard<std::mutex> lock(g_captureMutex);
+    GS_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
 }
 extern "C" void gs_device_download(void* dst, const void* src, size_t bytes)
 {
-    if (bytes)
+    if (!bytes) return;
+    if (g.stream != nullptr)
     {
-        // on the calling thread's stream, not the legacy stream: a legacy-stream copy depends on every blocking stream of the process,
-        // and another renderer's thread may be capturing on one (a frame re-captured after a list growth or a change of depth layers)
         GS_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g.stream));
         GS_CHECK(hipStreamSynchronize(g.stream));
+        return;
     }
+    std::lock_guard<std::mutex> lock(g_captureMutex);
+    GS_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
 }
 extern "C" void gs_device_memset(void* p, int value, size_t bytes)
 {
@@ -190,7 +206,12 @@ extern "C" int32_t gs_build_tile_list(GsTimer* timer, int32_t /*numBlocks*/, int
     const Screen scr = currentScreen();
     const int count = g.global.splatCount;
     // Default: the pairs are emitted in the order the sort would leave them (gs_staged.hip); sortTileList then finds nothing to do.
-    if (cfg.stagedBuilder == GS_STAGED_BUILDER_SORTED && radixSortSupported(4, count)) return stagedBuildTileListSorted(timer, tileListCapacity);
+    // (-1: no device memory for that builder's scratch -- this call emits in the reference's order, which needs none)
+    if (cfg.stagedBuilder == GS_STAGED_BUILDER_SORTED && radixSortSupported(4, count))
+    {
+        const int32_t emitted = stagedBuildTileListSorted(timer, tileListCapacity);
+        if (emitted >= 0) return emitted;
+    }
     gs_timer_start(timer);
     launchTileListCount(g.stream, count, scr, (const float2*) g.global.positionClipSpaceXY, (const float4*) g.global.screenEllipse,
                         g.scratch);

@@ -21,7 +21,16 @@ namespace
 // host-side cost of captured frames (diagnostic, gs_debug_host_times): time inside hipGraphLaunch, time waiting for the pair total
 std::atomic<long long> g_hostLaunchNs{0}, g_hostAwaitNs{0}, g_hostFrames{0};
 
-int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool lazy, int slot)
+// What gs_renderer_debug_layered_raster_report collects while it enqueues a layered frame with plain launches: an event pair around
+// every layer's raster launch and four counters per layer (entries consumed, tiles run, tiles that loaded / stored their state).
+struct LayerProbe
+{
+    hipEvent_t start[kMaxDepthLayers], stop[kMaxDepthLayers];
+    unsigned long long* counters = nullptr; // device, 4 per layer, zeroed by the caller
+    int layers = 0;
+};
+
+int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool lazy, int slot, LayerProbe* probe = nullptr)
 {
 #ifndef GS_PARAMS_FROM_HOST
 #define GS_PARAMS_FROM_HOST 0 // A/B builds: 1 = the kernels read the cameras from the pinned host slot itself (no copy node in the graph)
@@ -46,10 +55,14 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
     // Depth layers (gs_renderer_set_depth_layers): only where the emit pass carries the tile sort's first pass (two-pass sorts of 16-bit tile
     // indices) and with enough splats for every layer to have some.  Under a band cull the list's length lives on the device: every layer's
     // slice, the first one's too, is then cut out by the compaction kernels (gs_tiles_fast.hip LayerSlice), which needs the compaction on
-    const int fusedBits = cfg.listFusion ? tileListFusedSortBits(tBits, tileKeyBytes) : 0;
+    const int fusedBits = effectiveListFusion() ? tileListFusedSortBits(tBits, tileKeyBytes) : 0;
     float layerFraction[kMaxDepthLayers];
     const int wantLayers = effectiveDepthLayers(r, layerFraction);
-    const int layers = (wantLayers > 1 && (!cull || r->layerCompaction) && fusedBits > 0 && nv >= 4096 && g_ablation == 0) ? wantLayers : 1;
+    // ... and with the host-mapped word the layers' totals travel through: without one (hipHostGetDevicePointer failed) every layer's
+    // emit pass would copy ITS total into the word the host waits on -- the host would take the first layer's for the frame's, never see a
+    // later, larger layer overflow the list, and read a stale 0 as the listed sum: such a renderer renders one list per frame
+    const int layers = (wantLayers > 1 && (!cull || r->layerCompaction) && fusedBits > 0 && nv >= 4096 && g_ablation == 0 &&
+                        r->scratch.totalHostMapped != nullptr) ? wantLayers : 1;
     ushort4* tileBox = (layers > 1 && r->layerCompaction) ? r->layerTileBox : nullptr; // (the later layers' live test, gs_tiles_fast.hip)
     // the range table is reset to -1 by the clip kernel (one node less than a memset; see gs_ranges.hip) -- and the layers' tile status
     // bytes behind it with it (0xFF = untouched)
@@ -98,13 +111,16 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
     else
     {
         // (Morton storage: in the caller's order, from the caller-ordered copies of the inputs)
-        const bool callerOrder = r->splatToStorage != nullptr;
+        // (... unless the cull runs by blocks of Morton neighbours: storage order, only the blocks that can reach the band, gs_clip.hip)
+        BandBlockCull blocks;
+        const bool byBlocks = useBlockCull(r, &blocks);
+        const bool callerOrder = r->splatToStorage != nullptr && !byBlocks;
         launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) (callerOrder ? r->positionCaller : r->position),
-                            (const float4*) (callerOrder ? r->scaleAndRotationCaller : r->scaleAndRotation), nullptr, r->clipZ, nullptr, nullptr, nullptr,
+                            (const float4*) (callerOrder ? r->scaleAndRotationCaller : r->scaleAndRotation), nullptr, byBlocks ? nullptr : r->clipZ, nullptr, nullptr, nullptr,
                             nullptr, r->bandMask, r->bandSlotPrefix, r->bandCounts, params, clearTable, clearEntries, (float4*) r->tileRecord,
-                            (float4*) r->rasterRecord, views, r->splatToStorage, tileBox);
+                            (float4*) r->rasterRecord, views, callerOrder ? r->splatToStorage : nullptr, tileBox, byBlocks ? &blocks : nullptr);
         launchBandCompaction(g.stream, n, views, r->bandMask, r->bandSlotPrefix, r->bandCounts, r->bandOffsets, r->bandTotal, r->clipZ, r->depthKey[0],
-                             (uint32_t*) r->order[0], r->splatToStorage);
+                             (uint32_t*) r->order[0], r->splatToStorage, byBlocks ? (const float4*) r->positionCaller : nullptr, nullptr, params);
         countDevice = (const int*) r->bandTotal;
         if (r->shDegree != 0 && !lazy)
             launchSphericalHarmonicsGather(g.stream, n, countDevice, r->shDegree, r->shRowStride, r->order[0], (const float4*) r->position,
@@ -162,10 +178,16 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
             else if (l > 0 && r->layerCompaction)
             {
                 // the later layers walk only the splats that still have an open tile under their box (gs_tiles_fast.hip)
-                launchLayerCompaction(g.stream, scr, nv, views > 1 ? n : 0, r->layerTileBox, r->tileOpenBits, openWordsPerRow(scr.tilesX), r->layerAlive, order + begin, cnt, r->layerBlockCounts, r->layerLiveNibbles, live,
-                                      r->layerLiveCount, r->layerBlockOffsets, r->layerScanTotal);
-                layerOrder = live;
-                r->scratch.countDevice = r->layerLiveCount;
+                // (experiment, gs_renderer_debug_set_layer_compaction_reuse: lists in buffers that outlive the frame; mode 2 walks them again
+                // without launching the three compaction kernels)
+                const bool keep = r->layerReuse != 0 && r->layerLiveDebug != nullptr;
+                uint32_t* liveList = keep ? r->layerLiveDebug + (size_t) l * (size_t) nv : live;
+                int32_t* liveCount = keep ? r->layerLiveCountDebug + l : r->layerLiveCount;
+                if (!(keep && r->layerReuse == 2))
+                    launchLayerCompaction(g.stream, scr, nv, views > 1 ? n : 0, r->layerTileBox, r->tileOpenBits, openWordsPerRow(scr.tilesX), r->layerAlive, order + begin, cnt, r->layerBlockCounts, r->layerLiveNibbles, liveList,
+                                          liveCount, r->layerBlockOffsets, r->layerScanTotal);
+                layerOrder = liveList;
+                r->scratch.countDevice = liveCount;
             }
             const int walk = cull ? nv : cnt; // (splats the list passes' grids are sized for)
             launchTileListFastCount(g.stream, walk, scr, layerOrder, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, sortBits,
@@ -188,8 +210,14 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
             layer.openWordsPerRow = openWordsPerRow(scr.tilesX);
             layer.isFirst = l == 0;
             layer.isLast = l + 1 == layers;
+            if (probe != nullptr) GS_CHECK(hipEventRecord(probe->start[l], g.stream));
             launchRasterize(g.stream, scr, r->tileRange, r->values[sel], (const float2*) r->clipXY, (const float4*) r->conic, (const float4*) r->color,
-                            (uchar4*) r->backBuffer, nullptr, true, lazyColours, (const float4*) r->rasterRecord, views, n, &layer);
+                            (uchar4*) r->backBuffer, probe != nullptr ? probe->counters + 4 * l : nullptr, true, lazyColours, (const float4*) r->rasterRecord, views, n, &layer);
+            if (probe != nullptr)
+            {
+                GS_CHECK(hipEventRecord(probe->stop[l], g.stream));
+                probe->layers = l + 1;
+            }
             r->graphSelector = sel;
             begin = end;
         }
@@ -335,7 +363,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
         if (r->graphValid && (r->graphCapacity != r->tileListCapacity || r->graphSplats != n || r->graphRowBegin != scr.rowBegin ||
                               r->graphRowEnd != scr.rowEnd || r->graphCull != (int) cull ||
                               r->graphFootprint != scr.epanechnikov || r->graphLazy != (int) lazy || r->graphAblation != g_ablation ||
-                              r->graphFusion != ((int) cfg.listFusion | ((int) cfg.clipScanFusion << 1)) || r->graphLayers != (r->depthLayers > 0 ? r->depthLayers : r->autoLayers)))
+                              r->graphFusion != ((int) effectiveListFusion() | ((int) cfg.clipScanFusion << 1) | (effectivePixelsPerLane() << 2) | ((int) r->blockCull << 5)) || r->graphLayers != (r->depthLayers > 0 ? r->depthLayers : r->autoLayers)))
             r->graphValid = false;
         if (!r->graphValid)
         {
@@ -385,7 +413,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
             r->graphFootprint = scr.epanechnikov;
             r->graphLazy = (int) lazy;
             r->graphAblation = g_ablation;
-            r->graphFusion = (int) cfg.listFusion | ((int) cfg.clipScanFusion << 1);
+            r->graphFusion = (int) effectiveListFusion() | ((int) cfg.clipScanFusion << 1) | (effectivePixelsPerLane() << 2) | ((int) r->blockCull << 5);
             r->graphLayers = r->depthLayers > 0 ? r->depthLayers : r->autoLayers;
         }
         const int slot = r->graphSlot;
@@ -479,6 +507,54 @@ extern "C" void gs_renderer_debug_set_layer_compaction(GsRenderer* r, int enable
     r->layerCompaction = enabled != 0;
     r->graphValid = false;
 }
+// Experiment (profiles/r06_layer_compaction_bound.txt): what would a live-splat compaction that costs NOTHING buy a layered frame?
+// mode 1: the later layers' live lists are written to buffers of their own (same kernels, same frame); mode 2: the three compaction kernels
+// are not launched and the lists of the last mode-1 frame are walked again -- valid for the SAME camera only (the lists are that frame's).
+extern "C" void gs_renderer_debug_set_layer_compaction_reuse(GsRenderer* r, int mode)
+{
+    StreamScope scope(r);
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    r->layerReuse = (mode == 1 || mode == 2) ? mode : 0;
+    if (r->layerReuse != 0 && r->layerLiveDebug == nullptr)
+    {
+        r->layerLiveDebug = (uint32_t*) gs_device_alloc(sizeof(uint32_t) * (size_t) kMaxDepthLayers * (size_t) r->splatCount * (size_t) r->views + 64);
+        r->layerLiveCountDebug = (int32_t*) gs_device_alloc(sizeof(int32_t) * kMaxDepthLayers);
+    }
+    r->graphValid = false;
+}
+// A/B runs and tests: 0 = the band cull of a Morton-stored scene projects all N splats (round 5's kernel) instead of testing blocks first.
+extern "C" void gs_renderer_debug_set_block_cull(GsRenderer* r, int enabled)
+{
+    r->blockCull = enabled != 0;
+    r->graphValid = false;
+}
+// Blocks of 256 splats the last band-culled frame's block test kept, summed over its views (and the number of blocks x views in *total):
+// what the replicated projection of a multi-GPU rank still walks.  Synchronises the renderer's stream.
+extern "C" int64_t gs_renderer_debug_block_cull_kept(GsRenderer* r, int64_t* total)
+{
+    const int64_t blocks = ((int64_t) r->splatCount + 255) / 256 * r->views;
+    if (total) *total = blocks;
+    if (r->blockFlags == nullptr || blocks <= 0) return -1;
+    StreamScope scope(r);
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    std::vector<uint8_t> flags((size_t) blocks);
+    GS_CHECK(hipMemcpyAsync(flags.data(), r->blockFlags, (size_t) blocks, hipMemcpyDeviceToHost, g.stream));
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    int64_t kept = 0;
+    for (uint8_t f : flags) kept += f ? 1 : 0;
+    return kept;
+}
+// Splats the last band-culled frame kept (all views): the length of the culled list its depth sort ran over.  Synchronises the stream.
+extern "C" int64_t gs_renderer_debug_band_kept_splats(GsRenderer* r)
+{
+    if (r->bandTotal == nullptr) return -1;
+    StreamScope scope(r);
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    int64_t kept = 0;
+    GS_CHECK(hipMemcpyAsync(&kept, r->bandTotal, sizeof(int64_t), hipMemcpyDeviceToHost, g.stream));
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    return kept;
+}
 // Depth layers the last captured frame was made of (1 when it was not layered: band cull, one-pass tile sort, a small scene, or the choice).
 extern "C" int gs_renderer_depth_layers_in_use(const GsRenderer* r) { return (r->graphValid && r->graphLayersActive) ? r->graphLayers : 1; }
 // Pairs the last captured frame listed, summed over its depth layers (with one layer: the frame's pair total).
@@ -494,6 +570,58 @@ extern "C" int64_t gs_renderer_listed_pairs(GsRenderer* r)
         return totals[1];
     }
     return r->scratch.totalHost != nullptr ? *r->scratch.totalHost : 0;
+}
+// One frame of `camera` as the captured layered frame's kernels, launched plainly on the renderer's stream with an event pair around
+// every layer's raster launch (header).  The renderer must have rendered a layered captured frame before (buffers, capacity).
+extern "C" int gs_renderer_debug_layered_raster_report(GsRenderer* r, const GsCameraData* camera, GsLayeredRasterReport* out)
+{
+    if (r == nullptr || camera == nullptr || out == nullptr) return -1;
+    if (!r->useGraph || !r->graphValid || !r->graphLayersActive || r->views != 1 || r->paramsHost == nullptr) return -3;
+    StreamScope scope(r);
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    const Screen scr = makeScreen(r->width, r->height, r->rowBegin, r->rowEnd);
+    const bool strictBand = scr.rowBegin > 0 || scr.rowEnd < scr.tilesY;
+    const bool cull = r->splatCount > 0 && (r->bandCull == GS_BAND_CULL_ON || (r->bandCull == GS_BAND_CULL_AUTO && strictBand));
+    FrameParams fp{};
+    std::memcpy(fp.camera.view, camera->view, sizeof(fp.camera.view));
+    fp.camera.fovCotX = camera->fovCotangent[0];
+    fp.camera.fovCotY = camera->fovCotangent[1];
+    fp.camera.depthScale = camera->depthScaleBias[0];
+    fp.camera.depthBias = camera->depthScaleBias[1];
+    for (int k = 0; k != 3; ++k) fp.cameraPosition[k] = r->lastCameraPosition[k] = camera->position[k];
+    const int slot = r->graphSlot;
+    r->paramsHost[slot * kMaxViews] = fp;
+    LayerProbe probe;
+    for (int l = 0; l != kMaxDepthLayers; ++l)
+    {
+        GS_CHECK(hipEventCreate(&probe.start[l]));
+        GS_CHECK(hipEventCreate(&probe.stop[l]));
+    }
+    GS_CHECK(hipMalloc((void**) &probe.counters, sizeof(unsigned long long) * 4 * kMaxDepthLayers));
+    GS_CHECK(hipMemsetAsync(probe.counters, 0, sizeof(unsigned long long) * 4 * kMaxDepthLayers, g.stream));
+    *r->scratch.totalHost = -1;
+    enqueueCapturableFrame(r, scr, cull, useLazyColours(r), slot, &probe);
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    unsigned long long counters[4 * kMaxDepthLayers] = {};
+    GS_CHECK(hipMemcpyAsync(counters, probe.counters, sizeof(counters), hipMemcpyDeviceToHost, g.stream));
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    *out = GsLayeredRasterReport{};
+    out->layers = probe.layers;
+    for (int l = 0; l != probe.layers; ++l)
+    {
+        GS_CHECK(hipEventElapsedTime(&out->rasterMs[l], probe.start[l], probe.stop[l]));
+        out->consumedPairs[l] = (int64_t) counters[4 * l];
+        out->tilesRun[l] = (int64_t) counters[4 * l + 1];
+        out->stateTileLoads[l] = (int64_t) counters[4 * l + 2];
+        out->stateTileStores[l] = (int64_t) counters[4 * l + 3];
+    }
+    for (int l = 0; l != kMaxDepthLayers; ++l)
+    {
+        (void) hipEventDestroy(probe.start[l]);
+        (void) hipEventDestroy(probe.stop[l]);
+    }
+    (void) hipFree(probe.counters);
+    return probe.layers > 0 ? 0 : -3;
 }
 extern "C" void gs_debug_set_ablation(int mask) { g_ablation = mask; }
 extern "C" void gs_debug_set_clip_scan_fusion(int enabled) { cfg.clipScanFusion = enabled != 0; }

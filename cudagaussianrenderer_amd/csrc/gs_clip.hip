@@ -198,6 +198,92 @@ __device__ __forceinline__ ClipCamera cam_or(const FrameParams* __restrict__ par
     return params ? params[view].camera : camArg; // device-resident when the frame is a captured graph
 }
 
+// Upper bound on the largest eigenvalue of a splat's world-space covariance Sigma = (R S)(R S)' (GaussianRender.cu:215-224):
+// lmax = smax(R S)^2 <= (|R| max|s|)^2, and for the reference's un-normalised quaternion q = t u (|u| = 1) mat3_cast gives
+// R = (1 - t^2) I + t^2 R_u, so |R| <= |1 - t^2| + t^2 (1 for a unit quaternion).  Padded for the rounding of the kernel's own Sigma.
+__device__ __forceinline__ float covarianceEigenBound(const float4 sr)
+{
+    const uint32_t bits = __float_as_uint(sr.w);
+    const float qx = (float) ((bits >> 24) & 0xFFu) / 255.0f * 2.0f - 1.0f;
+    const float qy = (float) ((bits >> 16) & 0xFFu) / 255.0f * 2.0f - 1.0f;
+    const float qz = (float) ((bits >> 8) & 0xFFu) / 255.0f * 2.0f - 1.0f;
+    const float qw = (float) (bits & 0xFFu) / 255.0f * 2.0f - 1.0f;
+    const float t2 = (qx * qx + qy * qy) + (qz * qz + qw * qw);
+    const float rn = fabsf(1.0f - t2) + t2;
+    const float smax = fmaxf(fabsf(sr.x), fmaxf(fabsf(sr.y), fabsf(sr.z))); // (a NaN scale makes a NaN ellipse, which reaches no tile: ignored)
+    const float m = smax * rn;
+    return m * m * 1.0002f;
+}
+
+// What the bound needs of a camera besides its matrix: |W|^2 (largest Gershgorin row sum of W W'; 1 for a rigid camera) and the
+// view-space z range of the visible clip depths [-1, 1] (GaussianRender.cu:316-318), padded.  Per view and frame: the block test
+// computes them and leaves them for the band kernel's per-splat test.
+__device__ __forceinline__ BandViewTerms makeBandViewTerms(const ClipCamera& cam)
+{
+    const float* v = cam.view;
+    BandViewTerms t;
+    float wn = 0.0f;
+#pragma unroll
+    for (int r = 0; r != 3; ++r)
+    {
+        float row = 0.0f;
+#pragma unroll
+        for (int s = 0; s != 3; ++s) row += fabsf(v[0 + r] * v[0 + s] + v[4 + r] * v[4 + s] + v[8 + r] * v[8 + s]);
+        wn = fmaxf(wn, row);
+    }
+    t.wn = wn * 1.001f;
+    const float zA = (-1.0f - cam.depthBias) / cam.depthScale, zB = (1.0f - cam.depthBias) / cam.depthScale;
+    const float zLo = fminf(zA, zB), zHi = fmaxf(zA, zB);
+    t.zvLo = zLo - 1.0e-4f * fabsf(zLo);
+    t.zvHi = zHi + 1.0e-4f * fabsf(zHi);
+    t.sane = (cam.fovCotX > 0.0f && cam.fovCotY > 0.0f && t.zvHi < 0.0f) ? 1.0f : 0.0f; // (a camera the bound was not written for: everything is kept)
+    return t;
+}
+
+// true = NO splat with its centre in the box [cmin, cmax] and its covariance's largest eigenvalue <= lam can reach the band's tile rows.
+// cmin == cmax: the test of ONE splat.  Every rejection is a comparison that a NaN fails.
+__device__ __forceinline__ bool bandBoundRejects(const float cmin[3], const float cmax[3], float lam, const BandViewTerms& vt, const ClipCamera& cam,
+                                                 const Screen& scr)
+{
+    if (!(vt.sane > 0.5f)) return false;
+    const float* v = cam.view;
+    // view-space box of the centre box (interval arithmetic per output row, padded by the rounding of its four terms)
+    float lo[3], hi[3];
+#pragma unroll
+    for (int r = 0; r != 3; ++r)
+    {
+        float l = v[12 + r], h = v[12 + r], mag = fabsf(v[12 + r]);
+#pragma unroll
+        for (int c = 0; c != 3; ++c)
+        {
+            const float p0 = v[c * 4 + r] * cmin[c], p1 = v[c * 4 + r] * cmax[c];
+            l += fminf(p0, p1);
+            h += fmaxf(p0, p1);
+            mag += fmaxf(fabsf(p0), fabsf(p1));
+        }
+        lo[r] = l - 1.0e-5f * mag;
+        hi[r] = h + 1.0e-5f * mag;
+    }
+    const float zLo = fmaxf(lo[2], vt.zvLo), zHi = fminf(hi[2], vt.zvHi);
+    if (zLo > zHi) return true; // no centre of the box inside the visible depth range: nothing of it is drawn
+    const float dn = -zHi, df = -zLo; // distances in front of the camera, nearest and farthest (dn > 0: vt.sane)
+    if (!(dn > 0.0f)) return false;
+    const float rn = 1.0f / dn, rf = 1.0f / df;
+    // centre extremes in clip space, cut to the frustum (a visible centre has |clip x|, |clip y| <= 1)
+    const float cyMaxRaw = cam.fovCotY * hi[1] * (hi[1] >= 0.0f ? rn : rf), cyMinRaw = cam.fovCotY * lo[1] * (lo[1] <= 0.0f ? rn : rf);
+    const float cxMaxRaw = cam.fovCotX * hi[0] * (hi[0] >= 0.0f ? rn : rf), cxMinRaw = cam.fovCotX * lo[0] * (lo[0] <= 0.0f ? rn : rf);
+    if (cyMinRaw > 1.002f || cyMaxRaw < -1.002f || cxMinRaw > 1.002f || cxMaxRaw < -1.002f) return true; // every centre outside the frustum
+    const float cyMax = fminf(cyMaxRaw, 1.002f), cyMin = fmaxf(cyMinRaw, -1.002f);
+    const float cxMax = fminf(cxMaxRaw, 1.002f), cxMin = fmaxf(cxMinRaw, -1.002f);
+    // |J row 0|^2 + |J row 1|^2 = (cotX^2 + cx^2 + cotY^2 + cy^2) / d^2 with the centre's own clip coordinates in the shear terms
+    const float cx2 = fmaxf(cxMin * cxMin, cxMax * cxMax), cy2 = fmaxf(cyMin * cyMin, cyMax * cyMax);
+    const float jacobian = ((cam.fovCotX * cam.fovCotX + cx2) + (cam.fovCotY * cam.fovCotY + cy2)) * 1.004f * (rn * rn);
+    const float half = 1.01f * scr.extentFactor * __builtin_sqrtf(lam * vt.wn * jacobian + 2.0f * scr.traceBump) + 1.0e-5f;
+    // rows, as splatTileAabb takes them: kept iff (maxY + 1) / 2 * tilesPerScreenY > rowBegin and (minY + 1) / 2 * tilesPerScreenY < rowEnd
+    const float top = ((cyMax + half) + 1.0f) * 0.5f * scr.tilesPerScreenY, bottom = ((cyMin - half) + 1.0f) * 0.5f * scr.tilesPerScreenY;
+    return top < (float) scr.rowBegin - 1.0e-3f || bottom > (float) scr.rowEnd + 1.0e-3f;
+}
+
 constexpr int kBandBlock = 256;                // splats per workgroup of the band-cull kernel; the compaction's scan runs over these blocks
 constexpr int kBandSlots = kBandBlock / kWave; // 64-splat slots (one kept mask each) per workgroup
 
@@ -266,7 +352,8 @@ __global__ __launch_bounds__(256) void splatClipBandKernel(int count, Screen scr
                                                             unsigned long long* __restrict__ bandMask, int32_t* __restrict__ bandSlotPrefix,
                                                             int32_t* __restrict__ bandBlockCounts, int32_t* __restrict__ rangeTable,
                                                             int rangeEntries, const int32_t* __restrict__ outSlot,
-                                                            const uint8_t* __restrict__ blockFlags)
+                                                            const uint8_t* __restrict__ blockFlags, const BandViewTerms* __restrict__ viewTerms,
+                                                            const int32_t* __restrict__ storageToSplat)
 {
     __shared__ int slotKept[kBandSlots];
     const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
@@ -281,13 +368,29 @@ __global__ __launch_bounds__(256) void splatClipBandKernel(int count, Screen scr
     if (blockFlags != nullptr)
     {
         // Block cull (see blockBandTestKernel): the splats are walked in STORAGE order -- along the Morton curve -- and a block of 256
-        // neighbours that provably cannot reach the band is not projected at all; the kept mask of the others is left in storage order
-        // (bandMask here) and bandCallerMaskKernel turns it into the caller-ordered masks and counts the compaction runs over.
+        // neighbours that provably cannot reach the band is not projected at all.  A kept splat sets ITS bit in the caller-ordered keep
+        // mask (one fire-and-forget 64-bit atomic OR through storageToSplat; the block test zeroed the mask): the compaction runs in the
+        // caller's order, over masks nobody had to gather.
         const bool live = blockFlags[view * blocksPerView + blockIdx.x] != 0; // (uniform)
-        bool kept = false;
-        if (live && index < count) kept = projectSplat<true>(position[index], scaleAndRotation[index], cam_or(params, view, camArg), scr, view * count + index, view * count + index, o);
-        const unsigned long long mask = live ? __ballot(kept) : 0ull;
-        if (lane == 0 && blockBase + wave * kWave < count) bandMask[view * slotsPerView + (blockBase >> 6) + wave] = mask;
+        if (!live) return;
+        // ... and inside a kept block every splat is held to the same bound by itself (its own centre, its own covariance): a wave
+        // of 64 Morton neighbours none of which can reach the band skips the projection; the others project their candidates
+        const ClipCamera cam = cam_or(params, view, camArg);
+        float4 pd = make_float4(0.f, 0.f, 0.f, 0.f), sr = pd;
+        bool candidate = false;
+        if (index < count)
+        {
+            pd = position[index];
+            sr = scaleAndRotation[index];
+            const float c[3] = {pd.x, pd.y, pd.z};
+            candidate = !bandBoundRejects(c, c, covarianceEigenBound(sr), viewTerms[view], cam, scr);
+        }
+        if (__ballot(candidate) == 0ull) return;
+        if (candidate && projectSplat<true>(pd, sr, cam, scr, view * count + index, view * count + index, o))
+        {
+            const int caller = storageToSplat[index];
+            atomicOr(&bandMask[view * slotsPerView + (caller >> 6)], 1ull << (caller & 63));
+        }
         return;
     }
     const ClipCamera cam = params ? params[view].camera : camArg;
@@ -319,7 +422,8 @@ __global__ __launch_bounds__(256) void splatClipBandViewsKernel(int count, int v
                                                                  unsigned long long* __restrict__ bandMask, int32_t* __restrict__ bandSlotPrefix,
                                                                  int32_t* __restrict__ bandBlockCounts, int32_t* __restrict__ rangeTable,
                                                                  int rangeEntries, const int32_t* __restrict__ outSlot,
-                                                                 const uint8_t* __restrict__ blockFlags)
+                                                                 const uint8_t* __restrict__ blockFlags, const BandViewTerms* __restrict__ viewTerms,
+                                                                 const int32_t* __restrict__ storageToSplat)
 {
     __shared__ int slotKept[kMaxViews][kBandSlots];
     const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
@@ -330,7 +434,8 @@ __global__ __launch_bounds__(256) void splatClipBandViewsKernel(int count, int v
     if (blockBase >= count) return; // whole workgroup
     if (blockFlags != nullptr)
     {
-        // Block cull (see the single-view kernel): storage order, only the views whose test kept this block are projected, masks in storage order
+        // Block cull (see the single-view kernel): storage order, only the views whose test kept this block are looked at; a kept splat
+        // sets its bit in its view's caller-ordered keep mask
         const int slotsPerView = (count + kWave - 1) / kWave, blocksPerView = (count + kBandBlock - 1) / kBandBlock;
         bool any = false;
         bool live[kMaxViews];
@@ -340,22 +445,36 @@ __global__ __launch_bounds__(256) void splatClipBandViewsKernel(int count, int v
             live[view] = view < views && blockFlags[view * blocksPerView + blockIdx.x] != 0; // (uniform)
             any |= live[view];
         }
-        float4 pd = make_float4(0.f, 0.f, 0.f, 0.f);
-        Sym3 S{};
-        if (any && index < count)
+        if (!any) return;
+        // (inside a kept block every splat is held to the same bound by itself: a wave none of whose splats can reach the band in a
+        // view skips that view's projection; the world-space covariance is only made by a wave that projects in some view)
+        float4 pd = make_float4(0.f, 0.f, 0.f, 0.f), sr = pd;
+        float lam = 0.0f;
+        if (index < count)
         {
             pd = position[index];
-            S = splatCovariance(scaleAndRotation[index]);
+            sr = scaleAndRotation[index];
+            lam = covarianceEigenBound(sr);
         }
+        const float c[3] = {pd.x, pd.y, pd.z};
+        bool candidate[kMaxViews];
+        bool anyCandidate = false;
 #pragma unroll
         for (int view = 0; view != kMaxViews; ++view)
         {
-            if (view < views)
+            candidate[view] = live[view] && index < count && !bandBoundRejects(c, c, lam, viewTerms[view], params[view].camera, scr);
+            anyCandidate |= candidate[view];
+        }
+        if (__ballot(anyCandidate) == 0ull) return;
+        const Sym3 S = splatCovariance(sr);
+        const int caller = index < count ? storageToSplat[index] : 0;
+#pragma unroll
+        for (int view = 0; view != kMaxViews; ++view)
+        {
+            if (view < views && __ballot(candidate[view]) != 0ull)
             {
-                bool kept = false;
-                if (live[view] && index < count) kept = projectCovariance<true>(pd, S, params[view].camera, scr, view * count + index, view * count + index, o);
-                const unsigned long long mask = live[view] ? __ballot(kept) : 0ull;
-                if (lane == 0 && blockBase + wave * kWave < count) bandMask[view * slotsPerView + (blockBase >> 6) + wave] = mask;
+                if (candidate[view] && projectCovariance<true>(pd, S, params[view].camera, scr, view * count + index, view * count + index, o))
+                    atomicOr(&bandMask[view * slotsPerView + (caller >> 6)], 1ull << (caller & 63));
             }
         }
         return;
@@ -419,11 +538,6 @@ __global__ __launch_bounds__(256) void splatClipBandViewsKernel(int count, int v
 //     per block stored at set_scene; |W|^2 by Gershgorin on W W' (1 for a rigid camera).
 // Every float evaluation is padded (1 % on the extent, 1e-3 on the unit bounds, 1e-3 tiles on the row compare) and every rejection is
 // a comparison that a NaN fails: a block the bound cannot speak for is kept.
-struct BlockBoundAcc
-{
-    float lo[3], hi[3], lam;
-};
-
 // set_scene: centre box and largest covariance eigenvalue bound of every block of 256 splats in storage order.
 __global__ __launch_bounds__(256) void blockBoundsKernel(int count, const float4* __restrict__ position, const float4* __restrict__ scaleAndRotation,
                                                           BlockBound* __restrict__ bounds)
@@ -435,15 +549,12 @@ __global__ __launch_bounds__(256) void blockBoundsKernel(int count, const float4
     if (index < count)
     {
         const float4 pd = position[index];
-        const Sym3 S = splatCovariance(scaleAndRotation[index]);
         lo[0] = hi[0] = pd.x;
         lo[1] = hi[1] = pd.y;
         lo[2] = hi[2] = pd.z;
-        const float g0 = fabsf(S.xx) + fabsf(S.xy) + fabsf(S.xz), g1 = fabsf(S.xy) + fabsf(S.yy) + fabsf(S.yz), g2 = fabsf(S.xz) + fabsf(S.yz) + fabsf(S.zz);
-        lam = g0 + g1 + g2; // NaN stays NaN
-        lam = (lam == lam) ? fmaxf(g0, fmaxf(g1, g2)) : lam;
+        lam = covarianceEigenBound(scaleAndRotation[index]);
     }
-    // (a NaN eigenvalue bound must survive the reduction: the block is then kept by every test)
+    // (a NaN bound must survive the reduction: the block is then kept by every test)
     const auto maxNan = [](float a, float b) { return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b); };
 #pragma unroll
     for (int off = 32; off != 0; off >>= 1)
@@ -482,98 +593,48 @@ __global__ __launch_bounds__(256) void blockBoundsKernel(int count, const float4
     }
 }
 
-// Per frame: one lane per (block, view) -> flags[view][block] = 1 unless the bound proves that no splat of the block reaches the band.
+// Per frame: one lane per (block, view) -> flags[view][block] = 1 unless the bound proves that no splat of the block reaches the band;
+// lane 0 of every view leaves the view's terms for the band kernel's per-splat test.
 __global__ __launch_bounds__(256) void blockBandTestKernel(int blocks, Screen scr, ClipCamera camArg, const FrameParams* __restrict__ params,
-                                                            const BlockBound* __restrict__ bounds, uint8_t* __restrict__ flags)
+                                                            const BlockBound* __restrict__ bounds, uint8_t* __restrict__ flags,
+                                                            BandViewTerms* __restrict__ viewTermsOut, unsigned long long* __restrict__ bandMask,
+                                                            int slotsPerView)
 {
     const int block = blockIdx.x * blockDim.x + threadIdx.x;
     if (block >= blocks) return;
     const int view = blockIdx.y;
+    // the caller-ordered keep mask of this frame starts empty: the band kernel's kept splats OR their bits in (four words per 256 splats)
+#pragma unroll
+    for (int k = 0; k != kBandSlots; ++k)
+        if (block * kBandSlots + k < slotsPerView) bandMask[(size_t) view * slotsPerView + block * kBandSlots + k] = 0ull;
     const ClipCamera cam = cam_or(params, view, camArg);
+    const BandViewTerms vt = makeBandViewTerms(cam);
+    if (block == 0) viewTermsOut[view] = vt;
     const BlockBound b = bounds[block];
-    const float* v = cam.view;
-    // view-space box of the centre box (interval arithmetic per output row, padded by the rounding of its four terms)
-    float lo[3], hi[3];
-#pragma unroll
-    for (int r = 0; r != 3; ++r)
-    {
-        float l = v[12 + r], h = v[12 + r], mag = fabsf(v[12 + r]);
-#pragma unroll
-        for (int c = 0; c != 3; ++c)
-        {
-            const float p0 = v[c * 4 + r] * b.cmin[c], p1 = v[c * 4 + r] * b.cmax[c];
-            l += fminf(p0, p1);
-            h += fmaxf(p0, p1);
-            mag += fmaxf(fabsf(p0), fabsf(p1));
-        }
-        lo[r] = l - 1.0e-5f * mag;
-        hi[r] = h + 1.0e-5f * mag;
-    }
-    // the visible depth range: clip depth = depthScale * z + depthBias in [-1, 1] (GaussianRender.cu:316-318), padded
-    const float zA = (-1.0f - cam.depthBias) / cam.depthScale, zB = (1.0f - cam.depthBias) / cam.depthScale;
-    const float zvLo = fminf(zA, zB), zvHi = fmaxf(zA, zB);
-    const float zLo = fmaxf(lo[2], zvLo - 1.0e-4f * fabsf(zvLo)), zHi = fminf(hi[2], zvHi + 1.0e-4f * fabsf(zvHi));
-    bool reject = zLo > zHi; // no centre of the block inside the depth range
-    const float dn = -zHi, df = -zLo; // distances in front of the camera, nearest and farthest
-    const bool sane = dn > 0.0f && df >= dn && cam.fovCotX > 0.0f && cam.fovCotY > 0.0f; // (a camera the bound was not written for: keep)
-    if (!reject && sane)
-    {
-        // centre extremes in clip space, cut to the frustum (a visible centre has |clip x|, |clip y| <= 1)
-        const float cyMax = fminf(cam.fovCotY * hi[1] / (hi[1] >= 0.0f ? dn : df), 1.001f);
-        const float cyMin = fmaxf(cam.fovCotY * lo[1] / (lo[1] <= 0.0f ? dn : df), -1.001f);
-        const float cxMax = cam.fovCotX * hi[0] / (hi[0] >= 0.0f ? dn : df);
-        const float cxMin = cam.fovCotX * lo[0] / (lo[0] <= 0.0f ? dn : df);
-        reject = cyMin > 1.001f || cyMax < -1.001f || cxMin > 1.001f || cxMax < -1.001f; // every centre outside the frustum
-        // |W|^2 <= largest Gershgorin row sum of W W'
-        float wn = 0.0f;
-#pragma unroll
-        for (int r = 0; r != 3; ++r)
-        {
-            float row = 0.0f;
-#pragma unroll
-            for (int s = 0; s != 3; ++s) row += fabsf(v[0 + r] * v[0 + s] + v[4 + r] * v[4 + s] + v[8 + r] * v[8 + s]);
-            wn = fmaxf(wn, row);
-        }
-        const float jacobian = (cam.fovCotX * cam.fovCotX + cam.fovCotY * cam.fovCotY + 2.02f) / (dn * dn);
-        const float half = 1.01f * scr.extentFactor * sqrtf(b.lamMax * 1.001f * wn * 1.001f * jacobian + 2.0f * scr.traceBump) + 1.0e-5f;
-        // rows, as splatTileAabb takes them: kept iff (maxY + 1) / 2 * tilesPerScreenY > rowBegin and (minY + 1) / 2 * tilesPerScreenY < rowEnd
-        const float top = ((cyMax + half) + 1.0f) * 0.5f * scr.tilesPerScreenY, bottom = ((cyMin - half) + 1.0f) * 0.5f * scr.tilesPerScreenY;
-        reject = reject || top < (float) scr.rowBegin - 1.0e-3f || bottom > (float) scr.rowEnd + 1.0e-3f;
-    }
-    flags[(size_t) view * blocks + block] = reject ? 0 : 1;
+    flags[(size_t) view * blocks + block] = bandBoundRejects(b.cmin, b.cmax, b.lamMax, vt, cam, scr) ? 0 : 1;
 }
 
-// The storage-ordered keep mask of the block-culled band kernel -> what the compaction runs over: per 64 splats in the CALLER's order the
-// kept mask and the kept splats of the workgroup's earlier slots, per 256 their count (the tail of splatClipBandKernel, fed from a gather
-// of one bit per splat instead of a projection).  splatToStorage: caller index c of view v at entry v * count + c -> v * count + slot.
-__global__ __launch_bounds__(256) void bandCallerMaskKernel(int count, const unsigned long long* __restrict__ storageMask,
-                                                             const int32_t* __restrict__ splatToStorage, unsigned long long* __restrict__ bandMask,
+// What the compaction needs besides the caller-ordered keep masks the block-culled band kernel filled: per 64 splats the kept splats of
+// the workgroup's earlier slots, per 256 their count (the tail of splatClipBandKernel).  One lane per block of 256 splats.
+__global__ __launch_bounds__(256) void bandSlotCountsKernel(int count, const unsigned long long* __restrict__ bandMask,
                                                              int32_t* __restrict__ bandSlotPrefix, int32_t* __restrict__ bandBlockCounts)
 {
-    __shared__ int slotKept[kBandSlots];
-    const int t = threadIdx.x, lane = t & (kWave - 1), wave = t >> 6;
-    const int index = blockIdx.x * blockDim.x + t;
-    const int view = blockIdx.y;
-    const int blockBase = blockIdx.x * kBandBlock;
-    if (blockBase >= count) return; // whole workgroup
     const int slotsPerView = (count + kWave - 1) / kWave, blocksPerView = (count + kBandBlock - 1) / kBandBlock;
-    bool kept = false;
-    if (index < count)
+    const int block = blockIdx.x * blockDim.x + threadIdx.x;
+    if (block >= blocksPerView) return;
+    const int view = blockIdx.y;
+    int prefix = 0;
+#pragma unroll
+    for (int k = 0; k != kBandSlots; ++k)
     {
-        const int slot = splatToStorage[index]; // (view 0's part of the list: the slot within a view)
-        kept = (storageMask[view * slotsPerView + (slot >> 6)] >> (slot & 63)) & 1ull;
+        const int slot = block * kBandSlots + k;
+        if (slot < slotsPerView)
+        {
+            bandSlotPrefix[view * slotsPerView + slot] = prefix;
+            prefix += __popcll(bandMask[view * slotsPerView + slot]);
+        }
     }
-    const unsigned long long mask = __ballot(kept);
-    if (lane == 0) slotKept[wave] = __popcll(mask);
-    __syncthreads();
-    if (lane == 0 && blockBase + wave * kWave < count)
-    {
-        int prefix = 0;
-        for (int s = 0; s < wave; ++s) prefix += slotKept[s];
-        bandMask[view * slotsPerView + (blockBase >> 6) + wave] = mask;
-        bandSlotPrefix[view * slotsPerView + (blockBase >> 6) + wave] = prefix;
-        if (wave == 0) bandBlockCounts[view * blocksPerView + blockIdx.x] = slotKept[0] + slotKept[1] + slotKept[2] + slotKept[3];
-    }
+    bandBlockCounts[view * blocksPerView + block] = prefix;
 }
 
 // Order-preserving compaction of the splats flagged by the band cull: depth key + (virtual) splat index of every kept splat at
@@ -582,7 +643,8 @@ __global__ __launch_bounds__(256) void bandCallerMaskKernel(int count, const uns
 __global__ __launch_bounds__(256) void compactBandKernel(int count, const unsigned long long* __restrict__ bandMask,
                                                           const int32_t* __restrict__ bandSlotPrefix, const int32_t* __restrict__ blockOffsets,
                                                           const float* __restrict__ clipZ, const int32_t* __restrict__ splatToStorage,
-                                                          uint32_t* __restrict__ depthKey, uint32_t* __restrict__ splatOrder, int clipZByStorage)
+                                                          uint32_t* __restrict__ depthKey, uint32_t* __restrict__ splatOrder,
+                                                          const float4* __restrict__ positionCaller, ClipCamera camArg, const FrameParams* __restrict__ params)
 {
     const int index = blockIdx.x * blockDim.x + threadIdx.x;
     if (index >= count) return;
@@ -596,8 +658,10 @@ __global__ __launch_bounds__(256) void compactBandKernel(int count, const unsign
         const int out = view * count + (splatToStorage != nullptr ? splatToStorage[index] : index); // virtual splat (see the clip kernel)
         const unsigned long long lower = (lane == 0) ? 0ull : (~0ull >> (kWave - lane));
         const int pos = blockOffsets[view * blocksPerView + index / kBandBlock] + bandSlotPrefix[slot] + __popcll(mask & lower);
-        // (block cull: the band kernel walked the splats in storage order and left the clip depth under the storage slot)
-        depthKey[pos] = compactDepthKey(clipZ[clipZByStorage ? out : view * count + index]);
+        // (block cull: the band kernel walked the splats in storage order and stored no clip depth at all -- the key is made here from the
+        // caller-ordered position by the routine the clip kernel and the depth sort's key generation share: the same bits)
+        depthKey[pos] = positionCaller != nullptr ? depthKeyOfSplat(positionCaller[index], cam_or(params, view, camArg))
+                                                  : compactDepthKey(clipZ[view * count + index]);
         splatOrder[pos] = (uint32_t) out;
     }
 }
@@ -638,13 +702,15 @@ void launchUnpackEllipse(hipStream_t stream, int count, const float4* tileRecord
 
 void launchBandCompaction(hipStream_t stream, int count, int views, const unsigned long long* bandMask, const int32_t* bandSlotPrefix,
                           const int32_t* bandBlockCounts, int32_t* bandBlockOffsets, int64_t* bandTotal, const float* clipZ,
-                          uint32_t* depthKey, uint32_t* splatOrder, const int32_t* splatToStorage, bool clipZByStorage)
+                          uint32_t* depthKey, uint32_t* splatOrder, const int32_t* splatToStorage, const float4* positionCallerOrNull,
+                          const ClipCamera* cameraOrNull, const FrameParams* paramsDeviceOrNull)
 {
     if (count <= 0) return;
     const int blocks = (count + kBandBlock - 1) / kBandBlock;
     launchScanInt32(stream, blocks * views, bandBlockCounts, bandBlockOffsets, bandTotal);
     hipLaunchKernelGGL(compactBandKernel, dim3((count + 255) / 256, views), dim3(256), 0, stream, count, bandMask, bandSlotPrefix,
-                       bandBlockOffsets, clipZ, splatToStorage, depthKey, splatOrder, clipZByStorage ? 1 : 0);
+                       bandBlockOffsets, clipZ, splatToStorage, depthKey, splatOrder, positionCallerOrNull, cameraOrNull != nullptr ? *cameraOrNull : ClipCamera{},
+                       paramsDeviceOrNull);
 }
 
 void launchBlockBounds(hipStream_t stream, int count, const float4* position, const float4* scaleAndRotation, BlockBound* bounds)
@@ -665,18 +731,18 @@ void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const
     const ClipOutputs o{clipXY, clipZ, screenEllipse, conic, depthKey, splatOrder, tileRecord, rasterRecord, tileBox};
     if (bandMask != nullptr && blockCull != nullptr)
     {
-        // block test -> projection of the kept blocks in storage order -> caller-ordered masks and counts for the compaction
-        const int blocks = (count + kBandBlock - 1) / kBandBlock;
+        // block test (+ empty masks) -> projection of the kept blocks in storage order, kept splats OR their bits into the caller-ordered
+        // masks -> slot prefixes and block counts for the compaction
+        const int blocks = (count + kBandBlock - 1) / kBandBlock, slots = (count + kWave - 1) / kWave;
         hipLaunchKernelGGL(blockBandTestKernel, dim3((blocks + 255) / 256, views), dim3(256), 0, stream, blocks, scr, cam, paramsDevice, blockCull->bounds,
-                           blockCull->flags);
+                           blockCull->flags, blockCull->viewTerms, bandMask, slots);
         if (views > 1 && paramsDevice != nullptr)
             hipLaunchKernelGGL(splatClipBandViewsKernel, dim3(blocks), dim3(256), 0, stream, count, views, scr, paramsDevice, position, scaleAndRotation, o,
-                               blockCull->storageMask, nullptr, nullptr, rangeTableToClear, rangeEntries, nullptr, blockCull->flags);
+                               bandMask, nullptr, nullptr, rangeTableToClear, rangeEntries, nullptr, blockCull->flags, blockCull->viewTerms, blockCull->storageToSplat);
         else
             hipLaunchKernelGGL(splatClipBandKernel, dim3(blocks, views), dim3(256), 0, stream, count, scr, cam, paramsDevice, position, scaleAndRotation, o,
-                               blockCull->storageMask, nullptr, nullptr, rangeTableToClear, rangeEntries, nullptr, blockCull->flags);
-        hipLaunchKernelGGL(bandCallerMaskKernel, dim3(blocks, views), dim3(256), 0, stream, count, blockCull->storageMask, blockCull->splatToStorage, bandMask,
-                           bandSlotPrefix, bandBlockCounts);
+                               bandMask, nullptr, nullptr, rangeTableToClear, rangeEntries, nullptr, blockCull->flags, blockCull->viewTerms, blockCull->storageToSplat);
+        hipLaunchKernelGGL(bandSlotCountsKernel, dim3((blocks + 255) / 256, views), dim3(256), 0, stream, count, bandMask, bandSlotPrefix, bandBlockCounts);
         return;
     }
 #ifndef GS_CLIP_ALL_VIEWS
@@ -684,11 +750,11 @@ void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const
 #endif
     if (bandMask != nullptr && views > 1 && paramsDevice != nullptr && GS_CLIP_ALL_VIEWS)
         hipLaunchKernelGGL(splatClipBandViewsKernel, dim3((count + kBandBlock - 1) / kBandBlock), dim3(256), 0, stream, count, views, scr, paramsDevice,
-                           position, scaleAndRotation, o, bandMask, bandSlotPrefix, bandBlockCounts, rangeTableToClear, rangeEntries, bandOutSlot, nullptr);
+                           position, scaleAndRotation, o, bandMask, bandSlotPrefix, bandBlockCounts, rangeTableToClear, rangeEntries, bandOutSlot, nullptr, nullptr, nullptr);
     else if (bandMask != nullptr)
         hipLaunchKernelGGL(splatClipBandKernel, dim3((count + kBandBlock - 1) / kBandBlock, views), dim3(256), 0, stream, count, scr, cam,
                            paramsDevice, position, scaleAndRotation, o, bandMask, bandSlotPrefix, bandBlockCounts, rangeTableToClear,
-                           rangeEntries, bandOutSlot, nullptr);
+                           rangeEntries, bandOutSlot, nullptr, nullptr, nullptr);
     else
         hipLaunchKernelGGL(splatClipDataKernel, dim3((count + 255) / 256, views), dim3(256), 0, stream, count, scr, cam, paramsDevice, position,
                            scaleAndRotation, o, rangeTableToClear, rangeEntries);

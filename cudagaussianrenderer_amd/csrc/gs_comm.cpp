@@ -16,6 +16,7 @@
 #include <rccl/rccl.h>
 
 #include "gsplat_hip.h"
+#include "gsplat_hip_debug.h"
 
 namespace
 {

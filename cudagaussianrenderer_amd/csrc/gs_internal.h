@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include "gsplat_hip.h"
+#include "gsplat_hip_debug.h"
 
 // src/CudaErrorCheck.cpp:2-11 -- print and exit on a failed runtime call.
 #define GS_CHECK(call)                                                                       \
@@ -79,12 +80,16 @@ struct BlockBound
     float cmax[3];
     float pad;
 };
+struct BandViewTerms // what the bound needs of a camera besides its matrix (gs_clip.hip makeBandViewTerms), per view and frame
+{
+    float wn, zvLo, zvHi, sane;
+};
 struct BandBlockCull
 {
     const BlockBound* bounds = nullptr;          // [ceil(N / 256)], made at set_scene (launchBlockBounds)
     uint8_t* flags = nullptr;                    // [views][ceil(N / 256)]: 1 = the block may reach the band this frame
-    unsigned long long* storageMask = nullptr;   // [views][ceil(N / 64)]: the kept mask in storage order
-    const int32_t* splatToStorage = nullptr;     // caller index -> storage slot (the compaction runs in the caller's order)
+    const int32_t* storageToSplat = nullptr;     // storage slot -> caller's index: a kept splat sets its bit in the CALLER-ordered keep mask
+    BandViewTerms* viewTerms = nullptr;          // [kMaxViews], left by the block test for the band kernel's per-splat test
 };
 void launchBlockBounds(hipStream_t stream, int count, const float4* position, const float4* scaleAndRotation, BlockBound* bounds);
 
@@ -102,7 +107,7 @@ void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const
                          float4* rasterRecordOrNull = nullptr, int views = 1, const int32_t* bandOutSlotOrNull = nullptr,
                          ushort4* tileBoxOrNull = nullptr /* depth layers: the list builder's box per splat (gs_aabb.h splatTileBox) */,
                          // band cull of a Morton-stored scene by blocks (gs_clip.hip): position / scaleAndRotation are then the STORAGE-ordered
-                         // arrays, bandOutSlot is null, and the clip depth of a kept splat lies under its storage slot (launchBandCompaction: clipZByStorage)
+                         // arrays, bandOutSlot is null, clipZ is not written (launchBandCompaction makes the depth keys from positionCaller)
                          const BandBlockCull* blockCullOrNull = nullptr);
 // screenEllipse[i] = (cos, sin, extent x, extent y) from the 32-byte tile records the clip kernel can write instead.
 void launchUnpackEllipse(hipStream_t stream, int count, const float4* tileRecord, float4* screenEllipse);
@@ -116,7 +121,9 @@ void launchUnpackRasterRecord(hipStream_t stream, int count, const float4* raste
 // by the caller's index and the compaction runs in the CALLER's order (gs_clip.hip).
 void launchBandCompaction(hipStream_t stream, int count, int views, const unsigned long long* bandMask, const int32_t* bandSlotPrefix,
                           const int32_t* bandBlockCounts, int32_t* bandBlockOffsets, int64_t* bandTotal, const float* clipZ,
-                          uint32_t* depthKey, uint32_t* splatOrder, const int32_t* splatToStorageOrNull = nullptr, bool clipZByStorage = false);
+                          uint32_t* depthKey, uint32_t* splatOrder, const int32_t* splatToStorageOrNull = nullptr,
+                          // block cull: no clip depths were stored -- the keys are made from the caller-ordered positions and the camera(s)
+                          const float4* positionCallerOrNull = nullptr, const ClipCamera* cameraOrNull = nullptr, const FrameParams* paramsDeviceOrNull = nullptr);
 // Exclusive scan of n int32 on the device (one workgroup), total as int64.
 void launchScanInt32(hipStream_t stream, int n, const int32_t* in, int32_t* out, int64_t* total);
 // SH colour for the splats of a device-side index list only; coefficients in the [splat][rowStride] layout (rows of shCount floats,
@@ -327,12 +334,21 @@ struct RasterLayer
     int openWordsPerRow = 0;          //   (what the list builder of the next layers looks at)
     int isFirst = 1, isLast = 1;
 };
+// Experiment hooks of the raster launch (gs_renderer_debug_set_tile_order): the tile every grid slot renders (-1: none) instead of the
+// XCD-aware screen-order map, and where every tile leaves the number of list entries it consumed.
+struct RasterSchedule
+{
+    const int32_t* order = nullptr; // [grid slots of the launch]
+    int32_t* consumedOut = nullptr; // [(virtual) tiles]
+};
 bool rasterCanEvaluateColours(int degree, int shCount);
 void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileRange, const int32_t* values,
                      const float2* clipXY, const float4* conic, const float4* color, uchar4* backBuffer,
                      unsigned long long* consumedPairsOrNull, bool clearEmptyTiles = false,
                      const RasterColourSource* lazyColoursOrNull = nullptr, const float4* rasterRecordOrNull = nullptr, int views = 1,
-                     int viewSplats = 0, const RasterLayer* layerOrNull = nullptr);
+                     int viewSplats = 0, const RasterLayer* layerOrNull = nullptr, const RasterSchedule* scheduleOrNull = nullptr);
+// Grid slots launchRasterize uses for a band of `rows` tile rows (what a RasterSchedule::order table must cover).
+int rasterGridSlots(int tilesX, int rows);
 
 // The renderer sorts its splats on a 27-bit re-coding of getKey()'s 32-bit quantised depth (GaussianRender.cu:446-454): the
 // quantised value comes from a float, so it has at most 24 significant bits -- (position of the top bit, next 23 bits) says

@@ -20,7 +20,7 @@
 //     neighbouring tiles in both directions (which share splats) share an L2.
 // The kernel is VALU/transcendental-bound, not HBM-bound: per consumed entry it reads 44 B but does
 // ~11 VALU ops for each of 256 pixels ("Raster roofline").
-#include "gs_internal.h"
+#include "gs_state.h"
 #include "gs_sh_eval.h"
 
 namespace gs
@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(LAYER
                                                                   const float4* __restrict__ color, uchar4* __restrict__ backBuffer,
                                                                   unsigned long long* __restrict__ consumedPairs, int clearEmptyTiles,
                                                                   RasterColourSource lazy, unsigned long long* __restrict__ trace,
-                                                                  const float4* __restrict__ rasterRecord, int viewSplats, RasterLayer layer)
+                                                                  const float4* __restrict__ rasterRecord, int viewSplats, RasterLayer layer,
+                                                                  RasterSchedule schedule)
 {
     constexpr int THREADS = 256 / PPL;
     constexpr int GROUPS_X = kTileSize / PPL;
@@ -129,6 +130,14 @@ __global__ __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(LAYER
     // Larger blocks share more but balance worse: 8 x 8 51.4 MB at -2 % frames/s, 16 x 4 43.4 MB at -16 %; 4 x 4 69 MB.
     // Edge blocks have idle workgroups (they exit).
     int tile;
+    if (schedule.order != nullptr)
+    {
+        // Experiment (gs_renderer_debug_set_tile_order): grid slot -> tile from a table, e.g. the tiles that
+        // consumed most entries in the previous frame first.  The order in which tiles START changes no tile's arithmetic.
+        tile = schedule.order[blockIdx.x];
+        if (tile < 0) return;
+    }
+    else
     {
         constexpr int BW = GS_RASTER_BLOCK_W;
         const int rows = numTiles / scr.tilesX;
@@ -381,8 +390,16 @@ __global__ __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(LAYER
     }
 
     if (consumedPairs != nullptr && t == 0) atomicAdd(consumedPairs, (unsigned long long) (consumed - lead));
+    if (schedule.consumedOut != nullptr && t == 0) schedule.consumedOut[vtile] = consumed - lead; // (what a start order for the NEXT frame would be made from)
     if constexpr (LAYERED)
     {
+        // (diagnostics, gs_renderer_debug_layered_raster_report: tiles that ran in this layer and tiles that loaded their state -- the
+        // counter block of a layered launch is four words)
+        if (consumedPairs != nullptr && t == 0)
+        {
+            atomicAdd(consumedPairs + 1, 1ull);
+            if (tileStatus == 1u) atomicAdd(consumedPairs + 2, 1ull);
+        }
         // `stop` is the loop's exit by a vote (uniform over the workgroup: the vote is block-wide)
         bool stopped = consumed < count; // the loop left entries behind: only a vote does that
         if (consumed == count)
@@ -409,6 +426,7 @@ __global__ __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(LAYER
         }
         if (!stopped && !layer.isLast)
         {
+            if (consumedPairs != nullptr && t == 0) atomicAdd(consumedPairs + 3, 1ull); // (diagnostics: tiles that store their state)
             float4* state = layer.state + (size_t) view * scr.width * scr.height;
 #pragma unroll
             for (int i = 0; i != PPL; ++i)
@@ -471,7 +489,7 @@ int rasterPixelsPerLane() { return g_rasterPixelsPerLane; }
 void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileRange, const int32_t* values,
                      const float2* clipXY, const float4* conic, const float4* color, uchar4* backBuffer,
                      unsigned long long* consumedPairsOrNull, bool clearEmptyTiles, const RasterColourSource* lazyColours,
-                     const float4* rasterRecord, int views, int viewSplats, const RasterLayer* layerOrNull)
+                     const float4* rasterRecord, int views, int viewSplats, const RasterLayer* layerOrNull, const RasterSchedule* scheduleOrNull)
 {
     const int firstTile = scr.rowBegin * scr.tilesX;
     const int numTiles = (scr.rowEnd - scr.rowBegin) * scr.tilesX;
@@ -482,10 +500,11 @@ void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileR
     RasterColourSource lazy{};
     if (lazyColours != nullptr) lazy = *lazyColours;
     const RasterLayer noLayer{};
+    const RasterSchedule schedule = scheduleOrNull != nullptr ? *scheduleOrNull : RasterSchedule{};
 #define GS_LAUNCH_RASTER_L(PPL, EPAN, SH, LAYERED, LAYER)                                                                                 \
     hipLaunchKernelGGL((rasterizeTilesKernel<PPL, EPAN, SH, LAYERED>), dim3(gridTiles, views), dim3(256 / PPL), 0, stream, scr, firstTile, numTiles, \
                        tileRange, values, clipXY, conic, color, backBuffer, consumedPairsOrNull, clearEmptyTiles ? 1 : 0, lazy, g_rasterTrace, rasterRecord, \
-                       views > 1 ? viewSplats : 0, LAYER)
+                       views > 1 ? viewSplats : 0, LAYER, schedule)
 #define GS_LAUNCH_RASTER(PPL, EPAN, SH) GS_LAUNCH_RASTER_L(PPL, EPAN, SH, false, noLayer)
     const bool epan = scr.epanechnikov != 0;
     if (layerOrNull != nullptr)
@@ -504,7 +523,8 @@ void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileR
         return;
     }
     // on-demand colours: two pixels per lane only (the default shape), every degree the reference ingests (PlyParser.cpp:204-243)
-    if (lazyColours != nullptr && g_rasterPixelsPerLane == 2 && rasterCanEvaluateColours(lazy.degree, lazy.shCount))
+    const int pixelsPerLane = effectivePixelsPerLane(); // (the calling renderer's own setting, or the process-wide default)
+    if (lazyColours != nullptr && pixelsPerLane == 2 && rasterCanEvaluateColours(lazy.degree, lazy.shCount))
     {
         switch (lazy.degree)
         {
@@ -515,7 +535,7 @@ void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileR
         }
         return;
     }
-    switch (g_rasterPixelsPerLane)
+    switch (pixelsPerLane)
     {
     case 1:
         if (epan) GS_LAUNCH_RASTER(1, true, 0);
@@ -535,9 +555,17 @@ void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileR
 #undef GS_LAUNCH_RASTER_L
 }
 
+int rasterGridSlots(int tilesX, int rows)
+{
+    if (rows <= 0) return 0;
+    const int bh = rows < GS_RASTER_BLOCK_H ? rows : GS_RASTER_BLOCK_H;
+    const int blocks = ((tilesX + GS_RASTER_BLOCK_W - 1) / GS_RASTER_BLOCK_W) * ((rows + bh - 1) / bh);
+    return ((blocks + 7) / 8) * 8 * GS_RASTER_BLOCK_W * bh;
+}
+
 bool rasterCanEvaluateColours(int degree, int shCount)
 {
-    return degree >= 1 && degree <= 4 && shCount == 3 * (degree + 1) * (degree + 1) && g_rasterPixelsPerLane == 2;
+    return degree >= 1 && degree <= 4 && shCount == 3 * (degree + 1) * (degree + 1) && effectivePixelsPerLane() == 2;
 }
 
 } // namespace gs

@@ -25,6 +25,7 @@ namespace gs
 bool useLazyColours(const GsRenderer* r)
 {
     static const bool disabled = getenv("GS_NO_LAZY_SH") != nullptr;
+    StreamScope scope(r); // (the renderer's own pixels-per-lane setting decides with)
     return !disabled && r->shDegree != 0 && r->shPerSplat != nullptr && r->pipeline != GS_PIPELINE_REFERENCE &&
            rasterCanEvaluateColours(r->shDegree, r->shCount);
 }
@@ -39,6 +40,16 @@ RasterColourSource colourSource(const GsRenderer* r, const float* cameraPosition
     if (cameraPosition) src.cameraPosition = make_float3(cameraPosition[0], cameraPosition[1], cameraPosition[2]);
     src.params = paramsDevice;
     return src;
+}
+
+bool useBlockCull(const GsRenderer* r, BandBlockCull* cull)
+{
+    if (!r->blockCull || r->splatToStorage == nullptr || r->storageToSplat == nullptr || r->blockBounds == nullptr || r->blockFlags == nullptr) return false;
+    cull->bounds = r->blockBounds;
+    cull->flags = r->blockFlags;
+    cull->storageToSplat = r->storageToSplat;
+    cull->viewTerms = (BandViewTerms*) (r->blockFlags + r->blockFlagBytes); // (behind the flags, 16-byte aligned)
+    return true;
 }
 
 namespace
@@ -75,6 +86,11 @@ void freeLayerCompaction(GsRenderer* r)
     gs_device_free(r->layerLiveCount);
     gs_device_free(r->layerTileBox);
     gs_device_free(r->layerLiveNibbles);
+    gs_device_free(r->layerLiveDebug);
+    gs_device_free(r->layerLiveCountDebug);
+    r->layerLiveDebug = nullptr;
+    r->layerLiveCountDebug = nullptr;
+    r->layerReuse = 0;
     r->layerLiveNibbles = nullptr;
     r->layerTileBox = nullptr;
     r->layerAlive = nullptr;
@@ -91,8 +107,18 @@ void freeScene(GsRenderer* r)
         r->position = r->scaleAndRotation = r->sh = r->shPerSplat = nullptr;
         r->splatToStorage = nullptr;
         r->positionCaller = r->scaleAndRotationCaller = nullptr;
+        r->blockBounds = nullptr;
+        r->storageToSplat = nullptr;
         r->sceneShared = false;
     }
+    gs_device_free(r->storageToSplat);
+    r->storageToSplat = nullptr;
+    gs_device_free(r->blockBounds);
+    gs_device_free(r->blockFlags);
+
+    r->blockBounds = nullptr;
+    r->blockFlags = nullptr;
+
     gs_device_free(r->splatToStorage);
     gs_device_free(r->positionCaller);
     gs_device_free(r->scaleAndRotationCaller);
@@ -191,6 +217,8 @@ extern "C" void gs_renderer_destroy(GsRenderer* r)
     freeScene(r);
     freeTileList(r);
     gs_device_free(r->tileRange);
+    gs_device_free(r->tileOrder);
+    gs_device_free(r->tileConsumed);
     gs_device_free(r->layerState);
     gs_device_free(r->layerConsumed);
     gs_device_free(r->frameTotals);
@@ -288,6 +316,48 @@ int effectiveDepthLayers(const GsRenderer* r, float fraction[kMaxDepthLayers])
 } // namespace gs
 
 extern "C" int gs_renderer_colours_on_demand(const GsRenderer* r) { return useLazyColours(r) ? 1 : 0; }
+extern "C" void gs_renderer_set_footprint(GsRenderer* r, int footprint)
+{
+    r->footprint = footprint == GS_FOOTPRINT_EPANECHNIKOV ? GS_FOOTPRINT_EPANECHNIKOV : footprint == GS_FOOTPRINT_GAUSSIAN ? GS_FOOTPRINT_GAUSSIAN : -1;
+}
+extern "C" int gs_renderer_footprint(const GsRenderer* r) { return r->footprint >= 0 ? r->footprint : g_footprint; }
+// Experiment (tools/tile_order_experiment.py): the start order of the raster's tiles.
+extern "C" int gs_renderer_debug_raster_grid_slots(const GsRenderer* r)
+{
+    const Screen scr = makeScreen(r->width, r->height, r->rowBegin, r->rowEnd);
+    return rasterGridSlots(scr.tilesX, scr.rowEnd - scr.rowBegin);
+}
+extern "C" int gs_renderer_debug_set_tile_order(GsRenderer* r, const int32_t* slotToTileHost, int slots)
+{
+    StreamScope scope(r);
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    gs_device_free(r->tileOrder);
+    r->tileOrder = nullptr;
+    r->tileOrderSlots = 0;
+    if (slotToTileHost == nullptr || slots <= 0) return 0;
+    if (slots != gs_renderer_debug_raster_grid_slots(r)) return -1;
+    r->tileOrder = (int32_t*) gs_device_alloc(sizeof(int32_t) * (size_t) slots);
+    gs_device_upload(r->tileOrder, slotToTileHost, sizeof(int32_t) * (size_t) slots);
+    r->tileOrderSlots = slots;
+    return 0;
+}
+extern "C" int gs_renderer_debug_tile_consumed(GsRenderer* r, int32_t* perTileHost)
+{
+    StreamScope scope(r);
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    const Screen scr = makeScreen(r->width, r->height, 0, 0);
+    if (r->tileConsumed == nullptr)
+    {
+        r->tileConsumed = (int32_t*) gs_device_alloc(sizeof(int32_t) * (size_t) scr.totalTiles);
+        gs_device_memset(r->tileConsumed, 0, sizeof(int32_t) * (size_t) scr.totalTiles);
+        GS_CHECK(hipStreamSynchronize(g.stream));
+        return 1; // armed: the next plain frames leave their tiles' consumed entries
+    }
+    if (perTileHost != nullptr) gs_device_download(perTileHost, r->tileConsumed, sizeof(int32_t) * (size_t) scr.totalTiles);
+    return 0;
+}
+extern "C" void gs_renderer_debug_set_list_fusion(GsRenderer* r, int enabled) { r->listFusion = enabled < 0 ? -1 : (enabled != 0 ? 1 : 0); }
+extern "C" void gs_renderer_debug_set_raster_pixels_per_lane(GsRenderer* r, int ppl) { r->pixelsPerLane = (ppl == 1 || ppl == 2 || ppl == 4) ? ppl : 0; }
 
 extern "C" void gs_renderer_set_band_cull(GsRenderer* r, int mode)
 {
@@ -321,6 +391,12 @@ void allocateSceneIntermediates(GsRenderer* r, int32_t n)
     r->bandSlotPrefix = (int32_t*) gs_device_alloc(sizeof(int32_t) * waves);
     r->bandOffsets = (int32_t*) gs_device_alloc(sizeof(int32_t) * waves);
     r->bandTotal = (int64_t*) gs_device_alloc(sizeof(int64_t));
+    if (r->splatToStorage != nullptr)
+    {
+        // block-level band cull (Morton storage): one flag per block of 256 splats and view, the keep mask in storage order
+        r->blockFlagBytes = ((((size_t) n + 255) / 256) * (size_t) r->views + 15) / 16 * 16;
+        r->blockFlags = (uint8_t*) gs_device_alloc(r->blockFlagBytes + sizeof(BandViewTerms) * kMaxViews); // (+ the views' terms of the bound)
+    }
     // Demo.cpp:325: 8 pairs per splat to start with; grown on demand.
 #ifndef GS_INITIAL_LIST_FACTOR
 #define GS_INITIAL_LIST_FACTOR 8
@@ -380,6 +456,15 @@ extern "C" int gs_renderer_set_scene(GsRenderer* r, int32_t n, const float* posi
     gs_device_upload(r->position, inStorageOrder(position4, 4), f4);
     gs_device_upload(r->scaleAndRotation, inStorageOrder(scaleAndRotation4, 4), f4);
     gs_device_upload(r->color, inStorageOrder(color4, 4), f4);
+    if (r->splatToStorage != nullptr && n > 0)
+    {
+        // block-level band cull: centre box and covariance bound of every 256 Morton-neighbouring splats (gs_clip.hip), once per scene
+        r->storageToSplat = (int32_t*) gs_device_alloc(sizeof(int32_t) * (size_t) n); // (where a kept splat's bit goes in the caller-ordered keep mask)
+        gs_device_upload(r->storageToSplat, r->storageToSplatHost.data(), sizeof(int32_t) * (size_t) n);
+        r->blockBounds = (BlockBound*) gs_device_alloc(sizeof(BlockBound) * (((size_t) n + 255) / 256));
+        launchBlockBounds(g.stream, n, (const float4*) r->position, (const float4*) r->scaleAndRotation, r->blockBounds);
+        GS_CHECK(hipStreamSynchronize(g.stream));
+    }
     if (shDegree != 0)
     {
         // Demo.cpp:291-296
@@ -444,6 +529,8 @@ extern "C" int gs_renderer_share_scene(GsRenderer* r, const GsRenderer* owner)
     r->splatToStorage = owner->splatToStorage;
     r->positionCaller = owner->positionCaller;
     r->scaleAndRotationCaller = owner->scaleAndRotationCaller;
+    r->blockBounds = owner->blockBounds;
+    r->storageToSplat = owner->storageToSplat;
     r->storageToSplatHost = owner->storageToSplatHost;
     r->sceneShared = true;
     if (r->splatToStorage != nullptr) r->pipeline = GS_PIPELINE_TWO_LEVEL; // (see gs_renderer_set_pipeline)
@@ -721,13 +808,18 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         {
             // clip data for every splat + keep-mask, then an order-preserving compaction of (depth key, index)
             // (Morton storage: in the caller's order, from the caller-ordered copies of the inputs)
-            const bool callerOrder = r->splatToStorage != nullptr;
-            launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) (callerOrder ? r->positionCaller : r->position),
-                                (const float4*) (callerOrder ? r->scaleAndRotationCaller : r->scaleAndRotation), nullptr, r->clipZ, nullptr, nullptr,
+            // (... unless the cull runs by blocks of Morton neighbours: storage order, only the blocks that can reach the band, gs_clip.hip)
+            BandBlockCull blocks;
+            const bool byBlocks = useBlockCull(r, &blocks);
+            const bool callerOrder = r->splatToStorage != nullptr && !byBlocks;
+            const ClipCamera bandCamera = currentCamera();
+            launchSplatClipData(g.stream, n, scr, bandCamera, (const float4*) (callerOrder ? r->positionCaller : r->position),
+                                (const float4*) (callerOrder ? r->scaleAndRotationCaller : r->scaleAndRotation), nullptr, byBlocks ? nullptr : r->clipZ, nullptr, nullptr,
                                 nullptr, nullptr, r->bandMask, r->bandSlotPrefix, r->bandCounts, nullptr, r->tileRange, 2 * scr.totalTiles,
-                                (float4*) r->tileRecord, (float4*) r->rasterRecord, 1, r->splatToStorage);
+                                (float4*) r->tileRecord, (float4*) r->rasterRecord, 1, callerOrder ? r->splatToStorage : nullptr, nullptr,
+                                byBlocks ? &blocks : nullptr);
             launchBandCompaction(g.stream, n, 1, r->bandMask, r->bandSlotPrefix, r->bandCounts, r->bandOffsets, r->bandTotal, r->clipZ, r->depthKey[0],
-                                 (uint32_t*) r->order[0], r->splatToStorage);
+                                 (uint32_t*) r->order[0], r->splatToStorage, byBlocks ? (const float4*) r->positionCaller : nullptr, &bandCamera, nullptr);
             countDevice = (const int*) r->bandTotal; // low 32 bits of the little-endian int64 total
         }
         gs_timer_stop(stageTimers[1]);
@@ -789,7 +881,7 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         // pair count travels to the host, so the readback (GaussianRender.cu:793) costs no GPU idle time.
         gs_timer_start(stageTimers[2]);
         // (gs_set_list_fusion: the emit pass carries the first pass of the tile sort, finish() sorts on the remaining bits)
-        f.sortBits = (cfg.listFusion && native) ? tileListFusedSortBits(tileBits(scr.totalTiles), f.tileKeyBytes) : 0;
+        f.sortBits = (effectiveListFusion() && native) ? tileListFusedSortBits(tileBits(scr.totalTiles), f.tileKeyBytes) : 0;
         launchTileListFastCount(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, f.sortBits);
         launchTileListFastEmit(g.stream, n, scr, order, (const float2*) r->clipXY, (const float4*) r->ellipse, r->scratch, r->keys[0],
                                f.tileKeyBytes, r->values[0], r->tileListCapacity, 0, f.sortBits);
@@ -880,9 +972,13 @@ extern "C" int gs_renderer_finish(GsRenderer* r, GsFrameStats* stats)
     }
     gs_timer_start(stageTimers[5]);
     const RasterColourSource lazySource = colourSource(r, f.cameraPosition, nullptr);
+    RasterSchedule schedule;
+    schedule.consumedOut = r->tileConsumed; // (experiment hooks: null unless gs_renderer_debug_tile_consumed / _set_tile_order were used)
+    if (r->tileOrder != nullptr && r->tileOrderSlots == rasterGridSlots(scr.tilesX, scr.rowEnd - scr.rowBegin)) schedule.order = r->tileOrder;
     launchRasterize(g.stream, scr, r->tileRange, r->values[r->selector], (const float2*) r->clipXY, (const float4*) r->conic,
                     (const float4*) r->color, (uchar4*) r->backBuffer, consumed, r->pipeline != GS_PIPELINE_REFERENCE,
-                    f.lazyColours ? &lazySource : nullptr, r->pipeline != GS_PIPELINE_REFERENCE ? (const float4*) r->rasterRecord : nullptr);
+                    f.lazyColours ? &lazySource : nullptr, r->pipeline != GS_PIPELINE_REFERENCE ? (const float4*) r->rasterRecord : nullptr, 1, 0, nullptr,
+                    &schedule);
     r->colourStale = f.lazyColours;
     gs_timer_stop(stageTimers[5]);
     if (hipGetLastError() != hipSuccess) printf("kernel error renderDepthBuffer\n");

@@ -62,16 +62,44 @@ __global__ __launch_bounds__(256) void stagedSortedCheckKernel(int size, const u
     }
 }
 
-void ensureStagedScratch(StagedScratch& s, int splats, int capacityPairs, int tileKeyBytes)
+// The sorted builder's hidden scratch: 16 bytes per splat and, per entry of the CALLER's list capacity, two tile-index halves (2 or 4
+// bytes each), one value half and two depth halves -- 16 to 20 bytes per entry, 0.64-0.8 GB at a capacity of 40 M (the footprint the
+// header states).  The reference's builder needs none of it, so running out of device memory here is no reason to end the process
+// (ADVICE r05): false = could not be had -- everything this call allocated is given back and the caller emits in the reference's order.
+int64_t g_stagedScratchLimit = 0; // gs_debug_set_staged_scratch_limit: allocations beyond it fail as if the device were out of memory (tests)
+bool ensureStagedScratch(StagedScratch& s, int splats, int capacityPairs, int tileKeyBytes)
 {
+    const auto release = [](auto*& p) {
+        if (p) (void) hipFree(p);
+        p = nullptr;
+    };
+    const auto giveUp = [&]() {
+        for (int i = 0; i != 2; ++i)
+        {
+            release(s.depthKey[i]);
+            release(s.order[i]);
+            release(s.tileKeys[i]);
+            release(s.depth[i]);
+        }
+        release(s.values);
+        s.capacitySplats = 0;
+        s.capacityPairBytes = 0;
+        s.capacityPairs = 0;
+        (void) hipGetLastError(); // (the failed allocation's sticky error)
+        return false;
+    };
+    const auto alloc = [](auto*& p, size_t bytes) {
+        p = nullptr;
+        if (g_stagedScratchLimit > 0 && (int64_t) bytes > g_stagedScratchLimit) return false;
+        return hipMalloc((void**) &p, std::max<size_t>(bytes, 16)) == hipSuccess;
+    };
     if (splats > s.capacitySplats)
     {
         for (int i = 0; i != 2; ++i)
         {
-            if (s.depthKey[i]) GS_CHECK(hipFree(s.depthKey[i]));
-            if (s.order[i]) GS_CHECK(hipFree(s.order[i]));
-            GS_CHECK(hipMalloc((void**) &s.depthKey[i], sizeof(uint32_t) * (size_t) splats));
-            GS_CHECK(hipMalloc((void**) &s.order[i], sizeof(int32_t) * (size_t) splats));
+            release(s.depthKey[i]);
+            release(s.order[i]);
+            if (!alloc(s.depthKey[i], sizeof(uint32_t) * (size_t) splats) || !alloc(s.order[i], sizeof(int32_t) * (size_t) splats)) return giveUp();
         }
         s.capacitySplats = splats;
     }
@@ -80,22 +108,23 @@ void ensureStagedScratch(StagedScratch& s, int splats, int capacityPairs, int ti
     {
         for (int i = 0; i != 2; ++i)
         {
-            if (s.tileKeys[i]) GS_CHECK(hipFree(s.tileKeys[i]));
-            GS_CHECK(hipMalloc(&s.tileKeys[i], (size_t) keyBytes));
+            release(s.tileKeys[i]);
+            if (!alloc(s.tileKeys[i], (size_t) keyBytes)) return giveUp();
         }
         s.capacityPairBytes = keyBytes;
     }
     if (capacityPairs > s.capacityPairs)
     {
-        if (s.values) GS_CHECK(hipFree(s.values));
-        GS_CHECK(hipMalloc((void**) &s.values, sizeof(int32_t) * (size_t) capacityPairs));
+        release(s.values);
+        if (!alloc(s.values, sizeof(int32_t) * (size_t) capacityPairs)) return giveUp();
         for (int i = 0; i != 2; ++i)
         {
-            if (s.depth[i]) GS_CHECK(hipFree(s.depth[i]));
-            GS_CHECK(hipMalloc((void**) &s.depth[i], sizeof(uint32_t) * (size_t) capacityPairs));
+            release(s.depth[i]);
+            if (!alloc(s.depth[i], sizeof(uint32_t) * (size_t) capacityPairs)) return giveUp();
         }
         s.capacityPairs = capacityPairs;
     }
+    return true;
 }
 
 void ensureSortedCheck(StagedScratch& s)
@@ -118,7 +147,14 @@ int32_t stagedBuildTileListSorted(GsTimer* timer, int32_t tileListCapacity)
     StagedScratch& st = g.staged;
     const int tBits = tileBits(scr.totalTiles);
     const int tileKeyBytes = scr.totalTiles > 65536 ? 4 : 2;
-    if (n > 0) ensureStagedScratch(st, n, capacity, tileKeyBytes); // (before the timed interval: allocation is not the stage's work)
+    // (before the timed interval: allocation is not the stage's work.  No memory for the scratch: -1, the caller emits in the reference's order)
+    if (n > 0 && !ensureStagedScratch(st, n, capacity, tileKeyBytes))
+    {
+        static bool told = false;
+        if (!told) printf("gsplat_hip: no device memory for the sorted tile-list builder's scratch (%d splats, capacity %d): emitting in the reference's order\n", n, capacity);
+        told = true;
+        return -1;
+    }
     gs_timer_start(timer);
     if (n <= 0)
     {
@@ -137,7 +173,7 @@ int32_t stagedBuildTileListSorted(GsTimer* timer, int32_t tileListCapacity)
         const int orderSel = launchRadixSortPairs(g.stream, g.radix, 4, st.depthKey[0], st.depthKey[1], st.order[0], st.order[1], n, 0, kDepthKeyBits);
         const uint32_t* order = (const uint32_t*) st.order[orderSel];
         // (2) count / emit in depth order; the emit pass carries the tile sort's first pass when that sort is a two-pass one
-        const int sortBits = cfg.listFusion ? tileListFusedSortBits(tBits, tileKeyBytes) : 0;
+        const int sortBits = effectiveListFusion() ? tileListFusedSortBits(tBits, tileKeyBytes) : 0;
         g.scratch.tileRecord = nullptr;
         g.scratch.countDevice = nullptr;
         g.scratch.depthSorted = st.depthKey[orderSel]; // the emit pass decodes every pair's quantised depth from its splat's sorted code ...
@@ -219,6 +255,8 @@ extern "C" void gs_release_thread_scratch(void)
     if (st.unsortedEpochHost) (void) hipHostFree(st.unsortedEpochHost);
     st = StagedScratch{};
 }
+
+extern "C" void gs_debug_set_staged_scratch_limit(int64_t maxBytesPerAllocationOr0) { g_stagedScratchLimit = maxBytesPerAllocationOr0 > 0 ? maxBytesPerAllocationOr0 : 0; }
 
 extern "C" void gs_set_staged_builder(int mode)
 {

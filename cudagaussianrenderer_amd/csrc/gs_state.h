@@ -22,7 +22,7 @@ void setRasterPixelsPerLane(int ppl);
 int rasterPixelsPerLane();
 void setRasterTrace(unsigned long long* deviceBufferOrNull);
 
-extern int g_footprint; // process-wide, like the reference's #define
+extern int g_footprint; // process-wide, like the reference's #define: the staged calls' footprint and every renderer's default
 extern int g_ablation;  // diagnostics: stages left out of captured frames (gs_debug_set_ablation)
 
 // The reference keeps these in __constant__ symbols (GaussianRender.cu:42-43); here they are a host
@@ -56,6 +56,11 @@ struct State
     gs::RadixScratch radix;
     StagedScratch staged;
     int64_t lastDemand = 0;
+    // What the renderer whose call is running on this thread wants instead of the process-wide defaults (set and restored by
+    // StreamScope; -1 / 0 = the default): two threads that drive renderers with different footprints share no switch.
+    int footprint = -1;     // GS_FOOTPRINT_*, gs_renderer_set_footprint
+    int listFusion = -1;    // gs_renderer_debug_set_list_fusion
+    int pixelsPerLane = 0;  // gs_renderer_debug_set_raster_pixels_per_lane
 };
 // One state per host thread: like the reference, the staged calls are not re-entrant, but each host thread may drive
 // its own renderer / staged sequence on its own stream (bench.py runs one thread per frame in flight).
@@ -75,6 +80,10 @@ struct Settings
     unsigned long long* consumedDevice = nullptr; // counter of the staged gs_rasterize_tile
 };
 extern Settings cfg;
+// The settings in force for the call running on this thread: the renderer's own where it has one (StreamScope), else the process-wide default.
+inline int effectiveFootprint() { return g.footprint >= 0 ? g.footprint : g_footprint; }
+inline bool effectiveListFusion() { return g.listFusion >= 0 ? g.listFusion != 0 : cfg.listFusion; }
+inline int effectivePixelsPerLane() { return g.pixelsPerLane != 0 ? g.pixelsPerLane : rasterPixelsPerLane(); }
 
 Screen currentScreen();
 ClipCamera currentCamera();
@@ -160,6 +169,12 @@ struct GsRenderer
     uint8_t* layerLiveNibbles = nullptr;
     ushort4* layerTileBox = nullptr;          // the list builder's box per (virtual) splat, written by the clip kernel of a layered frame
     bool layerCompaction = true;
+    // experiment (gs_renderer_debug_set_layer_compaction_reuse): 1 = the later layers' live lists go to buffers of their own, 2 = the
+    // compaction kernels are NOT launched and the lists the last mode-1 frame left are walked again (same camera: the same lists) --
+    // the frame a compaction fused into the count pass at zero cost would be
+    int layerReuse = 0;
+    uint32_t* layerLiveDebug = nullptr; // [kMaxDepthLayers][splats x views]
+    int32_t* layerLiveCountDebug = nullptr; // [kMaxDepthLayers]
     int autoLayerChanges = 0;       // times the choice changed (each one re-captures the frame)
     int autoFramesSinceChange = 0;
     int64_t autoLastTotal = 0;      // the pair total of the last one-layer frame
@@ -184,6 +199,21 @@ struct GsRenderer
     int32_t *bandCounts = nullptr, *bandOffsets = nullptr, *bandSlotPrefix = nullptr;
     int64_t* bandTotal = nullptr;
     int bandCull = GS_BAND_CULL_AUTO;
+    // renderer state that the reference has as compile-time or process-wide switches (-1 / 0: the process-wide default at frame time)
+    int footprint = -1;    // gs_renderer_set_footprint
+    int listFusion = -1;   // gs_renderer_debug_set_list_fusion
+    int pixelsPerLane = 0; // gs_renderer_debug_set_raster_pixels_per_lane
+    // experiment (gs_renderer_debug_set_tile_order): the raster's start order from a table, and every tile's consumed entries of the last plain frame
+    int32_t* tileOrder = nullptr;
+    int tileOrderSlots = 0;
+    int32_t* tileConsumed = nullptr;
+    // block-level band cull (gs_clip.hip; Morton storage only): the per-block bounds made at set_scene (the scene owner's when shared),
+    // this renderer's per-frame block flags and storage-ordered keep masks
+    gs::BlockBound* blockBounds = nullptr;
+    uint8_t* blockFlags = nullptr;
+    size_t blockFlagBytes = 0; // (the views' BandViewTerms follow the flags in the same allocation)
+    int32_t* storageToSplat = nullptr; // device copy of storageToSplatHost (the scene owner's when shared)
+    bool blockCull = true; // gs_renderer_debug_set_block_cull (A/B and tests: 0 = every rank projects all N splats, round 5's band kernel)
     int32_t* tileRange = nullptr;
     uint8_t* backBufferOwned = nullptr;
     uint8_t* backBuffer = nullptr;
@@ -208,20 +238,33 @@ namespace gs
 {
 // The launchers enqueue on g.stream; a renderer that was given its own stream borrows the slot for the call, so that
 // several renderers (frames in flight) can be driven from one host thread on different streams.
+// ... and so it is with the renderer's own footprint, list-fusion and pixels-per-lane settings: in force for the calls made inside the scope.
 struct StreamScope
 {
     hipStream_t saved;
-    explicit StreamScope(GsRenderer* r) : saved(g.stream)
+    int savedFootprint, savedListFusion, savedPixelsPerLane;
+    explicit StreamScope(const GsRenderer* r) : saved(g.stream), savedFootprint(g.footprint), savedListFusion(g.listFusion), savedPixelsPerLane(g.pixelsPerLane)
     {
         if (r->hasStream) g.stream = r->stream;
+        g.footprint = r->footprint;
+        g.listFusion = r->listFusion;
+        g.pixelsPerLane = r->pixelsPerLane;
     }
-    ~StreamScope() { g.stream = saved; }
+    ~StreamScope()
+    {
+        g.stream = saved;
+        g.footprint = savedFootprint;
+        g.listFusion = savedListFusion;
+        g.pixelsPerLane = savedPixelsPerLane;
+    }
 };
 
 // ---- helpers of the renderer shared with the captured path (gs_renderer.hip) ----
 bool useLazyColours(const GsRenderer* r);
 RasterColourSource colourSource(const GsRenderer* r, const float* cameraPosition, const FrameParams* paramsDevice);
 bool growTileListIfNeeded(GsRenderer* r, int64_t demand);
+// The band cull of this renderer's next frame runs by blocks of Morton-neighbouring splats (fills `cull` for launchSplatClipData).
+bool useBlockCull(const GsRenderer* r, BandBlockCull* cull);
 int effectiveDepthLayers(const GsRenderer* r, float fraction[kMaxDepthLayers]);
 size_t rangeTableInts(const Screen& scr, int views); // ranges of all views + the depth layers' status bytes and open bits behind them, in ints
 int openWordsPerRow(int tilesX);

@@ -1122,7 +1122,8 @@ void ensureTileListFastScratch(TileListScratch& s, int count)
 // the groups, so no group disappears (profiles/r05_depth_layers.txt).  Three small kernels in front of the count pass make the groups
 // dense again: (1) every splat, in STORAGE order, has its box (8 bytes, left by the clip kernel) tested against the open bits and leaves one bit; (2) the layer's
 // slice of the depth order counts its live splats per block of 1 024 and (3) writes them out, in order, with the count for the passes'
-// device-side count.  The test is the count pass's own (same box, same limit on its size).
+// device-side count.  The test is the count pass's own: the same box (splatTileBox, left by the clip kernel) and the same limit on its
+// size (at most 32 tiles wide and kDoneBoxRows tall; larger boxes are kept unseen by both).
 constexpr int kCompactItems = 4;
 constexpr int kCompactBlock = kGroup * kCompactItems;
 constexpr int kCompactSelfSumBlocks = 4096; // (4 M splats in a layer's slice)
@@ -1171,7 +1172,10 @@ __global__ __launch_bounds__(kGroup) void layerAliveKernel(int count, Screen scr
                 const int w0 = box.x >> 5, w1 = (box.z - 1) >> 5;
                 const unsigned firstMask = 0xFFFFFFFFu << (box.x & 31), lastMask = 0xFFFFFFFFu >> (31 - ((box.z - 1) & 31));
                 unsigned open = 0;
-                if (w1 - w0 <= 1 && h <= kDoneBoxRows)
+                // (the count pass's own limit, gs_tiles_fast.hip "whole box": up to 32 tiles wide -- one or two words per row -- and
+                // kDoneBoxRows tall.  Round 5 looked at boxes of up to 64 tiles here, which the count pass keeps unseen: the results
+                // agreed only because the per-tile mask removed those pairs again)
+                if (w <= 32 && h <= kDoneBoxRows)
                 {
 #pragma unroll
                     for (int r = 0; r != kDoneBoxRows; ++r) // (independent loads)

@@ -12,13 +12,16 @@
  *   - the caller owns all device memory; the library keeps raw pointers until the next set-args call;
  *   - the staged calls keep their arguments in per-host-thread state (the reference keeps them in file-scope __constant__
  *     symbols): one host thread runs one frame at a time, exactly as in the reference; different threads may each drive
- *     their own GsRenderer concurrently (device, stream and global/tile-list args are thread-local, tuning knobs are global);
+ *     their own GsRenderer concurrently (device, stream and global/tile-list args are thread-local; everything that shapes a
+ *     renderer's frames -- footprint, pipeline, storage order, depth layers, views, band -- is renderer state; the process-wide
+ *     switches gs_set_footprint and gs_set_staged_builder are the defaults of the staged calls, as the reference's #define is);
  *   - a failed HIP API call prints "HIP error at <file> <line>: <msg>" and exit(EXIT_FAILURE)
  *     (src/CudaErrorCheck.cpp:2-11); a failed kernel launch prints "kernel error <stage>" and continues;
  *   - tileRange must be pre-set to 0xFF and the back buffer zeroed by the caller each frame
  *     (Demo.cpp:399,403); evaluateTileRange must be skipped when the list is empty (Demo.cpp:469).
  * Additions (absent in the reference because they are compile-time there): width/height, the
  * tile-row band used by the multi-GPU split, and the stream the stages are enqueued on.
+ * Diagnostics, A/B switches, counters and trace hooks are NOT part of the boundary: they live in gsplat_hip_debug.h.
  *
  * Matrices are glm layout: 16 floats, column-major, m[col*4+row].
  */
@@ -126,7 +129,11 @@ int32_t gs_build_tile_list(GsTimer* timer, int32_t numBlocks, int32_t tileListCa
  * list that is already in order on the compared bits is the identity, so it returns with the selectors untouched; any other list is
  * sorted as before.  Same sorted list as REFERENCE_ORDER + sort, bit for bit (keys and values), at 0.23 instead of 0.62 ms for the two
  * calls at BASELINE.json configs[2] (profiles/r05_staged_path.txt).  A list cut off by the capacity is a sorted subset of the full
- * list (the reference's is an arbitrary subset, .cu:700-703).
+ * list (the reference's is an arbitrary subset, .cu:700-703).  FOOTPRINT: this builder keeps library-owned scratch per host thread,
+ * sized by the CALLER'S capacity, not by the demand -- 16 bytes per splat + 16 (20 above 65 536 tiles) bytes per list entry of
+ * tileListCapacity: 0.13 GB at the reference's 8 entries per splat for 1 M splats, 0.64 GB at a capacity of 40 M -- freed by
+ * gs_release_thread_scratch.  When that memory cannot be had the call prints one line and emits in REFERENCE_ORDER instead (which
+ * needs no scratch beyond 8 bytes per 64 splats); it does not end the process.
  * REFERENCE_ORDER: (splat, local tile) emission order (gs_tiles.hip, the order the oracle emits in) and an unconditional sort. */
 #define GS_STAGED_BUILDER_REFERENCE_ORDER 0
 #define GS_STAGED_BUILDER_SORTED 1
@@ -144,46 +151,15 @@ void gs_sort_tile_list(GsTimer* timer, int32_t tileListSize, void** deviceTempSt
                        GsDoubleBufferU64* keys, GsDoubleBufferI32* values);
 void gs_evaluate_tile_range(GsTimer* timer, int32_t tileListSize);  /* .cu:891-906                    */
 void gs_rasterize_tile(GsTimer* timer);                             /* .cu:1019-1034                  */
-/* Addition: number of list entries the last gs_rasterize_tile loaded before tile-wide termination
- * (P_c of DESIGN.md); collected only when enabled, costs one atomic per tile. */
-void gs_set_collect_raster_stats(int enabled);
-int64_t gs_last_raster_consumed_pairs(void);
-/* Addition: radix sort used by the one-call renderer for its two sorts (depth keys of the splats; tile index of
- * the pairs). NATIVE = the three-kernel LSD sort of gs_radix.hip (default), ROCPRIM = rocPRIM's device sort. */
-#define GS_SORT_BACKEND_ROCPRIM 0
-#define GS_SORT_BACKEND_NATIVE 1
-void gs_set_sort_backend(int backend);
-/* Addition: the renderer's emit pass may carry the FIRST PASS of its tile sort (native backend, two-pass sorts of 16-bit tile
- * indices): the count pass also counts the pairs' low tile digits per group of 256 splats, a column scan turns the table into output
- * positions, and the emit pass ranks its pairs in LDS and writes them where the first scatter would have put them -- one histogram
- * kernel and one scatter kernel less per frame, the unsorted list is never written.  Same sorted list, same image, bit for bit
- * (replaces cub::DeviceRadixSort::SortPairs at GaussianRender.cu:806-855 together with the emission at :684-712).  Process-wide. */
-#ifndef GS_LIST_FUSION_DEFAULT
-#define GS_LIST_FUSION_DEFAULT 1
-#endif
-void gs_set_list_fusion(int enabled);
-int gs_get_list_fusion(void);
 /* The reference's compile-time option `#define EPANECHNIKOV_KERNEL` (GaussianRender.cu:8-9, README.md:133-136) as a
  * run-time switch: footprint extent sqrt(7) sigma instead of 3 sigma (.cu:298-302), density 1 - q/7 instead of exp(-q/2)
- * (.cu:977-981).  Process-wide, like the reference's #define; applies to the staged calls and to every renderer. */
+ * (.cu:977-981).  Process-wide, like the reference's #define: it applies to the staged calls and is the DEFAULT of every renderer;
+ * a renderer can be given a footprint of its own (gs_renderer_set_footprint below), so that two host threads with different
+ * footprints do not share a switch. */
 #define GS_FOOTPRINT_GAUSSIAN 0
 #define GS_FOOTPRINT_EPANECHNIKOV 1
 void gs_set_footprint(int footprint);
 int gs_get_footprint(void);
-int gs_get_sort_backend(void);
-/* The native sort on its own: stable LSD sort of (keyBytes in {2,4} key, int32 value) pairs on key bits
- * [beginBit, endBit); input in buffers 0, returns the index (0/1) of the buffers holding the result, -1 if the
- * size/key type is not supported. Device pointers, enqueued on the current stream. */
-int gs_radix_sort_pairs(int keyBytes, void* keys0, void* keys1, int32_t* values0, int32_t* values1, int32_t count, int beginBit,
-                        int endBit);
-/* Addition (tuning): pixels per lane of the raster kernel: 1 (four waves per tile), 2 (two waves, default) or
- * 4 (one wave per tile). */
-void gs_set_raster_pixels_per_lane(int pixelsPerLane);
-int gs_get_raster_pixels_per_lane(void);
-/* Diagnostics (tools/raster_trace.py): when set, every raster workgroup writes four uint64 to deviceBuffer[4 * tile]:
- * start and end on the 100 MHz wall clock, the tile's list length, and (dispatch index << 32 | consumed entries).
- * Process-wide; NULL (default) switches it off.  Not for captured frames (the pointer is a frozen kernel argument there). */
-void gs_debug_set_raster_trace(uint64_t* deviceBufferOrNull);
 
 /* ---- stream / device (additions) ------------------------------------------------------------- */
 void gs_set_device(int device);
@@ -308,8 +284,13 @@ void gs_renderer_set_band_cull(GsRenderer* r, int mode);
 /* Returns 0; -1 (nothing changed) for REFERENCE while the renderer holds a scene stored in Morton order (below): that pipeline
  * breaks depth ties by storage order.  A scene set while REFERENCE is selected is always stored in the caller's order. */
 int gs_renderer_set_pipeline(GsRenderer* r, int pipeline);
+/* This renderer's footprint: GS_FOOTPRINT_GAUSSIAN / GS_FOOTPRINT_EPANECHNIKOV, or -1 (default) = the process-wide setting at the
+ * time of each frame (gs_set_footprint).  Renderer state: frames of different renderers, driven from different host threads, may use
+ * different footprints at the same time.  A captured frame is re-captured when its footprint changes. */
+void gs_renderer_set_footprint(GsRenderer* r, int footprintOrMinus1);
+int gs_renderer_footprint(const GsRenderer* r); /* the footprint the next frame uses */
 /* 1 when the renderer's frames evaluate SH colours on demand inside the raster kernel instead of running the SH pass over all
- * splats (two-level pipeline, SH degree 1 or 3, two pixels per lane; GS_NO_LAZY_SH=1 in the environment turns it
+ * splats (two-level pipeline, SH degree 1..4, two pixels per lane; GS_NO_LAZY_SH=1 in the environment turns it
  * off).  Same colours bit for bit (one shared routine); a frame consumes only the front of its lists -- 88 K distinct splats
  * of 1 M at BASELINE.json configs[2] -- so most of the reference's evaluateSphericalHarmonics work is never needed.
  * GsRendererBuffers.color is brought up to date (one SH pass) when gs_renderer_buffers is called. */
@@ -339,10 +320,6 @@ int gs_renderer_colours_on_demand(const GsRenderer* r);
 int gs_renderer_set_depth_layers(GsRenderer* r, int layers, const float* fractions);
 int gs_renderer_depth_layers(const GsRenderer* r);        /* the setting (0 / -1 = the renderer chooses) */
 int gs_renderer_depth_layers_in_use(const GsRenderer* r); /* layers the last captured frame was made of */
-int gs_renderer_depth_layer_changes(const GsRenderer* r); /* layers = 0: times the renderer changed its choice (each one re-captures the frame; steps
-                                                           * down wait 16 frames, doubled whenever one is undone within 4 frames) */
-void gs_renderer_debug_set_layer_compaction(GsRenderer* r, int enabled); /* A/B: 0 = later layers walk all their splats, not only those with an open
-                                                                           * tile under their box (default 1; same lists and images) */
 /* Pairs the last captured frame listed: summed over its depth layers (gs_last_tile_list_demand then holds the largest layer's total,
  * which is what the list capacity must hold); the frame's pair total with one layer.  Waits for the renderer's stream. */
 int64_t gs_renderer_listed_pairs(GsRenderer* r);
@@ -402,26 +379,6 @@ int gs_renderer_views(const GsRenderer* r);
 int gs_renderer_render_views(GsRenderer* r, const GsCameraData* cameras);
 uint8_t* gs_renderer_back_buffer_view(GsRenderer* r, int view);
 int gs_renderer_read_back_buffer_view(GsRenderer* r, int view, uint8_t* hostRgba); /* waits for the renderer's stream; -1: no such view */
-/* Diagnostics (bench.py --ablate): leave stages out of the captured frames -- bit 0 clip, 1 depth sort, 2 pair count, 3 pair emit,
- * 4 tile sort, 5 ranges, 6 raster -- to measure what each stage costs the pipelined frame rate.  The images are garbage. */
-void gs_debug_set_ablation(int mask);
-/* A renderer with Morton storage (no band cull) has the depth sort make its own keys, so its clip kernel and the sort are independent:
- * the clip kernel may share the LAUNCH of the sort's first column scan (one kernel with both workloads: 17 instead of 18 kernels per
- * frame; same results, same routines).  Measured (profiles/r04_ab_experiments.txt): one frame at a time -- the reference's loop,
- * Demo.cpp:394-479 -- gains 3 % (0.275 -> 0.266 ms), four frames in flight lose 1 %; OFF by default, for hosts that render one frame
- * at a time to switch on.  Process-wide.  Frames whose stages are timed one by one (timed != 0) always launch the two separately, so
- * that the clip stage's time is its own. */
-void gs_debug_set_clip_scan_fusion(int enabled);
-int gs_debug_get_clip_scan_fusion(void);
-/* A captured frame hands its pair total to the host in the middle of the frame; the host waits for it at most this long (default
- * 30 s) and gives up at once when the stream reports anything but "not ready" -- print + exit, the reference's convention for a
- * failed runtime call (CudaErrorCheck.cpp:2-11), so that a faulted GPU ends the process instead of hanging it. */
-void gs_debug_set_await_timeout(double seconds);
-/* Diagnostics (tools/frame_pump): host-side cost of the captured frames of this process since the last reset -- average microseconds
- * per frame inside hipGraphLaunch and waiting for the frame's pair total; returns the number of frames averaged over. */
-long long gs_debug_host_times(double* launchMicroseconds, double* awaitMicroseconds, int reset);
-/* Number of captured frames that had to be rendered again because the list was too small (diagnostics). */
-int gs_renderer_captured_retries(const GsRenderer* r);
 /* The same frame in two halves, so that one host thread can keep several renderers (each with its own stream and
  * buffers, gs_renderer_set_stream) busy: begin() enqueues everything up to the pair emission and returns; finish()
  * picks up the pair count -- by then on the host -- and enqueues tile sort, ranges and raster. render() = begin + finish. */
@@ -475,14 +432,6 @@ int gs_gather_bands(GsComm* comm, uint8_t* deviceBackBuffer, int width, int heig
  * in the back buffer): ONE grouped send/receive set for all of them. */
 int gs_gather_bands_views(GsComm* comm, uint8_t* backBuffer, int width, int height, int views, const int32_t* tileRowBands, int root,
                           void* hipStream);
-/* Diagnostics: a one-rank RCCL communicator sends `bytes` from src to dst (both device memory) through the grouped ncclSend/ncclRecv
- * path gs_gather_bands uses, on one GPU; blocks until done.  0 = ok, -1 RCCL not loadable, -2 RCCL error. */
-int gs_debug_rccl_self_exchange(void* dst, const void* src, size_t bytes, void* hipStream);
-/* ... with the block cut into `parts` send/receive pairs inside one group (several operations per peer, as gs_gather_bands_views issues). */
-int gs_debug_rccl_self_exchange_parts(void* dst, const void* src, size_t bytes, int parts, void* hipStream);
-/* ... through `comms` (1..8) communicators, each on a stream of its own, all in flight at once and each used twice: how a host with
- * several frames in flight drives the gather (one communicator per frame in flight, never one communicator on two streams). */
-int gs_debug_rccl_self_exchange_streams(void* dst, const void* src, size_t bytes, int comms);
 
 const char* gs_version(void);
 

@@ -55,6 +55,34 @@ def test_bench_single_gpu_line_has_roofline_cpu_baseline_and_parity():
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0
     assert par["ok"] is True and par["views"] == 2 and par["max_lsb"] <= 3 and par["frac_gt1"] <= 1e-3
     assert all(abs(a - b) <= par["tolerance"]["pairs_abs"] for a, b in zip(par["pairs_gpu"], par["pairs_oracle"]))
+    # the kernel the timed loop runs has a roofline entry of its own (this small scene: one list per frame -> the block above)
+    tk = rf["timed_loop_kernel"]
+    assert tk["launches_per_frame"] == 1 and "one list" in tk["kernel"] and abs(tk["frac"] - rf["frac"]) < 1e-4
+    # no stage prints "reference bytes over our time" under a name that reads like a bandwidth of this machine
+    for stage in out["stages"].values():
+        assert "reference_bytes_over_our_time" in stage and "reference_formulation_GBps" not in stage
+
+
+def test_bench_line_prices_the_layered_raster_kernel_the_timed_loop_runs():
+    """Depth layers forced (two): roofline.timed_loop_kernel describes rasterizeTilesKernel<..., LAYERED> as the loop runs it -- two launches
+    per frame timed with HIP events, SURVEY.md 8(d)'s bytes per launch plus the open tiles' 16 B/px state round trip."""
+    out = _run_bench("--steps", "16", "--warmup", "8", "--splats", "300000", "--width", "1280", "--height", "720", "--cpu-frames", "0",
+                     "--no-extra", "--depth-layers", "2")
+    assert out["config"]["depth_layers"]["in_use"] == 2
+    rf = out["roofline"]
+    tk = rf["timed_loop_kernel"]
+    tiles = 80 * 45
+    assert "LAYERED" in tk["kernel"] and tk["launches_per_frame"] == 2 and len(tk["kernel_ms_by_layer"]) == 2
+    assert abs(tk["kernel_ms_per_frame"] - sum(tk["kernel_ms_by_layer"])) < 1e-3 and tk["kernel_ms_per_frame"] > 0
+    want = (44 * tk["consumed_pairs_per_frame"] + 8 * tiles * 2 + 4 * 256 * tk["tiles_run_per_frame"]
+            + 16 * 256 * (tk["state_tile_loads_per_frame"] + tk["state_tile_stores_per_frame"]))
+    assert abs(tk["algorithmic_bytes"] - want) <= 0.001 * want + 64 * 1024  # (the counts are rounded means over 32 frames)
+    assert abs(tk["achieved"] - tk["algorithmic_bytes"] / 1e9 / (tk["kernel_ms_per_frame"] / 1e3)) <= 0.01 * tk["achieved"] + 0.1
+    assert abs(tk["frac"] - tk["achieved"] / tk["peak"]) < 1e-4
+    # the layered frame consumes what the one-list frame consumes (same votes at the same entries): within the rounding of the two means
+    assert abs(tk["consumed_pairs_per_frame"] - out["config"]["consumed_pairs_per_frame"]) <= 2
+    # every tile an earlier layer leaves open stores its state once, and loads it at most once
+    assert 0 < tk["state_tile_loads_per_frame"] <= tk["state_tile_stores_per_frame"] <= tiles
 
 
 def _read_ppm(path):

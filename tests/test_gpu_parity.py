@@ -664,6 +664,105 @@ def test_band_cull_drops_nothing(gs, tmp_path, log_scale_mean):
         assert any(entry[0] > 0 for entry in lists[0])
 
 
+def _harsh_scene(n, seed):
+    """Splats a conservative bound has to survive: scales from 1e-4 to 2 with anisotropies up to 1000, arbitrary quaternion BYTES (the
+    reference does not renormalise: |q| from ~0 to 2, GaussianRender.cu:220-221), positions all over a box the cameras fly through."""
+    rng = np.random.default_rng(seed)
+    pos = np.ones((n, 4), np.float32)
+    centres = rng.uniform(-4, 4, (48, 3))
+    pos[:, :3] = (centres[rng.integers(0, 48, n)] + rng.normal(0, 0.6, (n, 3))).astype(np.float32)
+    pos[: n // 8, :3] = rng.uniform(-6, 6, (n // 8, 3))
+    sr = np.zeros((n, 4), np.float32)
+    base = np.exp(rng.uniform(np.log(1e-4), np.log(2.0), n))
+    ratio = np.exp(rng.uniform(np.log(1e-3), 0.0, (n, 3)))
+    ratio[np.arange(n), rng.integers(0, 3, n)] = 1.0
+    sr[:, :3] = (base[:, None] * ratio).astype(np.float32)
+    sr[:, 3] = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    bad = ~np.isfinite(sr[:, 3])
+    sr[bad, 3] = np.float32(0.0)  # (a NaN bit pattern survives the upload, but numpy comparisons below would not)
+    col = rng.uniform(0, 1, (n, 4)).astype(np.float32)
+    col[:, 3] = rng.uniform(0.05, 0.9, n)
+    return pos, sr, col
+
+
+def test_block_cull_drops_nothing(gs, tmp_path):
+    """The band cull of a Morton-stored scene tests blocks of 256 neighbouring splats first (centre box + covariance bound against the
+    band, gs_clip.hip blockBandTestKernel) and projects only the blocks that remain.  The bound must be CONSERVATIVE: a block it
+    rejects may hold no splat the per-splat keep mask would have kept.  1 000 random cameras -- inside and outside the cloud, any
+    orientation, so splats straddle the near plane and lie behind the camera -- over a harsh scene (anisotropy 1000, un-normalised
+    quaternions, extents from sub-pixel to screen-filling), random bands: the number of kept splats, the band's sorted pair list
+    and the image equal those of the kernel that projects every splat (round 5's), frame for frame.  Chains of three views as
+    well (the all-views kernel), and on a benign scene the test must actually reject most blocks of a narrow band."""
+    from cudagaussianrenderer_amd import scenes
+
+    w, h = 640, 368
+    tx, ty = gs.tile_counts(w, h)
+    n = 60_000
+    scene = _harsh_scene(n, seed=11)
+    rng = np.random.default_rng(12)
+    pair = []
+    for blocks in (True, False):
+        r = gs.Renderer(w, h, band_cull=1, storage_order=gs.STORAGE_ORDER_MORTON)
+        r.set_block_cull(blocks)
+        r.set_scene(*scene)
+        pair.append(r)
+    assert pair[0].block_cull_kept()[1] == (n + 255) // 256
+    rejected_blocks = 0
+    for k in range(1000):
+        q = rng.normal(0, 1, 4)
+        q /= np.linalg.norm(q)
+        cam = gs.camera_from_pose(rng.uniform(-6, 6, 3), q, w, h)
+        rb = int(rng.integers(0, ty))
+        band = (rb, int(rng.integers(rb + 1, ty + 1)))
+        got = []
+        for r in pair:
+            gs.lib().gs_renderer_set_tile_rows(r.handle, band[0], band[1])
+            r.render(cam)
+            b = r.buffers()
+            got.append((r.band_kept_splats(), b.tileListSize, r.download(b.values, b.tileListSize, np.int32), r.read_image()))
+        kept, total = pair[0].block_cull_kept()
+        rejected_blocks += total - kept
+        assert got[0][0] == got[1][0], (k, band, got[0][0], got[1][0])  # a rejected block held a splat the keep mask keeps
+        assert got[0][1] == got[1][1] and np.array_equal(got[0][2], got[1][2]) and np.array_equal(got[0][3], got[1][3]), (k, band)
+    assert rejected_blocks > 0
+    for r in pair:
+        r.close()
+    # chains of three views (captured): the all-views band kernel behind the same block flags
+    chains = []
+    for blocks in (True, False):
+        r = gs.Renderer(w, h, band_cull=1, views=3, storage_order=gs.STORAGE_ORDER_MORTON)
+        r.set_block_cull(blocks)
+        r.set_graph(True)
+        r.set_scene(*scene)
+        chains.append(r)
+    for k in range(40):
+        cams = []
+        for _ in range(3):
+            q = rng.normal(0, 1, 4)
+            q /= np.linalg.norm(q)
+            cams.append(gs.camera_from_pose(rng.uniform(-6, 6, 3), q, w, h))
+        rb = int(rng.integers(0, ty))
+        band = (rb, int(rng.integers(rb + 1, ty + 1)))
+        got = []
+        for r in chains:
+            gs.lib().gs_renderer_set_tile_rows(r.handle, band[0], band[1])
+            r.render_views(cams)
+            got.append((r.band_kept_splats(), [r.read_image(view=v) for v in range(3)]))
+        assert got[0][0] == got[1][0], (k, band)
+        assert all(np.array_equal(a, b_) for a, b_ in zip(got[0][1], got[1][1])), (k, band)
+    for r in chains:
+        r.close()
+    # a benign scene, a narrow band of an orbit view: the test earns its keep
+    ply = _ply_scene(gs, tmp_path, 200_000, 0, log_scale_mean=-4.0)
+    r = gs.Renderer(w, h, tile_rows=(10, 12), storage_order=gs.STORAGE_ORDER_MORTON)
+    r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"])
+    for p_, q_ in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 4):
+        r.render(gs.camera_from_pose(p_, q_, w, h))
+        kept, total = r.block_cull_kept()
+        assert 0 < kept < 0.8 * total, (kept, total)  # (782 blocks of 256 Morton neighbours: a block spans ~5 of the 23 tile rows)
+    r.close()
+
+
 def test_captured_frames_equal_regular_frames(gs, tmp_path):
     """hipGraph replay (device-side list sizes, camera through a memcpy node) vs the regular path: same list, same image,
     for every camera of an orbit, full frame and band-culled sub-band."""
@@ -841,6 +940,76 @@ def test_epanechnikov_footprint(gs, gsref, tmp_path, degree):
     assert not np.array_equal(img_g, img_e)
     vis = ell_g[:, 2] > 0
     assert np.allclose(ell_e[vis, 2:] / ell_g[vis, 2:], np.sqrt(7.0) / 3.0, rtol=1e-5)
+
+
+def test_two_threads_with_different_footprints_share_no_switch(gs, gsref, tmp_path):
+    """The footprint is renderer state (gs_renderer_set_footprint; the reference has it as a compile-time #define,
+    GaussianRender.cu:8-9, and round 5 as ONE process-wide switch that two threads raced on): a Gaussian and an Epanechnikov renderer
+    driven concurrently from two host threads -- plain and captured frames, and the reference-shaped pipeline, whose staged calls take
+    the footprint from the calling thread's state -- each match the oracle run with their footprint, frame after frame, while the
+    process-wide switch stays where it was and a renderer without a footprint of its own follows it."""
+    import threading
+
+    w, h = 640, 360
+    ply = _ply_scene(gs, tmp_path, 30000, 3, log_scale_mean=-3.0)
+    n = ply["vertexCount"]
+    cam = gs.camera_from_bounds(ply["boundsMin"], ply["boundsMax"], w, h)
+    scene = (ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+    sh_al = gs.realign_spherical_harmonics(ply["sh"], ply["shCount"], n)
+    want = {}
+    try:
+        for footprint in (gs.FOOTPRINT_GAUSSIAN, gs.FOOTPRINT_EPANECHNIKOV):
+            gsref.set_footprint(footprint == gs.FOOTPRINT_EPANECHNIKOV)
+            want[footprint] = gsref.render(*scene[:3], sh_al, ply["shDegree"], ply["shCount"], cam, w, h)[0]
+    finally:
+        gsref.set_footprint(False)
+    assert not np.array_equal(want[gs.FOOTPRINT_GAUSSIAN], want[gs.FOOTPRINT_EPANECHNIKOV])
+    assert gs.lib().gs_get_footprint() == gs.FOOTPRINT_GAUSSIAN
+    failures = []
+    start = threading.Barrier(2)
+
+    def worker(footprint):
+        try:
+            gs.lib().gs_set_device(0)
+            renderers = []
+            for pipeline, graph in ((gs.PIPELINE_TWO_LEVEL, False), (gs.PIPELINE_TWO_LEVEL, True), (gs.PIPELINE_REFERENCE, False)):
+                r = gs.Renderer(w, h, pipeline=pipeline)
+                r.set_footprint(footprint)
+                r.set_graph(graph)
+                r.set_scene(*scene)
+                renderers.append(r)
+            start.wait()
+            first = {}
+            for frame in range(40):
+                for k, r in enumerate(renderers):
+                    r.render(cam)
+                    img = r.read_image()
+                    if k not in first:
+                        first[k] = img
+                        _assert_image_close(img, want[footprint], f"footprint {footprint}, renderer {k}")
+                    elif not np.array_equal(img, first[k]):
+                        failures.append((footprint, frame, k, "a frame differs from this renderer's first frame"))
+                        return
+            assert gs.lib().gs_renderer_footprint(renderers[0].handle) == footprint
+            for r in renderers:
+                r.close()
+        except BaseException as exc:  # noqa: BLE001
+            failures.append((footprint, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(fp,)) for fp in (gs.FOOTPRINT_GAUSSIAN, gs.FOOTPRINT_EPANECHNIKOV)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not failures, failures
+    # nobody touched the process-wide switch; a renderer without a footprint of its own follows it
+    assert gs.lib().gs_get_footprint() == gs.FOOTPRINT_GAUSSIAN
+    r = gs.Renderer(w, h)
+    r.set_scene(*scene)
+    assert gs.lib().gs_renderer_footprint(r.handle) == gs.FOOTPRINT_GAUSSIAN
+    r.render(cam)
+    _assert_image_close(r.read_image(), want[gs.FOOTPRINT_GAUSSIAN], "default footprint")
+    r.close()
 
 
 @pytest.mark.parametrize("graph", [False, True])
@@ -1110,7 +1279,11 @@ def test_eight_bands_stitch_to_the_single_gpu_frame(gs, tmp_path, width, height,
 def test_full_size_parity_with_oracle(gs, gsref, tmp_path_factory, config):
     """One view of each full-size configuration through the renderer's default path (two-level sort, colours on demand) AND
     as a captured frame, against the serial oracle's frame: image within the tolerance at the top of this file, the same number
-    of pairs (borderline tiles aside), the same consumed-entry count to a vote's rounding.
+    of pairs (borderline tiles aside), the same consumed-entry count to a vote's rounding.  And the renderer's sorted pair list is held
+    to EQUALITY, not to a count: the oracle's list stage (buildTileList + stable sort + ranges, GaussianRender.cu:375-405, 645-679, 806-888)
+    is fed the GPU's own clip data, as the staged-list tests do at small sizes, and its sorted values and its range table must equal
+    the renderer's entry for entry -- 5.4 M pairs at C3, 64 M at C5.  PAIR_SLACK survives only where the oracle's OWN clip data is
+    used (the count against the oracle's frame: its ellipse axis goes through glibc's atan2 / cos / sin).
       C2 = configs[1]: 100 k procedural splats, SH degree 0, 1024x1024 (the reference's native case, Demo.cpp:258-269);
       C3 = configs[2]: 1 M splats, SH degree 3, 1920x1080 (the bench workload);
       C5 = configs[4]: 5 M splats, SH degree 3, 3840x2160 (full frame on one GPU)."""
@@ -1138,6 +1311,22 @@ def test_full_size_parity_with_oracle(gs, gsref, tmp_path_factory, config):
         gs.lib().gs_set_collect_raster_stats(0)
     stats = _assert_image_close(got, want, config)
     assert abs(st.tileListSize - rst.tileListSize) <= PAIR_SLACK(rst.tileListSize), (st.tileListSize, rst.tileListSize)
+    # the product's list against the oracle's list stage on the GPU's clip data: equality
+    b = r.buffers()
+    assert b.tileListSize == st.tileListSize and b.keyBytes == 2
+    xy = r.download(b.positionClipSpaceXY, 2 * n, np.float32).reshape(n, 2)
+    z = r.download(b.positionClipSpaceZ, n, np.float32)
+    ell = r.download(b.screenEllipse, 4 * n, np.float32).reshape(n, 4)
+    got_values = r.download(b.values, b.tileListSize, np.int32)
+    tiles = ((w + 15) // 16) * ((h + 15) // 16)
+    got_ranges = r.download(b.tileRange, 2 * tiles, np.int32)
+    rk, rv, total = gsref.build_tile_list(xy, z, ell, w, h)
+    assert total == st.tileListSize, (total, st.tileListSize)  # no slack: same clip data, same predicate
+    rsk, rsv = gsref.sort_tile_list(rk, rv, gs.sort_end_bit(w, h))
+    del rk, rv
+    assert np.array_equal(got_values, rsv)
+    assert np.array_equal(got_ranges, gsref.evaluate_tile_ranges(rsk, tiles).reshape(-1))
+    del rsk, rsv, got_values, xy, z, ell
     assert abs(st.consumedPairs - rst.consumedPairs) <= 0.002 * rst.consumedPairs + 64, (st.consumedPairs, rst.consumedPairs)
     assert np.array_equal(got[..., 3], want[..., 3])  # alpha: 255 exactly where the oracle's tiles had work
     # the captured frame (what bench.py times) hands out the same bytes
@@ -1392,7 +1581,8 @@ def test_overlap_audit_build_finds_no_differing_decision(tmp_path):
     (`make audit`: gs_tiles_fast.hip with -DGS_AUDIT_OVERLAP, otherwise the same objects) checks them at RUN time: every tile the
     count pass decides also goes through gs_overlap_exact.h, every tile of the reference's box outside the tight box too, and
     differing decisions are counted.  The harsh scenes of test_two_level_pipeline_equals_reference_pipeline and an orbit of the
-    clustered .ply scene run through it in a child process (the product library stays the one this process has loaded)."""
+    clustered .ply scene run through it in a child process (the product library stays the one this process has loaded) -- and so does
+    one full-size frame each of BASELINE.json configs[2] and configs[4] (round 5 audited scenes of up to 200 k splats only)."""
     import json
     import os
     import subprocess
@@ -1436,6 +1626,13 @@ w, h = 1920, 1080
 cams = [gs.camera_from_pose(p, q, w, h) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 8)]
 for order in ("caller", "morton"):
     run(f"clustered ply 200000 @ 1080p, 8-view orbit, {order}", w, h, (ply["position"], ply["scaleAndRotation"], ply["color"]), cams, storage_order=order)
+# one frame each of BASELINE.json configs[2] and configs[4] at full size (1 M splats at 1080p: 9 M decided tiles; 5 M at 2160p: 100 M)
+for n_full, wf, hf in ((1_000_000, 1920, 1080), (5_000_000, 3840, 2160)):
+    scenes.write_synthetic_ply(path, n_full, sh_degree=0, seed=1234)
+    full = gs.parse_ply(path)
+    run(f"clustered ply {n_full} @ {wf}x{hf}, default camera", wf, hf, (full["position"], full["scaleAndRotation"], full["color"]),
+        [gs.camera_from_bounds(full["boundsMin"], full["boundsMax"], wf, hf)])
+    del full
 # the same builder behind the staged buildTileList (gs_staged.hip: clip data from the caller's arrays instead of the packed records)
 from tests.gpu_helpers import StagedFrame
 pos, sr, col = gs.generate_random_gaussians(40000, seed=11, min_scale=0.0004, max_scale=0.9)
@@ -1450,7 +1647,7 @@ print("AUDIT " + json.dumps(report))
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("AUDIT ")][-1]
     report = json.loads(line[6:])
-    assert len(report) == 10
+    assert len(report) == 12
     for entry in report:
         units, slow, exact, changed, audited, differing, dropped, dropped_hits = entry["stats"]
         assert audited > entry["pairs"] > 0, entry  # every listed pair is a tile that was decided, and audited
@@ -1552,6 +1749,40 @@ def test_release_thread_scratch_and_carry_on(gs, gsref):
     assert np.array_equal(other["lists"][0], first[0]) and np.array_equal(other["lists"][1], first[1])
 
 
+def test_sorted_builder_without_memory_for_its_scratch_emits_in_reference_order(gs, gsref):
+    """the default staged builder keeps hidden scratch sized by the CALLER's list capacity (16-20 bytes per entry).  When
+    that memory cannot be had (here: a test hook that fails allocations above 64 KB), buildTileList must not end the process: the call
+    emits in the reference's order -- which needs no such scratch --, sortTileList sorts, and the frame's lists are the same lists.
+    With the limit lifted the next call is the sorted builder again."""
+    w, h = 640, 368
+    pos, sr, col = _procedural(gs, 20000, seed=6)
+    cam = gs.camera_from_bounds([-4] * 3, [4] * 3, w, h)
+
+    def lists():
+        f = StagedFrame(pos, sr, col, cam, w, h, capacity=4_000_000)  # (above the demand: a list cut off by the capacity is another subset per builder)
+        f.begin()
+        f.run_clip()
+        keys, values, size = f.run_build()
+        assert size < 4_000_000
+        sk, sv = f.run_sort()
+        f.free_sort_temp()
+        return keys, values, sk, sv
+
+    gs.lib().gs_release_thread_scratch()
+    want = lists()  # the sorted builder: the list leaves buildTileList in order
+    assert np.array_equal(want[0], want[2]) and np.array_equal(want[1], want[3]) and len(want[0]) > 20000
+    gs.lib().gs_release_thread_scratch()
+    gs.lib().gs_debug_set_staged_scratch_limit(64 * 1024)
+    try:
+        got = lists()
+    finally:
+        gs.lib().gs_debug_set_staged_scratch_limit(0)
+    assert not np.array_equal(got[0], got[2])  # emitted in (splat, local tile) order: the sort had work to do
+    assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+    again = lists()
+    assert np.array_equal(again[0], want[0]) and np.array_equal(again[1], want[1])
+
+
 def test_one_shot_render_equals_the_renderer(gs, tmp_path):
     """gs_render (scene and camera in, image out) gives the bytes a Renderer gives, SH degree 3 and 0, and an
     empty scene gives an empty image."""
@@ -1635,6 +1866,54 @@ def test_depth_layers_give_byte_identical_frames(gs, gsref, tmp_path, degree, w,
     sh_al = gs.realign_spherical_harmonics(ply["sh"], ply["shCount"], n) if degree else None
     ref, _, _ = gsref.render(ply["position"], ply["scaleAndRotation"], ply["color"], sh_al, degree, ply["shCount"], cams[0], w, h)
     _assert_image_close(want[0], ref, "one layer vs oracle")
+
+
+def test_depth_layers_with_wide_boxes_over_stopped_tiles(gs):
+    """the later layers' live test and the count pass's whole-box test must be ONE predicate (boxes of up to 32 x 8 tiles are
+    looked at, larger ones are kept unseen by both).  A scene made for the difference: an opaque wall in front stops every tile in the
+    first layer; behind it lie flat, wide splats whose boxes are 20-70 tiles wide and 1-12 tall -- narrower than, between and beyond
+    the two limits -- over nothing but stopped tiles, and a few that stick out over the wall's edge into open tiles.  Two, three and
+    four layers give the one-list frame's bytes."""
+    w, h = 1280, 720
+    rng = np.random.default_rng(21)
+    quat = _bits_to_float(gs.encode_vec4([0.0, 0.0, 0.0, 1.0]))
+    wall_n, wide_n = 6000, 600
+    pos = np.ones((wall_n + wide_n, 4), np.float32)
+    sr = np.zeros((wall_n + wide_n, 4), np.float32)
+    col = rng.uniform(0, 1, (wall_n + wide_n, 4)).astype(np.float32)
+    # the wall: big, opaque splats on the plane z = 0 over x in [-3, 2.2] (the right edge of the screen stays open)
+    pos[:wall_n, 0] = rng.uniform(-3.0, 2.2, wall_n)
+    pos[:wall_n, 1] = rng.uniform(-2.0, 2.0, wall_n)
+    pos[:wall_n, 2] = 0.0
+    sr[:wall_n, :3] = rng.uniform(0.08, 0.2, (wall_n, 3))
+    col[:wall_n, 3] = 0.99
+    pos[:wall_n, 3] = 0.99
+    # behind it: flat splats, very wide in x, thin in y and z
+    pos[wall_n:, 0] = rng.uniform(-1.5, 1.5, wide_n)
+    pos[wall_n:, 1] = rng.uniform(-1.8, 1.8, wide_n)
+    pos[wall_n:, 2] = rng.uniform(-3.0, -0.5, wide_n)
+    sr[wall_n:, 0] = rng.uniform(0.25, 1.1, wide_n)
+    sr[wall_n:, 1] = rng.uniform(0.002, 0.12, wide_n)
+    sr[wall_n:, 2] = 0.002
+    col[wall_n:, 3] = rng.uniform(0.3, 0.9, wide_n)
+    pos[wall_n:, 3] = col[wall_n:, 3]
+    sr[:, 3] = quat
+    cam = gs.camera_from_pose([0, 0, 6], [0, 0, 0, 1], w, h)
+    images = {}
+    for layers in (1, 2, 3, 4):
+        r = gs.Renderer(w, h)
+        r.set_graph(True)
+        r.set_depth_layers(layers, [0.5, 0.7, 0.85][: layers - 1] if layers > 1 else None)  # the wall's 6 000 splats fill the first layer
+        r.set_scene(pos, sr, col)
+        r.render(cam)
+        r.render(cam)
+        assert r.depth_layers_in_use() == layers
+        images[layers] = (r.read_image(), r.listed_pairs())
+        r.close()
+    assert images[1][0][..., :3].any()
+    for layers in (2, 3, 4):
+        assert np.array_equal(images[layers][0], images[1][0]), layers
+        assert images[layers][1] < images[1][1]  # the later layers listed fewer pairs: the wall did stop tiles
 
 
 def test_depth_layers_with_views_bands_and_a_list_that_must_grow(gs, tmp_path):

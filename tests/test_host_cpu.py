@@ -19,17 +19,24 @@ def _load_npz(path):
 
 def test_library_exports_every_declared_symbol(gs):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    header = open(os.path.join(root, "include", "gsplat_hip.h")).read()
-    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-    declared = set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", header))
-    assert len(declared) >= 45
     from cudagaussianrenderer_amd import _capi
 
+    def declared_in(name):
+        header = open(os.path.join(root, "include", name)).read()
+        header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+        return set(re.findall(r"\b(gs_[a-z0-9_]+)\s*\(", header))
+
+    boundary, lab = declared_in("gsplat_hip.h"), declared_in("gsplat_hip_debug.h")
+    assert len(boundary) >= 45 and len(lab) >= 20 and not (boundary & lab)
+    # the boundary header holds the reference's interface, the documented additions and the one-call renderer -- no diagnostics,
+    # no A/B switches (round 5's header carried 29 of them): those are declared in gsplat_hip_debug.h only
+    assert not [n for n in boundary if "debug" in n], sorted(n for n in boundary if "debug" in n)
+    assert lab == set(_capi.DEBUG_SYMBOLS), lab ^ set(_capi.DEBUG_SYMBOLS)
     lib = C.CDLL(_capi.LIB_PATH)
-    for name in sorted(declared):
-        assert hasattr(lib, name), f"{name} declared in gsplat_hip.h but not exported"
+    for name in sorted(boundary | lab):
+        assert hasattr(lib, name), f"{name} declared in a public header but not exported"
     # the Python binding covers the same surface
-    assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
+    assert boundary | lab == set(_capi.SIGNATURES), (boundary | lab) ^ set(_capi.SIGNATURES)
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -196,7 +203,8 @@ def test_tile_row_bands():
 
 def test_public_header_is_plain_c(tmp_path):
     """include/gsplat_hip.h is the drop-in boundary: it must compile as C99 (no C++ types in the signatures), and a C
-    program must link against the library and call a host-side entry point."""
+    program must link against the library and call a host-side entry point.  The same holds for the lab's header
+    (gsplat_hip_debug.h), and the boundary header must be usable WITHOUT it."""
     import shutil
     import subprocess
 
@@ -208,6 +216,10 @@ def test_public_header_is_plain_c(tmp_path):
                    'int main(void) { GsGlobalArgs a; GsTileListArgs t; (void) a; (void) t;\n'
                    '  printf("%d %d\\n", gs_sort_end_bit(1920, 1080), gs_sort_end_bit(1024, 1024)); return 0; }\n')
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)],
+                   check=True)
+    lab = tmp_path / "lab.c"
+    lab.write_text('#include "gsplat_hip_debug.h"\nint main(void) { gs_debug_set_ablation(0); return gs_get_list_fusion() == GS_LIST_FUSION_DEFAULT ? 0 : 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(lab)],
                    check=True)
     exe = tmp_path / "cabi"
     libdir = os.path.join(root, "cudagaussianrenderer_amd")

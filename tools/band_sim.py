@@ -27,6 +27,7 @@ ap.add_argument("--ablate", type=int, default=0, help="gs_debug_set_ablation mas
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--depth-layers", type=int, default=1, help="gs_renderer_set_depth_layers of the bands' renderers (0 / -1: the renderer chooses)")
+ap.add_argument("--block-cull", type=int, default=1, help="gs_renderer_debug_set_block_cull: 1 = the band cull tests blocks of 256 Morton neighbours first (round 6), 0 = every band projects all splats (round 5)")
 args = ap.parse_args()
 W, H = args.width, args.height
 gs.lib().gs_set_sort_backend(args.sort_backend)
@@ -52,13 +53,16 @@ cal.close()
 D = args.inflight
 gs.lib().gs_debug_set_ablation(args.ablate)
 shared_streams = [torch.cuda.Stream() for _ in range(D)]
+kept_blocks = []
 def measure(world, bands):
     times = []
+    kept_blocks.clear()
     for band in bands:
         streams = shared_streams
         rs = []
         for d in range(D):
             r = gs.Renderer(W, H, tile_rows=band if world > 1 else None, band_cull=args.cull, pipeline=args.pipeline, views=args.views, storage_order=args.storage_order)
+            r.set_block_cull(bool(args.block_cull))
             r.set_scene(ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
             r.set_stream(streams[d].cuda_stream)
             r.set_graph(bool(args.graph))
@@ -86,6 +90,9 @@ def measure(world, bands):
         run(args.frames, 16)
         torch.cuda.synchronize()
         times.append(1e3 * (time.perf_counter() - t) / args.frames)
+        kept, total = rs[0].block_cull_kept()
+        if world > 1 and kept >= 0 and args.block_cull:
+            kept_blocks.append(round(kept / max(total, 1), 3))
         for r in rs:
             r.close()
     return times
@@ -99,7 +106,8 @@ for world in [int(x) for x in args.worlds.split(",")]:
         times = measure(world, bands)
         worst = max(times)
         base = base or worst
-        print(f"world {world}: per-band ms {[round(x, 3) for x in times]} -> slowest {worst:.3f} ms, speed-up vs 1 GPU {base / worst:.2f}x (gather not included)")
+        print(f"world {world}: per-band ms {[round(x, 3) for x in times]} -> slowest {worst:.3f} ms, speed-up vs 1 GPU {base / worst:.2f}x (gather not included)"
+              + (f"; blocks of 256 splats the block test kept, per band: {kept_blocks}" if kept_blocks else ""))
         if world == 1 or it == args.rebalance:
             break
         # re-cut: the rows of a band that took longer than the mean get proportionally more weight (gamma > 1: only part of a band's

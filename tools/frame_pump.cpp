@@ -16,6 +16,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "gsplat_hip.h"
+#include "gsplat_hip_debug.h" // gs_debug_host_times
 
 int main(int argc, char** argv)
 {
