@@ -292,6 +292,55 @@ class Rig:
         self.pipelined_layers(r)
         return elapsed / frames
 
+    def small_step_orbit(self, fine_cameras, frames=360):
+        """The host the reference is -- an interactive viewer whose camera moves a little per frame (Demo.cpp:371-392): the orbit in 1-degree
+        steps, ONE renderer, one frame, then a synchronise, then the next camera; with the raster's tiles started in screen order and
+        longest-first by the previous frame's consumption (gs_renderer_set_tile_start_order).  Frames per second of the loop, and the
+        raster stage's HIP-event time from the same path with plain launches."""
+        import torch
+
+        gs = self.ctx["gs"]
+        r, stream = self.renderers[0], self.streams[0]
+        self.lone_frame_layers(r)
+        out = {}
+        for name, mode in (("screen_order", gs.TILE_START_ORDER_SCREEN), ("previous_frame", gs.TILE_START_ORDER_PREVIOUS_FRAME)):
+            r.set_tile_start_order(mode)
+            for phase in range(2):
+                torch.cuda.synchronize(self.ctx["device"])
+                t0 = time.perf_counter()
+                for i in range(frames if phase else 32):
+                    r.render(fine_cameras[i % len(fine_cameras)])
+                    stream.synchronize()
+                elapsed = time.perf_counter() - t0
+            state = r.tile_order_state()
+            # the keep rule's other half: the same loop on the bench's own orbit (45-degree steps, nothing to predict) must not lose
+            for phase in range(2):
+                torch.cuda.synchronize(self.ctx["device"])
+                t0 = time.perf_counter()
+                for i in range(256 if phase else 32):
+                    r.render(self.cameras[i % len(self.cameras)])
+                    stream.synchronize()
+                coarse = time.perf_counter() - t0
+            with torch.cuda.stream(stream):
+                for i in range(8):
+                    r.render(fine_cameras[i % len(fine_cameras)], timed=2)
+                r.collect_stage_times()
+                for i in range(frames):
+                    r.render(fine_cameras[i % len(fine_cameras)], timed=2)
+                n, sums = r.collect_stage_times()
+            out[name] = {"frames_per_s": round(frames / elapsed, 1), "ms": round(1e3 * elapsed / frames, 4), "raster_ms_plain_launches": round(sums.msRasterize / n, 4),
+                         "clip_ms_plain_launches": round(sums.msClipData / n, 4), "frames_per_s_on_the_45_degree_orbit": round(256 / coarse, 1),
+                         "stages_ms_plain_launches_sum": round((sums.msClipData + sums.msBuildTileList + sums.msSortTileList + sums.msTileRanges + sums.msRasterize) / n, 4)}
+            if state is not None and mode != gs.TILE_START_ORDER_SCREEN:
+                out[name]["table_in_force_after_last_frame"] = bool(state[0])
+                out[name]["consumption_mismatch_last_two_frames"] = round(state[1] / max(state[2], 1), 3)
+        r.set_tile_start_order(gs.TILE_START_ORDER_SCREEN)
+        self.pipelined_layers(r)
+        out["what"] = ("the orbit in 1-degree steps, one renderer, captured frames, one frame then a stream synchronise (the reference's loop): the raster's tiles "
+                       "started in the XCD-aware screen order against longest-first by the previous frame's consumption (gs_renderer_set_tile_start_order; "
+                       "same image bytes); raster_ms_plain_launches: the raster stage's HIP-event time on the same camera path with plain launches")
+        return out
+
     def lone_frame_layers(self, r):
         """The depth-layer choice of a host that renders ONE frame at a time: GS_DEPTH_LAYERS_CHOOSE where the timed loop runs under
         GS_DEPTH_LAYERS_CHOOSE_PIPELINED (the default); an explicit --depth-layers stays."""
@@ -538,8 +587,9 @@ def timed_loop_kernel(layered, args, tiles, band_h, one_list_ms, one_list_achiev
     a time), algorithmic bytes = SURVEY.md 8(d)'s per launch -- 44 B per consumed entry, the range table once per launch, 4 B per pixel
     of every tile a launch writes -- plus the 16 B per pixel an open tile's state costs each time it is stored or loaded.  The `valu`
     sub-block prices the same kernel against the vector ALU's issue rate, which is what bounds it: VALU wave
-    instructions per frame from the committed counter pass (profiles/r05_layers_pmc.txt; OFFLINE, like roofline.traffic) over
-    1 024 SIMDs x one wave instruction per 4 cycles at 2.4 GHz."""
+    instructions per frame from the committed counter pass (profiles/rNN_pmc_raster_layered.json; OFFLINE, like roofline.traffic, and
+    attached only when the kernel sources hash to what the counters were collected with) over 1 024 SIMDs x one wave instruction per
+    4 cycles at 2.4 GHz."""
     if layered is None:
         return {"kernel": f"rasterizeTilesKernel<2, {'epanechnikov' if args.epanechnikov else 'gaussian'}, SH {args.sh_degree}, one list>",
                 "launches_per_frame": 1, "kernel_ms_per_frame": round(one_list_ms, 4), "achieved": round(one_list_achieved, 1), "peak": HBM_PEAK_GBS,
@@ -553,13 +603,27 @@ def timed_loop_kernel(layered, args, tiles, band_h, one_list_ms, one_list_achiev
     default_scene = (args.splats == 1_000_000 and (args.width, args.height) == (1920, 1080) and args.sh_degree == 3 and args.seed == 1234
                      and args.opacity_mean == 1.0 and args.log_scale_mean == -3.6 and not args.epanechnikov)
     if default_scene and round(layered["launches"]) == 2:
-        per_launch = 9_090_689.3  # SQ_INSTS_VALU per dispatch of rasterizeTilesKernel<2, false, 3, true>, profiles/r05_layers_pmc.txt
-        issue_peak = SIMDS * 2.4e9 / 4.0  # wave instructions per second: 1 024 SIMDs, 4 cycles per wave64 instruction
-        floor_ms = 1e3 * per_launch * layered["launches"] / issue_peak
-        valu = {"wave_instructions_per_frame": round(per_launch * layered["launches"]), "issue_peak_per_s": issue_peak,
-                "ms_at_issue_peak": round(floor_ms, 4), "frac": round(floor_ms / ms, 4),
-                "source": "OFFLINE: SQ_INSTS_VALU per dispatch from profiles/r05_layers_pmc.txt (rocprofv3 --pmc pass of this workload with two depth "
-                          "layers, round 5's kernel; the LAYERED raster loop is unchanged since), not measured in this run"}
+        import glob
+
+        here, found = source_hash(), None
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r??_pmc_raster_layered.json")), reverse=True):
+            with open(path) as f:
+                c = json.load(f)
+            if c.get("source_hash") == here:
+                found = (c, "profiles/" + os.path.basename(path))
+                break
+        if found is None:
+            valu = {"note": f"no profiles/rNN_pmc_raster_layered.json was collected with this run's kernel sources (hash {here})"}
+        else:
+            c, name = found
+            per_launch = c["SQ_INSTS_VALU_per_dispatch"]
+            issue_peak = SIMDS * 2.4e9 / 4.0  # wave instructions per second: 1 024 SIMDs, 4 cycles per wave64 instruction
+            floor_ms = 1e3 * per_launch * layered["launches"] / issue_peak
+            valu = {"wave_instructions_per_frame": round(per_launch * layered["launches"]), "issue_peak_per_s": issue_peak,
+                    "ms_at_issue_peak": round(floor_ms, 4), "frac": round(floor_ms / ms, 4), "valu_issue_frac_by_counters": c.get("valu_issue_frac"),
+                    "waves_per_simd": c.get("waves_per_simd"),
+                    "source": f"OFFLINE: SQ_INSTS_VALU per dispatch of the LAYERED instantiation from {name} (a separate rocprofv3 --pmc pass of this workload "
+                              "with two depth layers, one frame in flight, same kernel sources by hash), not measured in this run"}
     return {"kernel": f"rasterizeTilesKernel<2, {'epanechnikov' if args.epanechnikov else 'gaussian'}, SH {args.sh_degree}, LAYERED>",
             "bound": "hbm", "launches_per_frame": round(layered["launches"], 2), "kernel_ms_per_frame": round(ms, 4),
             "kernel_ms_by_layer": [round(v, 4) for v in layered["ms_by_layer"]],
@@ -796,6 +860,11 @@ def main():
             "sustained": {"frames_per_s": round(frames / sustained_s, 1), "frames": frames, "seconds": round(sustained_s, 3),
                           "what": "the pipelined loop of `value` over >= 1.5 s, synchronised every 512 frames"},
         }
+        if not args.no_extra:
+            fine = [gs.camera_from_pose(p, q, W, H) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 360)]
+            latency["small_step_orbit"] = rig.small_step_orbit(fine)
+            rig.run_frames(16 * depth)  # (renderer 0 settles its depth layers again, untimed)
+            rig.sync_all()
     if world > 1:
         chain_gather_ms = rig.gather_ms(8)
         per_rank = {"timed_region_s_own_clock": [round(v, 5) for v in multigpu.all_gather_floats(rig.own_seconds, world, tensor_device)],

@@ -18,6 +18,8 @@ FOOTPRINT_GAUSSIAN = 0      # exp(-q/2), 3 sigma extent
 FOOTPRINT_EPANECHNIKOV = 1  # the reference's EPANECHNIKOV_KERNEL option: 1 - q/7, sqrt(7) sigma extent
 PIPELINE_REFERENCE = 0  # the reference's stage order: one 64-bit tile|depth radix sort of all pairs
 PIPELINE_TWO_LEVEL = 1  # default: depth-sort the splats, emit, stable-sort the pairs on the tile bits
+TILE_START_ORDER_SCREEN = 0  # the raster's tiles start in the XCD-aware screen order
+TILE_START_ORDER_PREVIOUS_FRAME = 1  # ... longest first by the previous frame's consumption (include/gsplat_hip.h)
 STORAGE_ORDER_CALLER = 0  # splats stored in the caller's order (the reference's behaviour)
 STAGED_BUILDER_REFERENCE_ORDER = 0  # gs_set_staged_builder: (splat, local tile) emission order + unconditional sort
 DEPTH_LAYERS_CHOOSE = 0  # gs_renderer_set_depth_layers: the renderer chooses from the frames' pair totals (for one frame at a time: two layers from 16 M pairs, three from 40 M)
@@ -409,6 +411,19 @@ class Renderer:
     def listed_pairs(self):
         """Pairs the last captured frame listed, summed over its depth layers."""
         return int(lib().gs_renderer_listed_pairs(self.handle))
+
+    def set_tile_start_order(self, mode):
+        """TILE_START_ORDER_SCREEN (default) or TILE_START_ORDER_PREVIOUS_FRAME: the raster's tiles started longest-first by the previous
+        frame's consumption (interactive cameras; same image bytes)."""
+        if lib().gs_renderer_set_tile_start_order(self.handle, int(mode)) != 0:
+            raise ValueError("gs_renderer_set_tile_start_order: unknown mode")
+
+    def tile_order_state(self):
+        """(table in force for the next frame, sum |consumed now - before|, sum consumed now, frames seen) or None."""
+        out = (C.c_int32 * 4)()
+        if lib().gs_renderer_debug_tile_order_state(self.handle, out) != 0:
+            return None
+        return tuple(int(v) for v in out)
 
     def set_footprint(self, footprint):
         """This renderer's footprint (FOOTPRINT_GAUSSIAN / FOOTPRINT_EPANECHNIKOV; -1 = the process-wide gs_set_footprint at frame time)."""

@@ -76,6 +76,23 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
     if (r->shDegree != 0 && !cull && !lazy)
         launchSphericalHarmonics(g.stream, n, r->shDegree, r->shCount, (const float4*) r->position, r->sh, unused, (float4*) r->color,
                                  params);
+    // gs_renderer_set_tile_start_order: the raster launches start their tiles by the table the previous frame left; the kernel that makes
+    // the next frame's table follows the frame's last raster launch
+    RasterSchedule schedule;
+    // (its buffers were made before the capture began: prepareTileStartOrder.  The two graph instances are launched alternately, so the
+    // instance's slot is the frame's parity: this frame's counters in one buffer, the previous frame's in the other)
+    const bool orderActive = tileStartOrderSchedule(r, scr, slot, &schedule);
+    const RasterSchedule* scheduleOrNull = &schedule;
+    // ... and the table itself is made at the start of the frame from the previous frame's counters: by the plain clip kernel's first eight
+    // workgroups, or (band cull, the clip kernel riding in the sort's scan launch) by a small kernel of its own right here
+    TileOrderArgs orderArgs = orderActive ? tileOrderArgsFor(r, scr, slot) : TileOrderArgs{};
+    if (orderActive) orderArgs.skipFlagDevice = &params[0].pad; // (renderCaptured sets it per replay: the camera jumped)
+    bool orderBuilt = !orderActive;
+    if (!orderBuilt && (cull || (g_ablation & 1) || (cfg.clipScanFusion && r->splatToStorage != nullptr && !(g_ablation & 2))))
+    {
+        launchTileStartOrder(g.stream, scr, orderArgs);
+        orderBuilt = true;
+    }
     const int* countDevice = nullptr;
     // Morton storage: the depth sort makes its own keys, so the clip kernel and the sort do not depend on each other -- the clip kernel
     // is handed to the sort and shares the launch of its first column scan (gs_internal.h RadixScanCompanion): 17 kernels per frame.
@@ -84,7 +101,8 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
         launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation, nullptr, nullptr, nullptr,
                             nullptr, r->splatToStorage != nullptr ? nullptr : r->depthKey[0],
                             r->splatToStorage != nullptr ? nullptr : (uint32_t*) r->order[0], nullptr, nullptr, nullptr, params, clearTable,
-                            clearEntries, (float4*) r->tileRecord, (float4*) r->rasterRecord, views, nullptr, tileBox);
+                            clearEntries, (float4*) r->tileRecord, (float4*) r->rasterRecord, views, nullptr, tileBox, nullptr, orderBuilt ? nullptr : &orderArgs);
+        orderBuilt = true;
     };
     if (!cull)
     {
@@ -212,7 +230,8 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
             layer.isLast = l + 1 == layers;
             if (probe != nullptr) GS_CHECK(hipEventRecord(probe->start[l], g.stream));
             launchRasterize(g.stream, scr, r->tileRange, r->values[sel], (const float2*) r->clipXY, (const float4*) r->conic, (const float4*) r->color,
-                            (uchar4*) r->backBuffer, probe != nullptr ? probe->counters + 4 * l : nullptr, true, lazyColours, (const float4*) r->rasterRecord, views, n, &layer);
+                            (uchar4*) r->backBuffer, probe != nullptr ? probe->counters + 4 * l : nullptr, true, lazyColours, (const float4*) r->rasterRecord, views, n, &layer,
+                            scheduleOrNull);
             if (probe != nullptr)
             {
                 GS_CHECK(hipEventRecord(probe->stop[l], g.stream));
@@ -249,7 +268,7 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
     r->radix.rangeTableForLastPass = nullptr;
     if (!(g_ablation & 64))
         launchRasterize(g.stream, scr, r->tileRange, r->values[sel], (const float2*) r->clipXY, (const float4*) r->conic,
-                        (const float4*) r->color, (uchar4*) r->backBuffer, nullptr, true, lazyColours, (const float4*) r->rasterRecord, views, n);
+                        (const float4*) r->color, (uchar4*) r->backBuffer, nullptr, true, lazyColours, (const float4*) r->rasterRecord, views, n, nullptr, scheduleOrNull);
     r->graphSelector = sel;
     r->graphKeyBytes = tileKeyBytes;
     return 0;
@@ -353,6 +372,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
         fp[v].camera.depthBias = camera->depthScaleBias[1];
         for (int k = 0; k != 3; ++k) fp[v].cameraPosition[k] = r->lastCameraPosition[k] = camera->position[k];
     }
+    if (r->tileStartOrder == GS_TILE_START_ORDER_PREVIOUS_FRAME && r->views == 1) fp[0].pad = cameraJumped(r, cameras[0].view) ? 1.0f : 0.0f;
     r->colourStale = lazy;
 
     // A frame whose pair demand exceeds the list capacity is NOT handed out (the reference would show it truncated and double
@@ -363,11 +383,12 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
         if (r->graphValid && (r->graphCapacity != r->tileListCapacity || r->graphSplats != n || r->graphRowBegin != scr.rowBegin ||
                               r->graphRowEnd != scr.rowEnd || r->graphCull != (int) cull ||
                               r->graphFootprint != scr.epanechnikov || r->graphLazy != (int) lazy || r->graphAblation != g_ablation ||
-                              r->graphFusion != ((int) effectiveListFusion() | ((int) cfg.clipScanFusion << 1) | (effectivePixelsPerLane() << 2) | ((int) r->blockCull << 5)) || r->graphLayers != (r->depthLayers > 0 ? r->depthLayers : r->autoLayers)))
+                              r->graphFusion != ((int) effectiveListFusion() | ((int) cfg.clipScanFusion << 1) | (effectivePixelsPerLane() << 2) | ((int) r->blockCull << 5) | (r->tileStartOrder << 6) | ((int) r->tileOrderManual << 7)) || r->graphLayers != (r->depthLayers > 0 ? r->depthLayers : r->autoLayers)))
             r->graphValid = false;
         if (!r->graphValid)
         {
             GS_CHECK(hipStreamSynchronize(g.stream)); // frames of the old instances drain before these are destroyed
+            prepareTileStartOrder(r, scr);            // (allocates under the capture mutex itself: before this block takes it)
             std::lock_guard<std::mutex> lock(g_captureMutex);
             // allocate everything the frame needs BEFORE capturing (no allocation may happen inside a capture)
             ensureTileListFastScratch(r->scratch, n * r->views);
@@ -413,7 +434,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
             r->graphFootprint = scr.epanechnikov;
             r->graphLazy = (int) lazy;
             r->graphAblation = g_ablation;
-            r->graphFusion = (int) effectiveListFusion() | ((int) cfg.clipScanFusion << 1) | (effectivePixelsPerLane() << 2) | ((int) r->blockCull << 5);
+            r->graphFusion = (int) effectiveListFusion() | ((int) cfg.clipScanFusion << 1) | (effectivePixelsPerLane() << 2) | ((int) r->blockCull << 5) | (r->tileStartOrder << 6) | ((int) r->tileOrderManual << 7);
             r->graphLayers = r->depthLayers > 0 ? r->depthLayers : r->autoLayers;
         }
         const int slot = r->graphSlot;

@@ -20,6 +20,7 @@
 #include "gs_depth_key.h"
 #include "gs_internal.h"
 #include "gs_radix_scan.h"
+#include "gs_tile_order.h"
 
 #pragma clang fp contract(off)
 
@@ -308,11 +309,20 @@ __device__ __forceinline__ void clipDataBlock(int block, int blocks, int view, i
 __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr, ClipCamera camArg, const FrameParams* __restrict__ params,
                                                             const float4* __restrict__ position,
                                                             const float4* __restrict__ scaleAndRotation, ClipOutputs o,
-                                                            int32_t* __restrict__ rangeTable, int rangeEntries)
+                                                            int32_t* __restrict__ rangeTable, int rangeEntries, TileOrderArgs tileOrder)
 {
+    // gs_renderer_set_tile_start_order: the frame's tile start order is made by the first eight workgroups of this launch (one per XCD;
+    // they are dispatched first and are done long before the clip stage's streaming ends) -- no kernel of its own, nothing on the
+    // frame's critical path
+    const int orderBlocks = tileOrder.slots > 0 ? kOrderWorkgroups : 0;
+    if ((int) blockIdx.x < orderBlocks) // (uniform per workgroup)
+    {
+        if (blockIdx.y == 0) tileStartOrderBody<256>((int) blockIdx.x, scr, tileOrder);
+        return;
+    }
     // gs_renderer_set_views: one grid row per camera
-    clipDataBlock((int) blockIdx.x, (int) gridDim.x, (int) blockIdx.y, (int) gridDim.y, count, scr, camArg, params, position, scaleAndRotation, o, rangeTable,
-                  rangeEntries);
+    clipDataBlock((int) blockIdx.x - orderBlocks, (int) gridDim.x - orderBlocks, (int) blockIdx.y, (int) gridDim.y, count, scr, camArg, params, position,
+                  scaleAndRotation, o, rangeTable, rangeEntries);
 }
 
 // The same, sharing its launch with the FIRST column scan of the depth sort (gs_internal.h RadixScanCompanion).  A renderer with Morton
@@ -724,7 +734,7 @@ void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const
                          uint32_t* depthKey, uint32_t* splatOrder, unsigned long long* bandMask, int32_t* bandSlotPrefix,
                          int32_t* bandBlockCounts, const FrameParams* paramsDevice, int32_t* rangeTableToClear, int rangeEntries,
                          float4* tileRecord, float4* rasterRecord, int views, const int32_t* bandOutSlot, ushort4* tileBox,
-                         const BandBlockCull* blockCull)
+                         const BandBlockCull* blockCull, const TileOrderArgs* tileOrder)
 {
     if (count <= 0) return;
     // views > 1: cameras from paramsDevice[view], results under view * count + splat
@@ -756,8 +766,11 @@ void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const
                            paramsDevice, position, scaleAndRotation, o, bandMask, bandSlotPrefix, bandBlockCounts, rangeTableToClear,
                            rangeEntries, bandOutSlot, nullptr, nullptr, nullptr);
     else
-        hipLaunchKernelGGL(splatClipDataKernel, dim3((count + 255) / 256, views), dim3(256), 0, stream, count, scr, cam, paramsDevice, position,
-                           scaleAndRotation, o, rangeTableToClear, rangeEntries);
+    {
+        const TileOrderArgs order = tileOrder != nullptr ? *tileOrder : TileOrderArgs{};
+        hipLaunchKernelGGL(splatClipDataKernel, dim3((count + 255) / 256 + (order.slots > 0 ? kOrderWorkgroups : 0), views), dim3(256), 0, stream, count, scr, cam,
+                           paramsDevice, position, scaleAndRotation, o, rangeTableToClear, rangeEntries, order);
+    }
 }
 
 void launchSplatClipDataWithScan(hipStream_t stream, const ClipWithScan& c, const RadixScanArgs& scan)

@@ -67,7 +67,7 @@ struct FrameParams
 {
     ClipCamera camera;
     float cameraPosition[3];
-    float pad;
+    float pad; // (view 0's: non-zero = the camera jumped since this renderer's previous frame, gs_renderer_set_tile_start_order)
 };
 
 // Block-level band cull (gs_clip.hip): per block of 256 splats in storage order, the box of the centres and a bound on the largest
@@ -93,6 +93,23 @@ struct BandBlockCull
 };
 void launchBlockBounds(hipStream_t stream, int count, const float4* position, const float4* scaleAndRotation, BlockBound* bounds);
 
+// The start order of a frame's raster tiles from the PREVIOUS frame's consumption (gs_renderer_set_tile_start_order, gs_tile_order.h): made
+// at the start of the frame -- by the first eight workgroups of the clip kernel (launchSplatClipData: tileOrderOrNull) or by a small kernel
+// of its own.  state: [0] the table is in force for this frame, [1] sum |now - prev| over the tiles, [2] sum now, [3] frames seen, [4..8]
+// the workgroups' partial sums and arrival count.
+struct TileOrderArgs
+{
+    const int32_t* now = nullptr; // per tile: entries consumed in the frame that just ended
+    int32_t* prev = nullptr;      // ... in the frame before it; cleared here: the frame that starts writes its own counters into it
+    int32_t* order = nullptr;     // [slots]: grid slot -> tile, -1 = none
+    int32_t* state = nullptr;
+    int slots = 0;
+    float maxMismatch = 0.35f;
+    int skip = 0;                          // the host saw the camera jump: clear the counters, withdraw the table, build nothing
+    const float* skipFlagDevice = nullptr; // ... the same from device memory (captured frames: FrameParams::pad of view 0, refreshed per replay)
+};
+void launchTileStartOrder(hipStream_t stream, const Screen& scr, const TileOrderArgs& args);
+
 // ---- launchers (one per stage); all enqueue on `stream` and return without synchronising --------
 void launchSphericalHarmonics(hipStream_t stream, int count, int degree, int shCount, const float4* position, const float* sh,
                               float3 cameraPosition, float4* color, const FrameParams* paramsDeviceOrNull = nullptr);
@@ -108,7 +125,10 @@ void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const
                          ushort4* tileBoxOrNull = nullptr /* depth layers: the list builder's box per splat (gs_aabb.h splatTileBox) */,
                          // band cull of a Morton-stored scene by blocks (gs_clip.hip): position / scaleAndRotation are then the STORAGE-ordered
                          // arrays, bandOutSlot is null, clipZ is not written (launchBandCompaction makes the depth keys from positionCaller)
-                         const BandBlockCull* blockCullOrNull = nullptr);
+                         const BandBlockCull* blockCullOrNull = nullptr,
+                         // gs_renderer_set_tile_start_order: the plain kernel (no band cull) builds this frame's tile start order with its first
+                         // eight workgroups; ignored by the band kernels (the caller launches launchTileStartOrder itself)
+                         const TileOrderArgs* tileOrderOrNull = nullptr);
 // screenEllipse[i] = (cos, sin, extent x, extent y) from the 32-byte tile records the clip kernel can write instead.
 void launchUnpackEllipse(hipStream_t stream, int count, const float4* tileRecord, float4* screenEllipse);
 // positionClipSpaceXY / Z / conic from the 32-byte raster records (cx, cy, conic.x, conic.y | conic.z, depth, 0, 0) the clip kernel can
@@ -338,8 +358,9 @@ struct RasterLayer
 // XCD-aware screen-order map, and where every tile leaves the number of list entries it consumed.
 struct RasterSchedule
 {
-    const int32_t* order = nullptr; // [grid slots of the launch]
-    int32_t* consumedOut = nullptr; // [(virtual) tiles]
+    const int32_t* order = nullptr;   // [grid slots of the launch]
+    int32_t* consumedOut = nullptr;   // [(virtual) tiles]: list entries the tile has consumed in this frame (all its layers)
+    const int32_t* enabled = nullptr; // device word: the table is used only while it is non-zero (null: always)
 };
 bool rasterCanEvaluateColours(int degree, int shCount);
 void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileRange, const int32_t* values,

@@ -22,6 +22,7 @@
 // ~11 VALU ops for each of 256 pixels ("Raster roofline").
 #include "gs_state.h"
 #include "gs_sh_eval.h"
+#include "gs_tile_order.h"
 
 namespace gs
 {
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(LAYER
     // Larger blocks share more but balance worse: 8 x 8 51.4 MB at -2 % frames/s, 16 x 4 43.4 MB at -16 %; 4 x 4 69 MB.
     // Edge blocks have idle workgroups (they exit).
     int tile;
-    if (schedule.order != nullptr)
+    if (schedule.order != nullptr && (schedule.enabled == nullptr || *schedule.enabled != 0))
     {
         // Experiment (gs_renderer_debug_set_tile_order): grid slot -> tile from a table, e.g. the tiles that
         // consumed most entries in the previous frame first.  The order in which tiles START changes no tile's arithmetic.
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(256 / PPL) __attribute__((amdgpu_waves_per_eu(LAYER
     }
 
     if (consumedPairs != nullptr && t == 0) atomicAdd(consumedPairs, (unsigned long long) (consumed - lead));
-    if (schedule.consumedOut != nullptr && t == 0) schedule.consumedOut[vtile] = consumed - lead; // (what a start order for the NEXT frame would be made from)
+    if (schedule.consumedOut != nullptr && t == 0) schedule.consumedOut[vtile] = consumedBefore + consumed - lead; // (what the NEXT frame's start order is made from)
     if constexpr (LAYERED)
     {
         // (diagnostics, gs_renderer_debug_layered_raster_report: tiles that ran in this layer and tiles that loaded their state -- the
@@ -553,6 +554,26 @@ void launchRasterize(hipStream_t stream, const Screen& scr, const int32_t* tileR
     }
 #undef GS_LAUNCH_RASTER
 #undef GS_LAUNCH_RASTER_L
+}
+
+// ---- the start order of the next frame's tiles (gs_renderer_set_tile_start_order) ---------------------------------------------------
+// The raster kernel's 60 us at BASELINE.json configs[2] are 36 us of full-chip work and a tail of tiles that consume several hundred
+// entries and happen to start late: the grid is dispatched in screen order.  Which tiles are long is only known by blending them --
+// but an interactive camera moves a little per frame (Demo.cpp:371-392), and the previous frame's consumption predicts this frame's:
+// starting the tiles longest-first by it takes the kernel from 62.5 to 48.1 us at 1-degree steps (46.5 with the frame's own counts;
+// tools/tile_order_experiment.py, profiles/r06_tile_order.txt).  This kernel -- one workgroup behind the frame's last raster launch --
+// makes the table: every tile keeps the XCD of its 8 x 4 block (its neighbours' splats are in that L2), and within an XCD the tiles
+// are started in descending order of the largest consumption in their 3 x 3 neighbourhood (a 1-degree step moves the image by about
+// one tile), bucketed by vote chunks of 32.  A wrong prediction is WORSE than none (tiles that turn out long all start last: +20 % at
+// 5 degrees on one view), so the table is only put in force when the last two frames' consumption differed by less than
+// maxMismatch (sum |now - previous| / sum now): a camera that jumps falls back to the screen order by itself.
+// (A first version ran as ONE workgroup: 35 us of latency behind every raster launch, more than the order saves.)
+__global__ __launch_bounds__(1024) void tileStartOrderKernel(Screen scr, TileOrderArgs args) { tileStartOrderBody<1024>((int) blockIdx.x, scr, args); }
+
+void launchTileStartOrder(hipStream_t stream, const Screen& scr, const TileOrderArgs& args)
+{
+    if (scr.rowEnd <= scr.rowBegin || args.slots <= 0) return;
+    hipLaunchKernelGGL(tileStartOrderKernel, dim3(kOrderWorkgroups), dim3(1024), 0, stream, scr, args);
 }
 
 int rasterGridSlots(int tilesX, int rows)

@@ -219,6 +219,8 @@ extern "C" void gs_renderer_destroy(GsRenderer* r)
     gs_device_free(r->tileRange);
     gs_device_free(r->tileOrder);
     gs_device_free(r->tileConsumed);
+    gs_device_free(r->tileConsumedPair);
+    gs_device_free(r->tileOrderState);
     gs_device_free(r->layerState);
     gs_device_free(r->layerConsumed);
     gs_device_free(r->frameTotals);
@@ -321,6 +323,114 @@ extern "C" void gs_renderer_set_footprint(GsRenderer* r, int footprint)
     r->footprint = footprint == GS_FOOTPRINT_EPANECHNIKOV ? GS_FOOTPRINT_EPANECHNIKOV : footprint == GS_FOOTPRINT_GAUSSIAN ? GS_FOOTPRINT_GAUSSIAN : -1;
 }
 extern "C" int gs_renderer_footprint(const GsRenderer* r) { return r->footprint >= 0 ? r->footprint : g_footprint; }
+namespace gs
+{
+static bool tileStartOrderWanted(const GsRenderer* r, int slots)
+{
+    return !r->tileOrderManual && r->tileStartOrder == GS_TILE_START_ORDER_PREVIOUS_FRAME && r->views == 1 && slots > 0;
+}
+void prepareTileStartOrder(GsRenderer* r, const Screen& scr)
+{
+    const int slots = rasterGridSlots(scr.tilesX, scr.rowEnd - scr.rowBegin);
+    if (!tileStartOrderWanted(r, slots)) return;
+    if (r->tileOrder != nullptr && r->tileOrderSlots == slots && r->tileConsumedPair != nullptr && r->tileOrderState != nullptr) return;
+    // (the band changed, or the first frame with the option: everything starts from zero -- the table is not in force until two
+    // consecutive frames resembled each other)
+    std::lock_guard<std::mutex> lock(g_captureMutex);
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    gs_device_free(r->tileOrder);
+    gs_device_free(r->tileConsumedPair);
+    gs_device_free(r->tileOrderState);
+    const size_t tiles = (size_t) scr.totalTiles;
+    r->tileOrder = (int32_t*) gs_device_alloc(sizeof(int32_t) * (size_t) slots);
+    r->tileConsumedPair = (int32_t*) gs_device_alloc(sizeof(int32_t) * 2 * tiles);
+    r->tileOrderState = (int32_t*) gs_device_alloc(sizeof(int32_t) * 16);
+    GS_CHECK(hipMemsetAsync(r->tileOrder, 0xFF, sizeof(int32_t) * (size_t) slots, g.stream));
+    GS_CHECK(hipMemsetAsync(r->tileConsumedPair, 0, sizeof(int32_t) * 2 * tiles, g.stream));
+    GS_CHECK(hipMemsetAsync(r->tileOrderState, 0, sizeof(int32_t) * 16, g.stream));
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    r->tileOrderSlots = slots;
+    r->graphValid = false;
+}
+bool tileStartOrderSchedule(const GsRenderer* r, const Screen& scr, int parity, RasterSchedule* schedule)
+{
+    *schedule = RasterSchedule{};
+    const int slots = rasterGridSlots(scr.tilesX, scr.rowEnd - scr.rowBegin);
+    if (r->tileOrderManual)
+    {
+        // experiments: a host table, no order kernel; the per-tile counters only when the host armed them
+        if (r->tileConsumedArmed) schedule->consumedOut = r->tileConsumed;
+        if (r->tileOrder != nullptr && r->tileOrderSlots == slots) schedule->order = r->tileOrder;
+        return false;
+    }
+    if (!tileStartOrderWanted(r, slots) || r->tileOrder == nullptr || r->tileOrderSlots != slots || r->tileConsumedPair == nullptr)
+    {
+        if (r->tileConsumedArmed) schedule->consumedOut = r->tileConsumed; // (experiments: the counters by themselves)
+        return false;
+    }
+    schedule->order = r->tileOrder;
+    schedule->consumedOut = r->tileConsumedPair + (size_t) (parity & 1) * (size_t) scr.totalTiles;
+    schedule->enabled = r->tileOrderState;
+    return true;
+}
+bool cameraJumped(GsRenderer* r, const float view[16])
+{
+    // the rotation part of the view matrix: a 1-degree step changes an entry by at most 0.0175, and beyond ~3 degrees the previous
+    // frame's consumption predicts poorly (profiles/r06_tile_order.txt: -23 % raster time at 1 degree, -9 % at 5 with one view at +20 %)
+    bool jumped = !r->tileOrderHaveLastView;
+    for (int c = 0; c != 3 && !jumped; ++c)
+        for (int k = 0; k != 3; ++k)
+            if (!(fabsf(view[c * 4 + k] - r->tileOrderLastView[c * 4 + k]) <= 0.06f)) jumped = true;
+    std::memcpy(r->tileOrderLastView, view, sizeof(r->tileOrderLastView));
+    r->tileOrderHaveLastView = true;
+    return jumped;
+}
+TileOrderArgs tileOrderArgsFor(const GsRenderer* r, const Screen& scr, int parity)
+{
+    const size_t tiles = (size_t) scr.totalTiles;
+    TileOrderArgs a;
+    a.now = r->tileConsumedPair + (size_t) ((parity & 1) ^ 1) * tiles; // the frame that just ended
+    a.prev = r->tileConsumedPair + (size_t) (parity & 1) * tiles;      // the one before it; cleared: this frame's raster writes it
+    a.order = r->tileOrder;
+    a.state = r->tileOrderState;
+    a.slots = r->tileOrderSlots;
+    a.maxMismatch = r->tileOrderMaxMismatch;
+    return a;
+}
+} // namespace gs
+
+extern "C" int gs_renderer_set_tile_start_order(GsRenderer* r, int mode)
+{
+    if (mode != GS_TILE_START_ORDER_SCREEN && mode != GS_TILE_START_ORDER_PREVIOUS_FRAME) return -1;
+    if (mode != r->tileStartOrder || r->tileOrderManual)
+    {
+        StreamScope scope(r);
+        GS_CHECK(hipStreamSynchronize(g.stream));
+        // (the next frame with the option starts its history afresh)
+        gs_device_free(r->tileConsumedPair);
+        r->tileConsumedPair = nullptr;
+        r->tileOrderManual = false;
+        r->graphValid = false;
+    }
+    r->tileStartOrder = mode;
+    return 0;
+}
+extern "C" int gs_renderer_tile_start_order(const GsRenderer* r) { return r->tileStartOrder; }
+extern "C" int gs_renderer_debug_tile_order_state(GsRenderer* r, int32_t out[4])
+{
+    for (int k = 0; k != 4; ++k) out[k] = 0;
+    if (r->tileOrderState == nullptr) return -1;
+    StreamScope scope(r);
+    GS_CHECK(hipStreamSynchronize(g.stream));
+    gs_device_download(out, r->tileOrderState, sizeof(int32_t) * 4);
+    return 0;
+}
+extern "C" void gs_renderer_debug_set_tile_order_max_mismatch(GsRenderer* r, float maxMismatch)
+{
+    r->tileOrderMaxMismatch = maxMismatch > 0.0f ? maxMismatch : 0.35f;
+    r->graphValid = false; // (a kernel argument of the captured frame)
+}
+
 // Experiment (tools/tile_order_experiment.py): the start order of the raster's tiles.
 extern "C" int gs_renderer_debug_raster_grid_slots(const GsRenderer* r)
 {
@@ -334,6 +444,8 @@ extern "C" int gs_renderer_debug_set_tile_order(GsRenderer* r, const int32_t* sl
     gs_device_free(r->tileOrder);
     r->tileOrder = nullptr;
     r->tileOrderSlots = 0;
+    r->tileOrderManual = slotToTileHost != nullptr && slots > 0; // (a host table switches the order kernel off until gs_renderer_set_tile_start_order is called again)
+    r->graphValid = false;
     if (slotToTileHost == nullptr || slots <= 0) return 0;
     if (slots != gs_renderer_debug_raster_grid_slots(r)) return -1;
     r->tileOrder = (int32_t*) gs_device_alloc(sizeof(int32_t) * (size_t) slots);
@@ -348,6 +460,7 @@ extern "C" int gs_renderer_debug_tile_consumed(GsRenderer* r, int32_t* perTileHo
     const Screen scr = makeScreen(r->width, r->height, 0, 0);
     if (r->tileConsumed == nullptr)
     {
+        r->tileConsumedArmed = true; // (the experiment's frames: per-tile counters; with the option on, the order kernel clears them after every frame)
         r->tileConsumed = (int32_t*) gs_device_alloc(sizeof(int32_t) * (size_t) scr.totalTiles);
         gs_device_memset(r->tileConsumed, 0, sizeof(int32_t) * (size_t) scr.totalTiles);
         GS_CHECK(hipStreamSynchronize(g.stream));
@@ -780,11 +893,27 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         ClipWithScan deferredClip;
         // (Morton storage on the native sort: no keys from the clip kernel -- the depth sort's first pass makes them in the caller's order)
         const bool keysFromSort = !cull && r->splatToStorage != nullptr && cfg.sortBackend == GS_SORT_BACKEND_NATIVE && radixSortSupported(4, n);
+        // gs_renderer_set_tile_start_order: this frame's tile start order is made at its start from the previous frame's consumption -- by the
+        // plain clip kernel's first eight workgroups, or (band cull, the clip kernel riding in the sort's scan launch) by a kernel of its own
+        prepareTileStartOrder(r, scr);
+        RasterSchedule scheduleProbe;
+        f.tileOrderParity = r->tileOrderParity;
+        f.tileOrderActive = tileStartOrderSchedule(r, scr, f.tileOrderParity, &scheduleProbe);
+        TileOrderArgs orderArgs = f.tileOrderActive ? tileOrderArgsFor(r, scr, f.tileOrderParity) : TileOrderArgs{};
+        if (f.tileOrderActive) orderArgs.skip = cameraJumped(r, camera->view) ? 1 : 0;
+        bool orderBuilt = !f.tileOrderActive;
         const auto launchClip = [&]() { // the clip kernel of a frame without band cull, by itself
             launchSplatClipData(g.stream, n, scr, currentCamera(), (const float4*) r->position, (const float4*) r->scaleAndRotation, nullptr, nullptr, nullptr,
                                 nullptr, keysFromSort ? nullptr : r->depthKey[0], r->splatToStorage != nullptr ? nullptr : (uint32_t*) r->order[0], nullptr,
-                                nullptr, nullptr, nullptr, r->tileRange, 2 * scr.totalTiles, (float4*) r->tileRecord, (float4*) r->rasterRecord);
+                                nullptr, nullptr, nullptr, r->tileRange, 2 * scr.totalTiles, (float4*) r->tileRecord, (float4*) r->rasterRecord, 1, nullptr, nullptr, nullptr,
+                                orderBuilt ? nullptr : &orderArgs);
+            orderBuilt = true;
         };
+        if (!orderBuilt && (cull || n <= 0 || (keysFromSort && cfg.clipScanFusion && !timed)))
+        {
+            launchTileStartOrder(g.stream, scr, orderArgs);
+            orderBuilt = true;
+        }
         if (!cull)
         {
             // The sort makes its own keys: the clip kernel shares the launch of the sort's first column scan (gs_internal.h
@@ -973,14 +1102,15 @@ extern "C" int gs_renderer_finish(GsRenderer* r, GsFrameStats* stats)
     gs_timer_start(stageTimers[5]);
     const RasterColourSource lazySource = colourSource(r, f.cameraPosition, nullptr);
     RasterSchedule schedule;
-    schedule.consumedOut = r->tileConsumed; // (experiment hooks: null unless gs_renderer_debug_tile_consumed / _set_tile_order were used)
-    if (r->tileOrder != nullptr && r->tileOrderSlots == rasterGridSlots(scr.tilesX, scr.rowEnd - scr.rowBegin)) schedule.order = r->tileOrder;
+    if (f.tileOrderActive) (void) tileStartOrderSchedule(r, scr, f.tileOrderParity, &schedule); // (begin() made the table; this frame's counters: its parity's buffer)
+    else (void) tileStartOrderSchedule(r, scr, 0, &schedule);                                    // (experiments' manual table / counters, or nothing)
     launchRasterize(g.stream, scr, r->tileRange, r->values[r->selector], (const float2*) r->clipXY, (const float4*) r->conic,
                     (const float4*) r->color, (uchar4*) r->backBuffer, consumed, r->pipeline != GS_PIPELINE_REFERENCE,
                     f.lazyColours ? &lazySource : nullptr, r->pipeline != GS_PIPELINE_REFERENCE ? (const float4*) r->rasterRecord : nullptr, 1, 0, nullptr,
                     &schedule);
     r->colourStale = f.lazyColours;
     gs_timer_stop(stageTimers[5]);
+    if (f.tileOrderActive) r->tileOrderParity ^= 1;
     if (hipGetLastError() != hipSuccess) printf("kernel error renderDepthBuffer\n");
     if (blocking) st.msRasterize = gs_timer_elapsed_ms(stageTimers[5]);
 

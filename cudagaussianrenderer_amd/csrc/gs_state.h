@@ -106,6 +106,8 @@ struct FrameState
     int orderSel = 0, tileKeyBytes = 2;
     int sortBits = 0; // low tile bits already sorted by the emit pass (gs_tiles_fast.hip), 0 = none
     bool lazyColours = false; // colours are evaluated by the raster kernel, entry by entry (no SH pass this frame)
+    bool tileOrderActive = false; // gs_renderer_set_tile_start_order: begin() made this frame's table; finish()'s raster uses it
+    int tileOrderParity = 0;
     float cameraPosition[3] = {0.f, 0.f, 0.f};
     int32_t size = 0;
     GsFrameStats st{};
@@ -203,10 +205,20 @@ struct GsRenderer
     int footprint = -1;    // gs_renderer_set_footprint
     int listFusion = -1;   // gs_renderer_debug_set_list_fusion
     int pixelsPerLane = 0; // gs_renderer_debug_set_raster_pixels_per_lane
-    // experiment (gs_renderer_debug_set_tile_order): the raster's start order from a table, and every tile's consumed entries of the last plain frame
+    // gs_renderer_set_tile_start_order: the raster's tiles started longest-first by the previous frame's consumption (gs_raster.hip
+    // tileStartOrderKernel); tileOrderManual: a table the host handed in instead (gs_renderer_debug_set_tile_order, experiments)
+    int tileStartOrder = GS_TILE_START_ORDER_SCREEN;
+    float tileOrderMaxMismatch = 0.35f;
+    bool tileOrderManual = false;
+    float tileOrderLastView[16] = {}; // the previous frame's view matrix (cameraJumped)
+    bool tileOrderHaveLastView = false;
+    bool tileConsumedArmed = false; // gs_renderer_debug_tile_consumed: the raster leaves its per-tile counters also when no order kernel runs
     int32_t* tileOrder = nullptr;
     int tileOrderSlots = 0;
-    int32_t* tileConsumed = nullptr;
+    int32_t* tileConsumed = nullptr;     // per tile: entries consumed in the frame being rendered (experiments: the one buffer)
+    int32_t* tileConsumedPair = nullptr; // the option's two buffers [2][tiles]: a frame writes the one of its parity, the other holds the previous frame's
+    int tileOrderParity = 0;             // parity of the next PLAIN frame (captured frames: the graph instance's slot)
+    int32_t* tileOrderState = nullptr;   // device: [0] table in force, [1] sum |now - previous|, [2] sum now, [3] frames seen
     // block-level band cull (gs_clip.hip; Morton storage only): the per-block bounds made at set_scene (the scene owner's when shared),
     // this renderer's per-frame block flags and storage-ordered keep masks
     gs::BlockBound* blockBounds = nullptr;
@@ -268,6 +280,15 @@ bool useBlockCull(const GsRenderer* r, BandBlockCull* cull);
 int effectiveDepthLayers(const GsRenderer* r, float fraction[kMaxDepthLayers]);
 size_t rangeTableInts(const Screen& scr, int views); // ranges of all views + the depth layers' status bytes and open bits behind them, in ints
 int openWordsPerRow(int tilesX);
+// gs_renderer_set_tile_start_order: prepareTileStartOrder makes the buffers the option needs (never inside a capture; takes the capture
+// mutex itself); tileStartOrderSchedule fills the raster launches' start-order arguments for this renderer's next frame and says whether
+// the order kernel follows the frame's last raster launch.
+void prepareTileStartOrder(GsRenderer* r, const Screen& scr);
+bool tileStartOrderSchedule(const GsRenderer* r, const Screen& scr, int parity, RasterSchedule* schedule);
+// (what the builder at the START of the frame of this parity works on: the previous frame's counters -- the other buffer -- as `now`)
+TileOrderArgs tileOrderArgsFor(const GsRenderer* r, const Screen& scr, int parity);
+// Did the camera turn by more than ~3 degrees since this renderer's previous frame (or is there none)?  Remembers `view` for the next call.
+bool cameraJumped(GsRenderer* r, const float view[16]);
 // Captured path (gs_capture.hip).  `cameras`: r->views of them (one frame per view, rendered by one chain).
 int renderCaptured(GsRenderer* r, const GsCameraData* cameras);
 // Allocation / legacy-stream work of one host thread must not overlap another thread's stream capture: set-up and capture

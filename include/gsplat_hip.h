@@ -323,6 +323,19 @@ int gs_renderer_depth_layers_in_use(const GsRenderer* r); /* layers the last cap
 /* Pairs the last captured frame listed: summed over its depth layers (gs_last_tile_list_demand then holds the largest layer's total,
  * which is what the list capacity must hold); the frame's pair total with one layer.  Waits for the renderer's stream. */
 int64_t gs_renderer_listed_pairs(GsRenderer* r);
+/* Addition: the order in which the raster's tiles START.  SCREEN (default): the XCD-aware screen order.  PREVIOUS_FRAME: the tiles that
+ * consumed the most list entries in the renderer's previous frame first (each on the XCD of its 8 x 4 block, neighbours' consumption
+ * counted in) -- for the host the reference is: an interactive viewer whose camera moves a little per frame (Demo.cpp:371-392).  The
+ * raster kernel's time is 36 us of full-chip work plus a tail of long tiles that happened to start late; which tiles are long is only
+ * known by blending them, but the previous frame knows: 62.5 -> 48.1 us at 1-degree camera steps on BASELINE.json configs[2]
+ * (profiles/r06_tile_order.txt).  One small kernel behind the frame's last raster launch makes the next frame's table, and puts it in
+ * force only when the last two frames' per-tile consumption differed by less than 35 % (a wrong prediction is worse than none): a camera
+ * that jumps gets the screen order by itself.  The order in which tiles start changes no byte of any frame.  Single-view renderers
+ * (gs_renderer_set_views 1), plain and captured frames, depth layers included; returns 0, -1 for an unknown mode. */
+#define GS_TILE_START_ORDER_SCREEN 0
+#define GS_TILE_START_ORDER_PREVIOUS_FRAME 1
+int gs_renderer_set_tile_start_order(GsRenderer* r, int mode);
+int gs_renderer_tile_start_order(const GsRenderer* r);
 /* Addition: how the renderer STORES the splats of the next gs_renderer_set_scene.  CALLER (default): in the caller's order, like the
  * reference (Demo.cpp:314-331).  MORTON: along a 3-D Morton curve through their positions -- the spatial ordering the reference's
  * author names as the cure for the raster's scattered gathers (README.md:138).  Frames are byte-identical either way, for every scene:

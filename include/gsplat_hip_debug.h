@@ -55,6 +55,12 @@ typedef struct GsLayeredRasterReport
     int64_t stateTileStores[4];
 } GsLayeredRasterReport;
 int gs_renderer_debug_layered_raster_report(GsRenderer* r, const GsCameraData* camera, GsLayeredRasterReport* out);
+/* gs_renderer_set_tile_start_order's state after the renderer's last frame: out[0] 1 = the table is in force for the next frame, out[1] sum
+ * over the tiles of |consumed now - consumed in the frame before|, out[2] sum consumed now, out[3] frames the order kernel has seen; -1 when
+ * the option never ran.  Waits for the renderer's stream.  ..._max_mismatch: the largest out[1] / out[2] at which the table is put in force
+ * (default 0.35). */
+int gs_renderer_debug_tile_order_state(GsRenderer* r, int32_t out[4]);
+void gs_renderer_debug_set_tile_order_max_mismatch(GsRenderer* r, float maxMismatch);
 /* Experiment ("start order of the raster's tiles"; tools/tile_order_experiment.py): plain (un-captured, single-view)
  * frames of this renderer start their raster tiles in the order of a table -- grid slot -> tile index, -1 = no tile; `slots` must be
  * gs_renderer_debug_raster_grid_slots (slot q runs on XCD q % 8); NULL / 0 = the XCD-aware screen order again.  The order in which tiles

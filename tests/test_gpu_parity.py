@@ -1012,6 +1012,67 @@ def test_two_threads_with_different_footprints_share_no_switch(gs, gsref, tmp_pa
     r.close()
 
 
+def test_tile_start_order_changes_no_byte_and_follows_the_camera(gs, tmp_path):
+    """gs_renderer_set_tile_start_order(PREVIOUS_FRAME): the raster's tiles start longest-first by the previous frame's consumption.  The
+    order in which tiles start is no part of any tile's arithmetic: plain, captured and two-layer captured frames of an orbit in 1-degree
+    steps are the screen-order renderer's bytes.  The order kernel puts its table in force while consecutive frames resemble each other
+    (small steps) and withdraws it by itself when the camera jumps (45 degrees), then engages again.  Band-culled frames (the builder as a
+    kernel of its own instead of the clip kernel's first workgroups) likewise."""
+    from cudagaussianrenderer_amd import scenes
+
+    w, h = 1280, 720
+    ply = _ply_scene(gs, tmp_path, 200_000, 3, log_scale_mean=-3.6)
+    scene = (ply["position"], ply["scaleAndRotation"], ply["color"], ply["sh"], ply["shDegree"], ply["shCount"])
+    fine = [gs.camera_from_pose(p, q, w, h) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 360)]
+    path = [fine[k] for k in range(0, 8)] + [fine[k] for k in (53, 98, 143)] + [fine[k] for k in range(143, 150)]  # small steps, three jumps, small steps
+    ref = gs.Renderer(w, h)
+    ref.set_scene(*scene)
+    want = []
+    for cam in path:
+        ref.render(cam)
+        want.append(ref.read_image())
+    ref.close()
+    assert all(img[..., :3].any() for img in want)
+    for name, graph, layers, cull in (("plain", False, 1, None), ("captured", True, 1, None), ("captured, two layers", True, 2, None),
+                                      ("captured, band cull on the full frame", True, 1, 1), ("plain, band cull", False, 1, 1)):
+        r = gs.Renderer(w, h, band_cull=cull)
+        r.set_graph(graph)
+        if graph:
+            r.set_depth_layers(layers)
+        r.set_tile_start_order(gs.TILE_START_ORDER_PREVIOUS_FRAME)
+        r.set_scene(*scene)
+        in_force, ratios = [], []
+        for k, cam in enumerate(path):
+            r.render(cam)
+            assert np.array_equal(r.read_image(), want[k]), (name, k)
+            state = r.tile_order_state()
+            assert state is not None and state[3] == k + 1, (name, state)
+            in_force.append(state[0])
+            ratios.append(round(state[1] / max(state[2], 1), 3))
+        print(name, "table in force after frame k:", in_force, "mismatch:", ratios)
+        # (the table of frame k is made at its start from frames k-1 and k-2: in_force[k] says whether frame k used one)
+        assert in_force[:2] == [0, 0]  # no two frames to compare yet
+        assert all(in_force[2:8]), (name, in_force, ratios)  # 1-degree steps: the previous frame predicts this one
+        # frames 8-10 jump by 45 degrees (the host sees the view matrix turn: the builder is skipped), frame 11 repeats frame 10's camera but
+        # its two predecessors differ (the device-side guard): withdrawn
+        assert not any(in_force[8:12]), (name, in_force, ratios)
+        assert all(in_force[12:]), (name, in_force, ratios)  # ... and back once two consecutive frames resemble each other again
+        if graph:
+            assert r.depth_layers_in_use() == layers
+        r.set_tile_start_order(gs.TILE_START_ORDER_SCREEN)
+        r.render(path[0])
+        assert np.array_equal(r.read_image(), want[0])
+        r.close()
+    # several views per chain: the option stands aside
+    r = gs.Renderer(w, h, views=2)
+    r.set_graph(True)
+    r.set_tile_start_order(gs.TILE_START_ORDER_PREVIOUS_FRAME)
+    r.set_scene(*scene)
+    r.render_views(path[:2])
+    assert np.array_equal(r.read_image(view=1), want[1]) and r.tile_order_state() is None
+    r.close()
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_renderer_empty_scene_and_scene_swap(gs, graph):
     """Zero splats render a cleared frame in every pipeline; replacing the scene (other size) on a live renderer, captured

@@ -117,6 +117,29 @@ for v, cam in enumerate(views):
     r.render(cam)
     assert np.array_equal(r.read_image(), base_img)
     t_own_global = raster_ms(cam, args.frames)
+    # what the product's order kernel does differently from a plain sort (gs_raster.hip tileStartOrderKernel): the key is the largest
+    # consumption in the tile's 3 x 3 neighbourhood, keys are bucketed by vote chunks of 32, and the order inside a bucket is arbitrary
+    grid = cons.reshape(ty, tx)
+    pad = np.pad(grid, 1)
+    dil = np.max([pad[1 + dy: 1 + dy + ty, 1 + dx: 1 + dx + tx] for dy in (-1, 0, 1) for dx in (-1, 0, 1)], axis=0).reshape(-1)
+    rng = np.random.default_rng(v)
+    variants = {}
+    for name, key in (("dilated", dil), ("bucketed", (cons >> 5) * 64 + rng.integers(0, 64, T)), ("dilated+bucketed", (dil >> 5) * 64 + rng.integers(0, 64, T))):
+        set_order(order_by(key.astype(np.int64), True))
+        r.render(cam)
+        assert np.array_equal(r.read_image(), base_img)
+        variants[name] = raster_ms(cam, args.frames)
+    print(f"view {v}: own consumption with the order kernel's key: " + " | ".join(f"{k} {t:.1f}" for k, t in variants.items()), flush=True)
+    # ... and the product itself: gs_renderer_set_tile_start_order on the SAME camera again and again -- the order kernel's table from a
+    # perfect predictor (then the experiment's manual mode again)
+    set_order(None)
+    r.set_tile_start_order(gs.TILE_START_ORDER_PREVIOUS_FRAME)
+    t_product = raster_ms(cam, args.frames)
+    state = r.tile_order_state()
+    r.render(cam)
+    assert np.array_equal(r.read_image(), base_img)
+    r.set_tile_start_order(gs.TILE_START_ORDER_SCREEN)
+    print(f"view {v}: the order kernel's own table, same camera repeated: {t_product:.1f} us (state {state})", flush=True)
     preds = []
     for back in (1, 5):
         set_order(None)
