@@ -325,4 +325,4 @@ extern "C" void gs_rasterize_tile(GsTimer* timer)
     reportLaunch("renderDepthBuffer");
 }
 
-extern "C" const char* gs_version(void) { return "gsplat_hip 0.3 (gfx950)"; }
+extern "C" const char* gs_version(void) { return "gsplat_hip 0.6 (gfx950)"; }
