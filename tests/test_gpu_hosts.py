@@ -184,3 +184,33 @@ def test_cpp_host_replays_a_recorded_camera_session(gs, gsref, demo_binary, tmp_
     dumps = [out + ".%05d.ppm" % k for k in (16, 32, 48)]
     assert all(os.path.exists(d) for d in dumps)
     assert np.array_equal(_read_ppm(dumps[-1]), _read_ppm(out)) and not np.array_equal(_read_ppm(dumps[0]), _read_ppm(out))
+
+
+def test_cpp_host_one_call_viewer_session_with_tile_start_order(gs, gsref, demo_binary, tmp_path, golden_dir):
+    """The viewer's recorded session through the ONE-CALL renderer of the C++ host (gsplat_demo --one-call --events), with and without
+    gs_renderer_set_tile_start_order (--tile-order: the raster's tiles started longest-first by the previous frame's consumption -- the
+    interactive camera is the host the option is for): the same final pose, which is the oracle's, and the same image bytes, which are the
+    staged frame loop's."""
+    sess = json.load(open(os.path.join(golden_dir, "camera_controls.json")))["sessions"][1]
+    w, h, frames = sess["width"] // 4, sess["height"] // 4, sess["frames"][:48]
+    frames = [(dt, b, k, x / 4.0, y / 4.0) for (dt, b, k, x, y) in frames]
+    events = tmp_path / "events.txt"
+    events.write_text("".join("%.9g %d %d %.9g %.9g\n" % tuple(f) for f in frames))
+    images, poses = {}, {}
+    for name, flags in (("staged", []), ("one_call", ["--one-call"]), ("one_call_tile_order", ["--one-call", "--tile-order"])):
+        out = str(tmp_path / (name + ".ppm"))
+        log = subprocess.run([demo_binary, "--procedural", "10000", str(w), str(h), str(len(frames)), out, "--events", str(events)] + flags,
+                             stdout=subprocess.PIPE, text=True, check=True).stdout
+        line = [ln for ln in log.splitlines() if ln.startswith("camera after")]
+        assert len(line) == 1, log
+        poses[name] = line[0]
+        images[name] = _read_ppm(out)
+        if "--tile-order" in flags:
+            assert "tile start order from the previous frame" in log
+    assert poses["one_call"] == poses["staged"] == poses["one_call_tile_order"]
+    states, _ = gsref.camera_controls_session(w, h, [-4] * 3, [4] * 3, frames, with_camera_data=True)
+    nums = [float(v) for v in poses["staged"].replace("camera after %d frames:" % len(frames), "").replace("position", "").replace("rotation", "")
+            .replace("anchor", "").replace("mode", "").split()]
+    assert np.array_equal(np.array(nums[:10], np.float32), states[-1, :10])
+    assert images["staged"].max() > 0
+    assert np.array_equal(images["one_call"], images["staged"]) and np.array_equal(images["one_call_tile_order"], images["staged"])

@@ -18,6 +18,9 @@
 //   ... --one-call                                           the same frames through gs_renderer_render (one call
 //                                                            instead of eight, captured frames, a device synchronise after each like
 //                                                            Demo.cpp:478); prints the wall clock per frame
+//   ... --one-call --events FILE [--tile-order]              the viewer's session through the one-call renderer; --tile-order: the raster's tiles started
+//                                                            longest-first by the previous frame's consumption (gs_renderer_set_tile_start_order:
+//                                                            an interactive camera moves a little per frame, Demo.cpp:371-392; same image bytes)
 //   ... --warm-up W                                          W more frames first that the printed averages leave out
 //   ... --dump-every K                                       every K-th frame as <out.ppm>.<frame>.ppm (the session as an image sequence)
 //
@@ -47,6 +50,7 @@ int main(int argc, char** argv)
     int dumpEvery = 0;
     int warmUp = 0; // frames rendered before the statistics start (first frames allocate scratch and meet cold clocks)
     bool oneCall = false; // the frame loop body as ONE call (gs_renderer_render, captured frames) instead of the eight staged ones
+    bool tileOrder = false; // --one-call: gs_renderer_set_tile_start_order(PREVIOUS_FRAME)
     std::vector<char*> positional;
     for (int i = 0; i < argc; ++i)
     {
@@ -59,6 +63,7 @@ int main(int argc, char** argv)
             gs_set_staged_builder(std::strcmp(argv[++i], "reference-order") == 0 ? GS_STAGED_BUILDER_REFERENCE_ORDER : GS_STAGED_BUILDER_SORTED);
         else if (std::strcmp(argv[i], "--warm-up") == 0 && i + 1 < argc) warmUp = std::atoi(argv[++i]);
         else if (std::strcmp(argv[i], "--one-call") == 0) oneCall = true;
+        else if (std::strcmp(argv[i], "--tile-order") == 0) tileOrder = true;
         else positional.push_back(argv[i]);
     }
     argc = (int) positional.size();
@@ -141,19 +146,57 @@ int main(int argc, char** argv)
         gs_renderer_set_graph(renderer, 1);
         // one frame at a time: the renderer chooses its depth layers for a lone frame (two from 16 M pairs per frame; same image bytes)
         gs_renderer_set_depth_layers(renderer, GS_DEPTH_LAYERS_CHOOSE, nullptr);
+        if (tileOrder) gs_renderer_set_tile_start_order(renderer, GS_TILE_START_ORDER_PREVIOUS_FRAME);
         gs::CameraControls controls((float) width, (float) height);
         controls.setBounds(boundsMin, boundsMax);
-        const gs::CameraData cam = controls.getCameraData();
+        gs::CameraData cam = controls.getCameraData();
+        // the viewer's recorded session, if any (one line per frame: dt mouseButtons keys cursorX cursorY; see --events above)
+        struct Step { float dt; GsCameraInput input; };
+        std::vector<Step> steps;
+        if (eventsFile != nullptr)
+        {
+            std::FILE* f = std::fopen(eventsFile, "r");
+            if (f == nullptr)
+            {
+                std::fprintf(stderr, "cannot open %s\n", eventsFile);
+                return 2;
+            }
+            Step e{};
+            unsigned buttons = 0, keys = 0;
+            while (std::fscanf(f, "%f %u %u %lf %lf", &e.dt, &buttons, &keys, &e.input.cursorX, &e.input.cursorY) == 5)
+            {
+                e.input.mouseButtons = buttons;
+                e.input.keys = keys;
+                steps.push_back(e);
+            }
+            std::fclose(f);
+        }
         std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
         for (int frame = -warmUp; frame != frames; ++frame)
         {
             if (frame == 0) t0 = std::chrono::steady_clock::now();
+            if (!steps.empty() && frame >= 0) // Demo.cpp:371-392
+            {
+                Step e = steps[std::min((size_t) frame, steps.size() - 1)];
+                if ((size_t) frame >= steps.size()) e.dt = 0.0f;
+                controls.setInput(e.input);
+                controls.update(e.dt);
+                cam = controls.getCameraData();
+            }
             if (gs_renderer_render(renderer, &cam, 0, nullptr) != 0) return 1;
             gs_synchronize(); // Demo.cpp:478 (the renderer's frames run on the library's current stream here)
         }
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / (frames > 0 ? frames : 1);
         std::printf("splats %d, %dx%d, %d frames (one call per frame, captured, synchronised after each)\n", splatCount, width, height, frames);
-        std::printf("Frame loop wall clock %.6f ms per frame (one-call renderer)\n", ms);
+        std::printf("Frame loop wall clock %.6f ms per frame (one-call renderer%s%s)\n", ms, steps.empty() ? "" : ", recorded session",
+                    tileOrder ? ", tile start order from the previous frame" : "");
+        if (!steps.empty())
+        {
+            const GsCameraControlsState st = controls.getState();
+            std::printf("camera after %d frames: position %.9g %.9g %.9g rotation %.9g %.9g %.9g %.9g anchor %.9g %.9g %.9g mode %d\n", frames,
+                        st.position[0], st.position[1], st.position[2], st.rotationXYZW[0], st.rotationXYZW[1], st.rotationXYZW[2], st.rotationXYZW[3],
+                        st.anchorPosition[0], st.anchorPosition[1], st.anchorPosition[2], st.mode);
+        }
         if (outPath != nullptr)
         {
             std::vector<unsigned char> image((size_t) width * height * 4);
