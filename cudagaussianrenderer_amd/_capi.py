@@ -162,6 +162,9 @@ SIGNATURES = {
     "gs_set_sort_backend": (None, [C.c_int]),
     "gs_set_staged_builder": (None, [C.c_int]),
     "gs_get_staged_builder": (C.c_int, []),
+    "gs_set_staged_tile_start_order": (None, [C.c_int]),
+    "gs_get_staged_tile_start_order": (C.c_int, []),
+    "gs_debug_staged_tile_order_state": (C.c_int, [C.POINTER(C.c_int32)]),
     "gs_release_thread_scratch": (None, []),
     "gs_set_list_fusion": (None, [C.c_int]),
     "gs_get_list_fusion": (C.c_int, []),
@@ -276,7 +279,7 @@ SIGNATURES = {
 DEBUG_SYMBOLS = frozenset([
     "gs_set_collect_raster_stats", "gs_last_raster_consumed_pairs", "gs_renderer_captured_retries", "gs_renderer_depth_layer_changes",
     "gs_renderer_debug_set_layer_compaction", "gs_renderer_debug_set_block_cull", "gs_renderer_debug_set_layer_compaction_reuse", "gs_renderer_debug_block_cull_kept", "gs_renderer_debug_band_kept_splats", "gs_renderer_debug_layered_raster_report",
-    "gs_renderer_debug_set_list_fusion", "gs_renderer_debug_raster_grid_slots", "gs_renderer_debug_tile_order_state", "gs_renderer_debug_set_tile_order_max_mismatch", "gs_renderer_debug_set_tile_order", "gs_renderer_debug_tile_consumed", "gs_renderer_debug_set_raster_pixels_per_lane", "gs_set_sort_backend", "gs_get_sort_backend",
+    "gs_renderer_debug_set_list_fusion", "gs_renderer_debug_raster_grid_slots", "gs_renderer_debug_tile_order_state", "gs_debug_staged_tile_order_state", "gs_renderer_debug_set_tile_order_max_mismatch", "gs_renderer_debug_set_tile_order", "gs_renderer_debug_tile_consumed", "gs_renderer_debug_set_raster_pixels_per_lane", "gs_set_sort_backend", "gs_get_sort_backend",
     "gs_set_list_fusion", "gs_get_list_fusion", "gs_radix_sort_pairs", "gs_set_raster_pixels_per_lane", "gs_get_raster_pixels_per_lane",
     "gs_debug_set_raster_trace", "gs_debug_set_ablation", "gs_debug_set_clip_scan_fusion", "gs_debug_get_clip_scan_fusion",
     "gs_debug_set_await_timeout", "gs_debug_set_staged_scratch_limit", "gs_debug_host_times", "gs_debug_rccl_self_exchange", "gs_debug_rccl_self_exchange_parts",

@@ -191,12 +191,88 @@ extern "C" void gs_evaluate_spherical_harmonics(GsTimer* timer, int32_t count)
     reportLaunch("evaluateSphericalHarmonics");
 }
 
+namespace gs
+{
+void freeStagedTileOrder(StagedTileOrder& t)
+{
+    if (t.consumedPair) (void) hipFree(t.consumedPair);
+    if (t.order) (void) hipFree(t.order);
+    if (t.state) (void) hipFree(t.state);
+    t = StagedTileOrder{};
+}
+namespace
+{
+// gs_set_staged_tile_start_order: the staged clip call's part -- buffers for the current screen and band (a change starts the history
+// afresh), the host-side look at the camera, and what the clip kernel's first eight workgroups need to make this frame's table.
+bool stagedTileOrderArgs(const Screen& scr, TileOrderArgs* args)
+{
+    StagedTileOrder& t = g.stagedTileOrder;
+    t.builtThisFrame = false;
+    if (cfg.stagedTileStartOrder != GS_TILE_START_ORDER_PREVIOUS_FRAME) return false;
+    const int slots = rasterGridSlots(scr.tilesX, scr.rowEnd - scr.rowBegin);
+    if (slots <= 0) return false;
+    if (t.order == nullptr || t.slots != slots || t.tiles != scr.totalTiles || t.firstTile != scr.rowBegin * scr.tilesX || t.rows != scr.rowEnd - scr.rowBegin)
+    {
+        std::lock_guard<std::mutex> lock(g_captureMutex); // (allocation: never while another thread captures)
+        GS_CHECK(hipStreamSynchronize(g.stream));
+        freeStagedTileOrder(t);
+        const size_t tiles = (size_t) scr.totalTiles;
+        GS_CHECK(hipMalloc((void**) &t.consumedPair, sizeof(int32_t) * 2 * tiles));
+        GS_CHECK(hipMalloc((void**) &t.order, sizeof(int32_t) * (size_t) slots));
+        GS_CHECK(hipMalloc((void**) &t.state, sizeof(int32_t) * 16));
+        GS_CHECK(hipMemsetAsync(t.consumedPair, 0, sizeof(int32_t) * 2 * tiles, g.stream));
+        GS_CHECK(hipMemsetAsync(t.order, 0xFF, sizeof(int32_t) * (size_t) slots, g.stream));
+        GS_CHECK(hipMemsetAsync(t.state, 0, sizeof(int32_t) * 16, g.stream));
+        t.slots = slots;
+        t.tiles = scr.totalTiles;
+        t.firstTile = scr.rowBegin * scr.tilesX;
+        t.rows = scr.rowEnd - scr.rowBegin;
+    }
+    // (the renderer's rule, gs_renderer.hip cameraJumped: a rotation entry moved by more than 0.06 -- about 3 degrees -- or no frame before)
+    const float* view = g.global.cameraData.view;
+    bool jumped = !t.haveLastView;
+    for (int c = 0; c != 3 && !jumped; ++c)
+        for (int k = 0; k != 3; ++k)
+            if (!(fabsf(view[c * 4 + k] - t.lastView[c * 4 + k]) <= 0.06f)) jumped = true;
+    std::memcpy(t.lastView, view, sizeof(t.lastView));
+    t.haveLastView = true;
+    *args = TileOrderArgs{};
+    args->now = t.consumedPair + (size_t) ((t.parity & 1) ^ 1) * (size_t) t.tiles; // the frame that just ended
+    args->prev = t.consumedPair + (size_t) (t.parity & 1) * (size_t) t.tiles;      // cleared: this frame's rasterizeTile writes it
+    args->order = t.order;
+    args->state = t.state;
+    args->slots = t.slots;
+    args->skip = jumped ? 1 : 0;
+    t.builtThisFrame = true;
+    return true;
+}
+} // namespace
+} // namespace gs
+
+extern "C" void gs_set_staged_tile_start_order(int mode)
+{
+    cfg.stagedTileStartOrder = mode == GS_TILE_START_ORDER_PREVIOUS_FRAME ? GS_TILE_START_ORDER_PREVIOUS_FRAME : GS_TILE_START_ORDER_SCREEN;
+}
+extern "C" int gs_get_staged_tile_start_order(void) { return cfg.stagedTileStartOrder; }
+extern "C" int gs_debug_staged_tile_order_state(int32_t out[4])
+{
+    for (int k = 0; k != 4; ++k) out[k] = 0;
+    if (g.stagedTileOrder.state == nullptr) return -1;
+    gs_device_download(out, g.stagedTileOrder.state, sizeof(int32_t) * 4);
+    return 0;
+}
+
 extern "C" void gs_evaluate_splat_clip_data(GsTimer* timer, int32_t count)
 {
+    const Screen scr = currentScreen();
+    TileOrderArgs tileOrder;
+    const bool ordered = count > 0 && stagedTileOrderArgs(scr, &tileOrder); // (before the timed interval: allocation is not the stage's work)
+    if (!ordered) g.stagedTileOrder.builtThisFrame = false;
     gs_timer_start(timer);
-    launchSplatClipData(g.stream, count, currentScreen(), currentCamera(), (const float4*) g.global.position,
+    launchSplatClipData(g.stream, count, scr, currentCamera(), (const float4*) g.global.position,
                         (const float4*) g.global.scaleAndRotation, (float2*) g.global.positionClipSpaceXY,
-                        g.global.positionClipSpaceZ, (float4*) g.global.screenEllipse, (float4*) g.global.conic, nullptr, nullptr);
+                        g.global.positionClipSpaceZ, (float4*) g.global.screenEllipse, (float4*) g.global.conic, nullptr, nullptr, nullptr, nullptr, nullptr,
+                        nullptr, nullptr, 0, nullptr, nullptr, 1, nullptr, nullptr, nullptr, ordered ? &tileOrder : nullptr);
     gs_timer_stop(timer);
     reportLaunch("evaluateSplatsClipData");
 }
@@ -318,10 +394,28 @@ extern "C" void gs_rasterize_tile(GsTimer* timer)
 {
     unsigned long long* consumed = cfg.collectRasterStats ? cfg.consumedDevice : nullptr;
     if (consumed) GS_CHECK(hipMemsetAsync(consumed, 0, sizeof(unsigned long long), g.stream));
+    // gs_set_staged_tile_start_order: the table this frame's evaluateSplatClipData made (same screen, same band), and this frame's counters
+    const Screen scr = currentScreen();
+    StagedTileOrder& order = g.stagedTileOrder;
+    RasterSchedule schedule;
+    const bool ordered = order.builtThisFrame && cfg.stagedTileStartOrder == GS_TILE_START_ORDER_PREVIOUS_FRAME && order.tiles == scr.totalTiles &&
+                         order.slots == rasterGridSlots(scr.tilesX, scr.rowEnd - scr.rowBegin) && order.firstTile == scr.rowBegin * scr.tilesX;
+    if (ordered)
+    {
+        schedule.order = order.order;
+        schedule.consumedOut = order.consumedPair + (size_t) (order.parity & 1) * (size_t) order.tiles;
+        schedule.enabled = order.state;
+    }
     gs_timer_start(timer);
-    launchRasterize(g.stream, currentScreen(), g.global.tileRange, g.tileList.values, (const float2*) g.global.positionClipSpaceXY,
-                    (const float4*) g.global.conic, (const float4*) g.global.color, (uchar4*) g.global.backBuffer, consumed);
+    launchRasterize(g.stream, scr, g.global.tileRange, g.tileList.values, (const float2*) g.global.positionClipSpaceXY,
+                    (const float4*) g.global.conic, (const float4*) g.global.color, (uchar4*) g.global.backBuffer, consumed, false, nullptr, nullptr, 1, 0, nullptr,
+                    ordered ? &schedule : nullptr);
     gs_timer_stop(timer);
+    if (ordered)
+    {
+        order.parity ^= 1;
+        order.builtThisFrame = false; // (one table, one frame: a second rasterizeTile without a clip call in between draws in screen order)
+    }
     reportLaunch("renderDepthBuffer");
 }
 

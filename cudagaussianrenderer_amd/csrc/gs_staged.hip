@@ -254,6 +254,7 @@ extern "C" void gs_release_thread_scratch(void)
     if (st.unsortedEpoch) (void) hipFree(st.unsortedEpoch);
     if (st.unsortedEpochHost) (void) hipHostFree(st.unsortedEpochHost);
     st = StagedScratch{};
+    freeStagedTileOrder(g.stagedTileOrder);
 }
 
 extern "C" void gs_debug_set_staged_scratch_limit(int64_t maxBytesPerAllocationOr0) { g_stagedScratchLimit = maxBytesPerAllocationOr0 > 0 ? maxBytesPerAllocationOr0 : 0; }

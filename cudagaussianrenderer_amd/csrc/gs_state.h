@@ -47,6 +47,21 @@ struct StagedScratch
     int epoch = 0;
 };
 
+// gs_set_staged_tile_start_order: what the staged rasterizeTile / evaluateSplatClipData pair of THIS host thread keeps between frames -- the
+// one-call renderer's tile start order (gs_renderer_set_tile_start_order) for the literal drop-in host, whose loop is the interactive
+// viewer (Demo.cpp:371-479).
+struct StagedTileOrder
+{
+    int32_t* consumedPair = nullptr; // [2][tiles]
+    int32_t* order = nullptr;        // [slots]
+    int32_t* state = nullptr;        // [16]
+    int slots = 0, tiles = 0, firstTile = -1, rows = 0;
+    int parity = 0;
+    float lastView[16] = {};
+    bool haveLastView = false;
+    bool builtThisFrame = false; // evaluateSplatClipData made a table for the frame rasterizeTile is about to draw
+};
+
 struct State
 {
     GsGlobalArgs global{};
@@ -55,6 +70,7 @@ struct State
     gs::TileListScratch scratch;
     gs::RadixScratch radix;
     StagedScratch staged;
+    StagedTileOrder stagedTileOrder;
     int64_t lastDemand = 0;
     // What the renderer whose call is running on this thread wants instead of the process-wide defaults (set and restored by
     // StreamScope; -1 / 0 = the default): two threads that drive renderers with different footprints share no switch.
@@ -75,6 +91,7 @@ struct Settings
     int sortBackend = GS_SORT_BACKEND_NATIVE;
     bool collectRasterStats = false;
     int stagedBuilder = GS_STAGED_BUILDER_SORTED; // gs_set_staged_builder: how the staged buildTileList emits (and whether sortTileList looks before it sorts)
+    int stagedTileStartOrder = GS_TILE_START_ORDER_SCREEN; // gs_set_staged_tile_start_order
     bool listFusion = GS_LIST_FUSION_DEFAULT != 0; // the emit pass carries the tile sort's first pass (gs_set_list_fusion)
     bool clipScanFusion = GS_CLIP_SCAN_FUSION_DEFAULT != 0; // Morton storage, no band cull: the clip kernel shares the launch of the depth sort's first column scan (gs_debug_set_clip_scan_fusion)
     unsigned long long* consumedDevice = nullptr; // counter of the staged gs_rasterize_tile
@@ -90,6 +107,7 @@ ClipCamera currentCamera();
 void reportLaunch(const char* stage);
 // gs_staged.hip: the staged buildTileList / sortTileList on the renderer's machinery (see there)
 int32_t stagedBuildTileListSorted(GsTimer* timer, int32_t tileListCapacity);
+void freeStagedTileOrder(StagedTileOrder& t);
 bool stagedListIsSorted(int32_t size, const uint64_t* keys, int endBit);
 // sortTileList proper; lookFirst: skip the sort when the list is already in order (a stable sort of a sorted list is the identity)
 void sortTileListImpl(GsTimer* timer, int32_t size, void** deviceTempStorage, size_t* tempStorageSizeInBytes, GsDoubleBufferU64* keys,

@@ -139,6 +139,15 @@ int32_t gs_build_tile_list(GsTimer* timer, int32_t numBlocks, int32_t tileListCa
 #define GS_STAGED_BUILDER_SORTED 1
 void gs_set_staged_builder(int mode);
 int gs_get_staged_builder(void);
+/* Addition: the tile start order of an interactive camera for the staged loop (the literal drop-in host IS the reference's viewer,
+ * Demo.cpp:371-479).  PREVIOUS_FRAME: gs_rasterize_tile starts its tiles longest-first by the entries they consumed in the calling
+ * thread's previous frame; the table is made by the first eight workgroups of gs_evaluate_splat_clip_data's kernel, withdrawn by itself
+ * when consecutive frames differ and not built when the camera (GsGlobalArgs.cameraData.view) turned by more than ~3 degrees -- see
+ * gs_renderer_set_tile_start_order below for the mechanism and the numbers (raster 62 -> 50 us at 1-degree steps; same image bytes).  Keeps
+ * per-thread scratch of 8 bytes per tile + 4 per grid slot (freed by gs_release_thread_scratch).  Default SCREEN (GS_TILE_START_ORDER_*
+ * are defined below).  Process-wide switch, per-thread history. */
+void gs_set_staged_tile_start_order(int mode);
+int gs_get_staged_tile_start_order(void);
 /* Addition: frees the scratch the staged calls of the CALLING host thread allocated behind the scenes (state is per host thread, like
  * the reference's file-scope symbols are per process); the next staged call allocates again.  Waits for the thread's stream first. */
 void gs_release_thread_scratch(void);

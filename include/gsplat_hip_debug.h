@@ -60,6 +60,7 @@ int gs_renderer_debug_layered_raster_report(GsRenderer* r, const GsCameraData* c
  * the option never ran.  Waits for the renderer's stream.  ..._max_mismatch: the largest out[1] / out[2] at which the table is put in force
  * (default 0.35). */
 int gs_renderer_debug_tile_order_state(GsRenderer* r, int32_t out[4]);
+int gs_debug_staged_tile_order_state(int32_t out[4]); /* the same for the calling thread's staged loop (gs_set_staged_tile_start_order) */
 void gs_renderer_debug_set_tile_order_max_mismatch(GsRenderer* r, float maxMismatch);
 /* Experiment ("start order of the raster's tiles"; tools/tile_order_experiment.py): plain (un-captured, single-view)
  * frames of this renderer start their raster tiles in the order of a table -- grid slot -> tile index, -1 = no tile; `slots` must be

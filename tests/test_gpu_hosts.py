@@ -197,7 +197,8 @@ def test_cpp_host_one_call_viewer_session_with_tile_start_order(gs, gsref, demo_
     events = tmp_path / "events.txt"
     events.write_text("".join("%.9g %d %d %.9g %.9g\n" % tuple(f) for f in frames))
     images, poses = {}, {}
-    for name, flags in (("staged", []), ("one_call", ["--one-call"]), ("one_call_tile_order", ["--one-call", "--tile-order"])):
+    for name, flags in (("staged", []), ("one_call", ["--one-call"]), ("one_call_tile_order", ["--one-call", "--tile-order"]),
+                        ("staged_tile_order", ["--tile-order"])):
         out = str(tmp_path / (name + ".ppm"))
         log = subprocess.run([demo_binary, "--procedural", "10000", str(w), str(h), str(len(frames)), out, "--events", str(events)] + flags,
                              stdout=subprocess.PIPE, text=True, check=True).stdout
@@ -207,10 +208,11 @@ def test_cpp_host_one_call_viewer_session_with_tile_start_order(gs, gsref, demo_
         images[name] = _read_ppm(out)
         if "--tile-order" in flags:
             assert "tile start order from the previous frame" in log
-    assert poses["one_call"] == poses["staged"] == poses["one_call_tile_order"]
+    assert poses["one_call"] == poses["staged"] == poses["one_call_tile_order"] == poses["staged_tile_order"]
     states, _ = gsref.camera_controls_session(w, h, [-4] * 3, [4] * 3, frames, with_camera_data=True)
     nums = [float(v) for v in poses["staged"].replace("camera after %d frames:" % len(frames), "").replace("position", "").replace("rotation", "")
             .replace("anchor", "").replace("mode", "").split()]
     assert np.array_equal(np.array(nums[:10], np.float32), states[-1, :10])
     assert images["staged"].max() > 0
     assert np.array_equal(images["one_call"], images["staged"]) and np.array_equal(images["one_call_tile_order"], images["staged"])
+    assert np.array_equal(images["staged_tile_order"], images["staged"])  # gs_set_staged_tile_start_order: the eight staged calls with the option

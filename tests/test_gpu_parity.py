@@ -1073,6 +1073,53 @@ def test_tile_start_order_changes_no_byte_and_follows_the_camera(gs, tmp_path):
     r.close()
 
 
+def test_staged_loop_with_the_tile_start_order(gs, gsref, tmp_path):
+    """gs_set_staged_tile_start_order(PREVIOUS_FRAME): the reference's own loop over the eight staged calls (the literal drop-in host IS the
+    interactive viewer, Demo.cpp:371-479) starts its raster tiles longest-first by the calling thread's previous frame.  Frames of a path
+    with 1-degree steps and a 45-degree jump are the screen-order frames byte for byte; the table engages after two similar frames, is
+    withdrawn at the jump, engages again; releasing the thread's scratch and switching the option off leave the loop as it was."""
+    from cudagaussianrenderer_amd import scenes
+
+    w, h = 1280, 720
+    ply = _ply_scene(gs, tmp_path, 150_000, 0, log_scale_mean=-3.6)
+    pos, sr, col = ply["position"], ply["scaleAndRotation"], ply["color"]
+    fine = [gs.camera_from_pose(p, q, w, h) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 360)]
+    path = [fine[k] for k in range(0, 6)] + [fine[60]] + [fine[k] for k in range(60, 66)]
+
+    def frames(option):
+        gs.lib().gs_set_staged_tile_start_order(1 if option else 0)
+        images, in_force = [], []
+        try:
+            for cam in path:
+                f = StagedFrame(pos, sr, col, cam, w, h, capacity=6_000_000)
+                f.begin()
+                f.run_clip()
+                f.run_build()
+                f.run_sort()
+                f.run_ranges()
+                images.append(f.run_raster())
+                f.free_sort_temp()
+                if option:
+                    state = (C.c_int32 * 4)()
+                    assert gs.lib().gs_debug_staged_tile_order_state(state) == 0
+                    in_force.append(int(state[0]))
+        finally:
+            gs.lib().gs_set_staged_tile_start_order(0)
+        return images, in_force
+
+    import ctypes as C
+
+    want, _ = frames(False)
+    got, in_force = frames(True)
+    assert all(img[..., :3].any() for img in want)
+    for k, (a, b_) in enumerate(zip(got, want)):
+        assert np.array_equal(a, b_), k
+    assert in_force[:2] == [0, 0] and all(in_force[2:6]) and not any(in_force[6:8]) and all(in_force[8:]), in_force
+    gs.lib().gs_release_thread_scratch()
+    again, _ = frames(False)
+    assert all(np.array_equal(a, b_) for a, b_ in zip(again, want))
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_renderer_empty_scene_and_scene_swap(gs, graph):
     """Zero splats render a cleared frame in every pipeline; replacing the scene (other size) on a live renderer, captured

@@ -20,7 +20,8 @@
 //                                                            Demo.cpp:478); prints the wall clock per frame
 //   ... --one-call --events FILE [--tile-order]              the viewer's session through the one-call renderer; --tile-order: the raster's tiles started
 //                                                            longest-first by the previous frame's consumption (gs_renderer_set_tile_start_order:
-//                                                            an interactive camera moves a little per frame, Demo.cpp:371-392; same image bytes)
+//                                                            an interactive camera moves a little per frame, Demo.cpp:371-392; same image bytes).
+//                                                            Without --one-call the flag switches the STAGED loop's form on (gs_set_staged_tile_start_order)
 //   ... --warm-up W                                          W more frames first that the printed averages leave out
 //   ... --dump-every K                                       every K-th frame as <out.ppm>.<frame>.ppm (the session as an image sequence)
 //
@@ -63,7 +64,11 @@ int main(int argc, char** argv)
             gs_set_staged_builder(std::strcmp(argv[++i], "reference-order") == 0 ? GS_STAGED_BUILDER_REFERENCE_ORDER : GS_STAGED_BUILDER_SORTED);
         else if (std::strcmp(argv[i], "--warm-up") == 0 && i + 1 < argc) warmUp = std::atoi(argv[++i]);
         else if (std::strcmp(argv[i], "--one-call") == 0) oneCall = true;
-        else if (std::strcmp(argv[i], "--tile-order") == 0) tileOrder = true;
+        else if (std::strcmp(argv[i], "--tile-order") == 0)
+        {
+            tileOrder = true;
+            gs_set_staged_tile_start_order(GS_TILE_START_ORDER_PREVIOUS_FRAME); // (the staged loop's switch; --one-call sets the renderer's)
+        }
         else positional.push_back(argv[i]);
     }
     argc = (int) positional.size();
@@ -385,8 +390,9 @@ int main(int argc, char** argv)
                 "Evaluate Tile Ranges %.6f ms\nRasterize %.6f ms\nTotal %.6f ms\n",
                 msSh / f, msClip / f, msBuild / f, msSort / f, msRanges / f, msRaster / f,
                 (msSh + msClip + msBuild + msSort + msRanges + msRaster) / f);
-    std::printf("Frame loop wall clock %.6f ms per frame (%s builder)\n", wallMs / f,
-                gs_get_staged_builder() == GS_STAGED_BUILDER_SORTED ? "sorted" : "reference-order");
+    std::printf("Frame loop wall clock %.6f ms per frame (%s builder%s)\n", wallMs / f,
+                gs_get_staged_builder() == GS_STAGED_BUILDER_SORTED ? "sorted" : "reference-order",
+                gs_get_staged_tile_start_order() == GS_TILE_START_ORDER_PREVIOUS_FRAME ? ", tile start order from the previous frame" : "");
 
     if (!events.empty())
     {

@@ -14,8 +14,8 @@ with open("/tmp/gs_demo/orbit.txt", "w") as f:
         f.write("0.016 2 0 %d 540\n" % (700 + 2 * i))
 PY
 for rep in 1 2; do
-  for flags in "" "--tile-order"; do
-    tools/gsplat_demo /tmp/gs_demo/scene.ply 1920 1080 400 --one-call --events /tmp/gs_demo/orbit.txt --warm-up 50 $flags | grep "Frame loop\|camera after" | cut -c1-200
+  for flags in "--one-call" "--one-call --tile-order" "" "--tile-order"; do
+    tools/gsplat_demo /tmp/gs_demo/scene.ply 1920 1080 400 --events /tmp/gs_demo/orbit.txt --warm-up 50 $flags | grep "Frame loop\|Rasterize\|Total" | cut -c1-200
   done
 done
 rm -rf /tmp/gs_demo
