@@ -279,7 +279,11 @@ __device__ __forceinline__ bool bandBoundRejects(const float cmin[3], const floa
     // |J row 0|^2 + |J row 1|^2 = (cotX^2 + cx^2 + cotY^2 + cy^2) / d^2 with the centre's own clip coordinates in the shear terms
     const float cx2 = fmaxf(cxMin * cxMin, cxMax * cxMax), cy2 = fmaxf(cyMin * cyMin, cyMax * cyMax);
     const float jacobian = ((cam.fovCotX * cam.fovCotX + cx2) + (cam.fovCotY * cam.fovCotY + cy2)) * 1.004f * (rn * rn);
-    const float half = 1.01f * scr.extentFactor * __builtin_sqrtf(lam * vt.wn * jacobian + 2.0f * scr.traceBump) + 1.0e-5f;
+    // (l0 + l1 = trace + 2 bump -- unless the reference's floor under the eigenvalues' radius is in force (GaussianRender.cu:284:
+    // sqrt(max(1e-12, mid^2 - det)) >= 1e-6) AND exceeds mid, which clamps l1 to 0: then l0 + l1 = mid + 1e-6.  That is every sub-pixel
+    // splat once the bump (1/pi)(2/W)(2/H) falls below 1e-6, i.e. from about 1600 x 900 on: its extent is 3 sqrt(bump + 1e-6), not
+    // 3 sqrt(2 bump).  tools/r06_fuzz.py found it: one splat of 8 139, 0.0006 clip units from a band's edge at 1944 x 1649.)
+    const float half = 1.01f * scr.extentFactor * __builtin_sqrtf(lam * vt.wn * jacobian + 2.0f * scr.traceBump + 2.0e-6f) + 1.0e-5f;
     // rows, as splatTileAabb takes them: kept iff (maxY + 1) / 2 * tilesPerScreenY > rowBegin and (minY + 1) / 2 * tilesPerScreenY < rowEnd
     const float top = ((cyMax + half) + 1.0f) * 0.5f * scr.tilesPerScreenY, bottom = ((cyMin - half) + 1.0f) * 0.5f * scr.tilesPerScreenY;
     return top < (float) scr.rowBegin - 1.0e-3f || bottom > (float) scr.rowEnd + 1.0e-3f;
@@ -542,7 +546,7 @@ __global__ __launch_bounds__(256) void splatClipBandViewsKernel(int count, int v
 //     [-1, 1] counts: d = -view z in [dn, df] (a block that straddles the near plane is cut at it, not kept wholesale);
 //   * its centre row: clip y = cotY * vy / d lies between the extremes of the box's view-space y over [dn, df], and in [-1, 1];
 //   * the reference's box is the bounding box of the ellipse's ORIENTED RECTANGLE: half height |sin| ex + |cos| ey <= k sqrt(l0 + l1)
-//     = k sqrt(trace(C) + 2 bump), and trace(C) = a' S a + b' S b <= lmax(S) |W|^2 (|J row 0|^2 + |J row 1|^2)
+//     <= k sqrt(trace(C) + 2 bump + 1e-6) (the 1e-6: the floor under the eigenvalues' radius, see bandBoundRejects), and trace(C) = a' S a + b' S b <= lmax(S) |W|^2 (|J row 0|^2 + |J row 1|^2)
 //     <= lmax(S) |W|^2 (cotX^2 + cotY^2 + 2) / dn^2 for a visible centre (|clip x|, |clip y| <= 1 bound the shear terms);
 //   * lmax(S) per splat by Gershgorin on the very covariance the kernel computes (un-normalised quaternions included), its maximum
 //     per block stored at set_scene; |W|^2 by Gershgorin on W W' (1 for a rigid camera).

@@ -752,6 +752,37 @@ def test_block_cull_drops_nothing(gs, tmp_path):
         assert all(np.array_equal(a, b_) for a, b_ in zip(got[0][1], got[1][1])), (k, band)
     for r in chains:
         r.close()
+    # Sub-pixel splats at a resolution whose trace bump is below the floor under the eigenvalues' radius (GaussianRender.cu:284: from about
+    # 1600 x 900 on): their extent is 3 sqrt(bump + 1e-6), not 3 sqrt(2 bump) -- the case tools/r06_fuzz.py found the first bound wrong on.
+    # 4 000 of them with their centres 0.002 ... 0.004 clip units below a band's lower edge (their boxes reach 0.00357 up) and above its
+    # upper edge, straight ahead of an axis-aligned camera.
+    w2, h2 = 1944, 1649
+    ty2 = gs.tile_counts(w2, h2)[1]
+    cam2 = gs.camera_from_pose([0, 0, 6], [0, 0, 0, 1], w2, h2)
+    cot_y = float(cam2.fovCotangent[1])
+    band2 = (40, 44)
+    tiny_n = 4000
+    tiny_pos = np.ones((tiny_n, 4), np.float32)
+    depth = rng.uniform(3.0, 9.0, tiny_n)  # distance in front of the camera
+    edges = np.where(np.arange(tiny_n) % 2 == 0, band2[0] * 16 * 2.0 / h2 - 1.0 - rng.uniform(0.002, 0.004, tiny_n),
+                     band2[1] * 16 * 2.0 / h2 - 1.0 + rng.uniform(0.002, 0.004, tiny_n))
+    tiny_pos[:, 0] = rng.uniform(-0.5, 0.5, tiny_n) * depth / float(cam2.fovCotangent[0])
+    tiny_pos[:, 1] = edges * depth / cot_y
+    tiny_pos[:, 2] = 6.0 - depth
+    tiny_sr = np.zeros((tiny_n, 4), np.float32)
+    tiny_sr[:, :3] = rng.uniform(1e-5, 2e-4, (tiny_n, 3))
+    tiny_sr[:, 3] = _bits_to_float(gs.encode_vec4([0.0, 0.0, 0.0, 1.0]))
+    tiny_col = rng.uniform(0.2, 1, (tiny_n, 4)).astype(np.float32)
+    kept = []
+    for blocks in (True, False):
+        r = gs.Renderer(w2, h2, tile_rows=band2, band_cull=1, storage_order=gs.STORAGE_ORDER_MORTON)
+        r.set_block_cull(blocks)
+        r.set_scene(tiny_pos, tiny_sr, tiny_col)
+        r.render(cam2)
+        kept.append((r.band_kept_splats(), r.read_image()))
+        r.close()
+    assert 0 < kept[1][0] < tiny_n  # some of them reach into the band, some do not
+    assert kept[0][0] == kept[1][0] and np.array_equal(kept[0][1], kept[1][1]), (kept[0][0], kept[1][0])
     # a benign scene, a narrow band of an orbit view: the test earns its keep
     ply = _ply_scene(gs, tmp_path, 200_000, 0, log_scale_mean=-4.0)
     r = gs.Renderer(w, h, tile_rows=(10, 12), storage_order=gs.STORAGE_ORDER_MORTON)
