@@ -3,7 +3,9 @@
 seconds; every CHECK-th frame of every renderer is read back and compared byte for byte with the first image of its view; free
 device memory before and after.  The first images are one-list frames; the soak runs under gs_renderer_set_depth_layers(layers)
 (-1 = the renderer chooses, for several frames in flight: two layers at the default workload), so it also holds the layered frames to the
-one-list frames' bytes.  usage (GPU box): python tools/soak.py [seconds=60] [renderers=4] [splats=1000000] [layers=-1]"""
+one-list frames' bytes.  tile_order = 1: gs_renderer_set_tile_start_order(PREVIOUS_FRAME) on every renderer (round 6); every thread then walks
+its own slice of the orbit in small steps with a jump now and then, so that the table engages, is withdrawn and engages again under load.
+usage (GPU box): python tools/soak.py [seconds=60] [renderers=4] [splats=1000000] [layers=-1] [tile_order=0]"""
 import ctypes as C
 import os
 import sys
@@ -29,6 +31,7 @@ def main():
     depth = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 1_000_000
     layers = int(sys.argv[4]) if len(sys.argv) > 4 else -1
+    tile_order = int(sys.argv[5]) if len(sys.argv) > 5 else 0
     W, H, CHECK = 1920, 1080, 997
     lib = gs.lib()
     lib.gs_set_device(0)
@@ -37,7 +40,10 @@ def main():
         path = os.path.join(tmp, "s.ply")
         scenes.write_synthetic_ply(path, n, sh_degree=3, seed=1234)
         ply = gs.parse_ply(path)
-    cams = [gs.camera_from_pose(p, q, W, H) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 8)]
+    cams = [gs.camera_from_pose(p, q, W, H) for p, q in scenes.orbit_camera_poses(ply["boundsMin"], ply["boundsMax"], 360 if tile_order else 8)]
+    if tile_order:
+        # 8 stretches of 12 one-degree steps, 45 degrees apart: small steps inside a stretch, a jump between stretches
+        cams = [cams[(45 * s + k) % 360] for s in range(8) for k in range(12)]
     streams = [torch.cuda.Stream(0) for _ in range(depth)]
     renderers = []
     for d in range(depth):
@@ -57,6 +63,8 @@ def main():
         want.append(renderers[0].read_image().copy())
     for r in renderers:  # every renderer captures its frames and sizes its scratch before the memory baseline is taken
         r.set_depth_layers(layers)
+        if tile_order:
+            r.set_tile_start_order(gs.TILE_START_ORDER_PREVIOUS_FRAME)
         for cam in cams[:4]:
             r.render(cam)
     torch.cuda.synchronize(0)
@@ -70,7 +78,7 @@ def main():
         torch.cuda.set_device(0)
         lib.gs_set_device(0)
         r = renderers[d]
-        i = d
+        i = d * 24 if tile_order else d  # (tile order: every thread walks the path frame by frame from its own starting point)
         while time.perf_counter() < stop and not bad:
             view = i % len(cams)
             r.render(cams[view])
@@ -92,6 +100,8 @@ def main():
     elapsed = time.perf_counter() - t0
     after = free_bytes()
     retries = [r.captured_retries() for r in renderers]
+    if tile_order:
+        print(f"tile start order: state of every renderer after its last frame (in force, sum |now - before|, sum now, frames seen) {[r.tile_order_state() for r in renderers]}")
     print(f"depth layers: setting {layers}, in use {[r.depth_layers_in_use() for r in renderers]}, choice changes {[int(lib.gs_renderer_depth_layer_changes(r.handle)) for r in renderers]}")
     print(f"{sum(frames)} frames in {elapsed:.1f} s = {sum(frames) / elapsed:.0f} frames/s on {depth} renderers; {sum(checks)} read-backs compared byte for byte, "
           f"{len(bad)} differing {bad[:3]}; captured retries {retries}; free device memory {before / 2**20:.0f} -> {after / 2**20:.0f} MiB")
