@@ -229,6 +229,46 @@ def test_public_header_is_plain_c(tmp_path):
     assert out == ["45", "44"]  # 32 + ceil(log2(tiles)): 8160 tiles -> 13 bits, 4096 tiles -> 12 bits
 
 
+def test_integration_guide_c_snippets_compile_against_the_boundary_header(tmp_path):
+    """INTEGRATION.md shows a reference maintainer the calls to write; its C blocks (the one-call renderer, the renderer's options,
+    the multi-GPU loop) must stay valid against include/gsplat_hip.h ALONE -- every name declared there, every argument list right.
+    The blocks abbreviate with "..." outside comments, which is dropped; their free variables are the parameters below."""
+    import re
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    blocks = re.findall(r"```c\n(.*?)```", open(os.path.join(root, "INTEGRATION.md")).read(), flags=re.S)
+    assert len(blocks) >= 3
+
+    def without_ellipses(code):
+        out, i = [], 0
+        while i < len(code):
+            if code.startswith("/*", i):
+                j = code.index("*/", i) + 2
+                out.append(code[i:j])
+                i = j
+            elif code.startswith("...", i):
+                i += 3
+            else:
+                out.append(code[i])
+                i += 1
+        return "".join(out)
+
+    body = "\n".join(without_ellipses(b) for b in blocks)
+    for name in ("gs_renderer_render", "gs_renderer_set_tile_start_order", "gs_renderer_set_footprint", "gs_gather_bands_views", "gs_comm_create"):
+        assert name + "(" in body, name
+    src = tmp_path / "guide.c"
+    src.write_text('#include <stddef.h>\n#include "gsplat_hip.h"\n'
+                   "void documented(int n, const float* position4, const float* scaleAndRotation4, const float* color4, const float* sh, int shDegree,\n"
+                   "                int shCount, const float* boundsMin, const float* boundsMax, void* myHipStream, GsRenderer* r2, int rowBegin, int rowEnd,\n"
+                   "                int rank, int world, const int32_t* bands, int width, int height, const GsCameraData* cams)\n{\n" + body + "\n}\n")
+    subprocess.run(["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-Werror", "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-Wno-unused-value",
+                    "-I", os.path.join(root, "include"), str(src)], check=True)
+
+
 def test_band_gather_entry_points_without_a_gpu(gs):
     """include/gsplat_hip.h multi-GPU section: pixel rows of a band, and a world of one (no RCCL, every call a no-op)."""
     import ctypes as C
