@@ -1124,7 +1124,7 @@ def cpu_baseline_and_parity(ply, cameras, W, H, views, gpu_images, gpu_pairs, ep
           all(abs(a - b) <= pair_slack for a, b in zip(pairs_gpu, pairs_oracle)))
     cpu = {
         "value": round(1.0 / best, 4), "unit": "frames/s", "cores": 1, "host_hardware_threads": gsref.hardware_concurrency(), "kind": "port",
-        "sample": f"view 0 of the same 1 M-splat scene at {W}x{H}, best of {len(view0)} full frames on one thread "
+        "sample": f"view 0 of the same {int(ply['vertexCount']) / 1e6:g} M-splat scene at {W}x{H}, best of {len(view0)} full frames on one thread "
                   f"(views 0..{done - 1} rendered once each for the parity check), g++ -O3 without -ffast-math",
         "best_ms": round(1e3 * best, 1), "mean_ms_over_views": round(1e3 * sum(all_s) / len(all_s), 1), "ms_by_stage_view0": per_stage,
         "all_cores": all_cores,
