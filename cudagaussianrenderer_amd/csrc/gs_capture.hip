@@ -502,7 +502,7 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
             r->autoLayers = next;
         }
         if (demand <= r->tileListCapacity) return 0;
-        if (demand > 0x7FFFFFFF) return -2;
+        if (demand > kMaxTileListCapacity) return -2;
         GS_CHECK(hipStreamSynchronize(g.stream)); // the truncated frame drains before its buffers are replaced
         {
             std::lock_guard<std::mutex> lock(g_captureMutex);

@@ -165,7 +165,7 @@ bool growTileListIfNeeded(GsRenderer* r, int64_t demand)
     if (demand <= r->tileListCapacity) return false;
     int64_t cap = r->tileListCapacity > 0 ? r->tileListCapacity : 1;
     while (cap < demand) cap <<= 1; // Demo.cpp:360
-    cap = std::min<int64_t>(cap, 0x7FFFFFFF);
+    cap = std::min<int64_t>(cap, kMaxTileListCapacity);
     allocTileList(r, (int32_t) cap);
     return true;
 }
@@ -514,7 +514,7 @@ void allocateSceneIntermediates(GsRenderer* r, int32_t n)
 #ifndef GS_INITIAL_LIST_FACTOR
 #define GS_INITIAL_LIST_FACTOR 8
 #endif
-    const int64_t initial = std::min<int64_t>((int64_t) std::max(n, 1) * GS_INITIAL_LIST_FACTOR * r->views, 0x7FFFFFFF);
+    const int64_t initial = std::min<int64_t>((int64_t) std::max(n, 1) * GS_INITIAL_LIST_FACTOR * r->views, kMaxTileListCapacity);
     if (r->tileListCapacity < initial) allocTileList(r, (int32_t) initial);
 }
 } // namespace
@@ -858,7 +858,7 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         GS_CHECK(hipStreamSynchronize(g.stream)); // pair count readback, as GaussianRender.cu:793
         const int64_t demand = *r->scratch.totalHost;
         g.lastDemand = demand;
-        if (demand > 0x7FFFFFFF) return -2;
+        if (demand > kMaxTileListCapacity) return -2;
         if (growTileListIfNeeded(r, demand)) st.grewTileList = 1;
         const int32_t size = (int32_t) demand;
         launchTileListEmit(g.stream, n, scr, (const float2*) r->clipXY, r->clipZ, (const float4*) r->ellipse, r->scratch, r->keys[0],
@@ -1042,7 +1042,7 @@ extern "C" int gs_renderer_finish(GsRenderer* r, GsFrameStats* stats)
         GS_CHECK(hipEventSynchronize(r->countReady));
         const int64_t demand = *r->scratch.totalHost;
         g.lastDemand = demand;
-        if (demand > 0x7FFFFFFF) return -2;
+        if (demand > kMaxTileListCapacity) return -2;
         if (growTileListIfNeeded(r, demand))
         {
             // the list did not fit: re-emit into the larger buffers (rare; the first frames of a scene)

@@ -292,6 +292,10 @@ struct StreamScope
 // ---- helpers of the renderer shared with the captured path (gs_renderer.hip) ----
 bool useLazyColours(const GsRenderer* r);
 RasterColourSource colourSource(const GsRenderer* r, const float* cameraPosition, const FrameParams* paramsDevice);
+// The longest pair list a renderer makes room for: a megabyte short of 2^31 entries, so that every "count + tile - 1" and every workgroup's
+// "first element of my tile" of the list kernels -- grids are sized for the capacity, rounded up to whole tiles and eight XCDs -- stays an int.
+// A frame that needs more returns -2 (the reference's `tileListCapacity *= 2`, Demo.cpp:360, overflows its int from 2^30 pairs on).
+constexpr int64_t kMaxTileListCapacity = 0x7FF00000;
 bool growTileListIfNeeded(GsRenderer* r, int64_t demand);
 // The band cull of this renderer's next frame runs by blocks of Morton-neighbouring splats (fills `cull` for launchSplatClipData).
 bool useBlockCull(const GsRenderer* r, BandBlockCull* cull);

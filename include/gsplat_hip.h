@@ -374,7 +374,9 @@ int gs_renderer_share_scene(GsRenderer* r, const GsRenderer* owner);
  *   timed == 0: no stage timers (throughput mode);
  *   timed == 1: per-stage timings in *stats, blocking after every stage like the reference's CudaTimer;
  *   timed == 2: one non-blocking event pair per stage on the stream; read the sums later with
- *               gs_renderer_collect_stage_times (the frames are not slowed by host waits). */
+ *               gs_renderer_collect_stage_times (the frames are not slowed by host waits).
+ * Returns 0; -2 when the frame needs more than 0x7FF00000 (2.146e9) list entries -- the int32 list sizes of the reference's interface end
+ * there (its own `tileListCapacity *= 2`, Demo.cpp:360, overflows from 2^30 entries on); the list grows by doubling up to that bound. */
 int gs_renderer_render(GsRenderer* r, const GsCameraData* camera, int timed, GsFrameStats* statsOrNull);
 /* Captured frames: gs_renderer_render (timed == 0, stats == NULL, TWO_LEVEL pipeline, native sort) replays the whole
  * frame as ONE hipGraph launch; list sizes stay on the device, the camera is refreshed by a memcpy node.  The call returns once

@@ -2287,3 +2287,40 @@ def test_depth_layers_with_a_slice_of_more_than_four_million_splats(gs):
     assert images[0][0][..., :3].max() > 0 and np.array_equal(images[0][0], images[1][0])
     assert images[1][1] < images[0][1]
 
+
+
+@pytest.mark.gpu
+def test_a_list_of_more_than_two_to_the_thirty_pairs(gs):
+    """Nothing in the path is sized for the bench: 5 M procedural splats with large extents at 3840x2160 need more than 2^30 list entries
+    per frame -- past the point where the reference's own `tileListCapacity *= 2` (Demo.cpp:360) overflows its int, and where any
+    doubled pair index of ours would.  The two-level path (plain and captured, one list and the renderer's choice of depth layers) gives
+    the bytes of the reference's stage order (staged builder + rocPRIM 64-bit sort of all pairs: an independent list path); the CPU
+    oracle's sort alone would take minutes at this size.  profiles/r06_large_lists.txt has the same up to 1.45e9 pairs -- a capacity at
+    the bound of 0x7FF00000 entries -- and the -2 beyond it (tools/large_lists.py, tools/large_lists_refused.py)."""
+    w, h = 3840, 2160
+    pos, sr, col = gs.generate_random_gaussians(5_000_000, seed=17, min_scale=0.08, max_scale=0.3)
+    cam = gs.camera_from_bounds([-4] * 3, [4] * 3, w, h)
+    want = None
+    for pipeline, storage, graph, layers in [(gs.PIPELINE_REFERENCE, "caller", False, 1), (gs.PIPELINE_TWO_LEVEL, "caller", False, 1),
+                                             (gs.PIPELINE_TWO_LEVEL, "morton", True, 1), (gs.PIPELINE_TWO_LEVEL, "morton", True, 0)]:
+        r = gs.Renderer(w, h, storage_order=storage)
+        r.set_scene(pos, sr, col)
+        r.set_pipeline(pipeline)
+        r.set_graph(graph)
+        if layers != 1:
+            r.set_depth_layers(layers)
+        for _ in range(3):  # (the list grows in the first frame; the choice of layers follows its total)
+            r.render(cam)
+        image = r.read_image().copy()
+        if graph:
+            assert r.depth_layers_in_use() == (1 if layers == 1 else 3)
+            assert (r.listed_pairs() > 2 ** 30) == (layers == 1)
+        else:
+            st = r.render(cam, stats=True)
+            assert int(st.tileListSize) > 2 ** 30 and int(st.tileListCapacity) >= int(st.tileListSize)
+        r.close()
+        if want is None:
+            want = image
+            assert want[..., :3].max() > 0
+        else:
+            assert np.array_equal(image, want), (pipeline, storage, graph, layers)
