@@ -222,6 +222,10 @@ SIGNATURES = {
     "gs_camera_controls_camera_data": (None, [C.c_void_p, C.POINTER(CameraData)]),
     "gs_camera_controls_get_state": (None, [C.c_void_p, C.POINTER(CameraControlsState)]),
     "gs_camera_controls_set_pose": (None, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "gs_graphics_gl_register_buffer": (C.c_void_p, [C.c_uint32, C.c_uint32]),
+    "gs_graphics_map": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "gs_graphics_unmap": (None, [C.c_void_p]),
+    "gs_graphics_unregister": (None, [C.c_void_p]),
     "gs_generate_random_gaussians": (None, [C.c_int32, C.c_uint64, C.c_float, C.c_float, C.POINTER(C.c_float),
                                             C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                             C.POINTER(C.c_float)]),

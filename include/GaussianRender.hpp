@@ -12,6 +12,7 @@
 //   parsePly / encodeVec4                               PlyParser.h:11-21          gs::parsePly / gs::encodeVec4
 //   realignSphericalHarmonics / generateRandomGaussians Demo.cpp:119-143,160-194   same names in namespace gs
 //   CameraControls (interactive camera)                 CameraControls.h:7-76      gs::CameraControls (input handed in, not polled from GLFW)
+//   CudaGraphicsResource (GL buffer -> device pointer)  Utilities.h:113-153        gs::GraphicsResource
 //
 // No glm dependency: vectors are plain structs with the same memory layout as float4 / glm::vec3.
 #pragma once
@@ -234,6 +235,38 @@ class CameraControls
         gs_camera_controls_camera_data(m_Handle, &c);
         return c;
     }
+};
+
+// Utilities.h:113-153 CudaGraphicsResource: a GL buffer object registered with the device; getBinding<T>() maps it for the scope of the
+// binding and hands out the device pointer (Demo.cpp:338,396,419: `globalArgs.backBuffer = colorBinding.getPtr()`).  The GL side of the
+// presentation (GLBuffer, GLVertexArray, the textured quad of Demo.cpp:481-525) is plain GL and stays the host's own code.
+struct GraphicsResource
+{
+  private:
+    GsGraphicsResource* m_Resource;
+
+  public:
+    template <typename T>
+    struct Binding
+    {
+      private:
+        T* m_Ptr;
+        GsGraphicsResource* m_Resource;
+
+      public:
+        explicit Binding(GsGraphicsResource* resource) : m_Ptr(static_cast<T*>(gs_graphics_map(resource, nullptr))), m_Resource(resource) {}
+        ~Binding() { gs_graphics_unmap(m_Resource); }
+        Binding(const Binding&) = delete;
+        Binding& operator=(const Binding&) = delete;
+        T* getPtr() const { return m_Ptr; }
+    };
+    GraphicsResource(std::uint32_t bufferId, std::uint32_t flags) : m_Resource(gs_graphics_gl_register_buffer(bufferId, flags)) {}
+    ~GraphicsResource() { gs_graphics_unregister(m_Resource); }
+    GraphicsResource(const GraphicsResource&) = delete;
+    GraphicsResource& operator=(const GraphicsResource&) = delete;
+    bool registered() const { return m_Resource != nullptr; } // addition: the reference finds out at its first map
+    template <typename T>
+    Binding<T> getBinding() { return Binding<T>(m_Resource); } // (C++17: the prvalue is constructed in place, as the reference relies on)
 };
 
 } // namespace gs

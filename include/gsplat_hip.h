@@ -226,6 +226,26 @@ void gs_camera_controls_get_state(const GsCameraControls* controls, GsCameraCont
 /* Addition (the reference only places the camera through setBounds): start a session from a saved pose. */
 void gs_camera_controls_set_pose(GsCameraControls* controls, const float position[3], const float rotationXYZW[4]);
 
+/* ---- GL interop: CudaGraphicsResource (Utilities.h:113-153), SURVEY 8(f4) --------------------------
+ * The one CUDA-specific piece of the reference's presentation: its GL pixel-unpack buffer is registered with the device
+ * (Demo.cpp:311,338), mapped once per frame (:396) and the mapped pointer is the frame's back buffer (:419); the texture upload and the
+ * quad of Demo.cpp:481-525 are plain GL and stay with the host unchanged.  A GL buffer id goes in, a device pointer comes out -- what
+ * GsGlobalArgs.backBuffer and gs_renderer_set_back_buffer take; the host needs no HIP header.  A GL context must be current on the
+ * calling thread (the reference's glfwMakeContextCurrent, Demo.cpp:230).  The GPU pool this library is tested on has no window system:
+ * what is tested there is that a registration without a context is refused cleanly; the mapped path is compiled, not run. */
+typedef struct GsGraphicsResource GsGraphicsResource;
+#define GS_GRAPHICS_REGISTER_FLAGS_NONE 0          /* cudaGraphicsRegisterFlagsNone (Demo.cpp:338) */
+#define GS_GRAPHICS_REGISTER_FLAGS_READ_ONLY 1     /* cudaGraphicsRegisterFlagsReadOnly */
+#define GS_GRAPHICS_REGISTER_FLAGS_WRITE_DISCARD 2 /* cudaGraphicsRegisterFlagsWriteDiscard */
+/* Utilities.h:139-142 cudaGraphicsGLRegisterBuffer.  The reference ignores that call's result and ends at the first map
+ * (checkCudaErrors, :127); here a failed registration prints its reason and returns NULL -- and mapping NULL ends the process the same way. */
+GsGraphicsResource* gs_graphics_gl_register_buffer(uint32_t glBufferId, uint32_t flags);
+/* Utilities.h:122-130 Binding(): cudaGraphicsMapResources (on the library's current stream; the reference: stream 0) +
+ * cudaGraphicsResourceGetMappedPointer.  Errors print and exit, like checkCudaErrors. */
+void* gs_graphics_map(GsGraphicsResource* resource, size_t* sizeInBytesOrNull);
+void gs_graphics_unmap(GsGraphicsResource* resource);      /* Utilities.h:131-134 ~Binding(): unchecked there and here */
+void gs_graphics_unregister(GsGraphicsResource* resource); /* Utilities.h:143-146; unmaps first if still mapped; NULL is a no-op */
+
 /* Demo.cpp:119-143 generateRandomGaussians with a seeded PRNG (splitmix64) instead of std::rand. */
 void gs_generate_random_gaussians(int32_t count, uint64_t seed, float minScale, float maxScale, const float minPosition[3],
                                   const float maxPosition[3], float* position4, float* scaleAndRotation4, float* color4);

@@ -216,3 +216,25 @@ def test_cpp_host_one_call_viewer_session_with_tile_start_order(gs, gsref, demo_
     assert images["staged"].max() > 0
     assert np.array_equal(images["one_call"], images["staged"]) and np.array_equal(images["one_call_tile_order"], images["staged"])
     assert np.array_equal(images["staged_tile_order"], images["staged"])  # gs_set_staged_tile_start_order: the eight staged calls with the option
+
+
+def test_gl_interop_without_a_context_is_refused_and_mapping_it_ends_the_process(gs):
+    """gs_graphics_* is the reference's CudaGraphicsResource (Utilities.h:113-153) over HIP's GL interop.  This pool has no
+    window system, so there is no GL context to register a buffer from: what can be run is the refusal -- a registration without a context
+    returns NULL with a message, unregister / unmap of NULL do nothing, the library renders on -- and the reference's error convention:
+    mapping a resource that was never registered prints and exits with EXIT_FAILURE (checkCudaErrors, Utilities.h:127), in a child."""
+    lib = gs.lib()
+    handle = lib.gs_graphics_gl_register_buffer(1, 0)
+    assert not handle
+    lib.gs_graphics_unmap(None)
+    lib.gs_graphics_unregister(None)
+    r = gs.Renderer(64, 64)
+    pos, sr, col = gs.generate_random_gaussians(1000, seed=3)
+    r.set_scene(pos, sr, col)
+    r.render(gs.camera_from_bounds([-4] * 3, [4] * 3, 64, 64))
+    assert int(r.read_image()[..., :3].sum()) > 0
+    r.close()
+    child = ("import sys; sys.path.insert(0, %r); import torch; import cudagaussianrenderer_amd as gs; lib = gs.lib(); lib.gs_set_device(0); "
+             "lib.gs_graphics_map(None, None); print('survived')" % ROOT)
+    proc = subprocess.run([sys.executable, "-c", child], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=ROOT)
+    assert proc.returncode == 1 and "survived" not in proc.stdout and "gs_graphics_map" in proc.stderr, (proc.returncode, proc.stdout, proc.stderr[-500:])

@@ -409,3 +409,31 @@ def test_ingest_is_clean_under_address_undefined_and_thread_sanitizers(tmp_path)
         assert run.returncode == 0, run.stderr[-2000:]
         assert run.stdout.split() == ["150000", "500", "150000", "-1"], run.stdout
         assert "runtime error" not in run.stderr and "Sanitizer" not in run.stderr, run.stderr[-2000:]
+
+
+def test_facade_presents_through_a_graphics_resource_like_the_reference(tmp_path):
+    """SURVEY.md 8(f4), the presentation's one device-specific piece: the reference registers its GL pixel-unpack buffer with the device,
+    maps it per frame and renders into the mapped pointer (Demo.cpp:338,396,419 over Utilities.h:113-153).  The same three statements
+    must compile against the facade with only the class renamed (gs::GraphicsResource), and the C ABI underneath must be usable from C
+    without any HIP or GL header.  What runs of it on a box without a window system is in tests/test_gpu_hosts.py."""
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cpp = tmp_path / "present.cpp"
+    cpp.write_text('#include "GaussianRender.hpp"\n'
+                   "void frame(unsigned glColorBufferId, gs::GlobalArgs& globalArgs)\n{\n"
+                   "    auto colorBufferResource = gs::GraphicsResource(glColorBufferId, GS_GRAPHICS_REGISTER_FLAGS_NONE); // Demo.cpp:338\n"
+                   "    {\n"
+                   "        auto colorBinding = colorBufferResource.getBinding<gs::uchar4_t>();                          // Demo.cpp:396\n"
+                   "        globalArgs.backBuffer = reinterpret_cast<decltype(globalArgs.backBuffer)>(colorBinding.getPtr()); // Demo.cpp:419\n"
+                   "        gs::setGlobalArgs(&globalArgs);\n"
+                   "    }\n}\n")
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(cpp)], check=True)
+    c = tmp_path / "present.c"
+    c.write_text('#include "gsplat_hip.h"\n'
+                 "void* frame(unsigned id) { GsGraphicsResource* r = gs_graphics_gl_register_buffer(id, GS_GRAPHICS_REGISTER_FLAGS_WRITE_DISCARD);\n"
+                 "  size_t bytes = 0; void* p = r ? gs_graphics_map(r, &bytes) : 0; gs_graphics_unmap(r); gs_graphics_unregister(r); return p; }\n")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(c)], check=True)
