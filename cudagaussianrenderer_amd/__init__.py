@@ -335,6 +335,8 @@ class Renderer:
     def __init__(self, width, height, tile_rows=None, pipeline=None, band_cull=None, views=1, storage_order=None):
         self.width, self.height = width, height
         self.handle = lib().gs_renderer_create(width, height)
+        if not self.handle:
+            raise ValueError(f"gs_renderer_create({width}, {height}) refused: at most 65536 pixels per axis")
         self.views = int(views)
         if self.views != 1 and lib().gs_renderer_set_views(self.handle, self.views) != 0:
             raise ValueError(f"views must be 1..4 (got {views})")

@@ -283,7 +283,9 @@ extern "C" int32_t gs_build_tile_list(GsTimer* timer, int32_t /*numBlocks*/, int
     const int count = g.global.splatCount;
     // Default: the pairs are emitted in the order the sort would leave them (gs_staged.hip); sortTileList then finds nothing to do.
     // (-1: no device memory for that builder's scratch -- this call emits in the reference's order, which needs none)
-    if (cfg.stagedBuilder == GS_STAGED_BUILDER_SORTED && radixSortSupported(4, count))
+    // (a capacity within a megabyte of 2^31 -- the caller's own buffers, the reference's int32 -- is beyond what the sorted builder's
+    // grids can be sized for without an int wrapping: such a call emits in the reference's order too, and sortTileList sorts)
+    if (cfg.stagedBuilder == GS_STAGED_BUILDER_SORTED && radixSortSupported(4, count) && tileListCapacity <= kMaxTileListCapacity)
     {
         const int32_t emitted = stagedBuildTileListSorted(timer, tileListCapacity);
         if (emitted >= 0) return emitted;
@@ -315,7 +317,7 @@ void gs::sortTileListImpl(GsTimer* timer, int32_t size, void** deviceTempStorage
     gs_timer_start(timer);
     // A stable sort of a list that is already in order on the compared bits is the identity: look first (one read of the keys).  The
     // default staged builder emits exactly such a list; any other list goes through the sort as before.
-    if (size > 0 && lookFirst && keys->selector == values->selector &&
+    if (size > 0 && size <= kMaxTileListCapacity && lookFirst && keys->selector == values->selector &&
         stagedListIsSorted(size, keys->buffers[keys->selector], sortEndBit(currentScreen().totalTiles)))
     {
         gs_timer_stop(timer);

@@ -192,6 +192,11 @@ static void allocRangeTable(GsRenderer* r, const Screen& scr)
 
 extern "C" GsRenderer* gs_renderer_create(int width, int height)
 {
+    if (width > kMaxScreenSize || height > kMaxScreenSize)
+    {
+        std::fprintf(stderr, "gsplat_hip: gs_renderer_create(%d, %d): at most %d pixels per axis\n", width, height, kMaxScreenSize);
+        return nullptr;
+    }
     GsRenderer* r = new GsRenderer{};
     const Screen scr = makeScreen(width, height, 0, 0);
     r->width = scr.width;
@@ -522,7 +527,7 @@ void allocateSceneIntermediates(GsRenderer* r, int32_t n)
 extern "C" int gs_renderer_set_scene(GsRenderer* r, int32_t n, const float* position4, const float* scaleAndRotation4,
                                      const float* color4, const float* sh, int shDegree, int shCount)
 {
-    if (n < 0 || (shDegree != 0 && sh == nullptr)) return -1;
+    if (n < 0 || (shDegree != 0 && sh == nullptr) || (int64_t) n * r->views > kMaxVirtualSplats) return -1;
     StreamScope scope(r);
     GS_CHECK(hipStreamSynchronize(g.stream));
     freeScene(r);
@@ -625,6 +630,7 @@ extern "C" int gs_renderer_share_scene(GsRenderer* r, const GsRenderer* owner)
     // Every refusal comes before anything of r is touched: a sharer that fails keeps the scene it had (the order list of a
     // Morton-stored scene is laid out per view, so the two renderers must agree on the views of a chain).
     if (owner->splatToStorage != nullptr && owner->views != r->views) return -1;
+    if ((int64_t) owner->splatCount * r->views > kMaxVirtualSplats) return -1;
     StreamScope scope(r);
     GS_CHECK(hipStreamSynchronize(g.stream));
     freeScene(r);
@@ -1169,6 +1175,7 @@ extern "C" int gs_render(const GsScene* scene, const GsCameraData* camera, int w
 {
     if (scene == nullptr || camera == nullptr || width <= 0 || height <= 0 || scene->splatCount < 0) return -1;
     GsRenderer* r = gs_renderer_create(width, height);
+    if (r == nullptr) return -1; // (more than kMaxScreenSize pixels per axis)
     int rc = gs_renderer_set_scene(r, scene->splatCount, scene->position, scene->scaleAndRotation, scene->color, scene->sphericalHarmonics,
                                    scene->sphericalHarmonicsDegree, scene->sphericalHarmonicsCount);
     if (rc == 0) rc = gs_renderer_render(r, camera, 0, nullptr);

@@ -296,6 +296,11 @@ RasterColourSource colourSource(const GsRenderer* r, const float* cameraPosition
 // "first element of my tile" of the list kernels -- grids are sized for the capacity, rounded up to whole tiles and eight XCDs -- stays an int.
 // A frame that needs more returns -2 (the reference's `tileListCapacity *= 2`, Demo.cpp:360, overflows its int from 2^30 pairs on).
 constexpr int64_t kMaxTileListCapacity = 0x7FF00000;
+// What else a renderer refuses instead of letting an int wrap: more than 65 536 pixels per axis (4 096 tiles: the list builder packs a
+// box's tile coordinates into 16 bits each, and tilesX * tilesY * views stays far below 2^31), and more than 2^30 splats x views per chain
+// (sorted indices, the two-records-per-splat addressing and n * views are ints; 2^30 splats are 64 GB of positions and shapes alone).
+constexpr int kMaxScreenSize = 65536;
+constexpr int64_t kMaxVirtualSplats = 1ll << 30;
 bool growTileListIfNeeded(GsRenderer* r, int64_t demand);
 // The band cull of this renderer's next frame runs by blocks of Morton-neighbouring splats (fills `cull` for launchSplatClipData).
 bool useBlockCull(const GsRenderer* r, BandBlockCull* cull);

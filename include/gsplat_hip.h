@@ -280,6 +280,10 @@ typedef struct GsFrameStats
     int32_t grewTileList;     /* 1 when the list buffers were re-allocated this frame */
 } GsFrameStats;
 
+/* Limits (each refused instead of letting a 32-bit index wrap; the reference's own interface is int32 throughout): at most 65 536
+ * pixels per axis (gs_renderer_create returns NULL with a message), at most 2^30 splats x views per chain (gs_renderer_set_scene /
+ * gs_renderer_share_scene return -1), at most 0x7FF00000 list entries per frame (gs_renderer_render returns -2).  Tested up to
+ * 16 384 x 16 384, 200 M splats and 1.72e9 entries (profiles/r06_large_lists.txt). */
 GsRenderer* gs_renderer_create(int width, int height);
 void gs_renderer_destroy(GsRenderer* r);
 /* The whole of Demo.cpp:278-479 for ONE frame as one call (SURVEY.md section 8(b)'s fused convenience): the scene as parsePly returns it

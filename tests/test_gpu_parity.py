@@ -2324,3 +2324,36 @@ def test_a_list_of_more_than_two_to_the_thirty_pairs(gs):
             assert want[..., :3].max() > 0
         else:
             assert np.array_equal(image, want), (pipeline, storage, graph, layers)
+
+
+@pytest.mark.gpu
+def test_sizes_beyond_the_int32_interface_are_refused(gs):
+    """include/gsplat_hip.h "Limits": more than 65 536 pixels per axis, more than 2^30 splats x views per chain -- refused before anything is
+    allocated or read (the arrays handed over below hold ONE splat), and the renderer that refused a scene keeps the one it had."""
+    import ctypes as C
+
+    with pytest.raises(ValueError):
+        gs.Renderer(65537, 16)
+    with pytest.raises(ValueError):
+        gs.Renderer(16, 1 << 20)
+    pos, sr, col = gs.generate_random_gaussians(2000, seed=5)
+    cam = gs.camera_from_bounds([-4] * 3, [4] * 3, 64, 64)
+    scene = gs._capi.Scene(2000, gs._fp(pos), gs._fp(sr), gs._fp(col), None, 0, 0)
+    assert gs.lib().gs_render(C.byref(scene), C.byref(cam), 65537, 16, None) == -1  # (the one-shot form: no renderer to make)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    for views, n_refused in ((1, (1 << 30) + 1), (4, (1 << 28) + 1)):
+        r = gs.Renderer(64, 64, views=views)
+        r.set_scene(pos, sr, col)
+        r.set_graph(True)
+        before = []
+        if views == 1:
+            r.render(cam)
+            before = [r.read_image().copy()]
+        assert gs.lib().gs_renderer_set_scene(r.handle, n_refused, fp(pos), fp(sr), fp(col), None, 0, 0) == -1
+        if views == 1:
+            r.render(cam)
+            assert np.array_equal(r.read_image(), before[0])
+        else:
+            r.render_views([cam] * 4)
+            assert int(r.read_image(view=3)[..., :3].sum()) > 0
+        r.close()

@@ -145,6 +145,7 @@ int main(int argc, char** argv)
             gs::parsePly(argv[1], p2, s2, c2, rows, d2, n2, lo2, hi2);
         }
         GsRenderer* renderer = gs_renderer_create(width, height);
+        if (renderer == nullptr) return 1;
         if (gs_renderer_set_scene(renderer, splatCount, &position[0].x, &scaleAndRotation[0].x, &color[0].x, shDegree != 0 ? rows.data() : nullptr, shDegree,
                                   shCount) != 0)
             return 1;
