@@ -465,7 +465,12 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
             //   first layered frame after a one-layer frame, P < 8 M: layers pay when most of the list lies behind the tiles' stop points --
             //                  listed / P was 0.32-0.38 where they paid and 0.66 on a scene of low opacities where they cost 10 % -- so above
             //                  0.5 the renderer goes back to one layer and does not try again for a while (256 frames, doubling);
-            //   two layers:    one below 1.5 M listed (pipelined) / 3.5 M (lone): the scene has become small; three from 18 M listed;
+            //   two layers:    one below 1.5 M listed (pipelined) / 3.5 M (lone): the scene has become small -- unless what is listed, scaled by the
+            //                  listed / total this scene showed on its first layered frame, says that the TOTAL still lies above 0.8 of the
+            //                  way up: the Epanechnikov run of the headline scene (4.76 M pairs, 1.51 M listed: share 0.32) stepped down at
+            //                  1.49 M listed, up again at once on the total, and so on thirteen times per run on two of four renderers
+            //                  (each a re-capture: 6 300-7 100 frames/s by luck) until the doubling hold had grown long enough;
+            //                  three from 18 M listed;
             //   three:         two below 6 M listed.
             // (a band under its cull -- a rank of a multi-GPU split -- skips the 4.5-8 M zone and its trial: layered bands gain 8 % at 8-11 M
             // pairs per chain, and a trial that does not pay costs two re-captures)
@@ -474,6 +479,9 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
             int next = r->autoLayers;
             bool atOnce = false; // (a failed trial is undone at once, whatever the hold says)
             if (r->autoBanFrames > 0) r->autoBanFrames -= 1;
+            // (the first layered frame after a change: what share of the last known total this scene lists in layers)
+            if (r->graphLayersActive && r->autoLayers > 1 && r->autoFramesSinceChange == 0 && r->autoLastTotal > 0 && listed > 0)
+                r->autoListedShare = (float) std::min(1.0, (double) listed / (double) r->autoLastTotal);
             if (!r->graphLayersActive || r->autoLayers == 1)
             {
                 r->autoLastTotal = demand;
@@ -486,7 +494,11 @@ int renderCaptured(GsRenderer* r, const GsCameraData* cameras)
                 r->autoBanFrames = r->autoBanLength;
                 r->autoBanLength = std::min(r->autoBanLength * 2, 1 << 16);
             }
-            else if (r->autoLayers == 2) next = listed < downToOne ? 1 : listed >= 18000000 ? 3 : 2;
+            else if (r->autoLayers == 2)
+            {
+                const bool totalStillUp = r->autoListedShare > 0.f && (double) listed / (double) r->autoListedShare >= 0.8 * (double) upToTwo;
+                next = (listed < downToOne && !totalStillUp) ? 1 : listed >= 18000000 ? 3 : 2;
+            }
             else next = listed < 6000000 ? 2 : r->autoLayers;
             // (a frame that cannot be layered -- band cull, one-pass tile sort -- keeps measuring totals; the wish costs nothing)
             // A change re-captures the frame (milliseconds), so a camera path whose totals straddle a threshold must not flap: steps up

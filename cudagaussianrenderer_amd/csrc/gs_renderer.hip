@@ -292,6 +292,7 @@ extern "C" int gs_renderer_set_depth_layers(GsRenderer* r, int layers, const flo
         r->autoBanFrames = 0;
         r->autoBanLength = 256;
         r->autoLastTotal = 0;
+        r->autoListedShare = 0.f;
         r->graphValid = false;
         return 0;
     }

@@ -198,6 +198,7 @@ struct GsRenderer
     int autoLayerChanges = 0;       // times the choice changed (each one re-captures the frame)
     int autoFramesSinceChange = 0;
     int64_t autoLastTotal = 0;      // the pair total of the last one-layer frame
+    float autoListedShare = 0.f;    // listed / total of the first layered frame after it (0: not known): what a layered frame's listed pairs say about its total
     int autoBanFrames = 0;          // frames left in which a scene below 8 M pairs is not tried with layers again (its listed / total was > 0.5)
     int autoBanLength = 256;
     int autoHoldFrames = 16;        // frames a choice is kept before it may go DOWN; doubles when a step down is undone at once
