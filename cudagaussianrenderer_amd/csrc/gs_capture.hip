@@ -83,20 +83,22 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
     // instance's slot is the frame's parity: this frame's counters in one buffer, the previous frame's in the other)
     const bool orderActive = tileStartOrderSchedule(r, scr, slot, &schedule);
     const RasterSchedule* scheduleOrNull = &schedule;
-    // ... and the table itself is made at the start of the frame from the previous frame's counters: by the plain clip kernel's first eight
-    // workgroups, or (band cull, the clip kernel riding in the sort's scan launch) by a small kernel of its own right here
+    // ... and the table itself is made at the start of the frame from the previous frame's counters: by the clip kernel's first eight
+    // workgroups (plain, or riding in the sort's scan launches), or (band cull) by a small kernel of its own right here
     TileOrderArgs orderArgs = orderActive ? tileOrderArgsFor(r, scr, slot) : TileOrderArgs{};
     if (orderActive) orderArgs.skipFlagDevice = &params[0].pad; // (renderCaptured sets it per replay: the camera jumped)
     bool orderBuilt = !orderActive;
-    if (!orderBuilt && (cull || (g_ablation & 1) || (cfg.clipScanFusion && r->splatToStorage != nullptr && !(g_ablation & 2))))
+    if (!orderBuilt && (cull || (g_ablation & 1)))
     {
         launchTileStartOrder(g.stream, scr, orderArgs);
         orderBuilt = true;
     }
     const int* countDevice = nullptr;
     // Morton storage: the depth sort makes its own keys, so the clip kernel and the sort do not depend on each other -- the clip kernel
-    // is handed to the sort and shares the launch of its first column scan (gs_internal.h RadixScanCompanion): 17 kernels per frame.
+    // is handed to the sort and shares the launch of its first column scan (gs_internal.h RadixScanCompanion,
+    // gs_debug_set_clip_scan_fusion): 17 kernels per frame; the tile start order's builder rides in the same launch.
     ClipWithScan deferredClip;
+    bool clipDeferred = false;
     const auto launchClip = [&]() {
         launchSplatClipData(g.stream, n, scr, unusedCamera, (const float4*) r->position, (const float4*) r->scaleAndRotation, nullptr, nullptr, nullptr,
                             nullptr, r->splatToStorage != nullptr ? nullptr : r->depthKey[0],
@@ -121,7 +123,11 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
                 deferredClip.rasterRecord = (float4*) r->rasterRecord;
                 deferredClip.views = views;
                 deferredClip.tileBox = tileBox;
-                r->radix.firstScanCompanion = RadixScanCompanion{&clipWithScanCompanion, &deferredClip};
+                deferredClip.parts = kClipScanParts;
+                if (!orderBuilt) deferredClip.tileOrder = orderArgs;
+                orderBuilt = true;
+                clipDeferred = true;
+                r->radix.firstScanCompanion = RadixScanCompanion{&clipWithScanCompanion, &deferredClip, kClipScanParts};
             }
             else launchClip();
         }
@@ -157,11 +163,11 @@ int enqueueCapturableFrame(GsRenderer* r, const Screen& scr, bool cull, bool laz
                                           : launchRadixSortPairs(g.stream, r->radix, 4, r->depthKey[0], r->depthKey[1], r->order[0], r->order[1], nv, 0,
                                                                  kDepthKeyBits, callerOrderedInput ? r->splatToStorage : nullptr,
                                                                  callerOrderedInput ? &keySource : nullptr);
-    if (r->radix.firstScanCompanion.launch != nullptr)
+    if (clipDeferred)
     {
-        // the sort could not take the clip kernel along (rows of more than 4096 tiles): by itself, then
+        // what the sort did not take along (rows of more than 4096 tiles: nothing of it; fewer scans than slices): by itself, then
         r->radix.firstScanCompanion = RadixScanCompanion{};
-        launchClip();
+        launchSplatClipDataRest(g.stream, deferredClip);
     }
     const uint32_t* order = (const uint32_t*) r->order[orderSel];
     // (gs_set_list_fusion: the emit pass carries the first pass of the tile sort.  Under ablation -- cumulative from the back -- the

@@ -334,17 +334,28 @@ __global__ __launch_bounds__(256) void splatClipDataKernel(int count, Screen scr
 // sort: the scan -- 512 workgroups that each add up one row of a 2 MB table, 5 us of pure latency -- rides in front of the clip kernel's
 // grid (its workgroups start first and are gone long before the clip stage's 22 us of streaming end).  One kernel, one dependent launch
 // and one chip-wide kernel boundary less per frame; the results are the two kernels' results (same routines, same order of operations).
+// Round 6: the clip kernel's workgroups can be dealt into slices, one per scan launch of the sort (kClipScanParts: measured, one slice is
+// what pays) -- the grid of a launch is [scan rows | the tile start order's eight builders (first slice only) | clip workgroups
+// firstBlock ..]; a clip workgroup does what it does in the plain kernel (its index and the total are the whole kernel's, so the range
+// table is cleared once).
 __global__ __launch_bounds__(256) void splatClipDataScanKernel(RadixScanArgs scan, int count, Screen scr, ClipCamera camArg,
                                                                 const FrameParams* __restrict__ params, const float4* __restrict__ position,
                                                                 const float4* __restrict__ scaleAndRotation, ClipOutputs o,
-                                                                int32_t* __restrict__ rangeTable, int rangeEntries)
+                                                                int32_t* __restrict__ rangeTable, int rangeEntries, int firstBlock, int clipBlocks,
+                                                                TileOrderArgs tileOrder)
 {
     if ((int) blockIdx.x < scan.rows) // (uniform per workgroup)
     {
         if (blockIdx.y == 0) radixColumnScanRow<256>((int) blockIdx.x, scan.nHost, scan.nDevice, scan.tileElements, scan.stride, scan.table, scan.scanned, scan.totals);
         return;
     }
-    clipDataBlock((int) blockIdx.x - scan.rows, (int) gridDim.x - scan.rows, (int) blockIdx.y, (int) gridDim.y, count, scr, camArg, params, position,
+    const int orderBlocks = tileOrder.slots > 0 ? kOrderWorkgroups : 0;
+    if ((int) blockIdx.x < scan.rows + orderBlocks)
+    {
+        if (blockIdx.y == 0) tileStartOrderBody<256>((int) blockIdx.x - scan.rows, scr, tileOrder);
+        return;
+    }
+    clipDataBlock(firstBlock + (int) blockIdx.x - scan.rows - orderBlocks, clipBlocks, (int) blockIdx.y, (int) gridDim.y, count, scr, camArg, params, position,
                   scaleAndRotation, o, rangeTable, rangeEntries);
 }
 
@@ -777,12 +788,33 @@ void launchSplatClipData(hipStream_t stream, int count, const Screen& scr, const
     }
 }
 
-void launchSplatClipDataWithScan(hipStream_t stream, const ClipWithScan& c, const RadixScanArgs& scan)
+namespace
+{
+// slices [first, end) of the deferred clip kernel in one launch, behind `scan` (rows == 0: no scan)
+void launchClipSlices(hipStream_t stream, ClipWithScan& c, const RadixScanArgs& scan, int first, int end)
 {
     const ClipOutputs o{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c.tileRecord, c.rasterRecord, c.tileBox};
-    const int clipBlocks = (c.count + 255) / 256;
-    hipLaunchKernelGGL(splatClipDataScanKernel, dim3(scan.rows + clipBlocks, c.views), dim3(256), 0, stream, scan, c.count, c.scr, c.camera, c.params, c.position,
-                       c.scaleAndRotation, o, c.rangeTableToClear, c.rangeEntries);
+    const int clipBlocks = (c.count + 255) / 256, parts = std::max(c.parts, 1);
+    const int firstBlock = (int) ((int64_t) clipBlocks * first / parts), endBlock = (int) ((int64_t) clipBlocks * end / parts);
+    TileOrderArgs order = c.tileOrder;
+    if (first != 0) order.slots = 0; // (the builder rides with the first slice)
+    const int orderBlocks = order.slots > 0 ? kOrderWorkgroups : 0;
+    if (scan.rows + orderBlocks + (endBlock - firstBlock) > 0)
+        hipLaunchKernelGGL(splatClipDataScanKernel, dim3(scan.rows + orderBlocks + (endBlock - firstBlock), c.views), dim3(256), 0, stream, scan, c.count, c.scr,
+                           c.camera, c.params, c.position, c.scaleAndRotation, o, c.rangeTableToClear, c.rangeEntries, firstBlock, clipBlocks, order);
+    c.done = end;
+}
+} // namespace
+
+void launchSplatClipDataWithScan(hipStream_t stream, ClipWithScan& c, const RadixScanArgs& scan)
+{
+    // (a scan offered after the last slice has gone is launched alone: the grid is then the scan's rows)
+    launchClipSlices(stream, c, scan, c.done, std::min(c.done + 1, std::max(c.parts, 1)));
+}
+
+void launchSplatClipDataRest(hipStream_t stream, ClipWithScan& c)
+{
+    if (c.done < std::max(c.parts, 1)) launchClipSlices(stream, c, RadixScanArgs{}, c.done, std::max(c.parts, 1));
 }
 
 } // namespace gs

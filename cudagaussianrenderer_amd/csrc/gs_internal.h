@@ -234,8 +234,10 @@ int launchSortPairs(hipStream_t stream, void* temp, size_t tempBytes, int keyByt
 // A kernel of the caller's that does not depend on the sort may SHARE THE LAUNCH of the sort's first scan (one kernel, one dependent
 // launch and one chip-wide kernel boundary less per frame): the caller leaves a companion in RadixScratch, and the next
 // launchRadixSortPairs hands it the arguments of its first scan instead of launching the scan kernel; the companion must launch ONE
-// kernel of 256-lane workgroups whose first `rows` workgroups (of grid row 0) call radixColumnScanRow<256> (gs_radix_scan.h).  One shot:
-// the sort clears it when it takes it; a sort that cannot (rows of more than 4096 tiles) leaves it, and the caller launches its kernel itself.
+// kernel of 256-lane workgroups whose first `rows` workgroups (of grid row 0) call radixColumnScanRow<256> (gs_radix_scan.h).  `shots`
+// scans in a row are offered to it (round 6 measured the clip kernel in slices, one per scan of the depth sort: kClipScanParts); the sort
+// clears the companion with its last shot.  A sort that cannot take it (rows of more than 4096 tiles) or runs out of passes leaves it set, and the
+// caller launches what is left of its kernel itself.
 struct RadixScanArgs
 {
     int rows; // digit rows = workgroups of the scan
@@ -250,6 +252,7 @@ struct RadixScanCompanion
 {
     void (*launch)(hipStream_t stream, const RadixScanArgs& scan, void* user) = nullptr;
     void* user = nullptr;
+    int shots = 1;
 };
 // The renderer's own radix sort (gs_radix.hip): 2- or 4-byte keys, int32 values, stable, bits [beginBit, endBit).
 struct RadixScratch
@@ -276,8 +279,10 @@ struct RadixScratch
     RadixScanCompanion firstScanCompanion; // see above; set per call by the renderer
 };
 // The clip stage of a frame whose depth sort makes its own keys (Morton storage, no band cull), deferred: launched by the sort as the
-// companion of its first column scan (gs_clip.hip splatClipDataScanKernel).  Writes the two 32-byte records per (virtual) splat and
-// resets the range table, exactly as launchSplatClipData does with the same arguments.
+// companion of its column scans (gs_clip.hip splatClipDataScanKernel): slice `done` of `parts` equal runs of its workgroups with every
+// scan the sort offers (kClipScanParts below: one slice is what pays), the tile start order's builder (gs_tile_order.h) with the first.
+// Writes the two 32-byte records per (virtual) splat and resets the range table, exactly as launchSplatClipData does with the same
+// arguments.
 struct ClipWithScan
 {
     int count = 0;
@@ -292,11 +297,24 @@ struct ClipWithScan
     float4* rasterRecord = nullptr;
     int views = 1;
     ushort4* tileBox = nullptr;
+    TileOrderArgs tileOrder{}; // slots > 0: the builder's eight workgroups ride in the first slice's launch
+    int parts = 1;             // slices the clip kernel's workgroups are dealt into
+    int done = 0;              // slices launched so far
 };
-void launchSplatClipDataWithScan(hipStream_t stream, const ClipWithScan& clip, const RadixScanArgs& scan);
+// Slices in use.  Round 6 measured 1, 2 and 3 (the depth sort has three scans, 5 us of latency each, and a third of the clip kernel's 22 us
+// would hide each of them): a slice pays the kernel's ramp-up again (a third takes 10.3 us beside its scan, not 7.3), so the lone
+// frame gains 3-5 us with two or three slices against 2-4 us with one, and with the tile start order -- whose builder needs the whole
+// kernel's 22 us to hide in -- slices lose what they gain (profiles/r06_clip_scan_slices.txt).  One slice: the whole kernel with the first scan.
+#ifndef GS_CLIP_SCAN_PARTS
+#define GS_CLIP_SCAN_PARTS 1
+#endif
+constexpr int kClipScanParts = GS_CLIP_SCAN_PARTS;
+// Launches slice clip.done with the scan in front of it (and counts it); ...Rest: the slices no scan took, in one launch of their own.
+void launchSplatClipDataWithScan(hipStream_t stream, ClipWithScan& clip, const RadixScanArgs& scan);
+void launchSplatClipDataRest(hipStream_t stream, ClipWithScan& clip);
 inline void clipWithScanCompanion(hipStream_t stream, const RadixScanArgs& scan, void* user)
 {
-    launchSplatClipDataWithScan(stream, *static_cast<const ClipWithScan*>(user), scan);
+    launchSplatClipDataWithScan(stream, *static_cast<ClipWithScan*>(user), scan);
 }
 bool radixSortSupported(int keyBytes, int n);
 // Passes launchRadixSortPairs makes over bits [beginBit, endBit) (digits of up to 9 bits); the sorted data ends in buffer pair passes % 2.

@@ -414,7 +414,7 @@ void runPassItems(hipStream_t stream, const K* keysIn, const int32_t* valuesIn, 
         // the caller has a kernel that does not depend on this sort and shares the launch of its first column scan (gs_internal.h)
         const RadixScanArgs scan{BITS > 8 ? 2 * kDigits : kDigits, n, s.countDevice, kTile, stride, s.table, s.scanned, s.chunkTotals};
         const RadixScanCompanion companion = s.firstScanCompanion;
-        s.firstScanCompanion = RadixScanCompanion{};
+        if (--s.firstScanCompanion.shots <= 0) s.firstScanCompanion = RadixScanCompanion{};
         companion.launch(stream, scan, companion.user);
     }
     else if (numTiles <= GS_SCAN_ROW_LIMIT)

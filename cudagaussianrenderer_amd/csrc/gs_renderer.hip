@@ -901,7 +901,7 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
         // (Morton storage on the native sort: no keys from the clip kernel -- the depth sort's first pass makes them in the caller's order)
         const bool keysFromSort = !cull && r->splatToStorage != nullptr && cfg.sortBackend == GS_SORT_BACKEND_NATIVE && radixSortSupported(4, n);
         // gs_renderer_set_tile_start_order: this frame's tile start order is made at its start from the previous frame's consumption -- by the
-        // plain clip kernel's first eight workgroups, or (band cull, the clip kernel riding in the sort's scan launch) by a kernel of its own
+        // clip kernel's first eight workgroups (plain, or riding in the sort's scan launches), or (band cull) by a kernel of its own
         prepareTileStartOrder(r, scr);
         RasterSchedule scheduleProbe;
         f.tileOrderParity = r->tileOrderParity;
@@ -916,11 +916,12 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
                                 orderBuilt ? nullptr : &orderArgs);
             orderBuilt = true;
         };
-        if (!orderBuilt && (cull || n <= 0 || (keysFromSort && cfg.clipScanFusion && !timed)))
+        if (!orderBuilt && (cull || n <= 0))
         {
             launchTileStartOrder(g.stream, scr, orderArgs);
             orderBuilt = true;
         }
+        bool clipDeferred = false;
         if (!cull)
         {
             // The sort makes its own keys: the clip kernel shares the launch of the sort's first column scan (gs_internal.h
@@ -936,7 +937,11 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
                 deferredClip.rangeEntries = 2 * scr.totalTiles;
                 deferredClip.tileRecord = (float4*) r->tileRecord;
                 deferredClip.rasterRecord = (float4*) r->rasterRecord;
-                r->radix.firstScanCompanion = RadixScanCompanion{&clipWithScanCompanion, &deferredClip};
+                deferredClip.parts = kClipScanParts;
+                if (!orderBuilt) deferredClip.tileOrder = orderArgs;
+                orderBuilt = true;
+                clipDeferred = true;
+                r->radix.firstScanCompanion = RadixScanCompanion{&clipWithScanCompanion, &deferredClip, kClipScanParts};
             }
             else launchClip();
         }
@@ -1003,11 +1008,11 @@ extern "C" int gs_renderer_begin(GsRenderer* r, const GsCameraData* camera, int 
                                            r->order[1], inputSel, n, 0, kDepthKeyBits);
             }
         }
-        if (r->radix.firstScanCompanion.launch != nullptr)
+        if (clipDeferred)
         {
-            // the sort could not take the clip kernel along (rows of more than 4096 tiles): by itself, then
+            // what the sort did not take along (rows of more than 4096 tiles: nothing of it; fewer scans than slices): by itself, then
             r->radix.firstScanCompanion = RadixScanCompanion{};
-            launchClip();
+            launchSplatClipDataRest(g.stream, deferredClip);
         }
         gs_timer_stop(stageTimers[6]);
         f.orderSel = orderSel;

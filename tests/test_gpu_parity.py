@@ -1064,9 +1064,15 @@ def test_tile_start_order_changes_no_byte_and_follows_the_camera(gs, tmp_path):
         want.append(ref.read_image())
     ref.close()
     assert all(img[..., :3].any() for img in want)
-    for name, graph, layers, cull in (("plain", False, 1, None), ("captured", True, 1, None), ("captured, two layers", True, 2, None),
-                                      ("captured, band cull on the full frame", True, 1, 1), ("plain, band cull", False, 1, 1)):
-        r = gs.Renderer(w, h, band_cull=cull)
+    # (Morton storage with gs_debug_set_clip_scan_fusion: the clip kernel rides in the launch of the depth sort's first column scan, and
+    # the builder's eight workgroups ride with it)
+    for name, graph, layers, cull, riding in (("plain", False, 1, None, False), ("captured", True, 1, None, False), ("captured, two layers", True, 2, None, False),
+                                              ("captured, band cull on the full frame", True, 1, 1, False), ("plain, band cull", False, 1, 1, False),
+                                              ("plain, clip kernel riding in the sort's scans", False, 1, None, True),
+                                              ("captured, clip kernel riding in the sort's scans", True, 1, None, True),
+                                              ("captured, two layers, clip kernel riding in the sort's scans", True, 2, None, True)):
+        gs.lib().gs_debug_set_clip_scan_fusion(1 if riding else 0)
+        r = gs.Renderer(w, h, band_cull=cull, storage_order="morton" if riding else None)
         r.set_graph(graph)
         if graph:
             r.set_depth_layers(layers)
@@ -1094,6 +1100,7 @@ def test_tile_start_order_changes_no_byte_and_follows_the_camera(gs, tmp_path):
         r.render(path[0])
         assert np.array_equal(r.read_image(), want[0])
         r.close()
+        gs.lib().gs_debug_set_clip_scan_fusion(0)
     # several views per chain: the option stands aside
     r = gs.Renderer(w, h, views=2)
     r.set_graph(True)
