@@ -115,7 +115,9 @@ void gs_debug_set_ablation(int mask);
  * frame; same results, same routines).  Measured (profiles/r04_ab_experiments.txt): one frame at a time -- the reference's loop,
  * Demo.cpp:394-479 -- gains 3 % (0.275 -> 0.266 ms), four frames in flight lose 1 %; OFF by default, for hosts that render one frame
  * at a time to switch on.  Process-wide.  Frames whose stages are timed one by one (timed != 0) always launch the two separately, so
- * that the clip stage's time is its own. */
+ * that the clip stage's time is its own.  Round 6: the builder of gs_renderer_set_tile_start_order rides in the shared launch as it does
+ * in the plain clip kernel (the two options of an interactive host add up: -2 ... -4 us on top of the start order's -14 us); dealing the
+ * clip kernel in slices to all three scans of the sort was measured and is no better (profiles/r06_clip_scan_slices.txt). */
 void gs_debug_set_clip_scan_fusion(int enabled);
 int gs_debug_get_clip_scan_fusion(void);
 /* A captured frame hands its pair total to the host in the middle of the frame; the host waits for it at most this long (default
