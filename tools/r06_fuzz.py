@@ -2,7 +2,9 @@
 """Round 6 fuzz: the two features whose correctness is "changes no byte" over random resolutions, bands, splat counts, scenes and cameras.
   (1) block-level band cull (Morton storage): kept-splat count, sorted list size and image equal with the block test on and off;
   (2) tile start order from the previous frame: frames of a random walk of the camera equal the screen-order renderer's.
-usage: r06_fuzz.py ITERATIONS [SEED]   (GPU box)"""
+usage: r06_fuzz.py ITERATIONS [SEED] [riding]   (GPU box)
+"riding": the renderer under test in (2) stores its splats along the Morton curve and gs_debug_set_clip_scan_fusion is on -- the clip
+kernel then rides in the launch of the depth sort's first column scan, and the tile start order's builder with it."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,6 +13,9 @@ import cudagaussianrenderer_amd as gs
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 lib = gs.lib()
+riding = len(sys.argv) > 3 and sys.argv[3] == "riding"
+if riding:
+    lib.gs_debug_set_clip_scan_fusion(1)
 
 
 def harsh(n):
@@ -91,7 +96,7 @@ for it in range(iters):
     ref = gs.Renderer(w, h, tile_rows=band)
     ref.set_footprint(footprint)
     ref.set_scene(*scene)
-    r = gs.Renderer(w, h, tile_rows=band)
+    r = gs.Renderer(w, h, tile_rows=band, storage_order=gs.STORAGE_ORDER_MORTON if riding else None)
     r.set_footprint(footprint)
     r.set_graph(graph)
     if graph:
@@ -118,4 +123,5 @@ for it in range(iters):
               f"blocks rejected), {order_frames} frames with the tile start order (images equal) -- {time.time() - t0:.0f} s", flush=True)
 print(f"r06_fuzz: {iters} random scenes, 241x129 ... 3840x2160 with ragged last tiles, 4 100 ... 120 000 harsh splats, 1-4 views per chain, plain and captured, both footprints: "
       f"{cull_frames} band frames equal with the block-level cull on and off ({100 * rejected / max(total_blocks, 1):.1f} % of the blocks rejected); "
-      f"{order_frames} frames of random camera walks equal with gs_renderer_set_tile_start_order on and off; no difference found")
+      f"{order_frames} frames of random camera walks equal with gs_renderer_set_tile_start_order on and off"
+      f"{' (Morton storage, the clip kernel and the builder riding in the sort's first scan launch)' if riding else ''}; no difference found")
