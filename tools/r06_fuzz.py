@@ -121,7 +121,7 @@ for it in range(iters):
     if (it + 1) % 25 == 0:
         print(f"{it + 1} scenes: {cull_frames} band frames with the block cull on and off (kept counts and images equal; {100 * rejected / max(total_blocks, 1):.1f} % of the "
               f"blocks rejected), {order_frames} frames with the tile start order (images equal) -- {time.time() - t0:.0f} s", flush=True)
+how = " (Morton storage, the clip kernel and the builder riding in the launch of the sort's first scan)" if riding else ""
 print(f"r06_fuzz: {iters} random scenes, 241x129 ... 3840x2160 with ragged last tiles, 4 100 ... 120 000 harsh splats, 1-4 views per chain, plain and captured, both footprints: "
       f"{cull_frames} band frames equal with the block-level cull on and off ({100 * rejected / max(total_blocks, 1):.1f} % of the blocks rejected); "
-      f"{order_frames} frames of random camera walks equal with gs_renderer_set_tile_start_order on and off"
-      f"{' (Morton storage, the clip kernel and the builder riding in the sort's first scan launch)' if riding else ''}; no difference found")
+      f"{order_frames} frames of random camera walks equal with gs_renderer_set_tile_start_order on and off" + how + "; no difference found")
